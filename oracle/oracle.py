@@ -1,0 +1,350 @@
+"""ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  See oracle/rsrl_oracle.c for scope and pinning status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
+FOURIER, TILE = 0, 1
+QLEARNING, SARSA, EXPECTED_SARSA = 0, 1, 2
+GREEDY, EGREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
+BLK_STEP, BLK_RESET, BLK_INNER, BLK_INIT, BLK_API = 0, 1, 2, 3, 4
+
+
+class Basis(C.Structure):
+    _fields_ = [("kind", C.c_int), ("dim", C.c_int), ("order", C.c_int),
+                ("n_tilings", C.c_int), ("tiles_per_dim", C.c_int),
+                ("lo", C.c_double * 8), ("hi", C.c_double * 8),
+                ("lo_f", C.c_float * 8), ("hi_f", C.c_float * 8)]
+
+
+class Agent(C.Structure):
+    _fields_ = [("domain", C.c_int), ("algo", C.c_int), ("policy", C.c_int),
+                ("shared_w", C.c_int), ("n_actions", C.c_int), ("basis", Basis),
+                ("seed", C.c_uint64), ("env_offset", C.c_int64),
+                ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
+                ("epsilon", C.c_double), ("tau", C.c_double),
+                ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("env_steps", C.c_uint64), ("episodes", C.c_uint64),
+                ("episodes_truncated", C.c_uint64), ("sum_episode_steps", C.c_uint64),
+                ("sum_abs_td_error", C.c_double), ("sum_reward", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile liboracle.so with the committed Makefile (gcc only)."""
+    src = [os.path.join(_HERE, f) for f in ("rsrl_oracle.c", "rsrl_oracle_impl.h", "rsrl_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    u32p = C.POINTER(C.c_uint32)
+    L.orc_domain_dim.restype = C.c_int
+    L.orc_domain_actions.restype = C.c_int
+    L.orc_basis_nfeat.restype = C.c_int
+    L.orc_basis_nfeat.argtypes = [C.POINTER(Basis)]
+    L.orc_mulhi.restype = C.c_uint32
+    L.orc_mulhi.argtypes = [C.c_uint32, C.c_uint32]
+    L.orc_eps_threshold.restype = C.c_uint32
+    L.orc_eps_threshold.argtypes = [C.c_double]
+    L.orc_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u32p]
+    L.orc_agent_init.argtypes = [C.POINTER(Agent)] + [C.c_int] * 8 + [C.c_uint64, C.c_int64] + \
+        [C.c_double] * 5 + [C.c_uint32]
+    for S, R in (("f64", C.c_double), ("f32", C.c_float)):
+        Rp = C.POINTER(R)
+        g = lambda n: getattr(L, f"{n}_{S}")
+        g("orc_domain_step").restype = C.c_int
+        g("orc_domain_step").argtypes = [C.c_int, Rp, C.c_int, Rp]
+        g("orc_domain_is_terminal").restype = C.c_int
+        g("orc_domain_is_terminal").argtypes = [C.c_int, Rp]
+        g("orc_domain_reset").argtypes = [C.c_int, Rp]
+        g("orc_fourier_project").argtypes = [C.c_int, C.c_int, Rp, Rp, Rp, Rp]
+        g("orc_q_evaluate").argtypes = [C.POINTER(Basis), Rp, C.c_int, Rp, Rp]
+        g("orc_q_evaluate_index").restype = R
+        g("orc_q_evaluate_index").argtypes = [C.POINTER(Basis), Rp, C.c_int, Rp, C.c_int]
+        g("orc_find_max").restype = C.c_int
+        g("orc_find_max").argtypes = [Rp, C.c_int, Rp]
+        g("orc_q_update_index").argtypes = [C.POINTER(Basis), Rp, C.c_int, Rp, C.c_int, R, R]
+        g("orc_argmaxima").restype = C.c_int
+        g("orc_argmaxima").argtypes = [Rp, C.c_int, C.POINTER(C.c_int), Rp]
+        g("orc_argmax_first").restype = C.c_int
+        g("orc_argmax_first").argtypes = [Rp, C.c_int]
+        g("orc_greedy_probs").argtypes = [Rp, C.c_int, Rp]
+        g("orc_egreedy_probs").argtypes = [Rp, C.c_int, R, Rp]
+        g("orc_softmax_probs").argtypes = [Rp, C.c_int, R, Rp]
+        g("orc_policy_probs").argtypes = [C.c_int, Rp, C.c_int, R, R, Rp]
+        g("orc_policy_sample").restype = C.c_int
+        g("orc_policy_sample").argtypes = [C.c_int, Rp, C.c_int, C.c_uint32, R, u32p]
+        g("orc_policy_mode").restype = C.c_int
+        g("orc_policy_mode").argtypes = [C.c_int, Rp, C.c_int, R]
+        g("orc_td_error").restype = R
+        g("orc_td_error").argtypes = [C.POINTER(Agent), Rp, Rp, C.c_int, R, Rp, C.c_int, u32p, Rp]
+        g("orc_handle").restype = R
+        g("orc_handle").argtypes = [C.POINTER(Agent), Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
+        g("orc_run_create").restype = C.c_void_p
+        g("orc_run_create").argtypes = [C.POINTER(Agent), C.c_int64]
+        g("orc_run_destroy").argtypes = [C.c_void_p]
+        g("orc_run_state").restype = Rp
+        g("orc_run_state").argtypes = [C.c_void_p]
+        g("orc_run_action").restype = C.POINTER(C.c_int32)
+        g("orc_run_action").argtypes = [C.c_void_p]
+        g("orc_run_ep_step").restype = u32p
+        g("orc_run_ep_step").argtypes = [C.c_void_p]
+        g("orc_run_weights").restype = Rp
+        g("orc_run_weights").argtypes = [C.c_void_p]
+        g("orc_run_t").restype = C.c_uint64
+        g("orc_run_t").argtypes = [C.c_void_p]
+        g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
+        g("orc_run_reset").argtypes = [C.c_void_p]
+        g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_rollout_greedy").restype = C.c_int
+        g("orc_run_rollout_greedy").argtypes = [C.c_void_p, C.c_int64, u32p, Rp]
+
+
+def _np_dtype(prec):
+    return np.float64 if prec == "f64" else np.float32
+
+
+def _ct(prec):
+    return C.c_double if prec == "f64" else C.c_float
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
+               algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
+               gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000):
+    ag = Agent()
+    lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
+                         int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
+                         max_episode_steps)
+    return ag
+
+
+def draw(seed, env_id, t, block):
+    out = (C.c_uint32 * 4)()
+    lib().orc_draw(seed, env_id, t, block, out)
+    return np.array(out[:], dtype=np.uint32)
+
+
+def philox(ctr, key):
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+    return [int(v) for v in out]
+
+
+def domain_step(domain, s, a, prec="f64"):
+    """One Domain::step from state s with action a -> (s', reward, terminal)."""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    ns = np.array(s, dtype=dt).copy()
+    r = ct(0)
+    term = getattr(lib(), f"orc_domain_step_{prec}")(domain, _ptr(ns, ct), int(a), C.byref(r))
+    return ns, float(r.value), bool(term)
+
+
+def domain_reset(domain, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    s = np.zeros(lib().orc_domain_dim(domain), dtype=dt)
+    getattr(lib(), f"orc_domain_reset_{prec}")(domain, _ptr(s, ct))
+    return s
+
+
+def domain_is_terminal(domain, s, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    s = np.array(s, dtype=dt)
+    return bool(getattr(lib(), f"orc_domain_is_terminal_{prec}")(domain, _ptr(s, ct)))
+
+
+def domain_bounds(domain):
+    lo = (C.c_double * 8)()
+    hi = (C.c_double * 8)()
+    lib().orc_domain_bounds(domain, lo, hi)
+    d = lib().orc_domain_dim(domain)
+    return np.array(lo[:d]), np.array(hi[:d])
+
+
+def fourier_project(domain, order, s, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    lo, hi = domain_bounds(domain)
+    lo, hi = lo.astype(dt), hi.astype(dt)
+    s = np.array(s, dtype=dt)
+    D = len(s)
+    phi = np.zeros((order + 1) ** D, dtype=dt)
+    getattr(lib(), f"orc_fourier_project_{prec}")(order, D, _ptr(lo, ct), _ptr(hi, ct), _ptr(s, ct),
+                                                  _ptr(phi, ct))
+    return phi
+
+
+def tile_indices(ag_or_basis, s):
+    b = ag_or_basis.basis if isinstance(ag_or_basis, Agent) else ag_or_basis
+    s = np.array(s, dtype=np.float32)
+    idx = (C.c_int * b.n_tilings)()
+    lib().orc_tile_indices(C.byref(b), _ptr(s, C.c_float), idx)
+    return np.array(idx[:], dtype=np.int32)
+
+
+def n_features(ag):
+    return lib().orc_basis_nfeat(C.byref(ag.basis))
+
+
+def q_evaluate(ag, W, s, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    W = np.ascontiguousarray(W, dtype=dt)
+    s = np.array(s, dtype=dt)
+    q = np.zeros(ag.n_actions, dtype=dt)
+    getattr(lib(), f"orc_q_evaluate_{prec}")(C.byref(ag.basis), _ptr(W, ct), ag.n_actions, _ptr(s, ct),
+                                             _ptr(q, ct))
+    return q
+
+
+def argmaxima(v, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    v = np.array(v, dtype=dt)
+    ixs = (C.c_int * max(1, len(v)))()
+    mx = ct(0)
+    n = getattr(lib(), f"orc_argmaxima_{prec}")(_ptr(v, ct), len(v), ixs, C.byref(mx))
+    return list(ixs[:n]), float(mx.value)
+
+
+def argmax_first(v, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    v = np.array(v, dtype=dt)
+    return getattr(lib(), f"orc_argmax_first_{prec}")(_ptr(v, ct), len(v))
+
+
+def find_max(v, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    v = np.array(v, dtype=dt)
+    val = ct(0)
+    i = getattr(lib(), f"orc_find_max_{prec}")(_ptr(v, ct), len(v), C.byref(val))
+    return i, float(val.value)
+
+
+def policy_probs(policy, q, eps=0.0, tau=1.0, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    q = np.array(q, dtype=dt)
+    p = np.zeros(len(q), dtype=dt)
+    getattr(lib(), f"orc_policy_probs_{prec}")(policy, _ptr(q, ct), len(q), ct(eps), ct(tau), _ptr(p, ct))
+    return p
+
+
+def policy_sample(policy, q, x, eps=0.0, tau=1.0, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    q = np.array(q, dtype=dt)
+    xx = (C.c_uint32 * 4)(*[int(v) for v in x])
+    return getattr(lib(), f"orc_policy_sample_{prec}")(policy, _ptr(q, ct), len(q),
+                                                       lib().orc_eps_threshold(eps), ct(tau), xx)
+
+
+def policy_mode(policy, q, tau=1.0, prec="f64"):
+    dt, ct = _np_dtype(prec), _ct(prec)
+    q = np.array(q, dtype=dt)
+    return getattr(lib(), f"orc_policy_mode_{prec}")(policy, _ptr(q, ct), len(q), ct(tau))
+
+
+def handle(ag, W, s, a, r, ns, term, x_inner=(0, 0, 0, 0), prec="f64"):
+    """Agent handle on one transition; W (F,A) is updated in place; returns the TD error."""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    assert W.dtype == dt and W.flags.c_contiguous
+    s = np.array(s, dtype=dt)
+    ns = np.array(ns, dtype=dt)
+    xx = (C.c_uint32 * 4)(*[int(v) for v in x_inner])
+    return float(getattr(lib(), f"orc_handle_{prec}")(C.byref(ag), _ptr(W, ct), _ptr(s, ct), int(a), ct(r),
+                                                      _ptr(ns, ct), int(term), xx))
+
+
+class Run:
+    """N independent (or shared-W) learners stepped by the oracle's driver loop."""
+
+    def __init__(self, ag, n_envs, prec="f64"):
+        self.ag, self.n, self.prec = ag, int(n_envs), prec
+        self._dt, self._ct = _np_dtype(prec), _ct(prec)
+        self._L = lib()
+        self._h = C.c_void_p(getattr(self._L, f"orc_run_create_{prec}")(C.byref(ag), self.n))
+        self.D = ag.basis.dim
+        self.A = ag.n_actions
+        self.F = n_features(ag)
+
+    def _f(self, name):
+        return getattr(self._L, f"{name}_{self.prec}")
+
+    def close(self):
+        if self._h:
+            self._f("orc_run_destroy")(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def state(self):      # (N, D) view
+        return np.ctypeslib.as_array(self._f("orc_run_state")(self._h), shape=(self.n, self.D))
+
+    @property
+    def action(self):
+        return np.ctypeslib.as_array(self._f("orc_run_action")(self._h), shape=(self.n,))
+
+    @property
+    def ep_step(self):
+        return np.ctypeslib.as_array(self._f("orc_run_ep_step")(self._h), shape=(self.n,))
+
+    @property
+    def weights(self):    # per-env (N, F, A) or shared (F, A) view
+        shape = (self.F, self.A) if self.ag.shared_w else (self.n, self.F, self.A)
+        return np.ctypeslib.as_array(self._f("orc_run_weights")(self._h), shape=shape)
+
+    @property
+    def t(self):
+        return int(self._f("orc_run_t")(self._h))
+
+    def set_epsilon(self, eps):
+        self._f("orc_run_set_epsilon")(self._h, float(eps))
+
+    def reset(self):
+        self._f("orc_run_reset")(self._h)
+
+    def train(self, n_steps):
+        st = Stats()
+        self._f("orc_run_train")(self._h, int(n_steps), C.byref(st))
+        return st.as_dict()
+
+    def rollout_greedy(self, step_limit):
+        n_states = np.zeros(self.n, dtype=np.uint32)
+        tot = np.zeros(self.n, dtype=self._dt)
+        rc = self._f("orc_run_rollout_greedy")(self._h, int(step_limit),
+                                               n_states.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               _ptr(tot, self._ct))
+        if rc != 0:
+            raise ValueError("rollout_greedy: invalid step_limit or policy has no mode")
+        return n_states, tot

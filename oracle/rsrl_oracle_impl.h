@@ -1,0 +1,547 @@
+/*
+ * rsrl_oracle_impl.h -- type-generic body of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+ *
+ * Included twice by rsrl_oracle.c: once with R = double (suffix _f64, the
+ * reference-faithful precision: every number in tspooner/rsrl is f64,
+ * rsrl_domains/src/lib.rs:49) and once with R = float (suffix _f32, same
+ * algorithm in the device's arithmetic type, transcendentals evaluated in
+ * double and rounded once, dot products / AXPY as explicit fma chains -- the
+ * op order the HIP kernels use).
+ *
+ * Every function cites the reference file:line it restates.  Paths are
+ * relative to /root/reference.  Nothing here is copied: the reference is
+ * Rust, this is a C restatement of its arithmetic.
+ */
+
+#ifndef R
+#error "define R, FN(), RC() before including"
+#endif
+
+/* ------------------------------------------------------------------ */
+/* transcendental helpers: evaluate in double, round once to R         */
+/* ------------------------------------------------------------------ */
+static inline R FN(cos_)(R x) { return (R)cos((double)x); }
+static inline R FN(sin_)(R x) { return (R)sin((double)x); }
+static inline R FN(exp_)(R x) { return (R)exp((double)x); }
+/* cos(pi * x): reference computes (PI * cx).cos() in f64 (lfa Fourier, recalled).
+ * For R = double this is literally that; for R = float it is the correctly
+ * rounded cospi of the f32 argument, i.e. what a good cospif approximates. */
+static inline R FN(cospi_)(R x) { return (R)cos(M_PI * (double)x); }
+static inline R FN(fma_)(R a, R b, R c) { return (R)RC(fma)(a, b, c); }
+
+/* clip!(lb, x, ub) = lb.max(ub.min(x))   rsrl_domains/src/macros.rs:20-24 */
+static inline R FN(clip_)(R lb, R x, R ub) {
+    R m = (ub < x) ? ub : x;          /* ub.min(x) (NaN-free inputs) */
+    return (lb > m) ? lb : m;         /* lb.max(..) */
+}
+/* wrap!(lb, x, ub)                       rsrl_domains/src/macros.rs:3-18 */
+static inline R FN(wrap_)(R lb, R x, R ub) {
+    R nx = x, diff = ub - lb;
+    while (nx > ub) nx -= diff;
+    while (nx < lb) nx += diff;
+    return nx;
+}
+
+/* ------------------------------------------------------------------ */
+/* Domains                                                             */
+/* ------------------------------------------------------------------ */
+
+/* MountainCar::update_state + dv      mountain_car/discrete.rs:58-65
+ * constants                            mountain_car/discrete.rs:8-22 */
+static void FN(mc_update_state)(R* s, int a) {
+    const R X_MIN = (R)-1.2, X_MAX = (R)0.6, V_MIN = (R)-0.07, V_MAX = (R)0.07;
+    const R FORCE_G = (R)-0.0025, FORCE_CAR = (R)0.001, HILL_FREQ = (R)3.0;
+    const R act = (R)(a - 1);                           /* ALL_ACTIONS = [-1,0,1] */
+    R x = s[0], v = s[1];
+    R dv = FORCE_CAR * act + FORCE_G * FN(cos_)(HILL_FREQ * x);
+    v = FN(clip_)(V_MIN, v + dv, V_MAX);
+    x = FN(clip_)(X_MIN, x + v, X_MAX);
+    s[0] = x; s[1] = v;
+}
+static int FN(mc_is_terminal)(const R* s) { return s[0] >= (R)0.6; }   /* discrete.rs:76-82 */
+
+/* runge_kutta4                         rsrl_domains/src/ode.rs:1-43
+ * f ignores the time argument; dim fixed at 4 for both users. */
+typedef void (*FN(grad_fn))(R ctl, const R* y, R* out);
+static void FN(rk4)(FN(grad_fn) f, R ctl, R* y, R dx) {
+    R k1[4], k2[4], k3[4], k4[4], t[4];
+    int i;
+    f(ctl, y, k1); for (i = 0; i < 4; i++) k1[i] *= dx;
+    for (i = 0; i < 4; i++) t[i] = y[i] + k1[i] / (R)2.0;
+    f(ctl, t, k2); for (i = 0; i < 4; i++) k2[i] *= dx;
+    for (i = 0; i < 4; i++) t[i] = y[i] + k2[i] / (R)2.0;
+    f(ctl, t, k3); for (i = 0; i < 4; i++) k3[i] *= dx;
+    for (i = 0; i < 4; i++) t[i] = y[i] + k3[i];
+    f(ctl, t, k4); for (i = 0; i < 4; i++) k4[i] *= dx;
+    for (i = 0; i < 4; i++)
+        y[i] += (k1[i] + (R)2.0 * k2[i] + (R)2.0 * k3[i] + k4[i]) / (R)6.0;
+}
+
+/* CartPole::grad                        cart_pole.rs:52-72; consts cart_pole.rs:7-26, consts.rs:4-10 */
+static void FN(cp_grad)(R force, const R* y, R* out) {
+    const R G = (R)9.8, FOUR_THIRDS = (R)(4.0 / 3.0);
+    const R POLE_COM = (R)0.5, POLE_MASS = (R)0.1, CART_MASS = (R)1.0;
+    const R POLE_MOMENT = POLE_COM * POLE_MASS, TOTAL_MASS = CART_MASS + POLE_MASS;
+    R dx = y[1], theta = y[2], dtheta = y[3];
+    R cos_t = FN(cos_)(theta), sin_t = FN(sin_)(theta);
+    R z = (force + POLE_MOMENT * dtheta * dtheta * sin_t) / TOTAL_MASS;
+    R numer = G * sin_t - cos_t * z;
+    R denom = FOUR_THIRDS * POLE_COM - POLE_MOMENT * cos_t * cos_t;
+    R ddtheta = numer / denom;
+    out[0] = dx;
+    out[2] = dtheta;
+    out[3] = ddtheta;
+    out[1] = z - POLE_COM * ddtheta * cos_t;
+}
+/* CartPole::update_state                cart_pole.rs:39-50 */
+static void FN(cp_update_state)(R* s, int a) {
+    const R TWELVE_DEG = (R)(M_PI / 15.0);
+    const R force = (a == 0) ? (R)-10.0 : (R)10.0;      /* ALL_ACTIONS cart_pole.rs:26 */
+    R ns[4] = { s[0], s[1], s[2], s[3] };
+    FN(rk4)(FN(cp_grad), force, ns, (R)0.02);
+    s[0] = FN(clip_)((R)-2.4, ns[0], (R)2.4);
+    s[1] = FN(clip_)((R)-6.0, ns[1], (R)6.0);
+    s[2] = FN(clip_)(-TWELVE_DEG, ns[2], TWELVE_DEG);
+    s[3] = FN(clip_)((R)-2.0, ns[3], (R)2.0);
+}
+/* CartPole::emit terminal predicate     cart_pole.rs:83-97 */
+static int FN(cp_is_terminal)(const R* s) {
+    const R TWELVE_DEG = (R)(M_PI / 15.0);
+    return s[0] <= (R)-2.4 || s[0] >= (R)2.4 || s[2] <= -TWELVE_DEG || s[2] >= TWELVE_DEG;
+}
+
+/* Acrobot::grad                         acrobot.rs:81-108; consts acrobot.rs:8-36 */
+static void FN(ac_grad)(R torque, const R* y, R* out) {
+    const R M1 = 1, M2 = 1, L1 = 1, LC1 = (R)0.5, LC2 = (R)0.5, I1 = 1, I2 = 1, G = (R)9.8;
+    const R PI_OVER_2 = (R)(M_PI / 2.0);
+    R theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+    R sin_t2 = FN(sin_)(theta2), cos_t2 = FN(cos_)(theta2);
+    R d1 = M1 * LC1 * LC1 + M2 * (L1 * L1 + LC2 * LC2 + (R)2.0 * L1 * LC2 * cos_t2) + I1 + I2;
+    R d2 = M2 * (LC2 * LC2 + L1 * LC2 * cos_t2) + I2;
+    R phi2 = M2 * LC2 * G * FN(cos_)(theta1 + theta2 - PI_OVER_2);
+    R phi1 = (R)-1.0 * L1 * LC2 * dtheta2 * dtheta2 * sin_t2
+           - (R)2.0 * M2 * L1 * LC2 * dtheta2 * dtheta1 * sin_t2
+           + (M1 * LC1 + M2 * L1) * G * FN(cos_)(theta1 - PI_OVER_2)
+           + phi2;
+    R dd1 = (torque + d2 / d1 * phi1 - M2 * L1 * LC2 * dtheta1 * dtheta1 * sin_t2 - phi2)
+          / (M2 * LC2 * LC2 + I2 - d2 * d2 / d1);
+    out[0] = dtheta1;
+    out[1] = dtheta2;
+    out[2] = dd1;
+    out[3] = -(d2 * dd1 + phi1) / d1;
+}
+/* Acrobot::update_state                 acrobot.rs:60-79 */
+static void FN(ac_update_state)(R* s, int a) {
+    const R PI_ = (R)M_PI;
+    const R torque = (R)(a - 1);                        /* ALL_ACTIONS acrobot.rs:35-36 */
+    R ns[4] = { s[0], s[1], s[2], s[3] };
+    FN(rk4)(FN(ac_grad), torque, ns, (R)0.2);
+    s[0] = FN(wrap_)(-PI_, ns[0], PI_);
+    s[1] = FN(wrap_)(-PI_, ns[1], PI_);
+    s[2] = FN(clip_)((R)-4.0 * PI_, ns[2], (R)4.0 * PI_);
+    s[3] = FN(clip_)((R)-9.0 * PI_, ns[3], (R)9.0 * PI_);
+}
+/* Acrobot::is_terminal                  acrobot.rs:56-58 */
+static int FN(ac_is_terminal)(const R* s) {
+    return FN(cos_)(s[0]) + FN(cos_)(s[0] + s[1]) < (R)-1.0;
+}
+
+/* Default::default()  discrete.rs:68-70, cart_pole.rs:75-77, acrobot.rs:111-113 */
+void FN(orc_domain_reset)(int domain, R* s) {
+    int i, d = orc_domain_dim(domain);
+    for (i = 0; i < d; i++) s[i] = 0;
+    if (domain == ORC_MOUNTAIN_CAR) { s[0] = (R)-0.5; s[1] = 0; }
+}
+int FN(orc_domain_is_terminal)(int domain, const R* s) {
+    switch (domain) {
+    case ORC_MOUNTAIN_CAR: return FN(mc_is_terminal)(s);
+    case ORC_CART_POLE:    return FN(cp_is_terminal)(s);
+    default:               return FN(ac_is_terminal)(s);
+    }
+}
+/* Domain::step          discrete.rs:84-95, cart_pole.rs:99-110, acrobot.rs:130-141
+ * s is advanced in place; returns terminal flag of the new state. */
+int FN(orc_domain_step)(int domain, R* s, int a, R* reward) {
+    int term;
+    switch (domain) {
+    case ORC_MOUNTAIN_CAR:
+        FN(mc_update_state)(s, a); term = FN(mc_is_terminal)(s);
+        *reward = term ? (R)0.0 : (R)-1.0; break;       /* REWARD_GOAL / REWARD_STEP */
+    case ORC_CART_POLE:
+        FN(cp_update_state)(s, a); term = FN(cp_is_terminal)(s);
+        *reward = term ? (R)-1.0 : (R)0.0; break;       /* REWARD_TERMINAL / REWARD_STEP */
+    default:
+        FN(ac_update_state)(s, a); term = FN(ac_is_terminal)(s);
+        *reward = term ? (R)0.0 : (R)-1.0; break;
+    }
+    return term;
+}
+
+/* ------------------------------------------------------------------ */
+/* Bases (crate lfa 0.15 -- NOT in /root/reference: parity unpinned)   */
+/* ------------------------------------------------------------------ */
+
+/* Fourier::project + with_bias()  (lfa 0.15, recalled; call site
+ * rsrl/examples/q_learning.rs:24).  Coefficient vectors: {0..=order}^D in
+ * lexicographic order (last dimension fastest), all-zero vector skipped;
+ * constant 1.0 feature stacked LAST.  F = (order+1)^D.
+ * s~_i = (s_i - lo_i)/(hi_i - lo_i); phi_k = cos(pi * sum_i c_ki s~_i). */
+void FN(orc_fourier_project)(int order, int D, const R* lo, const R* hi, const R* s, R* phi) {
+    int n1 = order + 1, F = 1, i, k, c[8];
+    R sc[8];
+    for (i = 0; i < D; i++) { F *= n1; sc[i] = (s[i] - lo[i]) / (hi[i] - lo[i]); }
+    for (k = 1; k < F; k++) {
+        int rem = k;
+        R cx = 0;
+        for (i = D - 1; i >= 0; i--) { c[i] = rem % n1; rem /= n1; }
+        for (i = 0; i < D; i++) cx = cx + (R)c[i] * sc[i];      /* fold(0.0, acc + c*v) */
+        phi[k - 1] = FN(cospi_)(cx);
+    }
+    phi[F - 1] = (R)1.0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Q function: VectorLFA over dense or sparse features                 */
+/* W is row-major (F, A) exactly like ndarray Array2 zeros((F,A))      */
+/*   (fa/linear.rs:293-301, weights.ncols() = A at :358)               */
+/* ------------------------------------------------------------------ */
+
+/* Function<(S,)>::evaluate -> Q(s,.) = W^T phi      fa/linear.rs:303-311 */
+void FN(orc_q_evaluate)(const orc_basis* b, const R* W, int A, const R* s, R* q) {
+    int F = orc_basis_nfeat(b), a, f;
+    if (b->kind == ORC_FOURIER) {
+        R* phi = (R*)malloc(sizeof(R) * (size_t)F);             /* reference allocs a feature array per call */
+        FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+        for (a = 0; a < A; a++) {
+            R acc = 0;
+            for (f = 0; f < F; f++) acc = FN(fma_)(phi[f], W[(size_t)f * A + a], acc);
+            q[a] = acc;
+        }
+        free(phi);
+    } else {
+        int idx[ORC_MAX_TILINGS], t;
+        float sf[8]; for (t = 0; t < b->dim; t++) sf[t] = (float)s[t];
+        orc_tile_indices(b, sf, idx);
+        for (a = 0; a < A; a++) {
+            R acc = 0;
+            for (t = 0; t < b->n_tilings; t++) acc = acc + W[(size_t)idx[t] * A + a];
+            q[a] = acc;
+        }
+    }
+}
+/* Enumerable::evaluate_index -> Q(s,a)              fa/linear.rs:360-362 */
+R FN(orc_q_evaluate_index)(const orc_basis* b, const R* W, int A, const R* s, int a) {
+    R q[ORC_MAX_ACTIONS];
+    FN(orc_q_evaluate)(b, W, A, s, q);      /* same arithmetic per column; the column is independent */
+    return q[a];
+}
+/* Enumerable::find_max: fold (i,x): if acc.1 > x {acc} else {(i,x)} => ties -> LAST   core.rs:96-105 */
+int FN(orc_find_max)(const R* q, int A, R* val) {
+    int i, bi = 0; R bv = q[0];
+    for (i = 1; i < A; i++) { if (bv > q[i]) { } else { bi = i; bv = q[i]; } }
+    if (val) *val = bv;
+    return bi;
+}
+/* Handler<StateActionUpdate>: W[:,a] += lr * error * phi(s)   fa/linear.rs:379-391 -> lfa update_index -> SGD (recalled) */
+void FN(orc_q_update_index)(const orc_basis* b, R* W, int A, const R* s, int a, R lr, R error) {
+    int F = orc_basis_nfeat(b), f;
+    R scale = lr * error;
+    if (b->kind == ORC_FOURIER) {
+        R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+        FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+        for (f = 0; f < F; f++) W[(size_t)f * A + a] = FN(fma_)(scale, phi[f], W[(size_t)f * A + a]);
+        free(phi);
+    } else {
+        int idx[ORC_MAX_TILINGS], t;
+        float sf[8]; for (t = 0; t < b->dim; t++) sf[t] = (float)s[t];
+        orc_tile_indices(b, sf, idx);
+        for (t = 0; t < b->n_tilings; t++) W[(size_t)idx[t] * A + a] += scale;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* utils.rs argmax helpers                                             */
+/* ------------------------------------------------------------------ */
+
+/* argmaxima           rsrl/src/utils.rs:6-21 (tolerance test first, max not raised by near-ties) */
+int FN(orc_argmaxima)(const R* v, int n, int* ixs, R* maxv) {
+    R max = -RMAX; int cnt = 0, i;
+    for (i = 0; i < n; i++) {
+        R d = v[i] - max; if (d < 0) d = -d;
+        if (d < (R)1e-7) { ixs[cnt++] = i; }
+        else if (v[i] > max) { max = v[i]; cnt = 0; ixs[cnt++] = i; }
+    }
+    if (maxv) *maxv = max;
+    return cnt;
+}
+/* argmax_first        rsrl/src/utils.rs:23-34 */
+int FN(orc_argmax_first)(const R* v, int n) {
+    int bi = 0, j; R bx = -RMAX;
+    for (j = 0; j < n; j++) if (v[j] - bx > (R)1e-7) { bi = j; bx = v[j]; }
+    return bi;
+}
+
+/* ------------------------------------------------------------------ */
+/* Policies                                                            */
+/* ------------------------------------------------------------------ */
+
+/* Greedy  Function<(S,)>: 1/|M| on argmaxima         policies/greedy.rs:30-44 */
+void FN(orc_greedy_probs)(const R* q, int A, R* p) {
+    int ixs[ORC_MAX_ACTIONS], n, i;
+    n = FN(orc_argmaxima)(q, A, ixs, NULL);
+    for (i = 0; i < A; i++) p[i] = 0;
+    for (i = 0; i < n; i++) p[ixs[i]] = (R)1.0 / (R)n;
+}
+/* EpsilonGreedy Function<(S,)>: eps/A + p*(1-eps)    policies/epsilon_greedy.rs:38-45 */
+void FN(orc_egreedy_probs)(const R* q, int A, R eps, R* p) {
+    int i; R pr = eps / (R)A;
+    FN(orc_greedy_probs)(q, A, p);
+    for (i = 0; i < A; i++) p[i] = pr + p[i] * ((R)1.0 - eps);
+}
+/* softmax_stable + softmax                            policies/softmax.rs:15-37 */
+void FN(orc_softmax_probs)(const R* q, int A, R tau, R* p) {
+    int i; R m = q[0], z = 0;
+    for (i = 1; i < A; i++) if (q[i] > m) m = q[i];             /* f64::max fold seeded with NaN */
+    for (i = 0; i < A; i++) { p[i] = FN(exp_)((q[i] - m) / tau); z += p[i]; }
+    for (i = 0; i < A; i++) { R v = p[i] / z; p[i] = (v < RMAX) ? v : RMAX; }
+}
+/* policy probabilities by kind                        Function<(S,)> of each policy */
+void FN(orc_policy_probs)(int policy, const R* q, int A, R eps, R tau, R* p) {
+    int i;
+    switch (policy) {
+    case ORC_GREEDY:  FN(orc_greedy_probs)(q, A, p); break;
+    case ORC_EGREEDY: FN(orc_egreedy_probs)(q, A, eps, p); break;
+    case ORC_SOFTMAX: FN(orc_softmax_probs)(q, A, tau, p); break;
+    default: for (i = 0; i < A; i++) p[i] = (R)1.0 / (R)A; break;   /* Random  random.rs:19-26 */
+    }
+}
+/* Greedy::sample -> argmax_choose_rng                 greedy.rs:77-81, utils.rs:63-79
+ * x_tie is the u32 draw used when |M| > 1 (slice.choose -> uniform index). */
+static int FN(greedy_sample)(const R* q, int A, uint32_t x_tie) {
+    int ixs[ORC_MAX_ACTIONS], n;
+    n = FN(orc_argmaxima)(q, A, ixs, NULL);
+    if (n == 1) return ixs[0];
+    return ixs[orc_mulhi(x_tie, (uint32_t)n)];
+}
+/* sample_probs_with_rng                               policies/mod.rs:45-61 */
+static int FN(sample_probs)(const R* p, int A, uint32_t x) {
+    R r = (R)(x >> 8) * (R)(1.0 / 16777216.0), acc = 0; int i;
+    for (i = 0; i < A; i++) { acc = acc + p[i]; if (acc > r) return i; }
+    return A - 1;
+}
+/* Policy::sample for the four policies; x[0]=explore draw, x[1]=random action, x[2]=tie/softmax u.
+ *   EpsilonGreedy::sample   epsilon_greedy.rs:74-80  (gen_bool(eps) -> Random else Greedy)
+ *   Random::sample          random.rs:43-45          (Uniform(0,A))
+ *   Softmax::sample         softmax.rs:131-139
+ * eps_thr = (uint32)(eps * 2^24): explore iff (x0 >> 8) < eps_thr  (integer, identical on device). */
+int FN(orc_policy_sample)(int policy, const R* q, int A, uint32_t eps_thr, R tau, const uint32_t x[4]) {
+    R p[ORC_MAX_ACTIONS];
+    switch (policy) {
+    case ORC_GREEDY:  return FN(greedy_sample)(q, A, x[2]);
+    case ORC_EGREEDY:
+        if ((x[0] >> 8) < eps_thr) return (int)orc_mulhi(x[1], (uint32_t)A);
+        return FN(greedy_sample)(q, A, x[2]);
+    case ORC_SOFTMAX:
+        FN(orc_softmax_probs)(q, A, tau, p);
+        return FN(sample_probs)(p, A, x[2]);
+    default: return (int)orc_mulhi(x[1], (uint32_t)A);
+    }
+}
+/* Policy::mode  greedy.rs:83 (find_max), epsilon_greedy.rs:82, softmax.rs:141-143 (argmax_first of probs),
+ * random.rs:47 panics -> -1 */
+int FN(orc_policy_mode)(int policy, const R* q, int A, R tau) {
+    R p[ORC_MAX_ACTIONS];
+    switch (policy) {
+    case ORC_GREEDY: case ORC_EGREEDY: return FN(orc_find_max)(q, A, NULL);
+    case ORC_SOFTMAX: FN(orc_softmax_probs)(q, A, tau, p); return FN(orc_argmax_first)(p, A);
+    default: return -1;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* TD control agents: Handler<&Transition>::handle                     */
+/* ------------------------------------------------------------------ */
+
+/* Computes the TD error delta for one transition with the PRE-update W and returns the
+ * error sent to the approximator (delta, or alpha*delta for ExpectedSARSA).
+ *   QLearning::handle      control/td/q_learning.rs:51-71
+ *   SARSA::handle          control/td/sarsa.rs:53-75  (inner policy.sample with its own draws x_inner)
+ *   ExpectedSARSA::handle  control/td/expected_sarsa.rs:45-66 */
+R FN(orc_td_error)(const orc_agent* ag, const R* W, const R* s, int a, R r, const R* ns, int term,
+                   const uint32_t x_inner[4], R* delta_out) {
+    const orc_basis* b = &ag->basis; int A = ag->n_actions;
+    R qsa = FN(orc_q_evaluate_index)(b, W, A, s, a);                   /* projection #1 */
+    R delta;
+    if (term) {
+        delta = r - qsa;
+    } else if (ag->algo == ORC_QLEARNING) {
+        R q[ORC_MAX_ACTIONS], m;
+        FN(orc_q_evaluate)(b, W, A, ns, q);                            /* projection #2 */
+        FN(orc_find_max)(q, A, &m);
+        delta = r + (R)ag->gamma * m - qsa;
+    } else if (ag->algo == ORC_SARSA) {
+        R q[ORC_MAX_ACTIONS]; int na;
+        FN(orc_q_evaluate)(b, W, A, ns, q);
+        na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x_inner);
+        delta = r + (R)ag->gamma * q[na] - qsa;
+    } else {
+        R q[ORC_MAX_ACTIONS], p[ORC_MAX_ACTIONS], ev = 0; int i;
+        FN(orc_q_evaluate)(b, W, A, ns, q);
+        FN(orc_policy_probs)(ag->policy, q, A, (R)ag->epsilon, (R)ag->tau, p);
+        for (i = 0; i < A; i++) ev = ev + q[i] * p[i];                 /* fold(0.0, acc + q*p) */
+        delta = r + (R)ag->gamma * ev - qsa;
+    }
+    if (delta_out) *delta_out = delta;
+    return (ag->algo == ORC_EXPECTED_SARSA) ? (R)ag->alpha * delta : delta;
+}
+/* Full handle on per-env weights: error with pre-update W, then the column AXPY (projection #3). */
+R FN(orc_handle)(const orc_agent* ag, R* W, const R* s, int a, R r, const R* ns, int term,
+                 const uint32_t x_inner[4]) {
+    R delta, e;
+    e = FN(orc_td_error)(ag, W, s, a, r, ns, term, x_inner, &delta);
+    FN(orc_q_update_index)(&ag->basis, W, ag->n_actions, s, a, (R)ag->lr, e);
+    return delta;
+}
+
+/* ------------------------------------------------------------------ */
+/* Vectorised driver loop (examples/q_learning.rs:34-55 x N envs)      */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    orc_agent ag;
+    int64_t n_envs;
+    R* state;        /* [N][D] */
+    int32_t* action; /* [N]    */
+    uint32_t* ep_step;
+    R* W;            /* per-env: [N][F][A]; shared: [F][A] */
+    uint64_t t;      /* global batch-step counter */
+} FN(orc_run);
+
+static R* FN(run_W)(FN(orc_run)* run, int64_t i) {
+    size_t FA = (size_t)orc_basis_nfeat(&run->ag.basis) * (size_t)run->ag.n_actions;
+    return run->ag.shared_w ? run->W : run->W + (size_t)i * FA;
+}
+
+void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
+    FN(orc_run)* run = (FN(orc_run)*)calloc(1, sizeof(*run));
+    size_t FA = (size_t)orc_basis_nfeat(&ag->basis) * (size_t)ag->n_actions;
+    run->ag = *ag; run->n_envs = n_envs;
+    run->state = (R*)calloc((size_t)n_envs * (size_t)ag->basis.dim, sizeof(R));
+    run->action = (int32_t*)calloc((size_t)n_envs, sizeof(int32_t));
+    run->ep_step = (uint32_t*)calloc((size_t)n_envs, sizeof(uint32_t));
+    run->W = (R*)calloc(ag->shared_w ? FA : FA * (size_t)n_envs, sizeof(R));   /* LFA::vector zero-inits */
+    run->t = 0;
+    return run;
+}
+void FN(orc_run_destroy)(void* h) {
+    FN(orc_run)* run = (FN(orc_run)*)h;
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run);
+}
+R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
+int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
+uint32_t* FN(orc_run_ep_step)(void* h) { return ((FN(orc_run)*)h)->ep_step; }
+R* FN(orc_run_weights)(void* h) { return ((FN(orc_run)*)h)->W; }
+uint64_t FN(orc_run_t)(void* h) { return ((FN(orc_run)*)h)->t; }
+void FN(orc_run_set_epsilon)(void* h, double eps) {
+    FN(orc_run)* run = (FN(orc_run)*)h; run->ag.epsilon = eps; run->ag.eps_thr = orc_eps_threshold(eps);
+}
+
+/* per-episode `Domain::default()` + initial `policy.sample`   examples/q_learning.rs:37-38 */
+void FN(orc_run_reset)(void* h) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
+    int D = ag->basis.dim, A = ag->n_actions; int64_t i;
+    for (i = 0; i < run->n_envs; i++) {
+        R q[ORC_MAX_ACTIONS]; uint32_t x[4];
+        R* s = run->state + (size_t)i * D;
+        FN(orc_domain_reset)(ag->domain, s);
+        FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, s, q);
+        orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INIT, x);
+        run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+        run->ep_step[i] = 0;
+    }
+}
+
+/* n_steps batch-steps of the driver loop; order of operations: SURVEY.md Appendix A.7.
+ * per-env W : transition -> handle (pre-update W) -> sample (post-update W) -> maybe reset+sample
+ * shared  W : all envs compute e_i, phi(s_i) on W_t; W_{t+1} = W_t + lr*sum_i e_i phi(s_i) x onehot(a_i)
+ *             (accumulated in env order); then all envs sample with W_{t+1}. N=1 == reference rule. */
+void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
+    int D = ag->basis.dim, A = ag->n_actions, F = orc_basis_nfeat(&ag->basis);
+    int64_t N = run->n_envs, i, k;
+    R* ns_all = (R*)malloc(sizeof(R) * (size_t)N * D);
+    uint8_t* term_all = (uint8_t*)malloc((size_t)N);
+    R* dW = ag->shared_w ? (R*)malloc(sizeof(R) * (size_t)F * A) : NULL;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    for (k = 0; k < n_steps; k++, run->t++) {
+        if (dW) memset(dW, 0, sizeof(R) * (size_t)F * A);
+        for (i = 0; i < N; i++) {
+            R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
+            R r, delta; int a = run->action[i], term; uint32_t xi[4];
+            memcpy(ns, s, sizeof(R) * D);
+            term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
+            term_all[i] = (uint8_t)term;
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
+            if (!ag->shared_w) {
+                delta = FN(orc_handle)(ag, FN(run_W)(run, i), s, a, r, ns, term, xi);
+            } else {
+                R e = FN(orc_td_error)(ag, run->W, s, a, r, ns, term, xi, &delta);
+                FN(orc_q_update_index)(&ag->basis, dW, A, s, a, (R)ag->lr, e);   /* dW += lr*e*phi(s) on column a */
+            }
+            acc.sum_abs_td_error += fabs((double)delta);
+            acc.sum_reward += (double)r;
+        }
+        if (dW) { int j; for (j = 0; j < F * A; j++) run->W[j] += dW[j]; }
+        for (i = 0; i < N; i++) {
+            R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
+            R q[ORC_MAX_ACTIONS]; uint32_t x[4]; int na;
+            FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, ns, q);     /* projection #4, UPDATED W */
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_STEP, x);
+            na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+            run->ep_step[i] += 1;
+            acc.env_steps += 1;
+            if (term_all[i] || (ag->max_episode_steps > 0 && run->ep_step[i] >= ag->max_episode_steps)) {
+                acc.episodes += 1;
+                if (!term_all[i]) acc.episodes_truncated += 1;
+                acc.sum_episode_steps += run->ep_step[i];
+                FN(orc_domain_reset)(ag->domain, ns);
+                FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, ns, q);
+                orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_RESET, x);
+                na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+                run->ep_step[i] = 0;
+            }
+            memcpy(s, ns, sizeof(R) * D);
+            run->action[i] = na;
+        }
+    }
+    free(ns_all); free(term_all); free(dW);
+    if (st) *st = acc;
+}
+
+/* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340
+ * One fresh default env per learner i, evaluated with learner i's weights. */
+int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
+    int A = ag->n_actions; int64_t i;
+    if (step_limit < 1 || ag->policy == ORC_RANDOM) return -1;
+    for (i = 0; i < run->n_envs; i++) {
+        R s[8], q[ORC_MAX_ACTIONS], r, tot = 0; int a, term; int64_t steps = 0;
+        const R* W = FN(run_W)(run, i);
+        FN(orc_domain_reset)(ag->domain, s);
+        /* first step happens eagerly, before take(limit-1)  (lib.rs:457-459) */
+        FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+        a = FN(orc_policy_mode)(ag->policy, q, A, (R)ag->tau);
+        term = FN(orc_domain_step)(ag->domain, s, a, &r);
+        while (steps < step_limit - 1) {
+            steps++; tot += r;
+            if (term) break;                                            /* successors stops after Terminal */
+            if (steps >= step_limit - 1) break;
+            FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+            a = FN(orc_policy_mode)(ag->policy, q, A, (R)ag->tau);
+            term = FN(orc_domain_step)(ag->domain, s, a, &r);
+        }
+        n_states[i] = (uint32_t)(steps + 1);
+        if (total_reward) total_reward[i] = tot;
+    }
+    return 0;
+}
