@@ -1,0 +1,214 @@
+/*
+ * rsrl_hip.h -- C ABI of librsrl_hip.so: the MI355X (gfx950) implementation of
+ * tspooner/rsrl's per-step TD-control hot path
+ *
+ *     env.transition(a) -> agent.handle(&t) -> policy.sample(s')
+ *                                   (rsrl/examples/q_learning.rs:34-55)
+ *
+ * vectorised over N independent environments.  The reference has no FFI of its
+ * own: its extension surface is Rust traits (Domain / Function / Enumerable /
+ * Handler / Policy / Parameterised).  Every entry point below stands in for one
+ * trait method on the path and cites it (paths relative to the reference
+ * repository).  INTEGRATION.md shows the Rust `extern "C"` block and the trait
+ * impls a maintainer would write on top of it.
+ *
+ * Conventions
+ *   - every function returns rsrl_hip_status (0 = OK, <0 = error); the message of
+ *     the last error on the calling thread is rsrl_hip_last_error().
+ *   - a ctx is NOT thread-safe (mirrors `&mut self` + Rc<RefCell>, core.rs:13-15);
+ *     distinct ctxs may be used from distinct threads.
+ *   - batched arrays are SoA, component-major: states f32[D][M], Q f32[A][M];
+ *     actions int32[M]; terminal flags uint8[M]; rewards / td errors f32[M].
+ *     A batch of M items addresses learners 0..M-1 of the ctx (M <= n_envs).
+ *   - array arguments may be HOST or DEVICE pointers (detected per call with
+ *     hipPointerGetAttributes); device pointers are used in place, host pointers
+ *     are staged through ctx-owned device buffers.  Nothing is freed by the
+ *     other side.
+ *   - all kernels of a ctx run on ONE HIP stream (the caller's, if given in the
+ *     config, else a ctx-owned one).  Calls taking host output pointers return
+ *     after the data has landed; calls with device pointers are asynchronous on
+ *     that stream (use rsrl_hip_sync).
+ *   - there is no CPU fallback: without a usable HIP device rsrl_hip_create fails.
+ */
+#ifndef RSRL_HIP_H
+#define RSRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSRL_HIP_ABI_VERSION 1
+
+typedef enum {
+    RSRL_HIP_OK      = 0,
+    RSRL_HIP_EINVAL  = -1,   /* bad argument / unsupported combination              */
+    RSRL_HIP_EHIP    = -2,   /* HIP runtime error (incl. no device)                  */
+    RSRL_HIP_ENOMEM  = -3,   /* allocation failed                                    */
+    RSRL_HIP_ERCCL   = -4,   /* RCCL error                                           */
+    RSRL_HIP_ESTATE  = -5    /* call not valid in the ctx's current state            */
+} rsrl_hip_status;
+
+/* rsrl_domains::{MountainCar, CartPole, Acrobot}
+ *   mountain_car/discrete.rs:8-102, cart_pole.rs:7-121, acrobot.rs:8-152 */
+typedef enum { RSRL_MOUNTAIN_CAR = 0, RSRL_CART_POLE = 1, RSRL_ACROBOT = 2 } rsrl_domain;
+/* lfa::basis::{Fourier (+with_bias), TileCoding}  (re-exported by rsrl/src/fa/linear.rs:11-14) */
+typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
+/* rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}
+ *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66 */
+typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2 } rsrl_algo;
+/* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}
+ *   greedy.rs:16-84, epsilon_greedy.rs:14-83, softmax.rs:55-143, random.rs:13-48 */
+typedef enum { RSRL_GREEDY = 0, RSRL_EPSILON_GREEDY = 1, RSRL_SOFTMAX = 2, RSRL_RANDOM = 3 } rsrl_policy;
+/* one LFA per learner (independent replicas) or one LFA shared by all learners
+ * (synchronous mini-batch rule; N=1 == the reference rule) */
+typedef enum { RSRL_W_PER_ENV = 0, RSRL_W_SHARED = 1 } rsrl_weight_mode;
+typedef enum { RSRL_W_F32 = 0, RSRL_W_BF16 = 1 } rsrl_weight_dtype;
+
+typedef struct rsrl_hip_ctx rsrl_hip_ctx;
+
+/* Everything the reference spreads over its constructors
+ *   MountainCar::default(), Fourier::from_space(n, space).with_bias(),
+ *   LFA::vector(basis, SGD(lr), n_actions), make_shared, Greedy::new /
+ *   EpsilonGreedy::new / Softmax::new, QLearning{q_func, gamma} ...
+ *   (rsrl/examples/q_learning.rs:19-32)                                      */
+typedef struct {
+    uint32_t struct_size;        /* = sizeof(rsrl_hip_config); checked                      */
+    int32_t  device;             /* HIP device ordinal                                       */
+    int32_t  domain;             /* rsrl_domain                                              */
+    int32_t  basis;              /* rsrl_basis                                               */
+    int32_t  order;              /* Fourier order n: F = (n+1)^D                             */
+    int32_t  n_tilings;          /* tile coding: T tilings ...                               */
+    int32_t  tiles_per_dim;      /*   ... x B^D cells: F = T*B^D                             */
+    int32_t  algo;               /* rsrl_algo                                                */
+    int32_t  policy;             /* rsrl_policy (behaviour policy; also SARSA's / ExpectedSARSA's) */
+    int32_t  weight_mode;        /* rsrl_weight_mode                                         */
+    int32_t  weight_dtype;       /* rsrl_weight_dtype (storage; arithmetic is always f32)    */
+    uint32_t max_episode_steps;  /* 0 = unbounded (examples/q_learning.rs:40); else cap + auto-reset
+                                    (examples/greedy_gq.rs:46 uses 1000)                     */
+    int64_t  n_envs;             /* learners owned by this ctx                                */
+    int64_t  env_offset;         /* global id of local learner 0: RNG streams are keyed by the
+                                    GLOBAL id, so results do not depend on the sharding       */
+    uint64_t seed;               /* StdRng::seed_from_u64 analogue (q_learning.rs:22)        */
+    double   gamma;              /* QLearning.gamma etc.                                      */
+    double   lr;                 /* SGD(lr)                                                   */
+    double   alpha;              /* ExpectedSARSA.alpha (expected_sarsa.rs:26,64)             */
+    double   epsilon;            /* EpsilonGreedy.epsilon (pub field, epsilon_greedy.rs:19)  */
+    double   tau;                /* Softmax.tau (softmax.rs:52); |tau| < 1e-7 is rejected (:63-66) */
+    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default)       */
+    uint32_t reserved0;
+    void*    stream;             /* hipStream_t to run on; NULL = ctx-owned stream           */
+} rsrl_hip_config;
+
+/* per-call statistics of rsrl_hip_train (the println! / Response{error} of the
+ * reference drivers, examples/q_learning.rs:54, control/td/q_learning.rs:17-20) */
+typedef struct {
+    uint64_t env_steps;            /* n_steps * n_envs                                        */
+    uint64_t episodes;             /* episodes finished (terminal or step cap)                */
+    uint64_t episodes_truncated;   /*   ... of which ended by the step cap                    */
+    uint64_t sum_episode_steps;    /* sum of lengths of the finished episodes                 */
+    double   sum_abs_td_error;     /* sum |delta|                                             */
+    double   sum_reward;
+} rsrl_hip_stats;
+
+int         rsrl_hip_abi_version(void);
+const char* rsrl_hip_last_error(void);
+/* README example values: MountainCar, Fourier(5), QLearning, gamma 0.9, SGD(0.001), Greedy */
+int rsrl_hip_config_init(rsrl_hip_config* cfg);
+
+int rsrl_hip_create(const rsrl_hip_config* cfg, rsrl_hip_ctx** out);
+int rsrl_hip_destroy(rsrl_hip_ctx* ctx);
+int rsrl_hip_sync(rsrl_hip_ctx* ctx);
+
+/* Space queries: Domain::state_space().dim(), action_space().card(), basis.n_features()
+ *   (examples/q_learning.rs:20; Parameterised::weights_dim, params/mod.rs:128) */
+int rsrl_hip_state_dim(const rsrl_hip_ctx* ctx);
+int rsrl_hip_n_actions(const rsrl_hip_ctx* ctx);
+int rsrl_hip_n_features(const rsrl_hip_ctx* ctx);
+int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* ctx);
+/* state_space() bounds: mountain_car/discrete.rs:97-99, cart_pole.rs:112-118, acrobot.rs:143-149 */
+int rsrl_hip_state_bounds(const rsrl_hip_ctx* ctx, double* lo /*[D]*/, double* hi /*[D]*/);
+
+/* per-episode `Domain::default()` + initial `policy.sample(rng, env.emit().state())`
+ *   examples/q_learning.rs:37-38 -- for every learner of the ctx */
+int rsrl_hip_reset(rsrl_hip_ctx* ctx);
+
+/* Domain::emit (state part)                         rsrl_domains/src/lib.rs:430 */
+int rsrl_hip_get_states(rsrl_hip_ctx* ctx, float* states /*[D][N]*/);
+int rsrl_hip_set_states(rsrl_hip_ctx* ctx, const float* states /*[D][N]*/);
+int rsrl_hip_get_actions(rsrl_hip_ctx* ctx, int32_t* actions /*[N]*/);
+int rsrl_hip_set_actions(rsrl_hip_ctx* ctx, const int32_t* actions /*[N]*/);
+
+/* Domain::transition                                rsrl_domains/src/lib.rs:436-446
+ * Steps every env of the ctx with `actions` (NULL: the ctx's pending actions).  Outputs are
+ * optional (NULL to skip).  The ctx's env state becomes s'; no auto-reset. */
+int rsrl_hip_domain_step(rsrl_hip_ctx* ctx, const int32_t* actions,
+                         float* from_states, float* next_states, float* rewards, uint8_t* terminal);
+/* `MountainCar::default()` for the envs whose mask byte is non-zero (NULL: all) */
+int rsrl_hip_domain_reset(rsrl_hip_ctx* ctx, const uint8_t* mask);
+
+/* Function<(S,)>::evaluate for VectorLFA: Q(s,.) = W^T phi(s)      rsrl/src/fa/linear.rs:303-311
+ * state m is evaluated with learner m's weights (or the shared weights). */
+int rsrl_hip_q_evaluate(rsrl_hip_ctx* ctx, const float* states /*[D][M]*/, int64_t M, float* q_out /*[A][M]*/);
+/* Enumerable::find_max (ties -> last index)                         rsrl/src/core.rs:96-105 */
+int rsrl_hip_q_find_max(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* idx_out, float* val_out);
+/* basis.project(s): dense features phi f32[F][M] (Fourier) -- lfa Basis::project */
+int rsrl_hip_project(rsrl_hip_ctx* ctx, const float* states, int64_t M, float* phi_out /*[F][M]*/);
+/* tile coding: active indices int32[T][M] */
+int rsrl_hip_tile_indices(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* idx_out /*[T][M]*/);
+
+/* Handler<&Transition>::handle for QLearning / SARSA / ExpectedSARSA
+ *   control/td/q_learning.rs:51-71, sarsa.rs:53-75, expected_sarsa.rs:45-66
+ * td_error_out (optional) = Response.error (q_learning.rs:17-20) */
+int rsrl_hip_handle(rsrl_hip_ctx* ctx, const float* from_states, const int32_t* actions,
+                    const float* rewards, const float* to_states, const uint8_t* terminal,
+                    int64_t M, float* td_error_out);
+
+/* Policy::sample / Policy::mode / Function<(S,)> of the policy (action probabilities)
+ *   policies/mod.rs:65-78; greedy.rs:30-44,77-83; epsilon_greedy.rs:38-45,74-82;
+ *   softmax.rs:74-82,131-143; random.rs:19-48 (mode of Random: RSRL_HIP_EINVAL, random.rs:47 panics) */
+int rsrl_hip_policy_sample(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
+int rsrl_hip_policy_mode(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
+int rsrl_hip_policy_probs(rsrl_hip_ctx* ctx, const float* states, int64_t M, float* probs_out /*[A][M]*/);
+/* the pub field EpsilonGreedy.epsilon (decayed by drivers, examples/sarsa_lambda.rs:68) */
+int rsrl_hip_set_epsilon(rsrl_hip_ctx* ctx, double epsilon);
+
+/* Parameterised::weights / weights_view_mut               rsrl/src/params/mod.rs:116-134
+ * w is row-major f32[F][A] (ndarray Array2 (F, A), fa/linear.rs:293-301); env_index is
+ * ignored in shared mode.  Also the checkpoint hook. */
+int rsrl_hip_get_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* w /*[F][A]*/);
+int rsrl_hip_set_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* w /*[F][A]*/);
+/* same weights broadcast to every learner (per-env mode) */
+int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
+
+/* The fused driver loop (examples/q_learning.rs:40-52) x n_envs x n_steps with auto-reset
+ * on terminal / step cap.  stats_out is a HOST pointer (optional). */
+int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out);
+/* batch-steps executed so far (the RNG counter) */
+uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
+
+/* Domain::rollout with the closure s -> policy.mode(s) and Some(step_limit), + n_states
+ *   rsrl_domains/src/lib.rs:448-479, :340; one fresh default env per learner, the ctx's
+ *   training envs are untouched.  step_limit >= 1. */
+int rsrl_hip_rollout_greedy(rsrl_hip_ctx* ctx, int64_t step_limit,
+                            uint32_t* n_states_out /*[N]*/, float* total_reward_out /*[N]*/);
+
+/* ---- multi-GPU (one process per GPU; no reference counterpart) -------------------------
+ * Shared-W mode across ranks: every batch-step all-reduces the (F x A) f32 weight delta
+ * over RCCL.  id_bytes is an ncclUniqueId (128 bytes) produced on rank 0 and distributed
+ * by the caller's control plane (torch.distributed / MPI / files). */
+int rsrl_hip_comm_unique_id(uint8_t* id_bytes /*[128]*/);
+int rsrl_hip_comm_init(rsrl_hip_ctx* ctx, const uint8_t* id_bytes, int world_size, int rank);
+
+/* ---- measurement hooks (bench.py) --------------------------------------------------------
+ * HIP-event timing of the kernels launched by train since the last reset, on the ctx's
+ * stream.  ms_total / launches = average launch duration of the dominant kernel. */
+int rsrl_hip_timing_enable(rsrl_hip_ctx* ctx, int enable);
+int rsrl_hip_timing_read(rsrl_hip_ctx* ctx, double* ms_total, uint64_t* launches, const char** kernel_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSRL_HIP_H */

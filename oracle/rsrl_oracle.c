@@ -173,7 +173,9 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
 #define FN(name) name##_f32
 #define RC(name) name##f
 #define RMAX FLT_MAX
+#define ORC_SEPARABLE 1
 #include "rsrl_oracle_impl.h"
+#undef ORC_SEPARABLE
 #undef R
 #undef FN
 #undef RC

@@ -1,0 +1,220 @@
+"""`Context`: one (domain, basis, algo, policy, N, W-mode) instance on one MI355X -- a thin numpy-facing
+wrapper over the C ABI (include/rsrl_hip.h).  All compute happens in librsrl_hip.so's HIP kernels."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
+FOURIER, TILE_CODING = 0, 1
+QLEARNING, SARSA, EXPECTED_SARSA = 0, 1, 2
+GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
+W_PER_ENV, W_SHARED = 0, 1
+W_F32, W_BF16 = 0, 1
+
+
+def _p(a):
+    """numpy array / raw device pointer (int) / None -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _in(a, dtype, shape=None):
+    if a is None or isinstance(a, int):
+        return a
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class Context:
+    def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
+                 algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
+                 n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
+                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None):
+        self._L = _abi.lib()
+        cfg = _abi.Config()
+        _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
+        cfg.device, cfg.domain, cfg.basis, cfg.order = device, domain, basis, order
+        cfg.n_tilings, cfg.tiles_per_dim = n_tilings, tiles_per_dim
+        cfg.algo, cfg.policy, cfg.weight_mode, cfg.weight_dtype = algo, policy, weight_mode, weight_dtype
+        cfg.max_episode_steps, cfg.n_envs, cfg.env_offset, cfg.seed = max_episode_steps, n_envs, env_offset, seed
+        cfg.gamma, cfg.lr, cfg.alpha, cfg.epsilon, cfg.tau = gamma, lr, alpha, epsilon, tau
+        cfg.steps_per_launch = steps_per_launch
+        cfg.stream = stream
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _abi.check(self._L.rsrl_hip_create(C.byref(cfg), C.byref(self._h)))
+        self.N = int(n_envs)
+        self.D = self._L.rsrl_hip_state_dim(self._h)
+        self.A = self._L.rsrl_hip_n_actions(self._h)
+        self.F = self._L.rsrl_hip_n_features(self._h)
+        self.shared = weight_mode == W_SHARED
+
+    # ---- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rsrl_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        _abi.check(self._L.rsrl_hip_sync(self._h))
+
+    # ---- spaces
+    def state_bounds(self):
+        lo, hi = (C.c_double * self.D)(), (C.c_double * self.D)()
+        _abi.check(self._L.rsrl_hip_state_bounds(self._h, lo, hi))
+        return np.array(lo[:]), np.array(hi[:])
+
+    # ---- env state
+    def reset(self):
+        _abi.check(self._L.rsrl_hip_reset(self._h))
+
+    @property
+    def states(self):
+        out = np.empty((self.D, self.N), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_get_states(self._h, _p(out)))
+        return out
+
+    @states.setter
+    def states(self, v):
+        _abi.check(self._L.rsrl_hip_set_states(self._h, _p(_in(v, np.float32, (self.D, self.N)))))
+
+    @property
+    def actions(self):
+        out = np.empty(self.N, dtype=np.int32)
+        _abi.check(self._L.rsrl_hip_get_actions(self._h, _p(out)))
+        return out
+
+    @actions.setter
+    def actions(self, v):
+        _abi.check(self._L.rsrl_hip_set_actions(self._h, _p(_in(v, np.int32, (self.N,)))))
+
+    def domain_step(self, actions=None):
+        """Domain::transition for every env -> (from, next, reward, terminal)"""
+        frm = np.empty((self.D, self.N), dtype=np.float32)
+        nxt = np.empty((self.D, self.N), dtype=np.float32)
+        rew = np.empty(self.N, dtype=np.float32)
+        term = np.empty(self.N, dtype=np.uint8)
+        _abi.check(self._L.rsrl_hip_domain_step(self._h, _p(_in(actions, np.int32, (self.N,))), _p(frm), _p(nxt),
+                                                _p(rew), _p(term)))
+        return frm, nxt, rew, term
+
+    def domain_reset(self, mask=None):
+        _abi.check(self._L.rsrl_hip_domain_reset(self._h, _p(_in(mask, np.uint8, (self.N,)))))
+
+    # ---- Q function
+    def _batch(self, states):
+        states = _in(states, np.float32)
+        if states.ndim != 2 or states.shape[0] != self.D:
+            raise ValueError(f"states must be [D={self.D}][M]")
+        return states, states.shape[1]
+
+    def q_evaluate(self, states):
+        states, M = self._batch(states)
+        out = np.empty((self.A, M), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_q_evaluate(self._h, _p(states), M, _p(out)))
+        return out
+
+    def q_find_max(self, states):
+        states, M = self._batch(states)
+        idx, val = np.empty(M, dtype=np.int32), np.empty(M, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_q_find_max(self._h, _p(states), M, _p(idx), _p(val)))
+        return idx, val
+
+    def project(self, states):
+        states, M = self._batch(states)
+        out = np.empty((self.F, M), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_project(self._h, _p(states), M, _p(out)))
+        return out
+
+    def tile_indices(self, states):
+        states, M = self._batch(states)
+        out = np.empty((self.cfg.n_tilings, M), dtype=np.int32)
+        _abi.check(self._L.rsrl_hip_tile_indices(self._h, _p(states), M, _p(out)))
+        return out
+
+    # ---- agent / policy
+    def handle(self, from_states, actions, rewards, to_states, terminal):
+        from_states, M = self._batch(from_states)
+        to_states, _ = self._batch(to_states)
+        td = np.empty(M, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_handle(self._h, _p(from_states), _p(_in(actions, np.int32, (M,))),
+                                           _p(_in(rewards, np.float32, (M,))), _p(to_states),
+                                           _p(_in(terminal, np.uint8, (M,))), M, _p(td)))
+        return td
+
+    def policy_sample(self, states):
+        states, M = self._batch(states)
+        out = np.empty(M, dtype=np.int32)
+        _abi.check(self._L.rsrl_hip_policy_sample(self._h, _p(states), M, _p(out)))
+        return out
+
+    def policy_mode(self, states):
+        states, M = self._batch(states)
+        out = np.empty(M, dtype=np.int32)
+        _abi.check(self._L.rsrl_hip_policy_mode(self._h, _p(states), M, _p(out)))
+        return out
+
+    def policy_probs(self, states):
+        states, M = self._batch(states)
+        out = np.empty((self.A, M), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_policy_probs(self._h, _p(states), M, _p(out)))
+        return out
+
+    def set_epsilon(self, eps):
+        _abi.check(self._L.rsrl_hip_set_epsilon(self._h, float(eps)))
+
+    # ---- Parameterised
+    def get_weights(self, env_index=0):
+        out = np.empty((self.F, self.A), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_get_weights(self._h, int(env_index), _p(out)))
+        return out
+
+    def set_weights(self, w, env_index=0):
+        _abi.check(self._L.rsrl_hip_set_weights(self._h, int(env_index), _p(_in(w, np.float32, (self.F, self.A)))))
+
+    def set_weights_all(self, w):
+        _abi.check(self._L.rsrl_hip_set_weights_all(self._h, _p(_in(w, np.float32, (self.F, self.A)))))
+
+    # ---- driver loop
+    def train(self, n_steps, want_stats=True):
+        st = _abi.Stats()
+        _abi.check(self._L.rsrl_hip_train(self._h, int(n_steps), C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    @property
+    def step_count(self):
+        return int(self._L.rsrl_hip_step_count(self._h))
+
+    def rollout_greedy(self, step_limit):
+        n_states = np.empty(self.N, dtype=np.uint32)
+        tot = np.empty(self.N, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit), _p(n_states), _p(tot)))
+        return n_states, tot
+
+    # ---- measurement
+    def timing_enable(self, on=True):
+        _abi.check(self._L.rsrl_hip_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self):
+        ms, n, name = C.c_double(), C.c_uint64(), C.c_char_p()
+        _abi.check(self._L.rsrl_hip_timing_read(self._h, C.byref(ms), C.byref(n), C.byref(name)))
+        return ms.value, int(n.value), (name.value or b"").decode()

@@ -1,0 +1,411 @@
+// device_core.hpp -- device-side building blocks of the TD-control hot path (gfx950).
+//
+// Everything here is the MI355X restatement of the reference arithmetic; each
+// block cites the reference source it stands in for (paths under the reference
+// repository).  Compiled with -ffp-contract=off: every fused multiply-add is
+// written out as fmaf so that the op order is explicit (and identical to the
+// f32 instantiation of the test oracle).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include <type_traits>
+#include <utility>
+
+namespace rsrl {
+
+// ---------------------------------------------------------------------------------------
+// compile-time loop: static_for<0,N>([&](auto I){ constexpr int i = I; ... })
+// keeps every register-array index a compile-time constant (no scratch).
+// ---------------------------------------------------------------------------------------
+template <int B, int E, class Fn>
+__host__ __device__ __forceinline__ void static_for(Fn&& fn) {
+    if constexpr (B < E) {
+        fn(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(fn);
+    }
+}
+constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 counter-based RNG (Salmon et al. SC'11).  Stands in for rand 0.7's
+// StdRng / thread_rng streams (examples/q_learning.rs:22, sarsa.rs:61): one independent
+// stream per (seed, GLOBAL env id), addressed by (batch-step, block) -- no state in HBM.
+// ---------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                     uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+enum : uint32_t { BLK_STEP = 0, BLK_RESET = 1, BLK_INNER = 2, BLK_INIT = 3, BLK_API = 4 };
+// key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block)
+__host__ __device__ __forceinline__ U4 draw(uint64_t seed, uint32_t env_id, uint64_t t, uint32_t block) {
+    return philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), env_id, block, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+__host__ __device__ __forceinline__ uint32_t mulhi_u32(uint32_t x, uint32_t n) {
+    return (uint32_t)(((uint64_t)x * n) >> 32);
+}
+
+// ---------------------------------------------------------------------------------------
+// Domains.  clip! = lb.max(ub.min(x)), wrap! = repeated +-(ub-lb)   (rsrl_domains/src/macros.rs:3-24)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float clipf(float lb, float x, float ub) { return fmaxf(lb, fminf(ub, x)); }
+__device__ __forceinline__ float wrapf(float lb, float x, float ub) {
+    const float diff = ub - lb;
+    while (x > ub) x -= diff;
+    while (x < lb) x += diff;
+    return x;
+}
+
+constexpr double kPi = 3.14159265358979323846;
+
+template <int DOMAIN> struct Domain;
+
+// MountainCar          rsrl_domains/src/mountain_car/discrete.rs:8-102
+template <> struct Domain<0> {
+    static constexpr int D = 2, A = 3;
+    __host__ __device__ static constexpr double lo_d(int i) { return i == 0 ? -1.2 : -0.07; }
+    __host__ __device__ static constexpr double hi_d(int i) { return i == 0 ? 0.6 : 0.07; }
+    __device__ static __forceinline__ void reset(float (&s)[D]) { s[0] = -0.5f; s[1] = 0.0f; }   // :68-70
+    __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) { return s[0] >= 0.6f; }  // :76-82
+    // update_state + dv (:58-65): v first, the NEW v moves x; no velocity reset at the left wall
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
+        const float act = (float)(a - 1);                              // ALL_ACTIONS [-1,0,1] (:22)
+        const float dv = 0.001f * act + -0.0025f * cosf(3.0f * s[0]);
+        const float v = clipf(-0.07f, s[1] + dv, 0.07f);
+        const float x = clipf(-1.2f, s[0] + v, 0.6f);
+        s[0] = x; s[1] = v;
+        const bool term = x >= 0.6f;
+        r = term ? 0.0f : -1.0f;                                       // REWARD_GOAL / REWARD_STEP (:19-20)
+        return term;
+    }
+};
+
+// classical RK4, f ignores time      rsrl_domains/src/ode.rs:1-43
+template <class Grad>
+__device__ __forceinline__ void rk4(const Grad& f, float (&y)[4], float dx) {
+    float k1[4], k2[4], k3[4], k4[4], t[4];
+    f(y, k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k1[i] *= dx; t[i] = y[i] + k1[i] / 2.0f; }
+    f(t, k2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k2[i] *= dx; t[i] = y[i] + k2[i] / 2.0f; }
+    f(t, k3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { k3[i] *= dx; t[i] = y[i] + k3[i]; }
+    f(t, k4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k4[i] *= dx;
+        y[i] += (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]) / 6.0f;
+    }
+}
+
+// CartPole             rsrl_domains/src/cart_pole.rs:7-121, consts.rs:4-10
+template <> struct Domain<1> {
+    static constexpr int D = 4, A = 2;
+    __host__ __device__ static constexpr double lo_d(int i) {
+        return i == 0 ? -2.4 : i == 1 ? -6.0 : i == 2 ? -(kPi / 15.0) : -2.0;
+    }
+    __host__ __device__ static constexpr double hi_d(int i) { return -lo_d(i); }
+    __device__ static __forceinline__ void reset(float (&s)[D]) { s[0] = s[1] = s[2] = s[3] = 0.0f; }   // :75-77
+    __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) {                          // :83-97
+        constexpr float TW = (float)(kPi / 15.0);
+        return s[0] <= -2.4f || s[0] >= 2.4f || s[2] <= -TW || s[2] >= TW;
+    }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
+        constexpr float TW = (float)(kPi / 15.0);
+        const float force = (a == 0) ? -10.0f : 10.0f;                 // ALL_ACTIONS (:26)
+        auto grad = [force](const float (&y)[4], float (&out)[4]) {    // CartPole::grad (:52-72)
+            constexpr float G = 9.8f, FOUR_THIRDS = (float)(4.0 / 3.0);
+            constexpr float POLE_COM = 0.5f, POLE_MOMENT = 0.5f * 0.1f, TOTAL_MASS = 1.0f + 0.1f;
+            const float dx = y[1], theta = y[2], dtheta = y[3];
+            float sin_t, cos_t;
+            sincosf(theta, &sin_t, &cos_t);
+            const float z = (force + POLE_MOMENT * dtheta * dtheta * sin_t) / TOTAL_MASS;
+            const float numer = G * sin_t - cos_t * z;
+            const float denom = FOUR_THIRDS * POLE_COM - POLE_MOMENT * cos_t * cos_t;
+            const float ddtheta = numer / denom;
+            out[0] = dx; out[2] = dtheta; out[3] = ddtheta;
+            out[1] = z - POLE_COM * ddtheta * cos_t;
+        };
+        float ns[4] = {s[0], s[1], s[2], s[3]};
+        rk4(grad, ns, 0.02f);                                          // update_state (:39-50)
+        s[0] = clipf(-2.4f, ns[0], 2.4f);
+        s[1] = clipf(-6.0f, ns[1], 6.0f);
+        s[2] = clipf(-TW, ns[2], TW);
+        s[3] = clipf(-2.0f, ns[3], 2.0f);
+        const bool term = is_terminal(s);
+        r = term ? -1.0f : 0.0f;                                       // REWARD_TERMINAL / REWARD_STEP (:23-24)
+        return term;
+    }
+};
+
+// Acrobot              rsrl_domains/src/acrobot.rs:8-152
+template <> struct Domain<2> {
+    static constexpr int D = 4, A = 3;
+    __host__ __device__ static constexpr double lo_d(int i) {
+        return i == 0 ? -kPi : i == 1 ? -kPi : i == 2 ? -4.0 * kPi : -9.0 * kPi;
+    }
+    __host__ __device__ static constexpr double hi_d(int i) { return -lo_d(i); }
+    __device__ static __forceinline__ void reset(float (&s)[D]) { s[0] = s[1] = s[2] = s[3] = 0.0f; }   // :111-113
+    __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) {                          // :56-58
+        return cosf(s[0]) + cosf(s[0] + s[1]) < -1.0f;
+    }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
+        constexpr float PI_ = (float)kPi;
+        const float torque = (float)(a - 1);                           // ALL_ACTIONS (:35-36)
+        auto grad = [torque](const float (&y)[4], float (&out)[4]) {   // Acrobot::grad (:81-108)
+            constexpr float M1 = 1.0f, M2 = 1.0f, L1 = 1.0f, LC1 = 0.5f, LC2 = 0.5f, I1 = 1.0f, I2 = 1.0f, G = 9.8f;
+            constexpr float PI_OVER_2 = (float)(kPi / 2.0);
+            const float theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+            float sin_t2, cos_t2;
+            sincosf(theta2, &sin_t2, &cos_t2);
+            const float d1 = M1 * LC1 * LC1 + M2 * (L1 * L1 + LC2 * LC2 + 2.0f * L1 * LC2 * cos_t2) + I1 + I2;
+            const float d2 = M2 * (LC2 * LC2 + L1 * LC2 * cos_t2) + I2;
+            const float phi2 = M2 * LC2 * G * cosf(theta1 + theta2 - PI_OVER_2);
+            const float phi1 = -1.0f * L1 * LC2 * dtheta2 * dtheta2 * sin_t2
+                             - 2.0f * M2 * L1 * LC2 * dtheta2 * dtheta1 * sin_t2
+                             + (M1 * LC1 + M2 * L1) * G * cosf(theta1 - PI_OVER_2)
+                             + phi2;
+            const float dd1 = (torque + d2 / d1 * phi1 - M2 * L1 * LC2 * dtheta1 * dtheta1 * sin_t2 - phi2)
+                            / (M2 * LC2 * LC2 + I2 - d2 * d2 / d1);
+            out[0] = dtheta1; out[1] = dtheta2; out[2] = dd1;
+            out[3] = -(d2 * dd1 + phi1) / d1;
+        };
+        float ns[4] = {s[0], s[1], s[2], s[3]};
+        rk4(grad, ns, 0.2f);                                           // update_state (:60-79)
+        s[0] = wrapf(-PI_, ns[0], PI_);
+        s[1] = wrapf(-PI_, ns[1], PI_);
+        s[2] = clipf(-4.0f * PI_, ns[2], 4.0f * PI_);
+        s[3] = clipf(-9.0f * PI_, ns[3], 9.0f * PI_);
+        const bool term = is_terminal(s);
+        r = term ? 0.0f : -1.0f;                                       // REWARD_TERMINAL / REWARD_STEP (:31-32)
+        return term;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// argmax helpers and policies
+// ---------------------------------------------------------------------------------------
+
+// Enumerable::find_max: fold `if acc.1 > x {acc} else {(i,x)}` => ties go to the LAST index   core.rs:96-105
+template <int A>
+__device__ __forceinline__ int find_max(const float (&q)[A], float& val) {
+    int bi = 0; float bv = q[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) { if (!(bv > q[i])) { bi = i; bv = q[i]; } }
+    val = bv;
+    return bi;
+}
+// argmaxima: tolerance test first, running max NOT raised by near-ties      utils.rs:6-21
+// returns the set as a bitmask (A <= 8 on this path)
+template <int A>
+__device__ __forceinline__ uint32_t argmaxima_mask(const float (&q)[A]) {
+    float mx = -FLT_MAX; uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = fabsf(q[i] - mx);
+        if (d < 1e-7f) mask |= (1u << i);
+        else if (q[i] > mx) { mx = q[i]; mask = (1u << i); }
+    }
+    return mask;
+}
+// argmax_first: index moves only if y - x > 1e-7                             utils.rs:23-34
+template <int A>
+__device__ __forceinline__ int argmax_first(const float (&v)[A]) {
+    int bi = 0; float bx = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < A; ++j) { if (v[j] - bx > 1e-7f) { bi = j; bx = v[j]; } }
+    return bi;
+}
+__device__ __forceinline__ int kth_set_bit(uint32_t mask, int k) {
+    for (int j = 0; j < k; ++j) mask &= mask - 1;                     // drop the k lowest set bits
+    return __ffs((int)mask) - 1;
+}
+// Greedy::sample -> argmax_choose_rng: the single maximum, else a uniform pick among the
+// maxima with the caller's rng                                 greedy.rs:77-81, utils.rs:63-79
+template <int A>
+__device__ __forceinline__ int greedy_sample(const float (&q)[A], uint32_t x_tie) {
+    const uint32_t mask = argmaxima_mask<A>(q);
+    const int n = __popc(mask);
+    if (n == 1) return __ffs((int)mask) - 1;
+    return kth_set_bit(mask, (int)mulhi_u32(x_tie, (uint32_t)n));
+}
+// softmax_stable + softmax                                                   softmax.rs:15-37
+template <int A>
+__device__ __forceinline__ void softmax_probs(const float (&q)[A], float tau, float (&p)[A]) {
+    float m = q[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) m = (q[i] > m) ? q[i] : m;
+    float z = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) { p[i] = expf((q[i] - m) / tau); z += p[i]; }
+#pragma unroll
+    for (int i = 0; i < A; ++i) p[i] = fminf(p[i] / z, FLT_MAX);
+}
+// sample_probs_with_rng: first index whose cumulative probability exceeds u, else the last   policies/mod.rs:45-61
+template <int A>
+__device__ __forceinline__ int sample_probs(const float (&p)[A], uint32_t x) {
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    float acc = 0.0f; int res = A - 1; bool found = false;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        acc = acc + p[i];
+        if (!found && acc > u) { res = i; found = true; }
+    }
+    return res;
+}
+enum : int { POL_GREEDY = 0, POL_EGREEDY = 1, POL_SOFTMAX = 2, POL_RANDOM = 3 };
+enum : int { ALG_QLEARNING = 0, ALG_SARSA = 1, ALG_ESARSA = 2 };
+
+struct PolicyParams { int kind; uint32_t eps_thr; float eps; float tau; };
+
+// Policy::sample.  x.x = explore draw, x.y = random action, x.z = tie-break / softmax u.
+//   EpsilonGreedy::sample  epsilon_greedy.rs:74-80 (gen_bool(eps) ? Random : Greedy)
+//   Random::sample         random.rs:43-45         (Uniform(0, A))
+//   Softmax::sample        softmax.rs:131-139
+template <int A>
+__device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float (&q)[A], const U4& x) {
+    switch (pp.kind) {
+    case POL_GREEDY: return greedy_sample<A>(q, x.z);
+    case POL_EGREEDY:
+        if ((x.x >> 8) < pp.eps_thr) return (int)mulhi_u32(x.y, (uint32_t)A);
+        return greedy_sample<A>(q, x.z);
+    case POL_SOFTMAX: { float p[A]; softmax_probs<A>(q, pp.tau, p); return sample_probs<A>(p, x.z); }
+    default: return (int)mulhi_u32(x.y, (uint32_t)A);
+    }
+}
+// Policy::mode   greedy.rs:83 (find_max), epsilon_greedy.rs:82, softmax.rs:141-143 (argmax_first of probs)
+template <int A>
+__device__ __forceinline__ int policy_mode(const PolicyParams& pp, const float (&q)[A]) {
+    if (pp.kind == POL_SOFTMAX) { float p[A]; softmax_probs<A>(q, pp.tau, p); return argmax_first<A>(p); }
+    float v; return find_max<A>(q, v);
+}
+// Function<(S,)> of the policy: action probabilities
+//   greedy.rs:30-44, epsilon_greedy.rs:38-45, softmax.rs:74-82, random.rs:22-26
+template <int A>
+__device__ __forceinline__ void policy_probs(const PolicyParams& pp, const float (&q)[A], float (&p)[A]) {
+    if (pp.kind == POL_SOFTMAX) { softmax_probs<A>(q, pp.tau, p); return; }
+    if (pp.kind == POL_RANDOM) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) p[i] = 1.0f / (float)A;
+        return;
+    }
+    const uint32_t mask = argmaxima_mask<A>(q);
+    const float pg = 1.0f / (float)__popc(mask);
+#pragma unroll
+    for (int i = 0; i < A; ++i) p[i] = ((mask >> i) & 1u) ? pg : 0.0f;
+    if (pp.kind == POL_EGREEDY) {
+        const float pr = pp.eps / (float)A;
+#pragma unroll
+        for (int i = 0; i < A; ++i) p[i] = pr + p[i] * (1.0f - pp.eps);
+    }
+}
+
+struct AlgoParams { int kind; float gamma, lr, alpha; };
+
+// TD error of the three agents from Q(s,a), Q(s',.) (PRE-update W)
+//   QLearning::handle q_learning.rs:51-71 | SARSA::handle sarsa.rs:53-75 | ExpectedSARSA::handle expected_sarsa.rs:45-66
+// returns delta; `e` is the error sent to the approximator (alpha*delta for ExpectedSARSA, :64)
+template <int A>
+__device__ __forceinline__ float td_error(const AlgoParams& ap, const PolicyParams& pp, float qsa, const float (&qn)[A],
+                                          float r, bool term, const U4& x_inner, float& e) {
+    float delta;
+    if (term) {
+        delta = r - qsa;
+    } else if (ap.kind == ALG_QLEARNING) {
+        float m; find_max<A>(qn, m);
+        delta = r + ap.gamma * m - qsa;
+    } else if (ap.kind == ALG_SARSA) {
+        const int na = policy_sample<A>(pp, qn, x_inner);             // agent's own draw (sarsa.rs:61)
+        float qna = qn[0];
+#pragma unroll
+        for (int i = 1; i < A; ++i) qna = (na == i) ? qn[i] : qna;
+        delta = r + ap.gamma * qna - qsa;
+    } else {
+        float p[A]; policy_probs<A>(pp, qn, p);
+        float ev = 0.0f;
+#pragma unroll
+        for (int i = 0; i < A; ++i) ev = ev + qn[i] * p[i];           // fold(0.0, acc + q*p)
+        delta = r + ap.gamma * ev - qsa;
+    }
+    e = (ap.kind == ALG_ESARSA) ? ap.alpha * delta : delta;
+    return delta;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fourier basis (lfa::basis::Fourier + with_bias, call site examples/q_learning.rs:24).
+// F = (ORDER+1)^D; coefficient vectors in lexicographic order (last dim fastest), all-zero
+// skipped, constant 1 LAST.  Separable evaluation: per dimension ONE sincospi + the
+// angle-addition chain, then a complex product over dimensions -- 2 transcendental calls
+// instead of 35 for MountainCar order 5, and closer to the f64 value than cos(pi*fl(c.s~)).
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, int ORDER>
+struct FourierTables {
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = Dom::D, N1 = ORDER + 1;
+    float ct[D][N1], st[D][N1];
+    __device__ __forceinline__ void build(const float (&s)[D]) {
+        static_for<0, D>([&](auto Dd) {
+            constexpr int d = Dd;
+            constexpr float lo = (float)Dom::lo_d(d), hi = (float)Dom::hi_d(d);
+            const float sc = (s[d] - lo) / (hi - lo);
+            ct[d][0] = 1.0f; st[d][0] = 0.0f;
+            if constexpr (ORDER >= 1) sincospif(sc, &st[d][1], &ct[d][1]);
+            static_for<2, N1>([&](auto Nn) {
+                constexpr int n = Nn;
+                ct[d][n] = fmaf(-st[d][n - 1], st[d][1], ct[d][n - 1] * ct[d][1]);
+                st[d][n] = fmaf(ct[d][n - 1], st[d][1], st[d][n - 1] * ct[d][1]);
+            });
+        });
+    }
+};
+
+// register-resident projection: every feature index is a compile-time constant
+template <int DOMAIN, int ORDER>
+struct FourierReg {
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = Dom::D, N1 = ORDER + 1, F = ipow(N1, D);
+    __device__ static __forceinline__ void project(const float (&s)[D], float (&phi)[F]) {
+        FourierTables<DOMAIN, ORDER> tb;
+        tb.build(s);
+        static_for<1, F>([&](auto Kk) {
+            constexpr int k = Kk;
+            // digits of k, most significant = dimension 0
+            constexpr int c0 = (k / ipow(N1, D - 1)) % N1;
+            float re = tb.ct[0][c0], im = tb.st[0][c0];
+            static_for<1, D>([&](auto Dd) {
+                constexpr int d = Dd;
+                constexpr int cd = (k / ipow(N1, D - 1 - d)) % N1;
+                if constexpr (cd == 0) {
+                    // multiply by (1, 0): exact identity
+                } else if constexpr (d == 1 && c0 == 0) {
+                    re = tb.ct[d][cd]; im = tb.st[d][cd];             // (1,0) * z == z exactly
+                } else {
+                    const float nre = fmaf(-im, tb.st[d][cd], re * tb.ct[d][cd]);
+                    const float nim = fmaf(re, tb.st[d][cd], im * tb.ct[d][cd]);
+                    re = nre; im = nim;
+                }
+            });
+            phi[k - 1] = re;
+        });
+        phi[F - 1] = 1.0f;
+    }
+};
+
+}  // namespace rsrl

@@ -1,0 +1,440 @@
+// kernels_reg.hpp -- "register family" kernels: one thread per learner, Fourier features
+// (F <= 64) and, in the fused driver loop, the learner's whole weight matrix held in
+// VGPRs for the duration of the launch.
+//
+// HBM layout (SoA, learner index fastest => every wave access is one contiguous line):
+//   state  f32[D][N]      action i32[N]      ep_step u32[N]
+//   W      f32[A][F][N]   (per-env mode)     W f32[A][F] (shared mode, Nw = 1)
+#pragma once
+
+#include "device_core.hpp"
+
+namespace rsrl {
+
+struct DevStats {
+    unsigned long long env_steps, episodes, episodes_truncated, sum_episode_steps;
+    double sum_abs_td_error, sum_reward;
+};
+
+struct Common {
+    int64_t n_envs;        // learners in this ctx
+    int64_t env_offset;    // global id of learner 0
+    uint64_t seed;
+    PolicyParams pol;
+    AlgoParams alg;
+    uint32_t max_episode_steps;
+    float* state;          // [D][N]
+    int32_t* action;       // [N]
+    uint32_t* ep_step;     // [N]
+    float* W;              // [A][F][Nw]
+    int64_t w_stride;      // Nw: n_envs (per-env) or 1 (shared)
+};
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-level reduction of the per-thread statistics into stats[blockIdx.x]
+__device__ __forceinline__ void block_stats_accumulate(DevStats* __restrict__ stats, unsigned long long n_ep,
+                                                       unsigned long long n_trunc, unsigned long long sum_len,
+                                                       double sum_abs, double sum_r) {
+    __shared__ unsigned long long sh_u[3][kBlock / 64];
+    __shared__ double sh_d[2][kBlock / 64];
+    n_ep = wave_sum(n_ep); n_trunc = wave_sum(n_trunc); sum_len = wave_sum(sum_len);
+    sum_abs = wave_sum(sum_abs); sum_r = wave_sum(sum_r);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sh_u[0][wave] = n_ep; sh_u[1][wave] = n_trunc; sh_u[2][wave] = sum_len;
+        sh_d[0][wave] = sum_abs; sh_d[1][wave] = sum_r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && stats) {
+        DevStats acc = stats[blockIdx.x];
+        for (int w = 0; w < nw; ++w) {
+            acc.episodes += sh_u[0][w]; acc.episodes_truncated += sh_u[1][w]; acc.sum_episode_steps += sh_u[2][w];
+            acc.sum_abs_td_error += sh_d[0][w]; acc.sum_reward += sh_d[1][w];
+        }
+        stats[blockIdx.x] = acc;
+    }
+}
+
+// Q(s,.) = W^T phi(s) with phi in registers and W streamed from memory (learner-fastest layout)
+//   Function<(S,)>::evaluate for VectorLFA        fa/linear.rs:303-311
+template <int A, int F>
+__device__ __forceinline__ void q_from_mem(const float* __restrict__ W, int64_t stride, int64_t wi,
+                                           const float (&phi)[F], float (&q)[A]) {
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc = fmaf(phi[f], W[((int64_t)(b * F + f)) * stride + wi], acc);
+        q[b] = acc;
+    }
+}
+template <int A, int F>
+__device__ __forceinline__ void q_from_reg(const float (&w)[A][F], const float (&phi)[F], float (&q)[A]) {
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc = fmaf(phi[f], w[b][f], acc);
+        q[b] = acc;
+    }
+}
+template <int A>
+__device__ __forceinline__ float select_a(const float (&q)[A], int a) {
+    float v = q[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) v = (a == i) ? q[i] : v;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused driver loop  (examples/q_learning.rs:40-52, order of operations SURVEY A.7)
+//   per step:  t = env.transition(a)            lib.rs:436-446
+//              agent.handle(&t)                 q_learning.rs:51-71 / sarsa.rs / expected_sarsa.rs
+//              a = policy.sample(rng, s')       with the UPDATED weights
+//              terminal or step cap -> fresh env + fresh policy.sample(s0)
+// The reference projects phi 4x per step (s, s', s, s'); here phi(s) and Q(s,.) are
+// carried over from the previous step (same W, same s => same values) and phi(s') is
+// projected once.  n_steps batch-steps per launch; W, phi(s), Q(s,.) live in VGPRs.
+// store_col: n_steps == 1 only -- write back just the updated column (the 608 B/step
+// streaming formulation); otherwise all A columns are written once at the end.
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int n_steps, int store_col,
+                                                      DevStats* __restrict__ stats) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = c.n_envs;
+
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        float s[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+        int a = c.action[i];
+        uint32_t ep = c.ep_step[i];
+        float w[A][F];
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
+
+        float phi_s[F], q_s[A];
+        Bas::project(s, phi_s);
+        q_from_reg<A, F>(w, phi_s, q_s);
+        int a_taken = a;
+
+        for (int k = 0; k < n_steps; ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            // ---- Domain::transition
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = Dom::step(ns, a, r);
+            // ---- handle: delta with the PRE-update weights
+            float phi_n[F], q_n[A];
+            Bas::project(ns, phi_n);
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const float qsa = select_a<A>(q_s, a);
+            U4 xin = U4{0, 0, 0, 0};
+            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            // ---- Handler<StateActionUpdate>: W[:,a] += lr * e * phi(s)     fa/linear.rs:379-391
+            const float scale = c.alg.lr * e;
+#pragma unroll
+            for (int b = 0; b < A; ++b) {
+                const float sb = (a == b) ? scale : 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) w[b][f] = fmaf(sb, phi_s[f], w[b][f]);
+            }
+            a_taken = a;
+            // ---- policy.sample(s') with the UPDATED weights
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            int na = policy_sample<A>(c.pol, q_n, x);
+            ep += 1;
+            sum_abs += (double)fabsf(delta);
+            sum_r += (double)r;
+            if (term || (c.max_episode_steps > 0 && ep >= c.max_episode_steps)) {
+                n_ep += 1; n_trunc += term ? 0 : 1; sum_len += ep;
+                Dom::reset(ns);                                        // new episode: Domain::default()
+                Bas::project(ns, phi_n);
+                q_from_reg<A, F>(w, phi_n, q_n);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(c.pol, q_n, xr);                 // fresh policy.sample(s0)
+                ep = 0;
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int f = 0; f < F; ++f) phi_s[f] = phi_n[f];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            a = na;
+        }
+
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = ep;
+        if (store_col) {
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                float v = w[0][f];
+#pragma unroll
+                for (int b = 1; b < A; ++b) v = (a_taken == b) ? w[b][f] : v;
+                c.W[((int64_t)(a_taken * F + f)) * N + i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int f = 0; f < F; ++f) c.W[((int64_t)(b * F + f)) * N + i] = w[b][f];
+        }
+    }
+
+    // per-launch statistics: block-level reduction into this block's own slot (no atomics: a slot
+    // has exactly one writer per launch, and launches are ordered on the ctx's stream)
+    block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// Trait-granular kernels (drop-in use, fine-grained parity).  W is read from memory.
+// ---------------------------------------------------------------------------------------
+
+// per-episode Domain::default() + initial policy.sample     examples/q_learning.rs:37-38
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_reset_reg(Common c, uint64_t t) {
+    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_envs) return;
+    float s[D]; Dom::reset(s);
+    float phi[F], q[A];
+    Bas::project(s, phi);
+    q_from_mem<A, F>(c.W, c.w_stride, c.w_stride == 1 ? 0 : i, phi, q);
+    const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
+#pragma unroll
+    for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
+    c.action[i] = policy_sample<A>(c.pol, q, x);
+    c.ep_step[i] = 0;
+}
+
+// basis.project: phi f32[F][M]
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_project_reg(const float* __restrict__ states, int64_t M,
+                                                        float* __restrict__ phi_out) {
+    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * M + i];
+    float phi[F];
+    Bas::project(s, phi);
+#pragma unroll
+    for (int f = 0; f < F; ++f) phi_out[(int64_t)f * M + i] = phi[f];
+}
+
+enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4 };
+
+// Function<(S,)>::evaluate / Enumerable::find_max / Policy::{sample,mode} / policy probabilities
+//   fa/linear.rs:303-311, core.rs:96-105, policies/mod.rs:65-78
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_qop_reg(Common c, int op, const float* __restrict__ states, int64_t M,
+                                                    uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
+    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * M + i];
+    float phi[F], q[A];
+    Bas::project(s, phi);
+    q_from_mem<A, F>(c.W, c.w_stride, c.w_stride == 1 ? 0 : i, phi, q);
+    if (op == QOP_EVALUATE) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * M + i] = q[b];
+    } else if (op == QOP_FIND_MAX) {
+        float v; const int bi = find_max<A>(q, v);
+        if (iout) iout[i] = bi;
+        if (fout) fout[i] = v;
+    } else if (op == QOP_SAMPLE) {
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+        iout[i] = policy_sample<A>(c.pol, q, x);
+    } else if (op == QOP_MODE) {
+        iout[i] = policy_mode<A>(c.pol, q);
+    } else {
+        float p[A]; policy_probs<A>(c.pol, q, p);
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * M + i] = p[b];
+    }
+}
+
+// Domain::transition on the ctx's envs      rsrl_domains/src/lib.rs:436-446
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock) void k_domain_step(Common c, const int32_t* __restrict__ actions,
+                                                        float* __restrict__ from_out, float* __restrict__ next_out,
+                                                        float* __restrict__ rew_out, uint8_t* __restrict__ term_out) {
+    using Dom = Domain<DOMAIN>;
+    constexpr int D = Dom::D;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        s[d] = c.state[(int64_t)d * N + i];
+        if (from_out) from_out[(int64_t)d * N + i] = s[d];
+    }
+    const int a = actions ? actions[i] : c.action[i];
+    float r;
+    const bool term = Dom::step(s, a, r);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        c.state[(int64_t)d * N + i] = s[d];
+        if (next_out) next_out[(int64_t)d * N + i] = s[d];
+    }
+    if (rew_out) rew_out[i] = r;
+    if (term_out) term_out[i] = term ? 1 : 0;
+}
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock) void k_domain_reset(Common c, const uint8_t* __restrict__ mask) {
+    using Dom = Domain<DOMAIN>;
+    constexpr int D = Dom::D;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (mask && !mask[i]) return;
+    float s[D]; Dom::reset(s);
+#pragma unroll
+    for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+    c.ep_step[i] = 0;
+}
+
+// Handler<&Transition>::handle on caller-supplied transitions (teacher forcing / drop-in use).
+// per-env mode: learner m's column is updated in place.
+// shared mode : phase 0 accumulates lr*e*phi(s) into dW (f32 atomics), phase 1 (k_apply_dw)
+//               applies it -- all M errors are computed against the same W_t.
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_handle_reg(Common c, const float* __restrict__ from, const int32_t* __restrict__ act,
+                                                       const float* __restrict__ rew, const float* __restrict__ to,
+                                                       const uint8_t* __restrict__ termf, int64_t M, uint64_t t,
+                                                       float* __restrict__ td_out, float* __restrict__ dW) {
+    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const bool shared = c.w_stride == 1;
+    const int64_t wi = shared ? 0 : i;
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * M + i]; ns[d] = to[(int64_t)d * M + i]; }
+    const int a = act[i];
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    float phi_s[F], phi_n[F], q_n[A];
+    Bas::project(s, phi_s);
+    Bas::project(ns, phi_n);
+    float qsa = 0.0f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) qsa = fmaf(phi_s[f], c.W[((int64_t)a * F + f) * c.w_stride + wi], qsa);
+    q_from_mem<A, F>(c.W, c.w_stride, wi, phi_n, q_n);
+    U4 xin = U4{0, 0, 0, 0};
+    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
+    float e;
+    const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+    const float scale = c.alg.lr * e;
+    if (!shared) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t idx = ((int64_t)a * F + f) * c.w_stride + wi;
+            c.W[idx] = fmaf(scale, phi_s[f], c.W[idx]);
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * phi_s[f]);
+    }
+    if (td_out) td_out[i] = delta;
+}
+__global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { W[j] += dW[j]; dW[j] = 0.0f; }
+}
+
+// Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states       lib.rs:448-479, :340
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_rollout_reg(Common c, int64_t step_limit, uint32_t* __restrict__ n_states,
+                                                        float* __restrict__ total_reward) {
+    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const bool shared = c.w_stride == 1;
+    float w[A][F];
+#pragma unroll
+    for (int b = 0; b < A; ++b)
+#pragma unroll
+        for (int f = 0; f < F; ++f) w[b][f] = c.W[((int64_t)(b * F + f)) * c.w_stride + (shared ? 0 : i)];
+    float s[D]; Dom::reset(s);
+    float phi[F], q[A], r, tot = 0.0f;
+    Bas::project(s, phi); q_from_reg<A, F>(w, phi, q);
+    int a = policy_mode<A>(c.pol, q);
+    bool term = Dom::step(s, a, r);                  // the first step is taken eagerly (lib.rs:457-459)
+    int64_t steps = 0;
+    while (steps < step_limit - 1) {
+        steps += 1; tot += r;
+        if (term) break;                             // successors() stops after a Terminal observation
+        if (steps >= step_limit - 1) break;
+        Bas::project(s, phi); q_from_reg<A, F>(w, phi, q);
+        a = policy_mode<A>(c.pol, q);
+        term = Dom::step(s, a, r);
+    }
+    n_states[i] = (uint32_t)(steps + 1);
+    if (total_reward) total_reward[i] = tot;
+}
+
+// get/set of one learner's weights as row-major f32[F][A] (ndarray (F, A))   params/mod.rs:116-134
+__global__ void k_weights_get(const float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F * A) return;
+    const int f = j / A, b = j % A;
+    out[j] = W[((int64_t)(b * F + f)) * stride + wi];
+}
+__global__ void k_weights_set(float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, const float* __restrict__ in) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F * A) return;
+    const int f = j / A, b = j % A;
+    W[((int64_t)(b * F + f)) * stride + wi] = in[j];
+}
+__global__ void k_weights_set_all(float* __restrict__ W, int64_t N, int F, int A, const float* __restrict__ in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int j = 0; j < F * A; ++j) {
+        const int f = j / A, b = j % A;
+        W[((int64_t)(b * F + f)) * N + i] = in[j];
+    }
+}
+
+}  // namespace rsrl

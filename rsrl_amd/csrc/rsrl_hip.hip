@@ -1,0 +1,607 @@
+// rsrl_hip.hip -- C ABI (include/rsrl_hip.h) over the gfx950 kernels.
+//
+// One ctx = one HIP device + one stream + one (domain, basis, algo, policy, N, W-mode)
+// instance, i.e. what the reference builds in examples/q_learning.rs:19-32.  There is no
+// CPU path in this library: every entry point launches HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rsrl_hip.h"
+#include "kernels_reg.hpp"
+
+using namespace rsrl;
+
+// ------------------------------------------------------------------------------- errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(_e == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(_e), __FILE__, __LINE__);                         \
+    } while (0)
+#define CHECK_CTX(ctx) do { if (!(ctx)) return fail(RSRL_HIP_EINVAL, "null ctx"); } while (0)
+
+// ------------------------------------------------------------------------------- ctx
+struct Scratch { void* p = nullptr; size_t cap = 0; };
+
+struct rsrl_hip_ctx {
+    rsrl_hip_config cfg{};
+    int D = 0, A = 0, F = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
+    float* W = nullptr; float* dW = nullptr;
+    int64_t w_stride = 0;
+    DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
+    size_t n_stat_slots = 0;
+    uint64_t t = 0;          // batch-steps executed (RNG counter)
+    uint64_t api_calls = 0;  // RNG counter of rsrl_hip_policy_sample
+    Scratch scratch[8];
+    // timing of train launches
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    const char* kernel_name = "";
+};
+
+static Common make_common(const rsrl_hip_ctx* c) {
+    Common k{};
+    k.n_envs = c->cfg.n_envs; k.env_offset = c->cfg.env_offset; k.seed = c->cfg.seed;
+    k.pol.kind = c->cfg.policy;
+    double v = c->cfg.epsilon * 16777216.0;
+    k.pol.eps_thr = v <= 0.0 ? 0u : (v >= 16777216.0 ? 16777216u : (uint32_t)v);
+    k.pol.eps = (float)c->cfg.epsilon; k.pol.tau = (float)c->cfg.tau;
+    k.alg.kind = c->cfg.algo; k.alg.gamma = (float)c->cfg.gamma; k.alg.lr = (float)c->cfg.lr;
+    k.alg.alpha = (float)c->cfg.alpha;
+    k.max_episode_steps = c->cfg.max_episode_steps;
+    k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride;
+    return k;
+}
+
+static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// ---- (domain, order) -> template instantiation -------------------------------------------
+// register family: F = (order+1)^D <= 36 features per learner held in VGPRs
+#define RSRL_REG_CASES(X)                                                             \
+    X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5)                                           \
+    X(1, 1) X(2, 1)
+
+static bool reg_supported(int domain, int order) {
+#define X(DM, OR) if (domain == DM && order == OR) return true;
+    RSRL_REG_CASES(X)
+#undef X
+    return false;
+}
+
+#define DISPATCH_REG(ctx, STMT)                                                                  \
+    do {                                                                                         \
+        bool _done = false;                                                                      \
+        RSRL_REG_CASES(STMT)                                                                     \
+        if (!_done) return fail(RSRL_HIP_EINVAL, "no kernel for domain %d order %d", (ctx)->cfg.domain, (ctx)->cfg.order); \
+    } while (0)
+
+// ---- host/device pointer staging ---------------------------------------------------------
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+static int scratch_reserve(rsrl_hip_ctx* c, int slot, size_t bytes) {
+    Scratch& s = c->scratch[slot];
+    if (s.cap >= bytes) return RSRL_HIP_OK;
+    if (s.p) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s.p)); s.p = nullptr; s.cap = 0; }
+    HIP_TRY(hipMalloc(&s.p, bytes));
+    s.cap = bytes;
+    return RSRL_HIP_OK;
+}
+// input: returns a device pointer holding the caller's data
+template <class T>
+static int stage_in(rsrl_hip_ctx* c, int slot, const T* user, size_t count, const T** dev) {
+    if (!user) { *dev = nullptr; return RSRL_HIP_OK; }
+    if (is_device_ptr(user)) { *dev = user; return RSRL_HIP_OK; }
+    int rc = scratch_reserve(c, slot, count * sizeof(T));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->scratch[slot].p, user, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    *dev = (const T*)c->scratch[slot].p;
+    return RSRL_HIP_OK;
+}
+// output: returns the device pointer kernels should write; flush copies back if user is host memory
+template <class T>
+struct OutBuf { T* user = nullptr; T* dev = nullptr; size_t count = 0; bool staged = false; };
+template <class T>
+static int stage_out(rsrl_hip_ctx* c, int slot, T* user, size_t count, OutBuf<T>* ob) {
+    ob->user = user; ob->count = count; ob->staged = false; ob->dev = nullptr;
+    if (!user) return RSRL_HIP_OK;
+    if (is_device_ptr(user)) { ob->dev = user; return RSRL_HIP_OK; }
+    int rc = scratch_reserve(c, slot, count * sizeof(T));
+    if (rc) return rc;
+    ob->dev = (T*)c->scratch[slot].p; ob->staged = true;
+    return RSRL_HIP_OK;
+}
+template <class T>
+static int flush_out(rsrl_hip_ctx* c, OutBuf<T>* ob, bool* need_sync) {
+    if (ob->staged) {
+        HIP_TRY(hipMemcpyAsync(ob->user, ob->dev, ob->count * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+        *need_sync = true;
+    }
+    return RSRL_HIP_OK;
+}
+#define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+#define KCHECK() HIP_TRY(hipGetLastError())
+
+// ------------------------------------------------------------------------------- API
+extern "C" {
+
+int rsrl_hip_abi_version(void) { return RSRL_HIP_ABI_VERSION; }
+const char* rsrl_hip_last_error(void) { return g_last_error.c_str(); }
+
+int rsrl_hip_config_init(rsrl_hip_config* cfg) {
+    if (!cfg) return fail(RSRL_HIP_EINVAL, "null cfg");
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (uint32_t)sizeof(*cfg);
+    cfg->domain = RSRL_MOUNTAIN_CAR; cfg->basis = RSRL_FOURIER; cfg->order = 5;
+    cfg->n_tilings = 8; cfg->tiles_per_dim = 8;
+    cfg->algo = RSRL_QLEARNING; cfg->policy = RSRL_GREEDY;
+    cfg->weight_mode = RSRL_W_PER_ENV; cfg->weight_dtype = RSRL_W_F32;
+    cfg->n_envs = 1; cfg->seed = 0;
+    cfg->gamma = 0.9; cfg->lr = 0.001; cfg->alpha = 1.0; cfg->epsilon = 0.1; cfg->tau = 1.0;
+    cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_destroy(rsrl_hip_ctx* c) {
+    if (!c) return RSRL_HIP_OK;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& s : c->scratch) if (s.p) (void)hipFree(s.p);
+    if (c->state) (void)hipFree(c->state);
+    if (c->action) (void)hipFree(c->action);
+    if (c->ep_step) (void)hipFree(c->ep_step);
+    if (c->W) (void)hipFree(c->W);
+    if (c->dW) (void)hipFree(c->dW);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RSRL_HIP_OK;
+}
+
+static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
+    c->cfg = *cfg;
+    switch (cfg->domain) {
+    case RSRL_MOUNTAIN_CAR: c->D = 2; c->A = 3; break;
+    case RSRL_CART_POLE:    c->D = 4; c->A = 2; break;
+    case RSRL_ACROBOT:      c->D = 4; c->A = 3; break;
+    default: return fail(RSRL_HIP_EINVAL, "unknown domain %d", cfg->domain);
+    }
+    if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
+    if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
+        return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
+    if (cfg->algo < 0 || cfg->algo > RSRL_EXPECTED_SARSA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
+    // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
+    if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
+        return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
+    if (cfg->weight_dtype != RSRL_W_F32) return fail(RSRL_HIP_EINVAL, "weight dtype %d not supported yet", cfg->weight_dtype);
+    if (cfg->basis == RSRL_FOURIER) {
+        if (!reg_supported(cfg->domain, cfg->order))
+            return fail(RSRL_HIP_EINVAL, "Fourier order %d on domain %d not supported yet", cfg->order, cfg->domain);
+        c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
+    } else {
+        return fail(RSRL_HIP_EINVAL, "basis %d not supported yet", cfg->basis);
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(RSRL_HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    const int64_t N = cfg->n_envs;
+    const bool shared = cfg->weight_mode == RSRL_W_SHARED;
+    c->w_stride = shared ? 1 : N;
+    const size_t w_elems = (size_t)c->A * c->F * (size_t)c->w_stride;
+    HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
+    HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
+    HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
+    HIP_TRY(hipMalloc((void**)&c->W, sizeof(float) * w_elems));
+    HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * (size_t)c->A * c->F));
+    c->n_stat_slots = grid_for(N);
+    HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
+    HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
+    HIP_TRY(hipMemsetAsync(c->W, 0, sizeof(float) * w_elems, c->stream));      // LFA::vector zero-initialises
+    HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * (size_t)c->A * c->F, c->stream));
+    HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
+    HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask);
+
+int rsrl_hip_create(const rsrl_hip_config* cfg, rsrl_hip_ctx** out) {
+    if (!cfg || !out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (cfg->struct_size != sizeof(rsrl_hip_config))
+        return fail(RSRL_HIP_EINVAL, "config struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(rsrl_hip_config));
+    rsrl_hip_ctx* c = new rsrl_hip_ctx();
+    int rc = create_impl(cfg, c);
+    if (rc == RSRL_HIP_OK) rc = rsrl_hip_domain_reset(c, nullptr);     // envs start at Domain::default()
+    if (rc == RSRL_HIP_OK) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "%s", hipGetErrorString(e)); }
+    if (rc != RSRL_HIP_OK) { std::string keep = g_last_error; rsrl_hip_destroy(c); g_last_error = keep; *out = nullptr; return rc; }
+    *out = c;
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_sync(rsrl_hip_ctx* c) {
+    CHECK_CTX(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_state_dim(const rsrl_hip_ctx* c) { return c ? c->D : RSRL_HIP_EINVAL; }
+int rsrl_hip_n_actions(const rsrl_hip_ctx* c) { return c ? c->A : RSRL_HIP_EINVAL; }
+int rsrl_hip_n_features(const rsrl_hip_ctx* c) { return c ? c->F : RSRL_HIP_EINVAL; }
+int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* c) { return c ? c->cfg.n_envs : RSRL_HIP_EINVAL; }
+uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* c) { return c ? c->t : 0; }
+
+int rsrl_hip_state_bounds(const rsrl_hip_ctx* c, double* lo, double* hi) {
+    CHECK_CTX(c);
+    if (!lo || !hi) return fail(RSRL_HIP_EINVAL, "null argument");
+    for (int i = 0; i < c->D; ++i) {
+        switch (c->cfg.domain) {
+        case 0: lo[i] = Domain<0>::lo_d(i); hi[i] = Domain<0>::hi_d(i); break;
+        case 1: lo[i] = Domain<1>::lo_d(i); hi[i] = Domain<1>::hi_d(i); break;
+        default: lo[i] = Domain<2>::lo_d(i); hi[i] = Domain<2>::hi_d(i); break;
+        }
+    }
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_set_epsilon(rsrl_hip_ctx* c, double eps) {
+    CHECK_CTX(c);
+    if (!(eps >= 0.0 && eps <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon must be in [0,1]");   // gen_bool panics otherwise
+    c->cfg.epsilon = eps;
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_reset(rsrl_hip_ctx* c) {
+    CHECK_CTX(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const Common k = make_common(c);
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_reset_reg<DM, OR>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, c->t); _done = true; }
+    DISPATCH_REG(c, X);
+#undef X
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_get_states(rsrl_hip_ctx* c, float* states) {
+    CHECK_CTX(c); if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(states, c->state, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
+    CHECK_CTX(c); if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_get_actions(rsrl_hip_ctx* c, int32_t* actions) {
+    CHECK_CTX(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(actions, c->action, sizeof(int32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
+    CHECK_CTX(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->action, actions, sizeof(int32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_states, float* next_states,
+                         float* rewards, uint8_t* terminal) {
+    CHECK_CTX(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t N = c->cfg.n_envs; const size_t DN = (size_t)c->D * N;
+    const int32_t* d_act; OutBuf<float> ofrom, onext, orew; OutBuf<uint8_t> oterm;
+    TRY(stage_in(c, 0, actions, (size_t)N, &d_act));
+    TRY(stage_out(c, 1, from_states, DN, &ofrom));
+    TRY(stage_out(c, 2, next_states, DN, &onext));
+    TRY(stage_out(c, 3, rewards, (size_t)N, &orew));
+    TRY(stage_out(c, 4, terminal, (size_t)N, &oterm));
+    const Common k = make_common(c);
+    const dim3 g(grid_for(N)), b(kBlock);
+    switch (c->cfg.domain) {
+    case 0: hipLaunchKernelGGL(k_domain_step<0>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
+    case 1: hipLaunchKernelGGL(k_domain_step<1>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
+    default: hipLaunchKernelGGL(k_domain_step<2>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
+    }
+    KCHECK();
+    bool sync = false;
+    TRY(flush_out(c, &ofrom, &sync)); TRY(flush_out(c, &onext, &sync));
+    TRY(flush_out(c, &orew, &sync)); TRY(flush_out(c, &oterm, &sync));
+    if (sync || (actions && !is_device_ptr(actions))) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
+    CHECK_CTX(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t N = c->cfg.n_envs;
+    const uint8_t* d_mask;
+    TRY(stage_in(c, 0, mask, (size_t)N, &d_mask));
+    const Common k = make_common(c);
+    const dim3 g(grid_for(N)), b(kBlock);
+    switch (c->cfg.domain) {
+    case 0: hipLaunchKernelGGL(k_domain_reset<0>, g, b, 0, c->stream, k, d_mask); break;
+    case 1: hipLaunchKernelGGL(k_domain_reset<1>, g, b, 0, c->stream, k, d_mask); break;
+    default: hipLaunchKernelGGL(k_domain_reset<2>, g, b, 0, c->stream, k, d_mask); break;
+    }
+    KCHECK();
+    if (mask && !is_device_ptr(mask)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M, float* fout, size_t fcount, int32_t* iout) {
+    CHECK_CTX(c);
+    if (!states || M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M, (long long)c->cfg.n_envs);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const float* d_states; OutBuf<float> of; OutBuf<int32_t> oi;
+    TRY(stage_in(c, 0, states, (size_t)c->D * M, &d_states));
+    TRY(stage_out(c, 1, fout, fcount, &of));
+    TRY(stage_out(c, 2, iout, (size_t)M, &oi));
+    const Common k = make_common(c);
+    const uint64_t call = c->api_calls;
+    if (op == QOP_SAMPLE) c->api_calls++;
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_qop_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, op, d_states, M, call, of.dev, oi.dev); _done = true; }
+    DISPATCH_REG(c, X);
+#undef X
+    KCHECK();
+    bool sync = !is_device_ptr(states);
+    TRY(flush_out(c, &of, &sync)); TRY(flush_out(c, &oi, &sync));
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_q_evaluate(rsrl_hip_ctx* c, const float* states, int64_t M, float* q_out) {
+    if (!q_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    return qop(c, QOP_EVALUATE, states, M, q_out, c ? (size_t)c->A * M : 0, nullptr);
+}
+int rsrl_hip_q_find_max(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* idx_out, float* val_out) {
+    return qop(c, QOP_FIND_MAX, states, M, val_out, (size_t)M, idx_out);
+}
+int rsrl_hip_policy_sample(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* actions_out) {
+    if (!actions_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    return qop(c, QOP_SAMPLE, states, M, nullptr, 0, actions_out);
+}
+int rsrl_hip_policy_mode(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* actions_out) {
+    CHECK_CTX(c);
+    if (!actions_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");   // random.rs:47
+    return qop(c, QOP_MODE, states, M, nullptr, 0, actions_out);
+}
+int rsrl_hip_policy_probs(rsrl_hip_ctx* c, const float* states, int64_t M, float* probs_out) {
+    if (!probs_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    return qop(c, QOP_PROBS, states, M, probs_out, c ? (size_t)c->A * M : 0, nullptr);
+}
+
+int rsrl_hip_project(rsrl_hip_ctx* c, const float* states, int64_t M, float* phi_out) {
+    CHECK_CTX(c);
+    if (!states || !phi_out || M < 1) return fail(RSRL_HIP_EINVAL, "bad argument");
+    if (c->cfg.basis != RSRL_FOURIER) return fail(RSRL_HIP_EINVAL, "dense projection needs a Fourier basis");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const float* d_states; OutBuf<float> of;
+    TRY(stage_in(c, 0, states, (size_t)c->D * M, &d_states));
+    TRY(stage_out(c, 1, phi_out, (size_t)c->F * M, &of));
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_project_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, d_states, M, of.dev); _done = true; }
+    DISPATCH_REG(c, X);
+#undef X
+    KCHECK();
+    bool sync = !is_device_ptr(states);
+    TRY(flush_out(c, &of, &sync));
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_tile_indices(rsrl_hip_ctx* c, const float*, int64_t, int32_t*) {
+    CHECK_CTX(c);
+    return fail(RSRL_HIP_EINVAL, "tile coding not supported yet");
+}
+
+int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* actions, const float* rewards,
+                    const float* to_states, const uint8_t* terminal, int64_t M, float* td_error_out) {
+    CHECK_CTX(c);
+    if (!from_states || !actions || !rewards || !to_states || !terminal) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch size");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const float *d_from, *d_rew, *d_to; const int32_t* d_act; const uint8_t* d_term; OutBuf<float> otd;
+    TRY(stage_in(c, 0, from_states, (size_t)c->D * M, &d_from));
+    TRY(stage_in(c, 1, actions, (size_t)M, &d_act));
+    TRY(stage_in(c, 2, rewards, (size_t)M, &d_rew));
+    TRY(stage_in(c, 3, to_states, (size_t)c->D * M, &d_to));
+    TRY(stage_in(c, 4, terminal, (size_t)M, &d_term));
+    TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
+    const Common k = make_common(c);
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_handle_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->dW); _done = true; }
+    DISPATCH_REG(c, X);
+#undef X
+    KCHECK();
+    if (c->w_stride == 1) {
+        const int n = c->A * c->F;
+        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+        KCHECK();
+    }
+    bool sync = true;   // inputs may be host memory staged asynchronously
+    TRY(flush_out(c, &otd, &sync));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
+    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    const bool shared = c->w_stride == 1;
+    if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int n = c->F * c->A; OutBuf<float> ow;
+    TRY(stage_out(c, 0, w, (size_t)n, &ow));
+    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->w_stride, shared ? 0 : env_index, c->F, c->A, ow.dev);
+    KCHECK();
+    bool sync = false; TRY(flush_out(c, &ow, &sync));
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
+    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    const bool shared = c->w_stride == 1;
+    if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int n = c->F * c->A; const float* d_w;
+    TRY(stage_in(c, 0, w, (size_t)n, &d_w));
+    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->w_stride, shared ? 0 : env_index, c->F, c->A, d_w);
+    KCHECK();
+    if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
+    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (c->w_stride == 1) return rsrl_hip_set_weights(c, 0, w);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int n = c->F * c->A; const float* d_w;
+    TRY(stage_in(c, 0, w, (size_t)n, &d_w));
+    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->W, c->cfg.n_envs, c->F, c->A, d_w);
+    KCHECK();
+    if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+// ---- the fused driver loop -----------------------------------------------------------------
+static int timing_begin(rsrl_hip_ctx* c) {
+    if (!c->timing) return RSRL_HIP_OK;
+    if (c->events_used == c->events.size()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+        c->events.emplace_back(a, b);
+    }
+    HIP_TRY(hipEventRecord(c->events[c->events_used].first, c->stream));
+    return RSRL_HIP_OK;
+}
+static int timing_end(rsrl_hip_ctx* c) {
+    if (!c->timing) return RSRL_HIP_OK;
+    HIP_TRY(hipEventRecord(c->events[c->events_used].second, c->stream));
+    c->events_used++;
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
+    CHECK_CTX(c);
+    if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
+    if (c->w_stride == 1) return fail(RSRL_HIP_EINVAL, "shared-W training not supported yet");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
+    const Common k = make_common(c);
+    const int64_t spl = c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256;
+    int64_t done = 0;
+    while (done < n_steps) {
+        const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
+        const int store_col = (chunk == 1 && c->cfg.steps_per_launch == 1) ? 1 : 0;
+        TRY(timing_begin(c));
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_train_reg<DM, OR>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, c->t, chunk, store_col, c->d_stats); \
+        c->kernel_name = "k_train_reg"; _done = true; }
+        DISPATCH_REG(c, X);
+#undef X
+        KCHECK();
+        TRY(timing_end(c));
+        c->t += (uint64_t)chunk;
+        done += chunk;
+    }
+    if (stats_out) {
+        HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        memset(stats_out, 0, sizeof(*stats_out));
+        stats_out->env_steps = (uint64_t)n_steps * (uint64_t)c->cfg.n_envs;
+        for (size_t b = 0; b < c->n_stat_slots; ++b) {          // fixed order: reproducible sums
+            stats_out->episodes += c->h_stats[b].episodes;
+            stats_out->episodes_truncated += c->h_stats[b].episodes_truncated;
+            stats_out->sum_episode_steps += c->h_stats[b].sum_episode_steps;
+            stats_out->sum_abs_td_error += c->h_stats[b].sum_abs_td_error;
+            stats_out->sum_reward += c->h_stats[b].sum_reward;
+        }
+    }
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
+    CHECK_CTX(c);
+    if (!n_states_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1 (unbounded rollouts are not offered)");
+    if (c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t N = c->cfg.n_envs;
+    OutBuf<uint32_t> on; OutBuf<float> ot;
+    TRY(stage_out(c, 0, n_states_out, (size_t)N, &on));
+    TRY(stage_out(c, 1, total_reward_out, (size_t)N, &ot));
+    const Common k = make_common(c);
+#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
+        hipLaunchKernelGGL((k_rollout_reg<DM, OR>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, step_limit, on.dev, ot.dev); _done = true; }
+    DISPATCH_REG(c, X);
+#undef X
+    KCHECK();
+    bool sync = false;
+    TRY(flush_out(c, &on, &sync)); TRY(flush_out(c, &ot, &sync));
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_comm_unique_id(uint8_t*) { return fail(RSRL_HIP_ERCCL, "RCCL support not built yet"); }
+int rsrl_hip_comm_init(rsrl_hip_ctx*, const uint8_t*, int, int) { return fail(RSRL_HIP_ERCCL, "RCCL support not built yet"); }
+
+int rsrl_hip_timing_enable(rsrl_hip_ctx* c, int enable) {
+    CHECK_CTX(c);
+    c->timing = enable != 0;
+    c->events_used = 0;
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_timing_read(rsrl_hip_ctx* c, double* ms_total, uint64_t* launches, const char** kernel_name) {
+    CHECK_CTX(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->events_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = c->events_used;
+    if (kernel_name) *kernel_name = c->kernel_name;
+    return RSRL_HIP_OK;
+}
+
+}  // extern "C"

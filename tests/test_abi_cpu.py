@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every symbol
+include/rsrl_hip.h declares (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def abi():
+    import __graft_entry__ as g
+    g.build()
+    from rsrl_amd import _abi
+    return _abi
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "rsrl_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsrl_hip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(abi):
+    L = abi.lib()
+    names = header_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/rsrl_hip.h but not exported"
+    assert sorted(abi.SYMBOLS) == names, "python binding table and header drifted apart"
+    assert L.rsrl_hip_abi_version() == 1
+
+
+def test_config_struct_layout_and_defaults(abi):
+    cfg = abi.Config()
+    assert abi.lib().rsrl_hip_config_init(C.byref(cfg)) == 0
+    assert cfg.struct_size == C.sizeof(abi.Config)          # README example defaults (q_learning.rs:19-32)
+    assert (cfg.domain, cfg.basis, cfg.order, cfg.algo, cfg.policy) == (0, 0, 5, 0, 0)
+    assert (cfg.gamma, cfg.lr) == (0.9, 0.001)
+
+
+def test_no_cpu_fallback_without_device(abi):
+    import rsrl_amd
+    try:
+        import subprocess
+        has_gpu = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True).stdout.count("gfx950") > 0
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(rsrl_amd.RsrlHipError) as ei:
+        rsrl_amd.Context(n_envs=4)
+    assert ei.value.code == -2            # RSRL_HIP_EHIP: no device -> loud failure, never an eager fallback
+
+
+def test_bad_struct_size_rejected(abi):
+    cfg = abi.Config()
+    abi.lib().rsrl_hip_config_init(C.byref(cfg))
+    cfg.struct_size = 12
+    h = C.c_void_p()
+    assert abi.lib().rsrl_hip_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"struct_size" in abi.lib().rsrl_hip_last_error()
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under rsrl_amd/ may reference it
+    for dp, _, fns in os.walk(os.path.join(ROOT, "rsrl_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("test oracle", "").replace("f32 oracle", "").replace(
+                    "the oracle", ""), f"{fn} mentions the oracle"

@@ -1,0 +1,324 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the headline configuration
+MountainCar + Fourier(5) + {QLearning, SARSA, ExpectedSARSA} + {Greedy, EpsilonGreedy, Softmax, Random}.
+
+Tolerances (fp32 device vs f64 oracle unless noted), all from identical fp32-representable inputs:
+  phi       <= 3e-6   (input rounding of s~ alone allows pi*order*ulp ~ 1e-6; measured ~1.6e-6 worst)
+  Q, delta  <= 2e-5 * (1 + |Q|)
+  W after one update <= 1e-6 abs
+  teacher-forced 1000 steps: max|dW| <= 1e-3 * max(1, max|W|)
+  integer / index outputs (actions given identical Q, n_states from identical W with margins): exact
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+def rand_states(orc, domain, M, seed):
+    lo, hi = orc.domain_bounds(domain)
+    rng = np.random.default_rng(seed)
+    s = lo[:, None] + (hi - lo)[:, None] * rng.random((len(lo), M))
+    return s.astype(np.float32)
+
+
+def test_project_matches_oracle(ra, orc):
+    M = 4096
+    s = rand_states(orc, 0, M, 1)
+    with ra.Context(n_envs=M) as c:
+        phi = c.project(s)
+    assert phi.shape == (36, M)
+    worst64 = worst32 = 0.0
+    for m in range(0, M, 7):
+        worst64 = max(worst64, np.abs(phi[:, m] - orc.fourier_project(0, 5, s[:, m], "f64")).max())
+        worst32 = max(worst32, np.abs(phi[:, m] - orc.fourier_project(0, 5, s[:, m], "f32")).max())
+    assert worst64 <= 3e-6, worst64
+    assert worst32 <= 5e-7, worst32       # same op order, only sincospif vs correctly rounded differs
+    assert np.all(phi[-1] == 1.0)
+
+
+@pytest.mark.parametrize("domain,steps", [(0, 50), (1, 30), (2, 30)])
+def test_domain_step_matches_oracle(ra, orc, domain, steps):
+    N = 512
+    order = 5 if domain == 0 else 1
+    rng = np.random.default_rng(domain)
+    with ra.Context(domain=domain, order=order, n_envs=N) as c:
+        s0 = rand_states(orc, domain, N, 10 + domain)
+        if domain == 1:
+            s0 *= 0.5                       # start inside the non-terminal region
+        c.states = s0
+        cur = s0.copy()
+        for k in range(steps):
+            a = rng.integers(0, c.A, N).astype(np.int32)
+            frm, nxt, rew, term = c.domain_step(a)
+            assert np.array_equal(frm, cur)
+            for i in range(0, N, 5):
+                es, er, et = orc.domain_step(domain, cur[:, i], a[i], "f32")
+                # Acrobot: dt = 0.2 with |theta'| up to 9*pi amplifies sincos ulps through the 4 RK4 stages
+                t32, t64 = (2e-5, 2e-4) if domain == 2 else (2e-6, 1e-5)
+                assert np.allclose(nxt[:, i], es, rtol=t32, atol=t32), (k, i, nxt[:, i], es)
+                es64, er64, et64 = orc.domain_step(domain, cur[:, i], a[i], "f64")
+                assert np.allclose(nxt[:, i], es64, rtol=t64, atol=t64)
+                if np.all(nxt[:, i] == es):
+                    assert rew[i] == er and bool(term[i]) == et
+            cur = nxt
+            assert np.array_equal(c.states, nxt)
+
+
+def test_domain_golden_reference_vectors(ra):
+    # reference known-answer vectors straight through the HIP path (cart_pole.rs:143-183, discrete.rs:109-137)
+    with ra.Context(domain=1, order=1, n_envs=2) as c:
+        assert np.all(c.states == 0.0)
+        _, nxt, rew, term = c.domain_step(np.array([0, 1], dtype=np.int32))
+        e1 = np.array([-0.0032931628891235, -0.3293940797883472, 0.0029499634056967, 0.2951522145037250])
+        assert np.all(np.abs(nxt[:, 0] - e1) < 1e-6) and np.all(np.abs(nxt[:, 1] + e1) < 1e-6)
+        _, nxt, rew, term = c.domain_step(np.array([0, 1], dtype=np.int32))
+        e2 = np.array([-0.0131819582085161, -0.6597158115002169, 0.0118185373734479, 0.5921703414056713])
+        assert np.all(np.abs(nxt[:, 0] - e2) < 1e-6) and np.all(np.abs(nxt[:, 1] + e2) < 1e-6)
+        assert not term.any() and np.all(rew == 0.0)
+    with ra.Context(domain=0, order=5, n_envs=4) as c:
+        s = c.states
+        assert np.all(s[0] == np.float32(-0.5)) and np.all(s[1] == 0.0)
+        # terminal predicate x >= 0.6: put cars just below the goal moving right
+        c.states = np.array([[0.59, 0.55, 0.5, -1.2], [0.07, 0.0, 0.0, -0.07]], dtype=np.float32)
+        _, nxt, rew, term = c.domain_step(np.array([2, 2, 2, 0], dtype=np.int32))
+        assert list(term) == [1, 0, 0, 0] and list(rew) == [0.0, -1.0, -1.0, -1.0]
+        assert nxt[0, 0] == np.float32(0.6) and nxt[0, 3] == np.float32(-1.2)
+    with ra.Context(domain=2, order=1, n_envs=1) as c:
+        assert np.all(c.states == 0.0)
+
+
+def _random_w(F, A, seed, scale=0.5):
+    return (np.random.default_rng(seed).normal(size=(F, A)) * scale).astype(np.float32)
+
+
+def test_q_evaluate_and_find_max(ra, orc):
+    N = 256
+    s = rand_states(orc, 0, N, 3)
+    ag = orc.make_agent()
+    with ra.Context(n_envs=N) as c:
+        Ws = [_random_w(36, 3, 100 + i) for i in range(N)]
+        for i in range(0, N):
+            c.set_weights(Ws[i], i)
+        for i in (0, 17, N - 1):
+            assert np.array_equal(c.get_weights(i), Ws[i])
+        q = c.q_evaluate(s)
+        idx, val = c.q_find_max(s)
+        for i in range(N):
+            q64 = orc.q_evaluate(ag, Ws[i].astype(np.float64), s[:, i], "f64")
+            assert np.allclose(q[:, i], q64, rtol=0, atol=2e-5 * (1 + np.abs(q64).max()))
+            q32 = orc.q_evaluate(ag, Ws[i], s[:, i], "f32")
+            assert np.allclose(q[:, i], q32, rtol=0, atol=3e-6 * (1 + np.abs(q32).max()))
+            ei, ev = orc.find_max(q[:, i], "f32")
+            assert idx[i] == ei and val[i] == np.float32(ev)
+
+
+@pytest.mark.parametrize("policy,kw", [(0, {}), (1, {"epsilon": 0.3}), (2, {"tau": 0.7}), (3, {})])
+def test_policy_ops_exact_given_device_q(ra, orc, policy, kw):
+    N = 2048
+    s = rand_states(orc, 0, N, 4)
+    W = _random_w(36, 3, 7, 0.3)
+    with ra.Context(n_envs=N, policy=policy, seed=99, env_offset=1000, **kw) as c:
+        c.set_weights_all(W)
+        q = c.q_evaluate(s)
+        probs = c.policy_probs(s)
+        eps, tau = kw.get("epsilon", 0.1), kw.get("tau", 1.0)
+        if policy != 3:
+            mode = c.policy_mode(s)
+        else:
+            with pytest.raises(ra.RsrlHipError):
+                c.policy_mode(s)
+        a0 = c.policy_sample(s)
+        a1 = c.policy_sample(s)
+        for i in range(0, N, 3):
+            ep = orc.policy_probs(policy, q[:, i], eps=eps, tau=tau, prec="f32")
+            assert np.allclose(probs[:, i], ep, rtol=0, atol=3e-7)
+            if policy != 3:
+                assert mode[i] == orc.policy_mode(policy, q[:, i], tau=tau, prec="f32")
+        if policy != 2:      # softmax sampling depends on exp ulps; others are exact integer logic
+            for call, acts in ((0, a0), (1, a1)):
+                for i in range(0, N, 3):
+                    x = orc.draw(99, 1000 + i, call, orc.BLK_API)
+                    assert acts[i] == orc.policy_sample(policy, q[:, i], x, eps=eps, tau=tau, prec="f32")
+        # frequencies follow the probabilities (distributional parity, like the reference's own tests)
+        big = np.stack([c.policy_sample(s) for _ in range(20)])
+        freq = np.stack([(big == b).mean() for b in range(3)])
+        assert np.allclose(freq, probs.mean(axis=1), atol=0.02)
+
+
+def test_policy_ties_at_zero_weights(ra, orc):
+    # W = 0 => all Q equal => Greedy::sample picks uniformly among the maxima with the rng (utils.rs:63-79);
+    # probabilities are uniform (greedy.rs:30-44); mode/find_max -> last index (core.rs:96-105)
+    N = 30000
+    s = rand_states(orc, 0, N, 5)
+    with ra.Context(n_envs=N, policy=0) as c:
+        assert np.all(c.q_evaluate(s) == 0.0)
+        assert np.allclose(c.policy_probs(s), 1.0 / 3.0)
+        assert np.all(c.policy_mode(s) == 2)
+        a = c.policy_sample(s)
+        assert np.allclose(np.bincount(a, minlength=3) / N, 1 / 3, atol=0.02)
+        for i in range(0, N, 500):
+            assert a[i] == orc.policy_sample(0, [0.0, 0.0, 0.0], orc.draw(0, i, 0, orc.BLK_API), prec="f32")
+
+
+@pytest.mark.parametrize("algo,policy", [(0, 0), (0, 1), (1, 1), (2, 1), (2, 2), (1, 2)])
+def test_handle_single_update(ra, orc, algo, policy):
+    M = 128
+    rng = np.random.default_rng(algo * 10 + policy)
+    s = rand_states(orc, 0, M, 20)
+    a = rng.integers(0, 3, M).astype(np.int32)
+    kw = dict(gamma=0.95, lr=0.05, alpha=0.5, epsilon=0.2, tau=0.8)
+    ag = orc.make_agent(algo=algo, policy=policy, seed=5, **kw)
+    with ra.Context(n_envs=M, algo=algo, policy=policy, seed=5, **kw) as c:
+        c.states = s
+        frm, nxt, rew, term = c.domain_step(a)
+        term[::9] = 1                      # exercise the terminal branch (delta = r - Q(s,a))
+        Ws = [_random_w(36, 3, 300 + i) for i in range(M)]
+        for i in range(M):
+            c.set_weights(Ws[i], i)
+        td = c.handle(frm, a, rew, nxt, term)
+        for i in range(M):
+            x_in = orc.draw(5, i, 0, orc.BLK_INNER)
+            for prec, tol_d, tol_w in (("f64", 2e-5, 1e-6), ("f32", 4e-6, 3e-7)):
+                W = Ws[i].astype(np.float64 if prec == "f64" else np.float32).copy()
+                d = orc.handle(ag, W, frm[:, i], a[i], rew[i], nxt[:, i], term[i], x_in, prec)
+                if algo == 1 and policy == 2:
+                    tol_d = 3.0          # softmax-sampled inner action may legitimately differ by exp ulps
+                    continue
+                assert abs(td[i] - d) <= tol_d * (1 + abs(d)), (i, prec, td[i], d)
+                assert np.max(np.abs(c.get_weights(i) - W)) <= tol_w * (1 + abs(d)), (i, prec)
+
+
+def test_train_fused_equals_stepwise_bitwise(ra):
+    # K-step fusion must not change results: 96 steps as one launch == 96 single-step launches, bit for bit
+    kw = dict(n_envs=1000, policy=1, epsilon=0.1, seed=11, max_episode_steps=40)
+    with ra.Context(steps_per_launch=96, **kw) as a, ra.Context(steps_per_launch=1, **kw) as b, \
+            ra.Context(steps_per_launch=7, **kw) as d:
+        for c in (a, b, d):
+            c.reset()
+        sa, sb, sd = a.train(96), b.train(96), d.train(96)
+        assert np.array_equal(a.states, b.states) and np.array_equal(a.states, d.states)
+        assert np.array_equal(a.actions, b.actions) and np.array_equal(a.actions, d.actions)
+        for i in (0, 1, 500, 999):
+            assert np.array_equal(a.get_weights(i), b.get_weights(i))
+            assert np.array_equal(a.get_weights(i), d.get_weights(i))
+        assert sa["episodes"] == sb["episodes"] == sd["episodes"] > 0
+        assert sa["sum_episode_steps"] == sb["sum_episode_steps"]
+        assert abs(sa["sum_abs_td_error"] - sb["sum_abs_td_error"]) < 1e-6 * sa["sum_abs_td_error"]
+        assert sa["env_steps"] == 96 * 1000 and a.step_count == 96
+
+
+def test_train_sharding_invariance(ra):
+    # RNG streams are keyed by the GLOBAL env id: two half-size ctxs == one full-size ctx
+    kw = dict(policy=1, epsilon=0.2, seed=3, max_episode_steps=30)
+    with ra.Context(n_envs=512, **kw) as full, ra.Context(n_envs=256, **kw) as lo, \
+            ra.Context(n_envs=256, env_offset=256, **kw) as hi:
+        for c in (full, lo, hi):
+            c.reset()
+            c.train(70)
+        assert np.array_equal(full.states[:, :256], lo.states) and np.array_equal(full.states[:, 256:], hi.states)
+        assert np.array_equal(full.actions[256:], hi.actions)
+        assert np.array_equal(full.get_weights(300), hi.get_weights(44))
+
+
+@pytest.mark.parametrize("algo,policy", [(0, 1), (1, 1), (2, 1), (0, 0)])
+def test_train_free_running_vs_oracle_f32(ra, orc, algo, policy):
+    # same seeds, same RNG: the fp32 oracle and the device follow the same trajectories until a
+    # near-tie is resolved differently (cos/sincos ulps); short horizon from W = 0.
+    N, K = 256, 120
+    kw = dict(gamma=0.9, lr=0.001, alpha=0.7, epsilon=0.1)
+    ag = orc.make_agent(algo=algo, policy=policy, seed=21, max_episode_steps=50, **kw)
+    run = orc.Run(ag, N, "f32")
+    run.reset()
+    ost = run.train(K)
+    with ra.Context(n_envs=N, algo=algo, policy=policy, seed=21, max_episode_steps=50, **kw) as c:
+        c.reset()
+        st = c.train(K)
+        same = np.all(np.abs(c.states.T - run.state) <= 1e-5, axis=1) & (c.actions == run.action)
+        assert same.mean() >= 0.97, same.mean()
+        for i in np.flatnonzero(same)[:40]:
+            assert np.max(np.abs(c.get_weights(i) - run.weights[i])) <= 2e-6
+        assert st["episodes"] == ost["episodes"] or abs(st["episodes"] - ost["episodes"]) <= 2
+        assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 1e-3 * ost["sum_abs_td_error"]
+        assert abs(st["sum_reward"] - ost["sum_reward"]) <= 1e-3 * abs(ost["sum_reward"])
+
+
+def test_teacher_forced_1000_steps_vs_oracle_f64(ra, orc):
+    # the f64 oracle drives (its own transitions are fed to the device agent): W drift after 1000 updates
+    N, K = 64, 1000
+    ag = orc.make_agent(policy=1, epsilon=0.1, seed=8, gamma=0.9, lr=0.01, max_episode_steps=200)
+    run = orc.Run(ag, N, "f64")
+    run.reset()
+    with ra.Context(n_envs=N, policy=1, epsilon=0.1, seed=8, gamma=0.9, lr=0.01) as c:
+        for k in range(K):
+            s = run.state.copy()
+            a = run.action.copy()
+            # replay the oracle's transition to obtain (s', r, term) in f64
+            nxt = np.empty_like(s); rew = np.empty(N); term = np.empty(N, dtype=np.uint8)
+            for i in range(N):
+                nxt[i], rew[i], t = orc.domain_step(0, s[i], a[i])
+                term[i] = t
+            run.train(1)
+            c.handle(s.T.astype(np.float32), a, rew.astype(np.float32), nxt.T.astype(np.float32), term)
+        Wd = np.stack([c.get_weights(i) for i in range(N)])
+        Wo = run.weights
+        assert np.max(np.abs(Wo)) > 0.05
+        assert np.max(np.abs(Wd - Wo)) <= 1e-3 * max(1.0, np.max(np.abs(Wo)))
+
+
+def test_rollout_greedy_from_identical_weights(ra, orc):
+    # greedy rollout (lib.rs:448-479) from identical W: identical n_states unless an argmax margin < 1e-5 occurs
+    N = 64
+    ag = orc.make_agent(policy=1, epsilon=0.1, seed=2, gamma=0.99, lr=0.005, max_episode_steps=400)
+    run = orc.Run(ag, N, "f64")
+    run.reset()
+    run.train(3000)
+    W32 = run.weights.astype(np.float32)
+    run.weights[:] = W32                       # identical (fp32-representable) weights on both sides
+    n_o, tot_o = run.rollout_greedy(500)
+    with ra.Context(n_envs=N, policy=1) as c:
+        for i in range(N):
+            c.set_weights(W32[i], i)
+        n_d, tot_d = c.rollout_greedy(500)
+        n1, _ = c.rollout_greedy(1)
+        with pytest.raises(ra.RsrlHipError):
+            c.rollout_greedy(0)
+    assert np.all(n1 == 1)
+    agree = (n_d == n_o)
+    assert agree.mean() >= 0.9, (agree.mean(), n_d, n_o)
+    assert np.all(tot_d[agree] == tot_o[agree])
+    assert len(np.unique(n_o)) > 1             # the learners actually differ
+
+
+def test_learning_reduces_episode_length(ra):
+    # the README example learns: episodes get shorter than the 1000-step cap
+    with ra.Context(n_envs=4096, policy=1, epsilon=0.1, seed=0, max_episode_steps=1000) as c:
+        c.reset()
+        first = c.train(10000)
+        c.train(20000)
+        later = c.train(20000)
+        n, _ = c.rollout_greedy(500)
+    assert first["episodes"] > 0
+    m1 = first["sum_episode_steps"] / first["episodes"]
+    m2 = later["sum_episode_steps"] / later["episodes"]
+    assert m1 > 900 and m2 < 0.6 * m1, (m1, m2)       # oracle: 991 -> ~360 over the same schedule
+    assert (n < 500).mean() > 0.1                    # greedy policy already reaches the goal for a good share of learners
+
+
+def test_error_paths(ra):
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(n_envs=0)
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(policy=2, tau=0.0)          # Softmax::new panics (softmax.rs:63-66)
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(domain=7)
+    with ra.Context(n_envs=8) as c:
+        with pytest.raises(ra.RsrlHipError):
+            c.get_weights(8)
+        with pytest.raises(ra.RsrlHipError):
+            c.set_epsilon(1.5)
