@@ -38,6 +38,18 @@ def usable_cores():
     return n
 
 
+def pmc_traffic(kernel, envs, steps_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None
+    when no pass was collected for this kernel/configuration.  bench.py cannot run rocprofv3 on itself."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kernel]
+    except Exception:
+        return None
+    if rec["envs"] != envs or abs(rec["steps_per_launch"] - steps_per_launch) > 1e-9:
+        return None
+    return rec["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(seconds=12.0):
     """The CPU oracle (reference-faithful f64 port: 4 projections/step, heap-allocated feature vectors,
     one learner at a time) timed on this box's host cores, one independent group of learners per core."""
@@ -72,8 +84,8 @@ def cpu_baseline(seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
-    ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=20480)
+    ap.add_argument("--warmup", type=int, default=2048)
     ap.add_argument("--steps-per-launch", type=int, default=0, help="fuse depth (0 = library default)")
     ap.add_argument("--envs", type=int, default=N_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,7 +131,7 @@ def main():
         total_env_steps = args.steps * args.envs * world
         value = total_env_steps / dt
         avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
-        steps_per_launch = args.steps / max(1, launches)
+        steps_per_launch = args.steps / max(1, launches)   # exact: --steps is a multiple of the fuse depth by default
         algo_bytes_per_launch = BYTES_PER_ENV_STEP * args.envs * steps_per_launch
         achieved = algo_bytes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
         out = {
@@ -133,7 +145,9 @@ def main():
                        "envs_per_gpu": args.envs, "steps_per_launch": steps_per_launch,
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK,
+                         "traffic": pmc_traffic(kname, args.envs, round(steps_per_launch)),
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                          "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
                          "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                          "note": "algorithmic bytes = 608 B/env-step (unfused streaming formulation) x env-steps "

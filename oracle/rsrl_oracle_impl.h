@@ -248,9 +248,16 @@ void FN(orc_q_evaluate)(const orc_basis* b, const R* W, int A, const R* s, R* q)
         R* phi = (R*)malloc(sizeof(R) * (size_t)F);             /* reference allocs a feature array per call */
         FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
         for (a = 0; a < A; a++) {
+#ifdef ORC_SEPARABLE
+            /* device order: 4 interleaved partial sums, q = (acc0 + acc1) + (acc2 + acc3) */
+            R acc[4] = { 0, 0, 0, 0 };
+            for (f = 0; f < F; f++) acc[f & 3] = FN(fma_)(phi[f], W[(size_t)f * A + a], acc[f & 3]);
+            q[a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#else
             R acc = 0;
             for (f = 0; f < F; f++) acc = FN(fma_)(phi[f], W[(size_t)f * A + a], acc);
             q[a] = acc;
+#endif
         }
         free(phi);
     } else {

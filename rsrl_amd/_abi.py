@@ -83,7 +83,7 @@ def lib():
     """Load rsrl_amd/lib/librsrl_hip.so (built by __graft_entry__.build()); no fallback."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("RSRL_HIP_LIB", _build.LIB_PATH)   # override: A/B kernel variants only
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -72,6 +72,54 @@ __device__ __forceinline__ float wrapf(float lb, float x, float ub) {
 
 constexpr double kPi = 3.14159265358979323846;
 
+// ---------------------------------------------------------------------------------------
+// Branch-free fp32 trigonometry (no large-argument slow path => one basic block, so the
+// scheduler can interleave it with the Philox / FMA chains of a lone wave per SIMD).
+// Measured against f64: |err| <= 9e-8 (<= 1.7 ulp) on the stated ranges.
+// ---------------------------------------------------------------------------------------
+// sin(pi x), cos(pi x) for x in [0, 1] (scaled states s~): q = rint(2x), r = x - q/2 in [-1/4, 1/4]
+__device__ __forceinline__ void sincospi01(float x, float& sn, float& cs) {
+    const float q = rintf(x * 2.0f);
+    const float r = fmaf(q, -0.5f, x);                                  // exact
+    const float u = r * r;
+    float ps = 0.08100174367427826f;
+    ps = fmaf(ps, u, -0.5992020964622498f);
+    ps = fmaf(ps, u, 2.5501625537872314f);
+    ps = fmaf(ps, u, -5.167712688446045f);
+    ps = fmaf(ps, u, 3.1415927410125732f);
+    const float s = ps * r;                                             // sin(pi r)
+    float pc = 0.23132924735546112f;
+    pc = fmaf(pc, u, -1.335044503211975f);
+    pc = fmaf(pc, u, 4.058707237243652f);
+    pc = fmaf(pc, u, -4.934802055358887f);
+    const float c = fmaf(pc, u, 1.0f);                                  // cos(pi r)
+    const int qi = (int)q;                                              // 0, 1, 2
+    sn = (qi == 1) ? c : ((qi == 2) ? -s : s);
+    cs = (qi == 1) ? -s : ((qi == 2) ? -c : c);
+}
+// sin(x), cos(x) for |x| <= 100: Cody-Waite reduction by pi/2 (two-term, fma), polynomials on [-pi/4, pi/4]
+__device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
+    const float n = rintf(x * 0.6366197466850281f);
+    float r = fmaf(n, -1.5707963705062866f, x);
+    r = fmaf(n, 4.371138828673793e-08f, r);
+    const float u = r * r;
+    float ps = 2.715809387154877e-06f;
+    ps = fmaf(ps, u, -0.00019839033484458923f);
+    ps = fmaf(ps, u, 0.008333328180015087f);
+    ps = fmaf(ps, u, -0.1666666716337204f);
+    ps = fmaf(ps, u, 1.0f);
+    const float s = ps * r;
+    float pc = 2.4362980184378102e-05f;
+    pc = fmaf(pc, u, -0.001388643286190927f);
+    pc = fmaf(pc, u, 0.04166661202907562f);
+    pc = fmaf(pc, u, -0.5f);
+    const float c = fmaf(pc, u, 1.0f);
+    const int q = ((int)n) & 3;
+    sn = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
+    cs = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
+}
+__device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
+
 template <int DOMAIN> struct Domain;
 
 // MountainCar          rsrl_domains/src/mountain_car/discrete.rs:8-102
@@ -84,7 +132,7 @@ template <> struct Domain<0> {
     // update_state + dv (:58-65): v first, the NEW v moves x; no velocity reset at the left wall
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         const float act = (float)(a - 1);                              // ALL_ACTIONS [-1,0,1] (:22)
-        const float dv = 0.001f * act + -0.0025f * cosf(3.0f * s[0]);
+        const float dv = 0.001f * act + -0.0025f * cos_cw(3.0f * s[0]);
         const float v = clipf(-0.07f, s[1] + dv, 0.07f);
         const float x = clipf(-1.2f, s[0] + v, 0.6f);
         s[0] = x; s[1] = v;
@@ -135,7 +183,7 @@ template <> struct Domain<1> {
             constexpr float POLE_COM = 0.5f, POLE_MOMENT = 0.5f * 0.1f, TOTAL_MASS = 1.0f + 0.1f;
             const float dx = y[1], theta = y[2], dtheta = y[3];
             float sin_t, cos_t;
-            sincosf(theta, &sin_t, &cos_t);
+            sincos_cw(theta, sin_t, cos_t);
             const float z = (force + POLE_MOMENT * dtheta * dtheta * sin_t) / TOTAL_MASS;
             const float numer = G * sin_t - cos_t * z;
             const float denom = FOUR_THIRDS * POLE_COM - POLE_MOMENT * cos_t * cos_t;
@@ -164,7 +212,7 @@ template <> struct Domain<2> {
     __host__ __device__ static constexpr double hi_d(int i) { return -lo_d(i); }
     __device__ static __forceinline__ void reset(float (&s)[D]) { s[0] = s[1] = s[2] = s[3] = 0.0f; }   // :111-113
     __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) {                          // :56-58
-        return cosf(s[0]) + cosf(s[0] + s[1]) < -1.0f;
+        return cos_cw(s[0]) + cos_cw(s[0] + s[1]) < -1.0f;
     }
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         constexpr float PI_ = (float)kPi;
@@ -174,13 +222,13 @@ template <> struct Domain<2> {
             constexpr float PI_OVER_2 = (float)(kPi / 2.0);
             const float theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
             float sin_t2, cos_t2;
-            sincosf(theta2, &sin_t2, &cos_t2);
+            sincos_cw(theta2, sin_t2, cos_t2);
             const float d1 = M1 * LC1 * LC1 + M2 * (L1 * L1 + LC2 * LC2 + 2.0f * L1 * LC2 * cos_t2) + I1 + I2;
             const float d2 = M2 * (LC2 * LC2 + L1 * LC2 * cos_t2) + I2;
-            const float phi2 = M2 * LC2 * G * cosf(theta1 + theta2 - PI_OVER_2);
+            const float phi2 = M2 * LC2 * G * cos_cw(theta1 + theta2 - PI_OVER_2);
             const float phi1 = -1.0f * L1 * LC2 * dtheta2 * dtheta2 * sin_t2
                              - 2.0f * M2 * L1 * LC2 * dtheta2 * dtheta1 * sin_t2
-                             + (M1 * LC1 + M2 * L1) * G * cosf(theta1 - PI_OVER_2)
+                             + (M1 * LC1 + M2 * L1) * G * cos_cw(theta1 - PI_OVER_2)
                              + phi2;
             const float dd1 = (torque + d2 / d1 * phi1 - M2 * L1 * LC2 * dtheta1 * dtheta1 * sin_t2 - phi2)
                             / (M2 * LC2 * LC2 + I2 - d2 * d2 / d1);
@@ -366,7 +414,7 @@ struct FourierTables {
             constexpr float lo = (float)Dom::lo_d(d), hi = (float)Dom::hi_d(d);
             const float sc = (s[d] - lo) / (hi - lo);
             ct[d][0] = 1.0f; st[d][0] = 0.0f;
-            if constexpr (ORDER >= 1) sincospif(sc, &st[d][1], &ct[d][1]);
+            if constexpr (ORDER >= 1) sincospi01(sc, st[d][1], ct[d][1]);
             static_for<2, N1>([&](auto Nn) {
                 constexpr int n = Nn;
                 ct[d][n] = fmaf(-st[d][n - 1], st[d][1], ct[d][n - 1] * ct[d][1]);

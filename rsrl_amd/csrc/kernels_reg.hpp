@@ -67,27 +67,46 @@ __device__ __forceinline__ void block_stats_accumulate(DevStats* __restrict__ st
     }
 }
 
+// Dot products run as RSRL_DOT_SPLIT interleaved partial sums (acc_p takes the features f = p mod P in
+// ascending order; q = (acc0 + acc1) + (acc2 + acc3)): a lone wave per SIMD cannot hide the latency of
+// one 36-long dependent fma chain per action, 4 x 3 independent chains can.
+#ifndef RSRL_DOT_SPLIT
+#define RSRL_DOT_SPLIT 4
+#endif
+template <int P>
+__device__ __forceinline__ float combine_partials(const float (&acc)[P]) {
+    if constexpr (P == 1) return acc[0];
+    else if constexpr (P == 2) return acc[0] + acc[1];
+    else { static_assert(P == 4, "RSRL_DOT_SPLIT must be 1, 2 or 4"); return (acc[0] + acc[1]) + (acc[2] + acc[3]); }
+}
+
 // Q(s,.) = W^T phi(s) with phi in registers and W streamed from memory (learner-fastest layout)
 //   Function<(S,)>::evaluate for VectorLFA        fa/linear.rs:303-311
 template <int A, int F>
 __device__ __forceinline__ void q_from_mem(const float* __restrict__ W, int64_t stride, int64_t wi,
                                            const float (&phi)[F], float (&q)[A]) {
+    constexpr int P = RSRL_DOT_SPLIT;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float acc = 0.0f;
+        float acc[P];
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc = fmaf(phi[f], W[((int64_t)(b * F + f)) * stride + wi], acc);
-        q[b] = acc;
+        for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi[f], W[((int64_t)(b * F + f)) * stride + wi], acc[f % P]);
+        q[b] = combine_partials<P>(acc);
     }
 }
 template <int A, int F>
 __device__ __forceinline__ void q_from_reg(const float (&w)[A][F], const float (&phi)[F], float (&q)[A]) {
+    constexpr int P = RSRL_DOT_SPLIT;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
-        float acc = 0.0f;
+        float acc[P];
 #pragma unroll
-        for (int f = 0; f < F; ++f) acc = fmaf(phi[f], w[b][f], acc);
-        q[b] = acc;
+        for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi[f], w[b][f], acc[f % P]);
+        q[b] = combine_partials<P>(acc);
     }
 }
 template <int A>
@@ -107,10 +126,24 @@ __device__ __forceinline__ float select_a(const float (&q)[A], int a) {
 // The reference projects phi 4x per step (s, s', s, s'); here phi(s) and Q(s,.) are
 // carried over from the previous step (same W, same s => same values) and phi(s') is
 // projected once.  n_steps batch-steps per launch; W, phi(s), Q(s,.) live in VGPRs.
+//
+// Shape of the loop body (one wave per SIMD at N = 65 536, so single-wave ILP is what counts):
+//  * ALGO / POLICY are template parameters: no uniform branches splitting the body;
+//  * a TERMINAL transition needs no Q(s') (delta = r - Q(s,a)), so the projection slot is
+//    used for s0 instead: terminal resets cost nothing extra and do not diverge; only a
+//    step-cap truncation (needs both Q(s') and Q(s0)) takes the divergent slow path;
+//  * the loop is unrolled by two with ping-pong phi buffers (no phi(s) <- phi(s') moves).
 // store_col: n_steps == 1 only -- write back just the updated column (the 608 B/step
 // streaming formulation); otherwise all A columns are written once at the end.
 // ---------------------------------------------------------------------------------------
-template <int DOMAIN, int ORDER>
+#ifndef RSRL_RANK1_QPOST
+#define RSRL_RANK1_QPOST 0
+#endif
+#ifndef RSRL_K1_STORE_ALL
+#define RSRL_K1_STORE_ALL 1
+#endif
+
+template <int DOMAIN, int ORDER, int ALGO, int POLICY>
 __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int n_steps, int store_col,
                                                       DevStats* __restrict__ stats) {
     using Dom = Domain<DOMAIN>;
@@ -123,7 +156,10 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
     double sum_abs = 0.0, sum_r = 0.0;
 
     if (i < N) {
+        PolicyParams pol = c.pol; pol.kind = POLICY;
+        AlgoParams alg = c.alg; alg.kind = ALGO;
         const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
         float s[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
@@ -135,30 +171,33 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 #pragma unroll
             for (int f = 0; f < F; ++f) w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
 
-        float phi_s[F], q_s[A];
-        Bas::project(s, phi_s);
-        q_from_reg<A, F>(w, phi_s, q_s);
+        float phi_a[F], phi_b[F], q_s[A];
+        Bas::project(s, phi_a);
+        q_from_reg<A, F>(w, phi_a, q_s);
         int a_taken = a;
+        float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
 
-        for (int k = 0; k < n_steps; ++k) {
-            const uint64_t t = t0 + (uint64_t)k;
+        auto one_step = [&](const float (&phi_s)[F], float (&phi_n)[F], uint64_t t) {
             // ---- Domain::transition
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
             float r;
             const bool term = Dom::step(ns, a, r);
-            // ---- handle: delta with the PRE-update weights
-            float phi_n[F], q_n[A];
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) Dom::reset(ns);              // select, not a branch: phi/Q of s0 take the s' slot
+            float q_n[A];
             Bas::project(ns, phi_n);
             q_from_reg<A, F>(w, phi_n, q_n);
+            // ---- handle: delta with the PRE-update weights
             const float qsa = select_a<A>(q_s, a);
             U4 xin = U4{0, 0, 0, 0};
-            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
             // ---- Handler<StateActionUpdate>: W[:,a] += lr * e * phi(s)     fa/linear.rs:379-391
-            const float scale = c.alg.lr * e;
+            const float scale = alg.lr * e;
 #pragma unroll
             for (int b = 0; b < A; ++b) {
                 const float sb = (a == b) ? scale : 0.0f;
@@ -166,30 +205,49 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
                 for (int f = 0; f < F; ++f) w[b][f] = fmaf(sb, phi_s[f], w[b][f]);
             }
             a_taken = a;
-            // ---- policy.sample(s') with the UPDATED weights
+            // ---- policy.sample with the UPDATED weights (at s', or at s0 after a terminal transition)
+#if RSRL_RANK1_QPOST
+            {   // W changed by a rank-1 term in column a only: Q_post[a] = Q_pre[a] + scale * <phi(s), phi(s')>
+                constexpr int P = RSRL_DOT_SPLIT;
+                float dacc[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; ++f) dacc[f % P] = fmaf(phi_s[f], phi_n[f], dacc[f % P]);
+                const float dot = combine_partials<P>(dacc);
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
+            }
+#else
             q_from_reg<A, F>(w, phi_n, q_n);
-            const U4 x = draw(c.seed, gid, t, BLK_STEP);
-            int na = policy_sample<A>(c.pol, q_n, x);
-            ep += 1;
-            sum_abs += (double)fabsf(delta);
-            sum_r += (double)r;
-            if (term || (c.max_episode_steps > 0 && ep >= c.max_episode_steps)) {
-                n_ep += 1; n_trunc += term ? 0 : 1; sum_len += ep;
-                Dom::reset(ns);                                        // new episode: Domain::default()
+#endif
+            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            int na = policy_sample<A>(pol, q_n, x);
+            facc_abs += fabsf(delta);
+            facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {                           // step cap: Q(s') was needed above, now the new episode
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
                 Bas::project(ns, phi_n);
                 q_from_reg<A, F>(w, phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr);                 // fresh policy.sample(s0)
-                ep = 0;
+                na = policy_sample<A>(pol, q_n, xr);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
 #pragma unroll
-            for (int f = 0; f < F; ++f) phi_s[f] = phi_n[f];
-#pragma unroll
             for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
             a = na;
+        };
+
+        int k = 0;
+        for (; k + 1 < n_steps; k += 2) {
+            one_step(phi_a, phi_b, t0 + (uint64_t)k);
+            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
         }
+        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        sum_abs = (double)facc_abs; sum_r = (double)facc_r;
 
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
@@ -213,7 +271,149 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 
     // per-launch statistics: block-level reduction into this block's own slot (no atomics: a slot
     // has exactly one writer per launch, and launches are ordered on the ctx's stream)
-    block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// The single-step streaming kernel (K = 1): one launch = one batch-step, every learner's W
+// streamed from memory once -- the 608 B/env-step formulation:
+//   read  state 8 + action 4 + ep_step 4 + W 3*36*4 = 448 B,  write state 8 + action 4 + ep_step 4 + W[:,a] 144 B.
+// Compact on purpose: a cold launch is instruction-fetch bound, so W goes through ONE buffer
+// descriptor (SGPR row offset + 4*lane, no per-load 64-bit VALU address math), all 108 loads are
+// issued before any arithmetic, and only the touched column is kept/selected/stored.
+// Arithmetic is bit-identical to k_train_reg (same helpers, same op order).
+// Precondition (checked by the host): A*F*N*4 < 2^32.
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, int ORDER, int ALGO, int POLICY>
+__global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevStats* __restrict__ stats) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t N = c.n_envs;
+    const int64_t base = (int64_t)blockIdx.x * kBlock;                 // wave-uniform
+    const int64_t i = base + threadIdx.x;
+    const uint32_t row_bytes = (uint32_t)N * 4u;
+    const uint32_t total_bytes = (uint32_t)(A * F) * row_bytes - (uint32_t)base * 4u;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(c.W + base), 0, (int)total_bytes, 0x00020000);
+    const int voff = (int)threadIdx.x * 4;
+
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+
+    // all 108 loads in flight first (out-of-range lanes of the last block read in-bounds garbage or 0)
+    float wv[A][F];
+#pragma unroll
+    for (int b = 0; b < A; ++b)
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            wv[b][f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((uint32_t)(b * F + f) * row_bytes), 0));
+
+    if (i < N) {
+        PolicyParams pol = c.pol; pol.kind = POLICY;
+        AlgoParams alg = c.alg; alg.kind = ALGO;
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D], ns[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s[d] = c.state[(int64_t)d * N + i]; ns[d] = s[d]; }
+        const int a = c.action[i];
+        uint32_t ep = c.ep_step[i] + 1;
+        // ---- Domain::transition
+        float r;
+        const bool term = Dom::step(ns, a, r);
+        const bool trunc = !term && cap > 0 && ep >= cap;
+        if (term) Dom::reset(ns);
+        float phi_s[F], phi_n[F], q_n[A];
+        Bas::project(s, phi_s);
+        Bas::project(ns, phi_n);
+        U4 xin = U4{0, 0, 0, 0};
+        if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+        const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+        // ---- the touched column, Q(s,a) and Q(s',.) with the PRE-update weights
+        float wa[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            float v = wv[0][f];
+#pragma unroll
+            for (int b = 1; b < A; ++b) v = (a == b) ? wv[b][f] : v;
+            wa[f] = v;
+        }
+        constexpr int P = RSRL_DOT_SPLIT;
+        float qsa;
+        {
+            float acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi_s[f], wa[f], acc[f % P]);
+            qsa = combine_partials<P>(acc);
+        }
+        q_from_reg<A, F>(wv, phi_n, q_n);
+        float e;
+        const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        // ---- W[:,a] += lr * e * phi(s), written straight back to its column
+        const float scale = alg.lr * e;
+        const int col_off = (int)((uint32_t)(a * F) * row_bytes) + voff;
+#if RSRL_K1_STORE_ALL
+        // write every (action, feature) row as a FULL line (the untouched columns are rewritten unchanged)
+#pragma unroll
+        for (int f = 0; f < F; ++f) wa[f] = fmaf(scale, phi_s[f], wa[f]);
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float v = (a == b) ? wa[f] : wv[b][f];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, (int)((uint32_t)(b * F + f) * row_bytes), 0);
+            }
+        (void)col_off;
+#else
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            wa[f] = fmaf(scale, phi_s[f], wa[f]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, wa[f]), rs, col_off, (int)((uint32_t)f * row_bytes), 0);
+        }
+#endif
+        // ---- Q(s',.) with the UPDATED weights: only column a changed
+        {
+#if RSRL_RANK1_QPOST
+            float dacc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dacc[f % P] = fmaf(phi_s[f], phi_n[f], dacc[f % P]);
+            const float qa = fmaf(scale, combine_partials<P>(dacc), select_a<A>(q_n, a));
+#else
+            float acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi_n[f], wa[f], acc[f % P]);
+            const float qa = combine_partials<P>(acc);
+#endif
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
+        }
+        int na = policy_sample<A>(pol, q_n, x);
+        sum_abs = (double)fabsf(delta); sum_r = (double)r;
+        if (term) { n_ep = 1; sum_len = ep; ep = 0; }
+        if (trunc) {                               // step cap: new episode needs Q(s0) with the updated W
+            n_ep = 1; n_trunc = 1; sum_len = ep; ep = 0;
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int f = 0; f < F; ++f) wv[b][f] = (a == b) ? wa[f] : wv[b][f];
+            Dom::reset(ns);
+            Bas::project(ns, phi_n);
+            q_from_reg<A, F>(wv, phi_n, q_n);
+            const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+            na = policy_sample<A>(pol, q_n, xr);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+        c.action[i] = na;
+        c.ep_step[i] = ep;
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -356,9 +556,17 @@ __global__ __launch_bounds__(kBlock) void k_handle_reg(Common c, const float* __
     float phi_s[F], phi_n[F], q_n[A];
     Bas::project(s, phi_s);
     Bas::project(ns, phi_n);
-    float qsa = 0.0f;
+    float qsa;
+    {
+        constexpr int P = RSRL_DOT_SPLIT;
+        float acc[P];
 #pragma unroll
-    for (int f = 0; f < F; ++f) qsa = fmaf(phi_s[f], c.W[((int64_t)a * F + f) * c.w_stride + wi], qsa);
+        for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            acc[f % P] = fmaf(phi_s[f], c.W[((int64_t)a * F + f) * c.w_stride + wi], acc[f % P]);
+        qsa = combine_partials<P>(acc);
+    }
     q_from_mem<A, F>(c.W, c.w_stride, wi, phi_n, q_n);
     U4 xin = U4{0, 0, 0, 0};
     if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
@@ -376,10 +584,6 @@ __global__ __launch_bounds__(kBlock) void k_handle_reg(Common c, const float* __
         for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * phi_s[f]);
     }
     if (td_out) td_out[i] = delta;
-}
-__global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n) { W[j] += dW[j]; dW[j] = 0.0f; }
 }
 
 // Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states       lib.rs:448-479, :340
@@ -413,28 +617,6 @@ __global__ __launch_bounds__(kBlock) void k_rollout_reg(Common c, int64_t step_l
     }
     n_states[i] = (uint32_t)(steps + 1);
     if (total_reward) total_reward[i] = tot;
-}
-
-// get/set of one learner's weights as row-major f32[F][A] (ndarray (F, A))   params/mod.rs:116-134
-__global__ void k_weights_get(const float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, float* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= F * A) return;
-    const int f = j / A, b = j % A;
-    out[j] = W[((int64_t)(b * F + f)) * stride + wi];
-}
-__global__ void k_weights_set(float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, const float* __restrict__ in) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= F * A) return;
-    const int f = j / A, b = j % A;
-    W[((int64_t)(b * F + f)) * stride + wi] = in[j];
-}
-__global__ void k_weights_set_all(float* __restrict__ W, int64_t N, int F, int A, const float* __restrict__ in) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    for (int j = 0; j < F * A; ++j) {
-        const int f = j / A, b = j % A;
-        W[((int64_t)(b * F + f)) * N + i] = in[j];
-    }
 }
 
 }  // namespace rsrl

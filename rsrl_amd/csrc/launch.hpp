@@ -1,0 +1,29 @@
+// launch.hpp -- launchers of the fused train kernels, one translation unit per domain so the
+// (order x algo x policy) instantiations compile in parallel.
+#pragma once
+#include "kernels_reg.hpp"
+
+namespace rsrl {
+
+// returns false when no instantiation exists for (order, algo, policy)
+bool launch_train_reg_d0(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
+                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats);
+bool launch_train_reg_d1(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
+                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats);
+bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
+                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats);
+
+// chunk == -1 selects the single-step streaming kernel (k_step_reg)
+#define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
+    if (order == OR && algo == AL && policy == PO) {                                                        \
+        if (chunk == -1)                                                                                    \
+            hipLaunchKernelGGL((k_step_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats);              \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, chunk, store_col, stats); \
+        return true;                                                                                        \
+    }
+#define RSRL_TRAIN_POLICIES(DM, OR, AL) \
+    RSRL_TRAIN_CASE(DM, OR, AL, 0) RSRL_TRAIN_CASE(DM, OR, AL, 1) RSRL_TRAIN_CASE(DM, OR, AL, 2) RSRL_TRAIN_CASE(DM, OR, AL, 3)
+#define RSRL_TRAIN_ALGOS(DM, OR) RSRL_TRAIN_POLICIES(DM, OR, 0) RSRL_TRAIN_POLICIES(DM, OR, 1) RSRL_TRAIN_POLICIES(DM, OR, 2)
+
+}  // namespace rsrl

@@ -13,9 +13,39 @@
 #include <vector>
 
 #include "../../include/rsrl_hip.h"
-#include "kernels_reg.hpp"
+#include "launch.hpp"
 
 using namespace rsrl;
+
+namespace {
+__global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) { W[j] += dW[j]; dW[j] = 0.0f; }
+}
+
+// get/set of one learner's weights as row-major f32[F][A] (ndarray (F, A))   params/mod.rs:116-134
+__global__ void k_weights_get(const float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F * A) return;
+    const int f = j / A, b = j % A;
+    out[j] = W[((int64_t)(b * F + f)) * stride + wi];
+}
+__global__ void k_weights_set(float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, const float* __restrict__ in) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F * A) return;
+    const int f = j / A, b = j % A;
+    W[((int64_t)(b * F + f)) * stride + wi] = in[j];
+}
+__global__ void k_weights_set_all(float* __restrict__ W, int64_t N, int F, int A, const float* __restrict__ in) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    for (int j = 0; j < F * A; ++j) {
+        const int f = j / A, b = j % A;
+        W[((int64_t)(b * F + f)) * N + i] = in[j];
+    }
+}
+
+}  // namespace
 
 // ------------------------------------------------------------------------------- errors
 static thread_local std::string g_last_error;
@@ -523,19 +553,29 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
     if (c->w_stride == 1) return fail(RSRL_HIP_EINVAL, "shared-W training not supported yet");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
+    DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
+    if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
     const Common k = make_common(c);
     const int64_t spl = c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256;
+    // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
+    const bool stream_k1 = spl == 1 && (uint64_t)c->A * c->F * (uint64_t)c->cfg.n_envs * 4ull < (1ull << 32);
     int64_t done = 0;
     while (done < n_steps) {
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
-        const int store_col = (chunk == 1 && c->cfg.steps_per_launch == 1) ? 1 : 0;
+        const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
         TRY(timing_begin(c));
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_train_reg<DM, OR>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, c->t, chunk, store_col, c->d_stats); \
-        c->kernel_name = "k_train_reg"; _done = true; }
-        DISPATCH_REG(c, X);
-#undef X
+        {
+            const dim3 g(grid_for(k.n_envs)), b(kBlock);
+            const int kchunk = stream_k1 ? -1 : chunk;
+            bool ok;
+            switch (c->cfg.domain) {
+            case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            }
+            if (!ok) return fail(RSRL_HIP_EINVAL, "no fused kernel for domain %d order %d", c->cfg.domain, c->cfg.order);
+            c->kernel_name = stream_k1 ? "k_step_reg" : "k_train_reg";
+        }
         KCHECK();
         TRY(timing_end(c));
         c->t += (uint64_t)chunk;
