@@ -28,6 +28,7 @@ struct Common {
     uint32_t* ep_step;     // [N]
     float* W;              // [A][F][Nw]
     int64_t w_stride;      // Nw: n_envs (per-env) or 1 (shared)
+    int shared;            // one approximator for all learners (weight_mode == RSRL_W_SHARED)
 };
 
 constexpr int kBlock = 256;
@@ -420,77 +421,6 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
 // Trait-granular kernels (drop-in use, fine-grained parity).  W is read from memory.
 // ---------------------------------------------------------------------------------------
 
-// per-episode Domain::default() + initial policy.sample     examples/q_learning.rs:37-38
-template <int DOMAIN, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_reset_reg(Common c, uint64_t t) {
-    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
-    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_envs) return;
-    float s[D]; Dom::reset(s);
-    float phi[F], q[A];
-    Bas::project(s, phi);
-    q_from_mem<A, F>(c.W, c.w_stride, c.w_stride == 1 ? 0 : i, phi, q);
-    const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
-#pragma unroll
-    for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
-    c.action[i] = policy_sample<A>(c.pol, q, x);
-    c.ep_step[i] = 0;
-}
-
-// basis.project: phi f32[F][M]
-template <int DOMAIN, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_project_reg(const float* __restrict__ states, int64_t M,
-                                                        float* __restrict__ phi_out) {
-    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
-    constexpr int D = Dom::D, F = Bas::F;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    float s[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * M + i];
-    float phi[F];
-    Bas::project(s, phi);
-#pragma unroll
-    for (int f = 0; f < F; ++f) phi_out[(int64_t)f * M + i] = phi[f];
-}
-
-enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4 };
-
-// Function<(S,)>::evaluate / Enumerable::find_max / Policy::{sample,mode} / policy probabilities
-//   fa/linear.rs:303-311, core.rs:96-105, policies/mod.rs:65-78
-template <int DOMAIN, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_qop_reg(Common c, int op, const float* __restrict__ states, int64_t M,
-                                                    uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
-    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
-    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    float s[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * M + i];
-    float phi[F], q[A];
-    Bas::project(s, phi);
-    q_from_mem<A, F>(c.W, c.w_stride, c.w_stride == 1 ? 0 : i, phi, q);
-    if (op == QOP_EVALUATE) {
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * M + i] = q[b];
-    } else if (op == QOP_FIND_MAX) {
-        float v; const int bi = find_max<A>(q, v);
-        if (iout) iout[i] = bi;
-        if (fout) fout[i] = v;
-    } else if (op == QOP_SAMPLE) {
-        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
-        iout[i] = policy_sample<A>(c.pol, q, x);
-    } else if (op == QOP_MODE) {
-        iout[i] = policy_mode<A>(c.pol, q);
-    } else {
-        float p[A]; policy_probs<A>(c.pol, q, p);
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * M + i] = p[b];
-    }
-}
-
 // Domain::transition on the ctx's envs      rsrl_domains/src/lib.rs:436-446
 template <int DOMAIN>
 __global__ __launch_bounds__(kBlock) void k_domain_step(Common c, const int32_t* __restrict__ actions,
@@ -530,93 +460,6 @@ __global__ __launch_bounds__(kBlock) void k_domain_reset(Common c, const uint8_t
 #pragma unroll
     for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
     c.ep_step[i] = 0;
-}
-
-// Handler<&Transition>::handle on caller-supplied transitions (teacher forcing / drop-in use).
-// per-env mode: learner m's column is updated in place.
-// shared mode : phase 0 accumulates lr*e*phi(s) into dW (f32 atomics), phase 1 (k_apply_dw)
-//               applies it -- all M errors are computed against the same W_t.
-template <int DOMAIN, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_handle_reg(Common c, const float* __restrict__ from, const int32_t* __restrict__ act,
-                                                       const float* __restrict__ rew, const float* __restrict__ to,
-                                                       const uint8_t* __restrict__ termf, int64_t M, uint64_t t,
-                                                       float* __restrict__ td_out, float* __restrict__ dW) {
-    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
-    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const bool shared = c.w_stride == 1;
-    const int64_t wi = shared ? 0 : i;
-    float s[D], ns[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * M + i]; ns[d] = to[(int64_t)d * M + i]; }
-    const int a = act[i];
-    const float r = rew[i];
-    const bool term = termf[i] != 0;
-    float phi_s[F], phi_n[F], q_n[A];
-    Bas::project(s, phi_s);
-    Bas::project(ns, phi_n);
-    float qsa;
-    {
-        constexpr int P = RSRL_DOT_SPLIT;
-        float acc[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[p] = 0.0f;
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-            acc[f % P] = fmaf(phi_s[f], c.W[((int64_t)a * F + f) * c.w_stride + wi], acc[f % P]);
-        qsa = combine_partials<P>(acc);
-    }
-    q_from_mem<A, F>(c.W, c.w_stride, wi, phi_n, q_n);
-    U4 xin = U4{0, 0, 0, 0};
-    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
-    float e;
-    const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
-    const float scale = c.alg.lr * e;
-    if (!shared) {
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            const int64_t idx = ((int64_t)a * F + f) * c.w_stride + wi;
-            c.W[idx] = fmaf(scale, phi_s[f], c.W[idx]);
-        }
-    } else {
-#pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * phi_s[f]);
-    }
-    if (td_out) td_out[i] = delta;
-}
-
-// Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states       lib.rs:448-479, :340
-template <int DOMAIN, int ORDER>
-__global__ __launch_bounds__(kBlock) void k_rollout_reg(Common c, int64_t step_limit, uint32_t* __restrict__ n_states,
-                                                        float* __restrict__ total_reward) {
-    using Dom = Domain<DOMAIN>; using Bas = FourierReg<DOMAIN, ORDER>;
-    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
-    const int64_t N = c.n_envs;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const bool shared = c.w_stride == 1;
-    float w[A][F];
-#pragma unroll
-    for (int b = 0; b < A; ++b)
-#pragma unroll
-        for (int f = 0; f < F; ++f) w[b][f] = c.W[((int64_t)(b * F + f)) * c.w_stride + (shared ? 0 : i)];
-    float s[D]; Dom::reset(s);
-    float phi[F], q[A], r, tot = 0.0f;
-    Bas::project(s, phi); q_from_reg<A, F>(w, phi, q);
-    int a = policy_mode<A>(c.pol, q);
-    bool term = Dom::step(s, a, r);                  // the first step is taken eagerly (lib.rs:457-459)
-    int64_t steps = 0;
-    while (steps < step_limit - 1) {
-        steps += 1; tot += r;
-        if (term) break;                             // successors() stops after a Terminal observation
-        if (steps >= step_limit - 1) break;
-        Bas::project(s, phi); q_from_reg<A, F>(w, phi, q);
-        a = policy_mode<A>(c.pol, q);
-        term = Dom::step(s, a, r);
-    }
-    n_states[i] = (uint32_t)(steps + 1);
-    if (total_reward) total_reward[i] = tot;
 }
 
 }  // namespace rsrl

@@ -1,0 +1,443 @@
+// models.hpp -- the two function-approximator "models" behind the trait-granular and shared-W kernels.
+//
+// A Model bundles a basis with its weight layout and gives the kernels four operations:
+//   features(s)            basis.project(s)                                (lfa Basis::project)
+//   q_all / q_index        Function<(S,)>::evaluate / Enumerable::evaluate_index   fa/linear.rs:303-311,360-362
+//   update                 Handler<StateActionUpdate>: W[:,a] += scale*phi  fa/linear.rs:379-391 (per-env weights)
+//   accumulate             the same term added to a delta buffer            (shared weights)
+//
+//   FourierModel<DOMAIN, ORDER>  dense features in VGPRs; W f32[A][F][Nw], learner index fastest
+//   TileModel<DOMAIN, T>         T active indices (value 1.0);  W f32[Nw][F][A] (the reference's (F, A) rows per learner)
+#pragma once
+
+#include "kernels_reg.hpp"
+
+namespace rsrl {
+
+// geometry of the basis that is not a template parameter
+struct BasisGeom { int F; int tiles_per_dim; };
+
+template <int DOMAIN, int ORDER>
+struct FourierModel {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    static constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    static constexpr bool kDense = true;
+    struct Feat { float phi[F]; };
+    __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom&, Feat& ft) { Bas::project(s, ft.phi); }
+    __device__ static __forceinline__ int64_t widx(const Common& c, int64_t wi, int b, int f) {
+        return ((int64_t)(b * F + f)) * c.w_stride + wi;
+    }
+    __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom&, const Feat& ft, float (&q)[A]) {
+        q_from_mem<A, F>(c.W, c.w_stride, wi, ft.phi, q);
+    }
+    __device__ static __forceinline__ float q_index(const Common& c, int64_t wi, const BasisGeom&, const Feat& ft, int a) {
+        constexpr int P = RSRL_DOT_SPLIT;
+        float acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f % P] = fmaf(ft.phi[f], c.W[widx(c, wi, a, f)], acc[f % P]);
+        return combine_partials<P>(acc);
+    }
+    __device__ static __forceinline__ void update(const Common& c, int64_t wi, const BasisGeom&, const Feat& ft, int a, float scale) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t j = widx(c, wi, a, f);
+            c.W[j] = fmaf(scale, ft.phi[f], c.W[j]);
+        }
+    }
+    // dW has the shared layout [A][F]
+    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * ft.phi[f]);
+    }
+};
+
+// Dense grid tile coder (the build's deterministic definition; lfa's TileCoding is hashed
+// and never instantiated by the reference).  fp32, non-fused ops, identical to oracle/rsrl_oracle.c:orc_tile_indices
+// => indices are bit-exact:
+//   s~_i = (s_i - lo_i)/(hi_i - lo_i);  u_i = s~_i*(B-1);  off_i(t) = ((t*(2i+1)) mod T)/T
+//   cell_i = clamp((int)floorf(u_i + off_i), 0, B-1);  idx(t) = t*B^D + sum_i cell_i*B^i
+template <int DOMAIN, int T>
+struct TileModel {
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = Dom::D, A = Dom::A;
+    static constexpr bool kDense = false;
+    struct Feat { int idx[T]; };
+    __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
+        const int B = g.tiles_per_dim;
+        int BD = 1;
+#pragma unroll
+        for (int i = 0; i < D; ++i) BD *= B;
+        float u[D];
+        static_for<0, D>([&](auto Ii) {
+            constexpr int i = Ii;
+            constexpr float lo = (float)Dom::lo_d(i), hi = (float)Dom::hi_d(i);
+            const float num = s[i] - lo;
+            const float den = hi - lo;
+            const float sc = num / den;
+            u[i] = sc * (float)(B - 1);
+        });
+        static_for<0, T>([&](auto Tt) {
+            constexpr int t = Tt;
+            int lin = 0, stride = 1;
+            static_for<0, D>([&](auto Ii) {
+                constexpr int i = Ii;
+                constexpr float off = (float)((t * (2 * i + 1)) % T) / (float)T;
+                const float v = u[i] + off;
+                int cell = (int)floorf(v);
+                cell = cell < 0 ? 0 : cell;
+                cell = cell > B - 1 ? B - 1 : cell;
+                lin += cell * stride; stride *= B;
+            });
+            ft.idx[t] = t * BD + lin;
+        });
+    }
+    __device__ static __forceinline__ int64_t widx(const Common& c, int64_t wi, const BasisGeom& g, int f, int b) {
+        return (wi * (int64_t)g.F + f) * A + b;
+    }
+    __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int b = 0; b < A; ++b) q[b] = q[b] + c.W[widx(c, wi, g, ft.idx[t], b)];      // acc + w, tilings in order
+    }
+    __device__ static __forceinline__ float q_index(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc = acc + c.W[widx(c, wi, g, ft.idx[t], a)];
+        return acc;
+    }
+    __device__ static __forceinline__ void update(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a, float scale) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) c.W[widx(c, wi, g, ft.idx[t], a)] += scale;               // indices of distinct tilings never collide
+    }
+    // dW has the shared layout [F][A]
+    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) atomicAdd(&dW[(int64_t)ft.idx[t] * A + a], scale);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// generic trait-granular kernels
+// ---------------------------------------------------------------------------------------
+template <class M>
+__device__ __forceinline__ void load_state(const float* __restrict__ states, int64_t M_, int64_t i, float (&s)[M::D]) {
+#pragma unroll
+    for (int d = 0; d < M::D; ++d) s[d] = states[(int64_t)d * M_ + i];
+}
+
+// per-episode Domain::default() + initial policy.sample     examples/q_learning.rs:37-38
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_reset(Common c, BasisGeom g, uint64_t t) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_envs) return;
+    float s[D]; M::Dom::reset(s);
+    typename M::Feat ft; float q[A];
+    M::features(s, g, ft);
+    M::q_all(c, c.shared ? 0 : i, g, ft, q);
+    const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
+#pragma unroll
+    for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
+    c.action[i] = policy_sample<A>(c.pol, q, x);
+    c.ep_step[i] = 0;
+}
+
+enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4, QOP_FEATURES = 5 };
+
+// Function<(S,)>::evaluate / Enumerable::find_max / Policy::{sample,mode} / policy probabilities / basis.project
+//   fa/linear.rs:303-311, core.rs:96-105, policies/mod.rs:65-78
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_qop(Common c, BasisGeom g, int op, const float* __restrict__ states, int64_t Mn,
+                                                uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    float s[D]; load_state<M>(states, Mn, i, s);
+    typename M::Feat ft;
+    M::features(s, g, ft);
+    if (op == QOP_FEATURES) {
+        if constexpr (M::kDense) {
+#pragma unroll
+            for (int f = 0; f < M::F; ++f) fout[(int64_t)f * Mn + i] = ft.phi[f];
+        } else {
+#pragma unroll
+            for (int t = 0; t < (int)(sizeof(ft.idx) / sizeof(int)); ++t) iout[(int64_t)t * Mn + i] = ft.idx[t];
+        }
+        return;
+    }
+    float q[A];
+    M::q_all(c, c.shared ? 0 : i, g, ft, q);
+    if (op == QOP_EVALUATE) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
+    } else if (op == QOP_FIND_MAX) {
+        float v; const int bi = find_max<A>(q, v);
+        if (iout) iout[i] = bi;
+        if (fout) fout[i] = v;
+    } else if (op == QOP_SAMPLE) {
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+        iout[i] = policy_sample<A>(c.pol, q, x);
+    } else if (op == QOP_MODE) {
+        iout[i] = policy_mode<A>(c.pol, q);
+    } else {
+        float p[A]; policy_probs<A>(c.pol, q, p);
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
+    }
+}
+
+// Handler<&Transition>::handle on caller-supplied transitions (teacher forcing / drop-in use).
+// per-env weights: learner m's column is updated in place.
+// shared weights : lr*e*phi(s) is accumulated into dW; k_apply_dw then applies it -- all M errors are
+//                  computed against the same W_t (synchronous mini-batch rule).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const float* __restrict__ from, const int32_t* __restrict__ act,
+                                                   const float* __restrict__ rew, const float* __restrict__ to,
+                                                   const uint8_t* __restrict__ termf, int64_t Mn, uint64_t t,
+                                                   float* __restrict__ td_out, float* __restrict__ dW) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    const bool shared = c.shared != 0;
+    const int64_t wi = shared ? 0 : i;
+    float s[D], ns[D];
+    load_state<M>(from, Mn, i, s);
+    load_state<M>(to, Mn, i, ns);
+    const int a = act[i];
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    typename M::Feat fs, fn;
+    M::features(s, g, fs);
+    M::features(ns, g, fn);
+    const float qsa = M::q_index(c, wi, g, fs, a);
+    float q_n[A];
+    M::q_all(c, wi, g, fn, q_n);
+    U4 xin = U4{0, 0, 0, 0};
+    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
+    float e;
+    const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+    const float scale = c.alg.lr * e;
+    if (!shared) M::update(c, wi, g, fs, a, scale);
+    else M::accumulate(dW, g, fs, a, scale);
+    if (td_out) td_out[i] = delta;
+}
+
+// Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states, weights read from memory      lib.rs:448-479, :340
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64_t step_limit, uint32_t* __restrict__ n_states,
+                                                    float* __restrict__ total_reward) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.n_envs) return;
+    const int64_t wi = c.shared ? 0 : i;
+    float s[D]; M::Dom::reset(s);
+    typename M::Feat ft; float q[A], r, tot = 0.0f;
+    M::features(s, g, ft); M::q_all(c, wi, g, ft, q);
+    int a = policy_mode<A>(c.pol, q);
+    bool term = M::Dom::step(s, a, r);               // the first step is taken eagerly (lib.rs:457-459)
+    int64_t steps = 0;
+    while (steps < step_limit - 1) {
+        steps += 1; tot += r;
+        if (term) break;                             // successors() stops after a Terminal observation
+        if (steps >= step_limit - 1) break;
+        M::features(s, g, ft); M::q_all(c, wi, g, ft, q);
+        a = policy_mode<A>(c.pol, q);
+        term = M::Dom::step(s, a, r);
+    }
+    n_states[i] = (uint32_t)(steps + 1);
+    if (total_reward) total_reward[i] = tot;
+}
+
+// ---------------------------------------------------------------------------------------
+// Driver loop, generic form: weights stay in memory.  Used for
+//   * tile coding with per-learner tables (256 KiB per learner at 8 x 8^4 x 2: cannot live in registers);
+//   * shared weights (both bases): phase A / apply / phase C per batch-step, because every learner's error is
+//     taken against the same W_t and every learner then samples with the same W_{t+1}.
+// ---------------------------------------------------------------------------------------
+
+// per-learner weights, n_steps per launch, W in memory (no cross-learner dependence => fully fused)
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D]; load_state<M>(c.state, N, i, s);
+        int a = c.action[i];
+        uint32_t ep = c.ep_step[i];
+        typename M::Feat fs, fn;
+        M::features(s, g, fs);
+        float facc_abs = 0.0f, facc_r = 0.0f;
+        for (int k = 0; k < n_steps; ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = M::Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) M::Dom::reset(ns);
+            M::features(ns, g, fn);
+            const float qsa = M::q_index(c, i, g, fs, a);
+            float q_n[A];
+            M::q_all(c, i, g, fn, q_n);
+            U4 xin = U4{0, 0, 0, 0};
+            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            M::update(c, i, g, fs, a, c.alg.lr * e);
+            M::q_all(c, i, g, fn, q_n);                              // UPDATED weights
+            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            int na = policy_sample<A>(c.pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                M::Dom::reset(ns);
+                M::features(ns, g, fn);
+                M::q_all(c, i, g, fn, q_n);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(c.pol, q_n, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+            fs = fn;
+            a = na;
+        }
+        sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = ep;
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// wave64 sum via DPP (row_shr 1,2,4,8 then row_bcast 15 / 31); the total lands in lane 63
+#define RSRL_DPP_ADD(v, ctrl, row_mask) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp_to_lane63(float v) {
+    RSRL_DPP_ADD(v, 0x111, 0xf);   // row_shr:1
+    RSRL_DPP_ADD(v, 0x112, 0xf);   // row_shr:2
+    RSRL_DPP_ADD(v, 0x114, 0xf);   // row_shr:4
+    RSRL_DPP_ADD(v, 0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row total
+    RSRL_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    RSRL_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    return v;
+}
+
+// shared weights, phase A: transition + TD error against W_t + the learner's term lr*e*phi(s) of the
+// mini-batch delta.  The env state becomes s'; flags[i] bit0 = terminal, bit1 = truncated (phase C).
+//   dense basis : block-level reduction (DPP wave sums -> LDS -> one row of `partials` per block, fixed
+//                 order, no atomics => bitwise reproducible); k_dw_finalize sums the rows in block order.
+//   tile coding : f32 atomics straight into the dense delta table (sparse, 2*T entries per learner).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint64_t t, float* __restrict__ dW,
+                                                     float* __restrict__ partials, uint8_t* __restrict__ flags,
+                                                     DevStats* __restrict__ stats) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    typename M::Feat fs;
+    int a = 0;
+    float scale = 0.0f;
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D], ns[D];
+        load_state<M>(c.state, N, i, s);
+#pragma unroll
+        for (int d = 0; d < D; ++d) ns[d] = s[d];
+        a = c.action[i];
+        float r;
+        const bool term = M::Dom::step(ns, a, r);
+        const uint32_t ep = c.ep_step[i] + 1;
+        const bool trunc = !term && cap > 0 && ep >= cap;
+        typename M::Feat fn;
+        M::features(s, g, fs);
+        M::features(ns, g, fn);
+        const float qsa = M::q_index(c, 0, g, fs, a);
+        float q_n[A];
+        M::q_all(c, 0, g, fn, q_n);
+        U4 xin = U4{0, 0, 0, 0};
+        if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+        float e;
+        const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+        scale = c.alg.lr * e;
+        if constexpr (!M::kDense) M::accumulate(dW, g, fs, a, scale);
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+        c.ep_step[i] = ep;
+        flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+        sum_abs = (double)fabsf(delta); sum_r = (double)r;
+        if (term || trunc) { n_ep = 1; n_trunc = trunc ? 1 : 0; sum_len = ep; }
+    } else {
+        if constexpr (M::kDense) {
+#pragma unroll
+            for (int f = 0; f < M::F; ++f) fs.phi[f] = 0.0f;
+        }
+    }
+    if constexpr (M::kDense) {
+        constexpr int F = M::F, NW = kBlock / 64;
+        __shared__ float wave_part[NW][A * F];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            const float sb = (a == b) ? scale : 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const float tot = wave_sum_dpp_to_lane63(sb * fs.phi[f]);
+                if (lane == 63) wave_part[wave][b * F + f] = tot;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < A * F) {
+            float acc = wave_part[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) acc += wave_part[w][threadIdx.x];
+            partials[(int64_t)blockIdx.x * (A * F) + threadIdx.x] = acc;
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// shared weights, phase C (after W_{t+1} = W_t + dW): policy.sample with the updated weights; finished
+// episodes restart from Domain::default() with a fresh sample.
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_shared_c(Common c, BasisGeom g, uint64_t t, const uint8_t* __restrict__ flags) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t gid = (uint32_t)(c.env_offset + i);
+    const bool done = flags[i] != 0;
+    float s[D];
+    if (done) {
+        M::Dom::reset(s);
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.ep_step[i] = 0;
+    } else {
+        load_state<M>(c.state, N, i, s);
+    }
+    typename M::Feat ft; float q[A];
+    M::features(s, g, ft);
+    M::q_all(c, 0, g, ft, q);
+    const U4 x = draw(c.seed, gid, t, done ? BLK_RESET : BLK_STEP);
+    c.action[i] = policy_sample<A>(c.pol, q, x);
+}
+
+}  // namespace rsrl

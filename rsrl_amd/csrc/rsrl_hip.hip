@@ -14,6 +14,7 @@
 
 #include "../../include/rsrl_hip.h"
 #include "launch.hpp"
+#include "models.hpp"
 
 using namespace rsrl;
 
@@ -24,27 +25,34 @@ __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n)
 }
 
 // get/set of one learner's weights as row-major f32[F][A] (ndarray (F, A))   params/mod.rs:116-134
-__global__ void k_weights_get(const float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, float* __restrict__ out) {
+// device layouts: Fourier W[A][F][Nw] (learner fastest); tile coding W[Nw][F][A]
+__device__ __forceinline__ int64_t w_index(bool tile, int64_t stride, int64_t wi, int F, int A, int f, int b) {
+    return tile ? (wi * (int64_t)F + f) * A + b : ((int64_t)(b * F + f)) * stride + wi;
+}
+__global__ void k_weights_get(const float* __restrict__ W, bool tile, int64_t stride, int64_t wi, int F, int A, float* __restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F * A) return;
-    const int f = j / A, b = j % A;
-    out[j] = W[((int64_t)(b * F + f)) * stride + wi];
+    out[j] = W[w_index(tile, stride, wi, F, A, j / A, j % A)];
 }
-__global__ void k_weights_set(float* __restrict__ W, int64_t stride, int64_t wi, int F, int A, const float* __restrict__ in) {
+__global__ void k_weights_set(float* __restrict__ W, bool tile, int64_t stride, int64_t wi, int F, int A, const float* __restrict__ in) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= F * A) return;
-    const int f = j / A, b = j % A;
-    W[((int64_t)(b * F + f)) * stride + wi] = in[j];
+    W[w_index(tile, stride, wi, F, A, j / A, j % A)] = in[j];
 }
-__global__ void k_weights_set_all(float* __restrict__ W, int64_t N, int F, int A, const float* __restrict__ in) {
+// grid.x covers the learners, grid.y strides over the F*A weights
+__global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, int F, int A, const float* __restrict__ in) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    for (int j = 0; j < F * A; ++j) {
-        const int f = j / A, b = j % A;
-        W[((int64_t)(b * F + f)) * N + i] = in[j];
-    }
+    for (int j = blockIdx.y; j < F * A; j += gridDim.y) W[w_index(tile, N, i, F, A, j / A, j % A)] = in[j];
 }
-
+// shared-W dense basis: dW[j] = sum over blocks of partials[blk][j], ascending block order (reproducible)
+__global__ void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc = 0.0f;
+    for (int b = 0; b < n_blocks; ++b) acc += partials[(int64_t)b * n + j];
+    dW[j] = acc;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------- errors
@@ -75,6 +83,9 @@ struct rsrl_hip_ctx {
     bool own_stream = false;
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
+    float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
+    uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
+    size_t w_elems = 0; size_t dw_elems = 0;
     int64_t w_stride = 0;
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
     size_t n_stat_slots = 0;
@@ -98,31 +109,45 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.alg.kind = c->cfg.algo; k.alg.gamma = (float)c->cfg.gamma; k.alg.lr = (float)c->cfg.lr;
     k.alg.alpha = (float)c->cfg.alpha;
     k.max_episode_steps = c->cfg.max_episode_steps;
-    k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride;
+    k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
     return k;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
-// ---- (domain, order) -> template instantiation -------------------------------------------
-// register family: F = (order+1)^D <= 36 features per learner held in VGPRs
-#define RSRL_REG_CASES(X)                                                             \
-    X(0, 1) X(0, 2) X(0, 3) X(0, 4) X(0, 5)                                           \
-    X(1, 1) X(2, 1)
+// ---- (basis, domain, parameter) -> Model type ---------------------------------------------------
+// Fourier register family: F = (order+1)^D <= 36 features per learner held in VGPRs.
+// Tile coding: T tilings as a template parameter (indices in VGPRs), tiles_per_dim at run time.
+#define RSRL_MODELS(X)                                                                       \
+    X((FourierModel<0, 1>), RSRL_FOURIER, 0, 1) X((FourierModel<0, 2>), RSRL_FOURIER, 0, 2)  \
+    X((FourierModel<0, 3>), RSRL_FOURIER, 0, 3) X((FourierModel<0, 4>), RSRL_FOURIER, 0, 4)  \
+    X((FourierModel<0, 5>), RSRL_FOURIER, 0, 5)                                              \
+    X((FourierModel<1, 1>), RSRL_FOURIER, 1, 1) X((FourierModel<2, 1>), RSRL_FOURIER, 2, 1)  \
+    X((TileModel<0, 4>), RSRL_TILE_CODING, 0, 4) X((TileModel<0, 8>), RSRL_TILE_CODING, 0, 8) X((TileModel<0, 16>), RSRL_TILE_CODING, 0, 16) \
+    X((TileModel<1, 4>), RSRL_TILE_CODING, 1, 4) X((TileModel<1, 8>), RSRL_TILE_CODING, 1, 8) X((TileModel<1, 16>), RSRL_TILE_CODING, 1, 16) \
+    X((TileModel<2, 4>), RSRL_TILE_CODING, 2, 4) X((TileModel<2, 8>), RSRL_TILE_CODING, 2, 8) X((TileModel<2, 16>), RSRL_TILE_CODING, 2, 16)
 
-static bool reg_supported(int domain, int order) {
-#define X(DM, OR) if (domain == DM && order == OR) return true;
-    RSRL_REG_CASES(X)
+template <class T> struct Tag { using type = T; };
+#define RSRL_UNPAREN(...) __VA_ARGS__
+static bool model_match(const rsrl_hip_config& cfg, int basis, int domain, int param) {
+    return cfg.basis == basis && cfg.domain == domain && (basis == RSRL_FOURIER ? cfg.order : cfg.n_tilings) == param;
+}
+static bool model_supported(const rsrl_hip_config& cfg) {
+#define X(TYPE, BS, DM, P) if (model_match(cfg, BS, DM, P)) return true;
+    RSRL_MODELS(X)
 #undef X
     return false;
 }
-
-#define DISPATCH_REG(ctx, STMT)                                                                  \
-    do {                                                                                         \
-        bool _done = false;                                                                      \
-        RSRL_REG_CASES(STMT)                                                                     \
-        if (!_done) return fail(RSRL_HIP_EINVAL, "no kernel for domain %d order %d", (ctx)->cfg.domain, (ctx)->cfg.order); \
-    } while (0)
+// calls fn(Tag<Model>{}) for the ctx's model; false if none matches
+template <class Fn>
+static bool for_model(const rsrl_hip_ctx* c, Fn&& fn) {
+#define X(TYPE, BS, DM, P) if (model_match(c->cfg, BS, DM, P)) { fn(Tag<RSRL_UNPAREN TYPE>{}); return true; }
+    RSRL_MODELS(X)
+#undef X
+    return false;
+}
+static BasisGeom make_geom(const rsrl_hip_ctx* c) { return BasisGeom{c->F, c->cfg.tiles_per_dim}; }
+#define NO_MODEL(c) fail(RSRL_HIP_EINVAL, "no kernel for basis %d domain %d order %d tilings %d", (c)->cfg.basis, (c)->cfg.domain, (c)->cfg.order, (c)->cfg.n_tilings)
 
 // ---- host/device pointer staging ---------------------------------------------------------
 static bool is_device_ptr(const void* p) {
@@ -205,6 +230,8 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->ep_step) (void)hipFree(c->ep_step);
     if (c->W) (void)hipFree(c->W);
     if (c->dW) (void)hipFree(c->dW);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->flags) (void)hipFree(c->flags);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -230,12 +257,18 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
     if (cfg->weight_dtype != RSRL_W_F32) return fail(RSRL_HIP_EINVAL, "weight dtype %d not supported yet", cfg->weight_dtype);
     if (cfg->basis == RSRL_FOURIER) {
-        if (!reg_supported(cfg->domain, cfg->order))
-            return fail(RSRL_HIP_EINVAL, "Fourier order %d on domain %d not supported yet", cfg->order, cfg->domain);
+        if (cfg->order < 1) return fail(RSRL_HIP_EINVAL, "Fourier order must be >= 1");
         c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
+    } else if (cfg->basis == RSRL_TILE_CODING) {
+        if (cfg->tiles_per_dim < 1 || cfg->tiles_per_dim > 64) return fail(RSRL_HIP_EINVAL, "tiles_per_dim must be in [1, 64]");
+        int64_t cells = 1; for (int i = 0; i < c->D; ++i) cells *= cfg->tiles_per_dim;
+        if (cells * cfg->n_tilings > (int64_t)1 << 30) return fail(RSRL_HIP_EINVAL, "tile table too large");
+        c->F = (int)(cells * cfg->n_tilings);
     } else {
-        return fail(RSRL_HIP_EINVAL, "basis %d not supported yet", cfg->basis);
+        return fail(RSRL_HIP_EINVAL, "unknown basis %d", cfg->basis);
     }
+    if (!model_supported(*cfg))
+        return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
@@ -246,17 +279,22 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     const int64_t N = cfg->n_envs;
     const bool shared = cfg->weight_mode == RSRL_W_SHARED;
     c->w_stride = shared ? 1 : N;
-    const size_t w_elems = (size_t)c->A * c->F * (size_t)c->w_stride;
+    c->w_elems = (size_t)c->A * c->F * (size_t)c->w_stride;
+    c->dw_elems = (size_t)c->A * c->F;
+    c->n_stat_slots = grid_for(N);
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
-    HIP_TRY(hipMalloc((void**)&c->W, sizeof(float) * w_elems));
-    HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * (size_t)c->A * c->F));
-    c->n_stat_slots = grid_for(N);
+    HIP_TRY(hipMalloc((void**)&c->W, sizeof(float) * c->w_elems));
+    HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
+    if (shared) {
+        HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
+        if (cfg->basis == RSRL_FOURIER) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
+    }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(c->W, 0, sizeof(float) * w_elems, c->stream));      // LFA::vector zero-initialises
-    HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * (size_t)c->A * c->F, c->stream));
+    HIP_TRY(hipMemsetAsync(c->W, 0, sizeof(float) * c->w_elems, c->stream));      // LFA::vector zero-initialises
+    HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
     HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
     HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
     return RSRL_HIP_OK;
@@ -314,10 +352,11 @@ int rsrl_hip_reset(rsrl_hip_ctx* c) {
     CHECK_CTX(c);
     HIP_TRY(hipSetDevice(c->cfg.device));
     const Common k = make_common(c);
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_reset_reg<DM, OR>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, c->t); _done = true; }
-    DISPATCH_REG(c, X);
-#undef X
+    const BasisGeom g = make_geom(c);
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_reset<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, c->t);
+        })) return NO_MODEL(c);
     KCHECK();
     return RSRL_HIP_OK;
 }
@@ -395,21 +434,23 @@ int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
     return RSRL_HIP_OK;
 }
 
-static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M, float* fout, size_t fcount, int32_t* iout) {
+static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* fout, size_t fcount, int32_t* iout,
+               size_t icount = 0) {
     CHECK_CTX(c);
-    if (!states || M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M, (long long)c->cfg.n_envs);
+    if (!states || M_ < 1 || M_ > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M_, (long long)c->cfg.n_envs);
     HIP_TRY(hipSetDevice(c->cfg.device));
     const float* d_states; OutBuf<float> of; OutBuf<int32_t> oi;
-    TRY(stage_in(c, 0, states, (size_t)c->D * M, &d_states));
+    TRY(stage_in(c, 0, states, (size_t)c->D * M_, &d_states));
     TRY(stage_out(c, 1, fout, fcount, &of));
-    TRY(stage_out(c, 2, iout, (size_t)M, &oi));
+    TRY(stage_out(c, 2, iout, icount ? icount : (size_t)M_, &oi));
     const Common k = make_common(c);
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_qop_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, op, d_states, M, call, of.dev, oi.dev); _done = true; }
-    DISPATCH_REG(c, X);
-#undef X
+    const BasisGeom g = make_geom(c);
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_qop<M>), dim3(grid_for(M_)), dim3(kBlock), 0, c->stream, k, g, op, d_states, M_, call, of.dev, oi.dev);
+        })) return NO_MODEL(c);
     KCHECK();
     bool sync = !is_device_ptr(states);
     TRY(flush_out(c, &of, &sync)); TRY(flush_out(c, &oi, &sync));
@@ -441,26 +482,16 @@ int rsrl_hip_policy_probs(rsrl_hip_ctx* c, const float* states, int64_t M, float
 
 int rsrl_hip_project(rsrl_hip_ctx* c, const float* states, int64_t M, float* phi_out) {
     CHECK_CTX(c);
-    if (!states || !phi_out || M < 1) return fail(RSRL_HIP_EINVAL, "bad argument");
+    if (!phi_out) return fail(RSRL_HIP_EINVAL, "null argument");
     if (c->cfg.basis != RSRL_FOURIER) return fail(RSRL_HIP_EINVAL, "dense projection needs a Fourier basis");
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    const float* d_states; OutBuf<float> of;
-    TRY(stage_in(c, 0, states, (size_t)c->D * M, &d_states));
-    TRY(stage_out(c, 1, phi_out, (size_t)c->F * M, &of));
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_project_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, d_states, M, of.dev); _done = true; }
-    DISPATCH_REG(c, X);
-#undef X
-    KCHECK();
-    bool sync = !is_device_ptr(states);
-    TRY(flush_out(c, &of, &sync));
-    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
-    return RSRL_HIP_OK;
+    return qop(c, QOP_FEATURES, states, M, phi_out, (size_t)c->F * M, nullptr);
 }
 
-int rsrl_hip_tile_indices(rsrl_hip_ctx* c, const float*, int64_t, int32_t*) {
+int rsrl_hip_tile_indices(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* idx_out) {
     CHECK_CTX(c);
-    return fail(RSRL_HIP_EINVAL, "tile coding not supported yet");
+    if (!idx_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (c->cfg.basis != RSRL_TILE_CODING) return fail(RSRL_HIP_EINVAL, "tile indices need a tile-coding basis");
+    return qop(c, QOP_FEATURES, states, M, nullptr, 0, idx_out, (size_t)c->cfg.n_tilings * M);
 }
 
 int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* actions, const float* rewards,
@@ -477,13 +508,14 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_in(c, 4, terminal, (size_t)M, &d_term));
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_handle_reg<DM, OR>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->dW); _done = true; }
-    DISPATCH_REG(c, X);
-#undef X
+    const BasisGeom g = make_geom(c);
+    if (!for_model(c, [&](auto tag) {
+            using Mo = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->dW);
+        })) return NO_MODEL(c);
     KCHECK();
-    if (c->w_stride == 1) {
-        const int n = c->A * c->F;
+    if (c->cfg.weight_mode == RSRL_W_SHARED) {
+        const int n = (int)c->dw_elems;
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
@@ -495,12 +527,12 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
 
 int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
-    const bool shared = c->w_stride == 1;
+    const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; OutBuf<float> ow;
     TRY(stage_out(c, 0, w, (size_t)n, &ow));
-    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->w_stride, shared ? 0 : env_index, c->F, c->A, ow.dev);
+    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, ow.dev);
     KCHECK();
     bool sync = false; TRY(flush_out(c, &ow, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -508,27 +540,30 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
 }
 int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
-    const bool shared = c->w_stride == 1;
+    const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
-    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->w_stride, shared ? 0 : env_index, c->F, c->A, d_w);
+    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
-    if (c->w_stride == 1) return rsrl_hip_set_weights(c, 0, w);
+    if (c->cfg.weight_mode == RSRL_W_SHARED) return rsrl_hip_set_weights(c, 0, w);
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
-    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->W, c->cfg.n_envs, c->F, c->A, d_w);
+    const int gy = n < 1024 ? n : 1024;
+    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->F, c->A, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
+
+static int comm_allreduce_dw(rsrl_hip_ctx*) { return RSRL_HIP_OK; }   // single-rank: nothing to reduce
 
 // ---- the fused driver loop -----------------------------------------------------------------
 static int timing_begin(rsrl_hip_ctx* c) {
@@ -548,35 +583,73 @@ static int timing_end(rsrl_hip_ctx* c) {
     return RSRL_HIP_OK;
 }
 
+// shared weights: one batch-step = phase A (errors against W_t, delta accumulation) -> [finalize] ->
+// [all-reduce over ranks] -> apply -> phase C (sample with W_{t+1}); SURVEY Appendix A.7.
+static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
+    const dim3 grid(grid_for(k.n_envs)), block(kBlock);
+    const bool dense = c->cfg.basis == RSRL_FOURIER;
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_shared_a<M>), grid, block, 0, c->stream, k, g, c->t, c->dW, c->partials, c->flags, d_stats);
+        })) return NO_MODEL(c);
+    KCHECK();
+    const int n = (int)c->dw_elems;
+    if (dense) {
+        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(128), 0, c->stream, c->partials, (int)grid.x, n, c->dW);
+        KCHECK();
+    }
+    TRY(comm_allreduce_dw(c));
+    hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+    KCHECK();
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_shared_c<M>), grid, block, 0, c->stream, k, g, c->t, c->flags);
+        })) return NO_MODEL(c);
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+
 int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     CHECK_CTX(c);
     if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
-    if (c->w_stride == 1) return fail(RSRL_HIP_EINVAL, "shared-W training not supported yet");
     HIP_TRY(hipSetDevice(c->cfg.device));
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
     const Common k = make_common(c);
-    const int64_t spl = c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256;
+    const BasisGeom g = make_geom(c);
+    const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
+    const bool fourier = c->cfg.basis == RSRL_FOURIER;
+    const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
-    const bool stream_k1 = spl == 1 && (uint64_t)c->A * c->F * (uint64_t)c->cfg.n_envs * 4ull < (1ull << 32);
+    const bool stream_k1 = !shared && fourier && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     int64_t done = 0;
     while (done < n_steps) {
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
-        const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
         TRY(timing_begin(c));
-        {
-            const dim3 g(grid_for(k.n_envs)), b(kBlock);
+        if (shared) {
+            TRY(train_shared_step(c, k, g, d_stats));
+            c->kernel_name = "k_shared_a";
+        } else if (fourier) {
+            const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
+            const dim3 gr(grid_for(k.n_envs)), b(kBlock);
             const int kchunk = stream_k1 ? -1 : chunk;
             bool ok;
             switch (c->cfg.domain) {
-            case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
-            case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
-            default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, g, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
             }
-            if (!ok) return fail(RSRL_HIP_EINVAL, "no fused kernel for domain %d order %d", c->cfg.domain, c->cfg.order);
+            if (!ok) return NO_MODEL(c);
             c->kernel_name = stream_k1 ? "k_step_reg" : "k_train_reg";
+            KCHECK();
+        } else {
+            if (!for_model(c, [&](auto tag) {
+                    using M = typename decltype(tag)::type;
+                    hipLaunchKernelGGL((k_train_mem<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, c->t, chunk, d_stats);
+                })) return NO_MODEL(c);
+            c->kernel_name = "k_train_mem";
+            KCHECK();
         }
-        KCHECK();
         TRY(timing_end(c));
         c->t += (uint64_t)chunk;
         done += chunk;
@@ -608,10 +681,11 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_sta
     TRY(stage_out(c, 0, n_states_out, (size_t)N, &on));
     TRY(stage_out(c, 1, total_reward_out, (size_t)N, &ot));
     const Common k = make_common(c);
-#define X(DM, OR) if (!_done && c->cfg.domain == DM && c->cfg.order == OR) { \
-        hipLaunchKernelGGL((k_rollout_reg<DM, OR>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, step_limit, on.dev, ot.dev); _done = true; }
-    DISPATCH_REG(c, X);
-#undef X
+    const BasisGeom g = make_geom(c);
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_rollout<M>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev);
+        })) return NO_MODEL(c);
     KCHECK();
     bool sync = false;
     TRY(flush_out(c, &on, &sync)); TRY(flush_out(c, &ot, &sync));

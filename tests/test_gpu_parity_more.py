@@ -1,0 +1,171 @@
+"""GPU parity for the other §8 rows: tile coding (bit-exact indices), CartPole / Acrobot learners, shared
+weights (synchronous mini-batch rule).  Same tolerances as test_gpu_parity_mc.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+def rand_states(orc, domain, M, seed, shrink=1.0):
+    lo, hi = orc.domain_bounds(domain)
+    rng = np.random.default_rng(seed)
+    mid, half = (lo + hi) / 2, (hi - lo) / 2 * shrink
+    s = mid[:, None] + half[:, None] * (2 * rng.random((len(lo), M)) - 1)
+    return s.astype(np.float32)
+
+
+@pytest.mark.parametrize("domain", [0, 1, 2])
+@pytest.mark.parametrize("T,B", [(8, 8), (4, 5), (16, 4)])
+def test_tile_indices_bit_exact(ra, orc, domain, T, B):
+    M = 3000
+    s = rand_states(orc, domain, M, 100 * domain + T)
+    lo, hi = orc.domain_bounds(domain)
+    s[:, 0] = lo.astype(np.float32)              # edge cases: exactly on the bounds
+    s[:, 1] = hi.astype(np.float32)
+    ag = orc.make_agent(domain=domain, basis=orc.TILE, n_tilings=T, tiles_per_dim=B)
+    with ra.Context(domain=domain, basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=B, n_envs=M,
+                    weight_mode=ra.W_SHARED) as c:
+        assert c.F == T * B ** len(lo)
+        idx = c.tile_indices(s)
+    assert idx.shape == (T, M) and idx.dtype == np.int32
+    for m in range(M):
+        assert np.array_equal(idx[:, m], orc.tile_indices(ag, s[:, m])), m          # integer path: bit-exact
+    assert idx.min() >= 0 and idx.max() < T * B ** len(lo)
+
+
+def test_tile_q_and_handle_per_env(ra, orc):
+    M, T, B = 48, 8, 8
+    kw = dict(gamma=0.99, lr=0.1 / T, epsilon=0.1)
+    ag = orc.make_agent(domain=1, basis=orc.TILE, n_tilings=T, tiles_per_dim=B, algo=orc.SARSA, policy=orc.EGREEDY, seed=6, **kw)
+    rng = np.random.default_rng(0)
+    s = rand_states(orc, 1, M, 9, shrink=0.5)
+    a = rng.integers(0, 2, M).astype(np.int32)
+    with ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=B, algo=ra.SARSA,
+                    policy=ra.EPSILON_GREEDY, seed=6, n_envs=M, **kw) as c:
+        F = c.F
+        Ws = [(rng.normal(size=(F, 2)) * 0.1).astype(np.float32) for _ in range(M)]
+        for i in range(M):
+            c.set_weights(Ws[i], i)
+        assert np.array_equal(c.get_weights(5), Ws[5])
+        q = c.q_evaluate(s)
+        c.states = np.pad(s, ((0, 0), (0, 0)))
+        frm, nxt, rew, term = c.domain_step(a)
+        td = c.handle(frm, a, rew, nxt, term)
+        for i in range(M):
+            q32 = orc.q_evaluate(ag, Ws[i], s[:, i], "f32")
+            assert np.allclose(q[:, i], q32, rtol=0, atol=1e-6)
+            W = Ws[i].copy()
+            d = orc.handle(ag, W, frm[:, i], a[i], rew[i], nxt[:, i], term[i], orc.draw(6, i, 0, orc.BLK_INNER), "f32")
+            assert abs(td[i] - d) <= 2e-6 * (1 + abs(d))
+            assert np.max(np.abs(c.get_weights(i) - W)) <= 1e-6
+
+
+@pytest.mark.parametrize("domain,basis,algo,policy,kw", [
+    (1, "tile", 1, 1, dict(gamma=0.99, lr=0.0125, epsilon=0.1)),          # config C3 in small: CartPole SARSA tiles 8 x 8^4
+    (1, "fourier", 0, 1, dict(gamma=0.99, lr=0.01, epsilon=0.1)),         # CartPole QLearning Fourier(1)
+    (2, "fourier", 2, 2, dict(gamma=0.99, lr=0.01, alpha=0.5, tau=1.0)),  # Acrobot ExpectedSARSA Fourier(1) Softmax
+    (2, "tile", 0, 0, dict(gamma=0.99, lr=0.025)),                        # Acrobot QLearning tiles 4 x 6^4 Greedy
+])
+def test_train_per_env_vs_oracle_f32(ra, orc, domain, basis, algo, policy, kw):
+    N, K = 96, 60
+    if basis == "tile":
+        T, B = (8, 8) if domain == 1 else (4, 6)
+        okw = dict(basis=orc.TILE, n_tilings=T, tiles_per_dim=B)
+        dkw = dict(basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=B)
+    else:
+        okw, dkw = dict(basis=orc.FOURIER, order=1), dict(basis=ra.FOURIER, order=1)
+    ag = orc.make_agent(domain=domain, algo=algo, policy=policy, seed=13, max_episode_steps=40, **okw, **kw)
+    run = orc.Run(ag, N, "f32")
+    run.reset()
+    ost = run.train(K)
+    with ra.Context(domain=domain, algo=algo, policy=policy, seed=13, max_episode_steps=40, n_envs=N, **dkw, **kw) as c:
+        c.reset()
+        st = c.train(K)
+        tol = 2e-3 if domain == 2 else 1e-5            # Acrobot: chaotic RK4 (dt 0.2) amplifies sincos ulps over 60 steps
+        same = np.all(np.abs(c.states.T - run.state) <= tol * (1 + np.abs(run.state)), axis=1) & (c.actions == run.action)
+        assert same.mean() >= (0.85 if policy == 2 or domain == 2 else 0.95), same.mean()
+        for i in np.flatnonzero(same)[:10]:
+            assert np.max(np.abs(c.get_weights(i) - run.weights[i])) <= (5e-4 if domain == 2 else 5e-6)
+        assert abs(st["episodes"] - ost["episodes"]) <= max(2, 0.05 * ost["episodes"])
+        assert st["env_steps"] == N * K
+
+
+@pytest.mark.parametrize("basis", ["fourier", "tile"])
+def test_train_shared_weights_vs_oracle(ra, orc, basis):
+    # shared approximator: W_{t+1} = W_t + lr * sum_i e_i phi(s_i) x onehot(a_i), all errors against W_t
+    N, K = 600, 40                       # 600 envs = 3 thread blocks, the last one partially filled
+    if basis == "tile":
+        domain, okw, dkw, kw = 1, dict(basis=orc.TILE, n_tilings=8, tiles_per_dim=8), \
+            dict(basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8), dict(gamma=0.99, lr=0.0125 / 50, epsilon=0.1)
+        algo, policy = 1, 1
+    else:
+        domain, okw, dkw, kw = 0, dict(order=5), dict(order=5), dict(gamma=0.9, lr=0.001 / 50, epsilon=0.1)
+        algo, policy = 0, 1
+    ag = orc.make_agent(domain=domain, algo=algo, policy=policy, shared_w=True, seed=17, max_episode_steps=25, **okw, **kw)
+    run = orc.Run(ag, N, "f32")
+    run.reset()
+    ost = run.train(K)
+    with ra.Context(domain=domain, algo=algo, policy=policy, weight_mode=ra.W_SHARED, seed=17, max_episode_steps=25,
+                    n_envs=N, **dkw, **kw) as c:
+        c.reset()
+        st = c.train(K)
+        Wd, Wo = c.get_weights(), run.weights
+        assert np.max(np.abs(Wo)) > 1e-5
+        assert np.max(np.abs(Wd - Wo)) <= 2e-5 * max(1.0, np.max(np.abs(Wo))) + 1e-7
+        same = np.all(np.abs(c.states.T - run.state) <= 1e-5, axis=1) & (c.actions == run.action)
+        assert same.mean() >= 0.95, same.mean()
+        assert abs(st["episodes"] - ost["episodes"]) <= max(2, 0.02 * ost["episodes"])
+        assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 1e-3 * ost["sum_abs_td_error"]
+
+
+def test_shared_weights_dense_is_reproducible(ra):
+    # the dense delta reduction uses fixed-order block partials (no atomics): same seed => bitwise same W
+    kw = dict(n_envs=5000, weight_mode=ra.W_SHARED, policy=1, epsilon=0.1, lr=1e-6, seed=4, max_episode_steps=50)
+    out = []
+    for _ in range(2):
+        with ra.Context(**kw) as c:
+            c.reset()
+            c.train(60)
+            out.append((c.get_weights(), c.states, c.actions))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_shared_weights_n1_equals_reference_rule(ra):
+    # N = 1: the mini-batch rule collapses to the reference's one-update-at-a-time rule (per-env mode, N = 1)
+    kw = dict(n_envs=1, policy=1, epsilon=0.1, seed=9, max_episode_steps=100, steps_per_launch=1)
+    with ra.Context(weight_mode=ra.W_SHARED, **kw) as a, ra.Context(weight_mode=ra.W_PER_ENV, **kw) as b:
+        a.reset(), b.reset()
+        a.train(300), b.train(300)
+        assert np.allclose(a.get_weights(), b.get_weights(0), rtol=0, atol=1e-7)
+        assert np.allclose(a.states, b.states, atol=1e-6)
+
+
+def test_shared_handle_minibatch(ra, orc):
+    # rsrl_hip_handle in shared mode: all M errors against the same W_t, then one summed update
+    M = 64
+    ag = orc.make_agent(policy=orc.GREEDY, shared_w=True, gamma=0.9, lr=0.01)
+    rng = np.random.default_rng(3)
+    W0 = (rng.normal(size=(36, 3)) * 0.1).astype(np.float32)
+    s = rand_states(orc, 0, M, 5)
+    a = rng.integers(0, 3, M).astype(np.int32)
+    with ra.Context(n_envs=M, weight_mode=ra.W_SHARED, policy=0, gamma=0.9, lr=0.01) as c:
+        c.set_weights(W0)
+        c.states = s
+        frm, nxt, rew, term = c.domain_step(a)
+        td = c.handle(frm, a, rew, nxt, term)
+        Wd = c.get_weights()
+    W = W0.astype(np.float64)
+    dW = np.zeros_like(W)
+    for i in range(M):
+        Wi = W.copy()
+        d = orc.handle(ag, Wi, frm[:, i], a[i], rew[i], nxt[:, i], term[i])
+        dW += Wi - W
+        assert abs(td[i] - d) <= 2e-5 * (1 + abs(d))
+    assert np.max(np.abs(Wd - (W + dW))) <= 2e-6
