@@ -76,3 +76,17 @@ def test_product_never_imports_oracle():
     import subprocess
     out = subprocess.run(["ldd", os.path.join(ROOT, "rsrl_amd", "lib", "librsrl_hip.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_cpp_host_mirror_compiles_against_the_abi(abi, tmp_path):
+    # rsrl_amd/host/rsrl.hpp + the C++ counterpart of rsrl/examples/q_learning.rs build and link (no GPU needed)
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = tmp_path / "q_learning"
+    lib_dir = os.path.join(ROOT, "rsrl_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "examples", "q_learning.cpp"),
+                           "-L" + lib_dir, "-lrsrl_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    assert exe.exists()
