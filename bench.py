@@ -81,6 +81,35 @@ def cpu_baseline(seconds=12.0):
                       f"eps-greedy, {total} env-steps in {dt:.1f} s (oracle/rsrl_oracle.c, gcc -O2)"}
 
 
+def shared_w_leg(cp, rsrl_amd, make_sharded_context, envs_per_gpu=131072, steps=300, warmup=50):
+    """Secondary measurement (BASELINE.json configs[3]): 131 072 MountainCar envs per GPU, ONE shared Fourier(5)
+    approximator, per-batch-step all-reduce of the 432 B weight delta over RCCL.  Never part of `value`."""
+    try:
+        ctx = make_sharded_context(envs_per_gpu * cp.world, cp, domain=rsrl_amd.MOUNTAIN_CAR, order=5,
+                                   algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.9,
+                                   lr=0.001 / (envs_per_gpu * cp.world), weight_mode=rsrl_amd.W_SHARED, seed=0,
+                                   max_episode_steps=1000)
+        ctx.reset()
+        ctx.train(warmup, want_stats=False)
+        ctx.sync()
+        cp.barrier()
+        t0 = time.perf_counter()
+        ctx.train(steps, want_stats=False)
+        ctx.sync()
+        dt = cp.max_over_ranks(time.perf_counter() - t0)
+        w = ctx.get_weights()
+        import numpy as np
+        chk = np.array([float(np.abs(w).sum())])
+        lo, hi = -cp.max_over_ranks(-chk[0]), cp.max_over_ranks(chk[0])
+        ctx.close()
+        return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step RCCL "
+                            f"all-reduce of the 432 B delta", "n_gpus": cp.world, "steps": steps,
+                "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
+                "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
+    except Exception as e:                       # never let the secondary leg take the headline down
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,43 +118,35 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0, help="fuse depth (0 = library default)")
     ap.add_argument("--envs", type=int, default=N_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shared-leg", action="store_true", help="skip the secondary shared-W (RCCL) measurement")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        # control plane only (barrier + max over ranks): the data path has no collective in per-env mode
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo", init_method="env://")
+    from rsrl_amd.distributed import ControlPlane, make_sharded_context
+    cp = ControlPlane()          # gloo control plane (rendezvous / barrier / max over ranks); no-op for one rank
+    rank, local_rank, world = cp.rank, cp.info.local_rank, cp.world
     import rsrl_amd
+    device = local_rank % max(1, rsrl_amd.device_count())     # one rank per GPU; modulo only matters on under-sized test boxes
 
     ctx = rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, basis=rsrl_amd.FOURIER, order=5,
                            algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1,
                            gamma=0.9, lr=0.001, n_envs=args.envs, env_offset=rank * args.envs, seed=0,
-                           max_episode_steps=1000, steps_per_launch=args.steps_per_launch, device=local_rank)
+                           max_episode_steps=1000, steps_per_launch=args.steps_per_launch, device=device)
     ctx.reset()
     if args.warmup > 0:
         ctx.train(args.warmup, want_stats=False)
     ctx.sync()
-    if dist is not None:
-        dist.barrier()
+    cp.barrier()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
     ctx.train(args.steps, want_stats=False)
     ctx.sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.barrier()
-        dt = float(tt.item())
+    dt = cp.max_over_ranks(dt)
+    cp.barrier()
     kernel_ms, launches, kname = ctx.timing_read()
     ctx.timing_enable(False)
     n_states, _ = ctx.rollout_greedy(500)
+    shared = shared_w_leg(cp, rsrl_amd, make_sharded_context) if not args.no_shared_leg else None
 
     if rank == 0:
         total_env_steps = args.steps * args.envs * world
@@ -155,12 +176,13 @@ def main():
                                  "and frac may exceed 1 (see DESIGN.md)"},
             "greedy_rollout_mean_n_states": float(n_states.mean()),
         }
+        if shared is not None:
+            out["shared_w"] = shared
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    cp.close()
 
 
 if __name__ == "__main__":

@@ -114,6 +114,8 @@ typedef struct {
 } rsrl_hip_stats;
 
 int         rsrl_hip_abi_version(void);
+/* number of visible HIP devices (>= 0) or a negative status */
+int         rsrl_hip_device_count(void);
 const char* rsrl_hip_last_error(void);
 /* README example values: MountainCar, Fourier(5), QLearning, gamma 0.9, SGD(0.001), Greedy */
 int rsrl_hip_config_init(rsrl_hip_config* cfg);

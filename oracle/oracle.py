@@ -126,6 +126,7 @@ def _declare(L):
         g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
         g("orc_run_reset").argtypes = [C.c_void_p]
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
         g("orc_run_rollout_greedy").restype = C.c_int
         g("orc_run_rollout_greedy").argtypes = [C.c_void_p, C.c_int64, u32p, Rp]
 
@@ -337,6 +338,18 @@ class Run:
     def train(self, n_steps):
         st = Stats()
         self._f("orc_run_train")(self._h, int(n_steps), C.byref(st))
+        return st.as_dict()
+
+    def train_with_dw_hook(self, n_steps, hook):
+        """Shared-W training; hook(dW: np.ndarray view of the local delta) runs once per batch-step before the
+        delta is applied (in-place edits are kept) -- where a multi-rank run all-reduces it."""
+        st = Stats()
+        CB = C.CFUNCTYPE(None, C.POINTER(self._ct), C.c_int, C.c_void_p)
+
+        def _cb(ptr, n, _user):
+            hook(np.ctypeslib.as_array(ptr, shape=(n,)))
+        cb = CB(_cb)
+        self._f("orc_run_train_hook")(self._h, int(n_steps), C.byref(st), C.cast(cb, C.c_void_p), None)
         return st.as_dict()
 
     def rollout_greedy(self, step_limit):

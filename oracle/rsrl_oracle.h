@@ -89,6 +89,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     void  orc_run_set_epsilon_##S(void* h, double eps);                                                 \
     void  orc_run_reset_##S(void* h);                                                                   \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
+    void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
+                                 void (*dw_hook)(R* dW, int n, void* user), void* user);                \
     int   orc_run_rollout_greedy_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward);
 
 ORC_DECLARE(double, f64)

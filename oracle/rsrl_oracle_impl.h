@@ -507,7 +507,9 @@ void FN(orc_run_reset)(void* h) {
  * per-env W : transition -> handle (pre-update W) -> sample (post-update W) -> maybe reset+sample
  * shared  W : all envs compute e_i, phi(s_i) on W_t; W_{t+1} = W_t + lr*sum_i e_i phi(s_i) x onehot(a_i)
  *             (accumulated in env order); then all envs sample with W_{t+1}. N=1 == reference rule. */
-void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) {
+/* dw_hook (may be NULL): called once per batch-step in shared-W mode on the local delta (F*A values) before it is
+ * applied -- the place where a multi-rank run all-reduces the delta (tests/test_distributed_cpu.py). */
+void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_hook)(R* dW, int n, void* user), void* user) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
     int D = ag->basis.dim, A = ag->n_actions, F = orc_basis_nfeat(&ag->basis);
     int64_t N = run->n_envs, i, k;
@@ -533,6 +535,7 @@ void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) {
             acc.sum_abs_td_error += fabs((double)delta);
             acc.sum_reward += (double)r;
         }
+        if (dW && dw_hook) dw_hook(dW, F * A, user);
         if (dW) { int j; for (j = 0; j < F * A; j++) run->W[j] += dW[j]; }
         for (i = 0; i < N; i++) {
             R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
@@ -559,6 +562,8 @@ void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) {
     free(ns_all); free(term_all); free(dW);
     if (st) *st = acc;
 }
+
+void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) { FN(orc_run_train_hook)(h, n_steps, st, NULL, NULL); }
 
 /* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340
  * One fresh default env per learner i, evaluated with learner i's weights. */

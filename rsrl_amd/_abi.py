@@ -31,6 +31,7 @@ class Stats(C.Structure):
 # every symbol include/rsrl_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rsrl_hip_abi_version": (C.c_int, []),
+    "rsrl_hip_device_count": (C.c_int, []),
     "rsrl_hip_last_error": (C.c_char_p, []),
     "rsrl_hip_config_init": (C.c_int, [C.POINTER(Config)]),
     "rsrl_hip_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),

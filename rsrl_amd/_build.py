@@ -67,7 +67,7 @@ def _build_to(lib_path, extra_flags, verbose):
     jobs = [(s, os.path.join(obj_dir, os.path.basename(s) + ".o"), verbose, extra_flags) for s in sources()]
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         objs = list(ex.map(_compile_one, jobs))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-o", lib_path]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

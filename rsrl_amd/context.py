@@ -32,6 +32,14 @@ def _in(a, dtype, shape=None):
     return a
 
 
+def device_count():
+    """visible HIP devices (raises RsrlHipError when the runtime finds none)"""
+    n = _abi.lib().rsrl_hip_device_count()
+    if n < 0:
+        _abi.check(n)
+    return n
+
+
 class Context:
     def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
@@ -209,6 +217,18 @@ class Context:
         tot = np.empty(self.N, dtype=np.float32)
         _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit), _p(n_states), _p(tot)))
         return n_states, tot
+
+    # ---- multi-GPU (shared weights): RCCL communicator, one process per GPU
+    @staticmethod
+    def comm_unique_id():
+        """ncclUniqueId (128 bytes) -- call on rank 0 and distribute through the control plane"""
+        buf = (C.c_uint8 * 128)()
+        _abi.check(_abi.lib().rsrl_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, id_bytes, world_size, rank):
+        buf = (C.c_uint8 * 128)(*id_bytes)
+        _abi.check(self._L.rsrl_hip_comm_init(self._h, buf, int(world_size), int(rank)))
 
     # ---- measurement
     def timing_enable(self, on=True):

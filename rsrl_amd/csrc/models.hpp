@@ -14,6 +14,24 @@
 
 namespace rsrl {
 
+// wave64 sum via DPP (row_shr 1,2,4,8 then row_bcast 15 / 31); the total lands in lane 63
+#define RSRL_DPP_ADD(v, ctrl, row_mask) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp_to_lane63(float v) {
+    RSRL_DPP_ADD(v, 0x111, 0xf);   // row_shr:1
+    RSRL_DPP_ADD(v, 0x112, 0xf);   // row_shr:2
+    RSRL_DPP_ADD(v, 0x114, 0xf);   // row_shr:4
+    RSRL_DPP_ADD(v, 0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row total
+    RSRL_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    RSRL_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    return v;
+}
+
+// total broadcast to every lane
+__device__ __forceinline__ float wave_sum_all(float v) {
+    return __shfl(wave_sum_dpp_to_lane63(v), 63, 64);
+}
+
 // geometry of the basis that is not a template parameter
 struct BasisGeom { int F; int tiles_per_dim; };
 
@@ -48,9 +66,13 @@ struct FourierModel {
         }
     }
     // dW has the shared layout [A][F]
-    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale) {
+    // must be called by ALL lanes of the wave (uniform control flow); lanes without work pass valid = false
+    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
+                                                      bool valid) {
+        if (valid) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * ft.phi[f]);
+            for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * ft.phi[f]);
+        }
     }
 };
 
@@ -115,10 +137,30 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) c.W[widx(c, wi, g, ft.idx[t], a)] += scale;               // indices of distinct tilings never collide
     }
-    // dW has the shared layout [F][A]
-    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale) {
+    // dW has the shared layout [F][A].  Many learners sit in the same few tiles (all start at Domain::default()),
+    // so before the f32 atomics the wave folds its heavy hitters: up to kRounds times the first pending lane's
+    // key is broadcast, all lanes holding it are summed (DPP) and ONE atomic is issued for them.
+    // Must be called by ALL lanes of the wave (the DPP sum needs full exec); lanes without work pass valid = false.
+    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
+                                                      bool valid) {
+        constexpr int kRounds = 3;
 #pragma unroll
-        for (int t = 0; t < T; ++t) atomicAdd(&dW[(int64_t)ft.idx[t] * A + a], scale);
+        for (int t = 0; t < T; ++t) {
+            const int key = valid ? ft.idx[t] * A + a : -1;
+            bool pending = valid;
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const unsigned long long todo = __ballot(pending);
+                if (todo == 0ull) break;
+                const int leader = __ffsll((long long)todo) - 1;
+                const int lkey = __shfl(key, leader, 64);
+                const bool mine = pending && key == lkey;
+                const float tot = wave_sum_all(mine ? scale : 0.0f);
+                if (mine && (int)(threadIdx.x & 63) == leader) atomicAdd(&dW[lkey], tot);
+                pending = pending && !mine;
+            }
+            if (pending) atomicAdd(&dW[key], scale);
+        }
     }
 };
 
@@ -203,29 +245,34 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
                                                    float* __restrict__ td_out, float* __restrict__ dW) {
     constexpr int D = M::D, A = M::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Mn) return;
+    const bool valid = i < Mn;
     const bool shared = c.shared != 0;
-    const int64_t wi = shared ? 0 : i;
-    float s[D], ns[D];
-    load_state<M>(from, Mn, i, s);
-    load_state<M>(to, Mn, i, ns);
-    const int a = act[i];
-    const float r = rew[i];
-    const bool term = termf[i] != 0;
-    typename M::Feat fs, fn;
-    M::features(s, g, fs);
-    M::features(ns, g, fn);
-    const float qsa = M::q_index(c, wi, g, fs, a);
-    float q_n[A];
-    M::q_all(c, wi, g, fn, q_n);
-    U4 xin = U4{0, 0, 0, 0};
-    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
-    float e;
-    const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
-    const float scale = c.alg.lr * e;
-    if (!shared) M::update(c, wi, g, fs, a, scale);
-    else M::accumulate(dW, g, fs, a, scale);
-    if (td_out) td_out[i] = delta;
+    typename M::Feat fs;
+    int a = 0;
+    float scale = 0.0f;
+    if (valid) {
+        const int64_t wi = shared ? 0 : i;
+        float s[D], ns[D];
+        load_state<M>(from, Mn, i, s);
+        load_state<M>(to, Mn, i, ns);
+        a = act[i];
+        const float r = rew[i];
+        const bool term = termf[i] != 0;
+        typename M::Feat fn;
+        M::features(s, g, fs);
+        M::features(ns, g, fn);
+        const float qsa = M::q_index(c, wi, g, fs, a);
+        float q_n[A];
+        M::q_all(c, wi, g, fn, q_n);
+        U4 xin = U4{0, 0, 0, 0};
+        if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
+        float e;
+        const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+        scale = c.alg.lr * e;
+        if (!shared) M::update(c, wi, g, fs, a, scale);
+        if (td_out) td_out[i] = delta;
+    }
+    if (shared) M::accumulate(dW, g, fs, a, scale, valid);      // wave-uniform call (shared is a kernel argument)
 }
 
 // Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states, weights read from memory      lib.rs:448-479, :340
@@ -324,19 +371,6 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
-// wave64 sum via DPP (row_shr 1,2,4,8 then row_bcast 15 / 31); the total lands in lane 63
-#define RSRL_DPP_ADD(v, ctrl, row_mask) \
-    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false))
-__device__ __forceinline__ float wave_sum_dpp_to_lane63(float v) {
-    RSRL_DPP_ADD(v, 0x111, 0xf);   // row_shr:1
-    RSRL_DPP_ADD(v, 0x112, 0xf);   // row_shr:2
-    RSRL_DPP_ADD(v, 0x114, 0xf);   // row_shr:4
-    RSRL_DPP_ADD(v, 0x118, 0xf);   // row_shr:8   -> lane 15 of each row holds the row total
-    RSRL_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-    RSRL_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
-    return v;
-}
-
 // shared weights, phase A: transition + TD error against W_t + the learner's term lr*e*phi(s) of the
 // mini-batch delta.  The env state becomes s'; flags[i] bit0 = terminal, bit1 = truncated (phase C).
 //   dense basis : block-level reduction (DPP wave sums -> LDS -> one row of `partials` per block, fixed
@@ -377,7 +411,6 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
         float e;
         const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
-        if constexpr (!M::kDense) M::accumulate(dW, g, fs, a, scale);
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
         c.ep_step[i] = ep;
@@ -390,26 +423,27 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
             for (int f = 0; f < M::F; ++f) fs.phi[f] = 0.0f;
         }
     }
+    if constexpr (!M::kDense) M::accumulate(dW, g, fs, a, scale, i < N);      // all lanes call (DPP sums inside)
     if constexpr (M::kDense) {
-        constexpr int F = M::F, NW = kBlock / 64;
-        __shared__ float wave_part[NW][A * F];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        // block-level sum of the learners' terms through LDS, fixed order (reproducible):
+        //   tile[i][f] = lr*e_i*phi_i[f], act[i] = a_i;  thread (h, b, f) sums the learners of half h with a_i == b.
+        constexpr int F = M::F, AF = A * F, H = 2, PER = kBlock / H;
+        static_assert(H * AF <= kBlock, "dense shared-W reduction needs A*F*2 <= block size");
+        __shared__ float tile[kBlock][F + 1];          // +1: conflict-free rows
+        __shared__ int act[kBlock];
+        __shared__ float part[H][AF];
 #pragma unroll
-        for (int b = 0; b < A; ++b) {
-            const float sb = (a == b) ? scale : 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float tot = wave_sum_dpp_to_lane63(sb * fs.phi[f]);
-                if (lane == 63) wave_part[wave][b * F + f] = tot;
-            }
+        for (int f = 0; f < F; ++f) tile[threadIdx.x][f] = scale * fs.phi[f];
+        act[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < H * AF) {
+            const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
+            float acc = 0.0f;
+            for (int i = h * PER; i < (h + 1) * PER; ++i) acc += (act[i] == b) ? tile[i][f] : 0.0f;
+            part[h][j] = acc;
         }
         __syncthreads();
-        if (threadIdx.x < A * F) {
-            float acc = wave_part[0][threadIdx.x];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) acc += wave_part[w][threadIdx.x];
-            partials[(int64_t)blockIdx.x * (A * F) + threadIdx.x] = acc;
-        }
+        if (threadIdx.x < AF) partials[(int64_t)blockIdx.x * AF + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }

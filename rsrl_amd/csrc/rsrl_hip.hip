@@ -4,6 +4,7 @@
 // instance, i.e. what the reference builds in examples/q_learning.rs:19-32.  There is no
 // CPU path in this library: every entry point launches HIP kernels.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -45,13 +46,30 @@ __global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, i
     if (i >= N) return;
     for (int j = blockIdx.y; j < F * A; j += gridDim.y) W[w_index(tile, N, i, F, A, j / A, j % A)] = in[j];
 }
-// shared-W dense basis: dW[j] = sum over blocks of partials[blk][j], ascending block order (reproducible)
-__global__ void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// shared-W dense basis: dW[j] = sum over blocks of partials[blk][j] in a FIXED order (reproducible):
+// 8 interleaved partial sums (blocks b = p mod 8, ascending) per element, combined p = 0..7.
+__global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW) {
+    __shared__ float part[8][128];
+    const int jl = threadIdx.x & 127, p = threadIdx.x >> 7;
+    const int j = blockIdx.x * 128 + jl;
     float acc = 0.0f;
-    for (int b = 0; b < n_blocks; ++b) acc += partials[(int64_t)b * n + j];
-    dW[j] = acc;
+    if (j < n) {
+        for (int b0 = p; b0 < n_blocks; b0 += 64) {            // 8 loads in flight, added in ascending block order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int b = b0 + 8 * u; v[u] = b < n_blocks ? partials[(int64_t)b * n + j] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+    }
+    part[p][jl] = acc;
+    __syncthreads();
+    if (p == 0 && j < n) {
+        float tot = part[0][jl];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) tot += part[q][jl];
+        dW[j] = tot;
+    }
 }
 }  // namespace
 
@@ -97,6 +115,9 @@ struct rsrl_hip_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t events_used = 0;
     const char* kernel_name = "";
+    // multi-GPU shared-W: one RCCL communicator per ctx (one process per GPU)
+    ncclComm_t comm = nullptr;
+    int world_size = 1, rank = 0;
 };
 
 static Common make_common(const rsrl_hip_ctx* c) {
@@ -203,6 +224,11 @@ static int flush_out(rsrl_hip_ctx* c, OutBuf<T>* ob, bool* need_sync) {
 extern "C" {
 
 int rsrl_hip_abi_version(void) { return RSRL_HIP_ABI_VERSION; }
+int rsrl_hip_device_count(void) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    return n;
+}
 const char* rsrl_hip_last_error(void) { return g_last_error.c_str(); }
 
 int rsrl_hip_config_init(rsrl_hip_config* cfg) {
@@ -234,6 +260,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->flags) (void)hipFree(c->flags);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSRL_HIP_OK;
@@ -563,7 +590,19 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     return RSRL_HIP_OK;
 }
 
-static int comm_allreduce_dw(rsrl_hip_ctx*) { return RSRL_HIP_OK; }   // single-rank: nothing to reduce
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) return fail(RSRL_HIP_ERCCL, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+// The one exchange step of the path: sum the (F x A) f32 weight delta over the ranks so that every rank
+// applies the identical update and the replicas of W stay bit-identical.  In place, on the ctx's stream,
+// no host synchronisation.  At 432 B (MountainCar Fourier(5)) this is latency-bound, not link-bound.
+static int comm_allreduce_dw(rsrl_hip_ctx* c) {
+    if (!c->comm || c->world_size == 1) return RSRL_HIP_OK;
+    NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+    return RSRL_HIP_OK;
+}
 
 // ---- the fused driver loop -----------------------------------------------------------------
 static int timing_begin(rsrl_hip_ctx* c) {
@@ -595,7 +634,7 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     KCHECK();
     const int n = (int)c->dw_elems;
     if (dense) {
-        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(128), 0, c->stream, c->partials, (int)grid.x, n, c->dW);
+        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(1024), 0, c->stream, c->partials, (int)grid.x, n, c->dW);
         KCHECK();
     }
     TRY(comm_allreduce_dw(c));
@@ -693,8 +732,26 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_sta
     return RSRL_HIP_OK;
 }
 
-int rsrl_hip_comm_unique_id(uint8_t*) { return fail(RSRL_HIP_ERCCL, "RCCL support not built yet"); }
-int rsrl_hip_comm_init(rsrl_hip_ctx*, const uint8_t*, int, int) { return fail(RSRL_HIP_ERCCL, "RCCL support not built yet"); }
+int rsrl_hip_comm_unique_id(uint8_t* id_bytes) {
+    if (!id_bytes) return fail(RSRL_HIP_EINVAL, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the ABI");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id_bytes, &id, sizeof(id));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size, int rank) {
+    CHECK_CTX(c);
+    if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(RSRL_HIP_EINVAL, "bad communicator arguments");
+    if (c->comm) return fail(RSRL_HIP_ESTATE, "communicator already initialised");
+    if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no collective: shard by env_offset instead");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id_bytes, sizeof(id));
+    NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
+    c->world_size = world_size; c->rank = rank;
+    return RSRL_HIP_OK;
+}
 
 int rsrl_hip_timing_enable(rsrl_hip_ctx* c, int enable) {
     CHECK_CTX(c);

@@ -1,0 +1,103 @@
+"""Multi-GPU host logic: one process per GPU (launched by torch.distributed.run), environments sharded
+contiguously by GLOBAL id.  Per-env weights need no data-path collective at all; shared weights all-reduce the
+(F x A) weight delta once per batch-step over RCCL inside librsrl_hip.so (rsrl_hip_comm_*).  torch.distributed
+(gloo) is only the control plane here: rendezvous, the ncclUniqueId broadcast, barriers and the max-over-ranks
+of the timings."""
+import os
+from dataclasses import dataclass
+
+
+def shard_range(n_total, world, rank):
+    """Contiguous partition of [0, n_total): GPU g owns [offset, offset + count)."""
+    if not (0 <= rank < world) or n_total < 0:
+        raise ValueError("bad shard arguments")
+    base, rem = divmod(n_total, world)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+@dataclass
+class RankInfo:
+    rank: int = 0
+    local_rank: int = 0
+    world: int = 1
+
+    @staticmethod
+    def from_env(env=os.environ):
+        return RankInfo(int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1")))
+
+
+class ControlPlane:
+    """Thin wrapper over a torch.distributed (gloo) group; a no-op for world == 1."""
+
+    def __init__(self, info=None, backend="gloo"):
+        self.info = info or RankInfo.from_env()
+        self._dist = None
+        if self.info.world > 1:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group(backend=backend, init_method="env://", rank=self.info.rank,
+                                        world_size=self.info.world)
+            self._dist = dist
+
+    @property
+    def rank(self):
+        return self.info.rank
+
+    @property
+    def world(self):
+        return self.info.world
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def broadcast_bytes(self, payload, src=0):
+        """payload (bytes) on `src`, None elsewhere -> bytes on every rank"""
+        if self._dist is None:
+            return payload
+        box = [payload if self.rank == src else None]
+        self._dist.broadcast_object_list(box, src=src)
+        return box[0]
+
+    def max_over_ranks(self, value):
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, array):
+        """in-place sum of a numpy float64 array over the ranks (control-plane sized data only)"""
+        if self._dist is None:
+            return array
+        import torch
+        t = torch.from_numpy(array)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return array
+
+    def close(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=None, **cfg):
+    """Create this rank's Context for its shard of `total_envs` environments.  In shared-weight mode with more
+    than one rank the RCCL communicator is set up: rank 0 draws the ncclUniqueId, the control plane broadcasts it."""
+    if context_cls is None:
+        from .context import Context as context_cls
+    offset, count = shard_range(total_envs, control.world, control.rank)
+    cfg = dict(cfg)
+    if "device" not in cfg:
+        from .context import device_count
+        cfg["device"] = control.info.local_rank % max(1, device_count()) if context_cls.__name__ == "Context" else control.info.local_rank
+    ctx = context_cls(n_envs=count, env_offset=cfg.pop("env_offset", 0) + offset, **cfg)
+    shared = cfg.get("weight_mode", 0) == 1
+    if shared and control.world > 1:
+        fn = unique_id_fn or context_cls.comm_unique_id
+        uid = control.broadcast_bytes(fn() if control.rank == 0 else None, src=0)
+        ctx.comm_init(uid, control.world, control.rank)
+    return ctx

@@ -1,0 +1,112 @@
+"""world_size-2 gloo tests (CPU): the multi-GPU host logic -- contiguous sharding by global env id, the control
+plane (unique-id broadcast, max over ranks) -- and the sharding scheme itself checked with the oracle: shards
+keyed by GLOBAL env id reproduce the unsharded run (per-env weights: exactly; shared weights: the per-step
+delta all-reduce gives the unsharded update)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["RSRL_ROOT"])
+from rsrl_amd.distributed import ControlPlane, RankInfo, shard_range, make_sharded_context
+from oracle import oracle as orc
+
+cp = ControlPlane()
+out = {"rank": cp.rank, "world": cp.world}
+# control plane
+uid = cp.broadcast_bytes(bytes(range(128)) if cp.rank == 0 else None)
+out["uid_ok"] = uid == bytes(range(128))
+out["max"] = cp.max_over_ranks(1.5 + cp.rank)
+
+# make_sharded_context with a recording stand-in for the device Context (no GPU here)
+class FakeCtx:
+    calls = []
+    def __init__(self, **kw): self.kw = kw
+    @staticmethod
+    def comm_unique_id(): return b"U" * 128
+    def comm_init(self, uid, world, rank): FakeCtx.calls.append((uid, world, rank))
+ctx = make_sharded_context(1001, cp, context_cls=FakeCtx, weight_mode=1, seed=3)
+out["shard"] = [ctx.kw["env_offset"], ctx.kw["n_envs"], ctx.kw["device"]]
+out["comm"] = [(u == b"U" * 128, w, r) for (u, w, r) in FakeCtx.calls]
+
+# the sharding scheme, exercised with the oracle
+N, K = 24, 40
+off, cnt = shard_range(N, cp.world, cp.rank)
+kw = dict(policy=orc.EGREEDY, epsilon=0.1, seed=5, max_episode_steps=15)
+run = orc.Run(orc.make_agent(env_offset=off, **kw), cnt, "f64"); run.reset(); st = run.train(K)
+out["per_env_state"] = run.state.tolist(); out["per_env_w0"] = run.weights[0].tolist(); out["per_env_eps"] = st["episodes"]
+srun = orc.Run(orc.make_agent(env_offset=off, shared_w=True, lr=0.001 / N, **kw), cnt, "f64"); srun.reset()
+srun.train_with_dw_hook(K, lambda dW: cp.sum_over_ranks(dW))
+out["shared_w"] = srun.weights.tolist(); out["shared_state"] = srun.state.tolist()
+cp.barrier()
+print("RESULT " + json.dumps(out))
+cp.close()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_range_partitions_exactly():
+    from rsrl_amd.distributed import shard_range
+    for n, w in [(0, 3), (1, 2), (7, 8), (65536, 8), (1001, 2), (1048576, 8), (10, 3)]:
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (o1, c1), (o2, _) in zip(spans, spans[1:]):
+            assert o1 + c1 == o2
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_world2_gloo_sharding_and_control_plane(tmp_path, orc):
+    import json
+    port = _free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RSRL_ROOT=ROOT, GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, se[-2000:]
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")][0]
+        d = json.loads(line[7:])
+        res[d["rank"]] = d
+    assert sorted(res) == [0, 1]
+    for r in (0, 1):
+        assert res[r]["uid_ok"] and res[r]["max"] == 2.5 and res[r]["world"] == 2
+        assert res[r]["comm"] == [[True, 2, r]]
+    assert res[0]["shard"] == [0, 501, 0] and res[1]["shard"] == [501, 500, 1]
+
+    # unsharded reference runs
+    N, K = 24, 40
+    kw = dict(policy=orc.EGREEDY, epsilon=0.1, seed=5, max_episode_steps=15)
+    full = orc.Run(orc.make_agent(**kw), N, "f64"); full.reset(); st = full.train(K)
+    both = np.concatenate([np.array(res[0]["per_env_state"]), np.array(res[1]["per_env_state"])])
+    assert np.array_equal(both, full.state)                       # RNG keyed by GLOBAL env id: sharding is invisible
+    assert np.array_equal(np.array(res[1]["per_env_w0"]), full.weights[12])
+    assert res[0]["per_env_eps"] + res[1]["per_env_eps"] == st["episodes"]
+    sfull = orc.Run(orc.make_agent(shared_w=True, lr=0.001 / N, **kw), N, "f64"); sfull.reset(); sfull.train(K)
+    for r in (0, 1):                                              # every rank applied the same summed delta
+        assert np.allclose(np.array(res[r]["shared_w"]), sfull.weights, rtol=0, atol=1e-13)
+    sboth = np.concatenate([np.array(res[0]["shared_state"]), np.array(res[1]["shared_state"])])
+    assert np.allclose(sboth, sfull.state, rtol=0, atol=1e-12)
+    assert np.array_equal(np.array(res[0]["shared_w"]), np.array(res[1]["shared_w"]))   # replicas stay bit-identical

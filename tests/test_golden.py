@@ -1,0 +1,89 @@
+"""Committed golden vectors (tests/golden/vectors.json, made by tests/golden/make_golden.py).
+CPU: the oracle still reproduces them (guards the checker against drift).  GPU: the HIP path against the same
+vectors directly, without the live oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors.json")))
+
+
+def test_oracle_reproduces_golden(orc):
+    o = G["oracle"]
+    assert np.allclose(orc.fourier_project(0, 5, [-0.5, 0.0]), o["fourier5_phi_default_state"], rtol=0, atol=1e-15)
+    for rec in o["domain_steps"]:
+        ns, r, term = orc.domain_step(rec["domain"], np.array(rec["s"], dtype=np.float64), rec["a"])
+        assert np.allclose(ns, rec["ns"], rtol=0, atol=1e-14) and r == rec["r"] and term == rec["term"]
+    ag = orc.make_agent(domain=1, basis=orc.TILE, n_tilings=8, tiles_per_dim=8)
+    for rec in o["cartpole_tile_indices"]:
+        assert orc.tile_indices(ag, rec["s"]).tolist() == rec["idx"]
+    ref = G["reference"]
+    s = orc.domain_reset(orc.CART_POLE)
+    for exp in ref["cartpole_steps_action0"]:
+        s, _, _ = orc.domain_step(orc.CART_POLE, s, 0)
+        assert np.all(np.abs(s - np.array(exp)) < 1e-7)
+    assert orc.policy_sample(orc.GREEDY, ref["greedy_argmax"]["q"], (0, 0, 0, 0)) == ref["greedy_argmax"]["a"]
+    for case in ref["egreedy_probs"]["cases"]:
+        assert np.allclose(orc.policy_probs(orc.EGREEDY, case["q"], eps=ref["egreedy_probs"]["eps"]), case["p"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_matches_golden():
+    import rsrl_amd as ra
+    o = G["oracle"]
+    # Fourier(5) features of the default state
+    with ra.Context(n_envs=1) as c:
+        phi = c.project(np.array([[-0.5], [0.0]], dtype=np.float32))[:, 0]
+    assert np.max(np.abs(phi - np.array(o["fourier5_phi_default_state"]))) <= 3e-6
+    # domain steps (fp32 vs f64: 1e-5; Acrobot 2e-4, see test_gpu_parity_mc)
+    for dom in (0, 1, 2):
+        recs = [r for r in o["domain_steps"] if r["domain"] == dom]
+        S = np.array([r["s"] for r in recs], dtype=np.float32).T
+        with ra.Context(domain=dom, order=5 if dom == 0 else 1, n_envs=len(recs)) as c:
+            c.states = S
+            _, nxt, rew, term = c.domain_step(np.array([r["a"] for r in recs], dtype=np.int32))
+        tol = 2e-4 if dom == 2 else 1e-5
+        for k, r in enumerate(recs):
+            assert np.allclose(nxt[:, k], r["ns"], rtol=tol, atol=tol)
+            assert rew[k] == r["r"] and bool(term[k]) == r["term"]
+    # tile indices: bit-exact
+    recs = o["cartpole_tile_indices"]
+    with ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, n_envs=len(recs), weight_mode=ra.W_SHARED) as c:
+        idx = c.tile_indices(np.array([r["s"] for r in recs], dtype=np.float32).T)
+    for k, r in enumerate(recs):
+        assert idx[:, k].tolist() == r["idx"]
+    # one update per agent from a fixed non-zero W
+    W0 = np.array(o["W0"], dtype=np.float32)
+    for u in o["updates"]:
+        with ra.Context(n_envs=1, algo=u["algo"], policy=u["policy"], seed=5, gamma=u["gamma"], lr=u["lr"], alpha=u["alpha"],
+                        epsilon=u["epsilon"], tau=u["tau"]) as c:
+            c.set_weights(W0, 0)
+            td = c.handle(np.array([u["s"]], dtype=np.float32).T, np.array([u["a"]], dtype=np.int32),
+                          np.array([u["r"]], dtype=np.float32), np.array([u["ns"]], dtype=np.float32).T,
+                          np.array([u["term"]], dtype=np.uint8))
+            W = c.get_weights(0)
+        assert abs(td[0] - u["delta"]) <= 2e-5 * (1 + abs(u["delta"]))
+        assert np.max(np.abs(W[:, 2] - np.array(u["W_col2_after"]))) <= 1e-6 * (1 + abs(u["delta"]))
+        assert np.array_equal(W[:, :2], W0[:, :2])
+    # 1000 teacher-forced updates
+    tf = o["teacher_forced"]
+    with ra.Context(n_envs=4, **tf["config"]) as c:
+        for step in tf["transitions"]:
+            c.handle(np.array([e["s"] for e in step], dtype=np.float32).T, np.array([e["a"] for e in step], dtype=np.int32),
+                     np.array([e["r"] for e in step], dtype=np.float32), np.array([e["ns"] for e in step], dtype=np.float32).T,
+                     np.array([e["term"] for e in step], dtype=np.uint8))
+        Wd = np.stack([c.get_weights(i) for i in range(4)])
+    Wo = np.array(tf["W_after"])
+    assert np.max(np.abs(Wd - Wo)) <= 1e-3 * max(1.0, np.max(np.abs(Wo)))
+    # greedy rollout from fixed weights
+    gr = o["greedy_rollout"]
+    W = np.array(gr["W"], dtype=np.float32)
+    with ra.Context(n_envs=len(W), policy=1) as c:
+        for i in range(len(W)):
+            c.set_weights(W[i], i)
+        n, tot = c.rollout_greedy(gr["limit"])
+    agree = n == np.array(gr["n_states"])
+    assert agree.mean() >= 0.85
+    assert np.all(tot[agree] == np.array(gr["total_reward"])[agree])
