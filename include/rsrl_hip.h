@@ -163,7 +163,9 @@ int rsrl_hip_tile_indices(rsrl_hip_ctx* ctx, const float* states, int64_t M, int
 
 /* Handler<&Transition>::handle for QLearning / SARSA / ExpectedSARSA
  *   control/td/q_learning.rs:51-71, sarsa.rs:53-75, expected_sarsa.rs:45-66
- * td_error_out (optional) = Response.error (q_learning.rs:17-20) */
+ * td_error_out (optional) = Response.error (q_learning.rs:17-20).  Each call counts as one batch-step: it advances
+ * rsrl_hip_step_count, the counter that addresses the agent-side random draws (SARSA's inner policy sample,
+ * sarsa.rs:61; bf16 stochastic rounding), exactly as one step of rsrl_hip_train does. */
 int rsrl_hip_handle(rsrl_hip_ctx* ctx, const float* from_states, const int32_t* actions,
                     const float* rewards, const float* to_states, const uint8_t* terminal,
                     int64_t M, float* td_error_out);
@@ -188,7 +190,7 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 /* The fused driver loop (examples/q_learning.rs:40-52) x n_envs x n_steps with auto-reset
  * on terminal / step cap.  stats_out is a HOST pointer (optional). */
 int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out);
-/* batch-steps executed so far (the RNG counter) */
+/* batch-steps executed so far by rsrl_hip_train and rsrl_hip_handle (the RNG counter) */
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
 
 /* Domain::rollout with the closure s -> policy.mode(s) and Some(step_limit), + n_states

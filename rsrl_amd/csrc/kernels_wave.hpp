@@ -1,0 +1,460 @@
+// kernels_wave.hpp -- "wave family": ONE WAVEFRONT PER LEARNER for large Fourier bases
+// (order 7 on a 4-D state space: F = 8^4 = 4096 features, 3 x 4096 weights per learner).
+//
+// A learner's weight matrix does not fit one lane's registers, but it fits one WAVE's:
+// 64 lanes x 64 features x A actions.  The fused driver loop therefore still keeps W on-chip
+// for a whole launch; HBM sees W once per launch (coalesced 16 B/lane loads), and the
+// per-action dot products become per-lane partial sums + one DPP wave reduction whose
+// result is wave-uniform (every branch on the action, the terminal flag or the episode
+// counter is a scalar branch: no divergence anywhere).
+//
+// Internal feature order: k = c0*512 + c1*64 + c2*8 + c3 (the coefficient vector's digits,
+// dimension 0 most significant) for ALL k in [0, F); k = 0 (all-zero coefficient, cos 0 = 1)
+// plays the role of the constant feature that lfa's with_bias() stacks last.  Reference
+// feature f  <->  k = (f + 1) mod F.   Lane l owns, for every chunk j = 0..7, the 8 consecutive
+// k = j*512 + l*8 + v (v = 0..7): c0 = j, c1 = l>>3, c2 = l&7, c3 = v.
+//
+// HBM layout:  W  WT[N][A][F] (k order, learner-major: a wave streams its learner's rows
+//              with 16 B per lane), WT = f32 or bf16.  bf16: arithmetic stays f32, every
+//              UPDATED weight is rounded to bf16 with stochastic rounding (so fused and
+//              single-step launches round identically); registers hold the rounded values.
+#pragma once
+
+#include "models.hpp"
+
+namespace rsrl {
+
+constexpr int kWaveOrder = 7;
+constexpr int kWaveN1 = 8;
+
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+// stochastic rounding f32 -> bf16-representable f32: add 16 random bits below the kept mantissa, truncate
+__device__ __forceinline__ float round_bf16_sr(float x, uint32_t rnd16) {
+    uint32_t b = __builtin_bit_cast(uint32_t, x);
+    b += (rnd16 & 0xffffu);
+    return __builtin_bit_cast(float, b & 0xffff0000u);
+}
+
+template <class WT> struct WaveIO;
+template <> struct WaveIO<float> {
+    static constexpr bool kBf16 = false;
+    // 8 consecutive weights of lane l at element offset `off` (multiple of 8)
+    __device__ static __forceinline__ void load8(const float* __restrict__ base, int64_t off, float (&w)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(base + off);
+        const float4 b = *reinterpret_cast<const float4*>(base + off + 4);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    }
+    __device__ static __forceinline__ void store8(float* __restrict__ base, int64_t off, const float (&w)[8]) {
+        *reinterpret_cast<float4*>(base + off) = make_float4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<float4*>(base + off + 4) = make_float4(w[4], w[5], w[6], w[7]);
+    }
+};
+template <> struct WaveIO<bf16_t> {
+    static constexpr bool kBf16 = true;
+    __device__ static __forceinline__ void load8(const bf16_t* __restrict__ base, int64_t off, float (&w)[8]) {
+        const uint4 p = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off);
+        w[0] = bf16_to_f32(p.x & 0xffffu); w[1] = __builtin_bit_cast(float, p.x & 0xffff0000u);
+        w[2] = bf16_to_f32(p.y & 0xffffu); w[3] = __builtin_bit_cast(float, p.y & 0xffff0000u);
+        w[4] = bf16_to_f32(p.z & 0xffffu); w[5] = __builtin_bit_cast(float, p.z & 0xffff0000u);
+        w[6] = bf16_to_f32(p.w & 0xffffu); w[7] = __builtin_bit_cast(float, p.w & 0xffff0000u);
+    }
+    // values are already bf16-representable: plain truncation packs them exactly
+    __device__ static __forceinline__ void store8(bf16_t* __restrict__ base, int64_t off, const float (&w)[8]) {
+        auto pk = [](float lo, float hi) {
+            return (__builtin_bit_cast(uint32_t, lo) >> 16) | (__builtin_bit_cast(uint32_t, hi) & 0xffff0000u);
+        };
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(base) + off) =
+            make_uint4(pk(w[0], w[1]), pk(w[2], w[3]), pk(w[4], w[5]), pk(w[6], w[7]));
+    }
+};
+
+// wave total, broadcast as a wave-uniform value
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum_dpp_to_lane63(v)), 63));
+}
+
+template <int DOMAIN>
+struct WaveFourier {
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = Dom::D, A = Dom::A, N1 = kWaveN1, F = 4096;
+    static_assert(D == 4, "the wave family is laid out for 4-D state spaces");
+
+    // phi[j][v] = cos(pi * (j*s~0 + c1*s~1 + c2*s~2 + v*s~3)), evaluated exactly like the register family
+    // (per dimension one sincospi + the angle-addition chain, then the complex product over dimensions in
+    // dimension order) -- the same op order as the f32 oracle.
+    __device__ static __forceinline__ void project(const float (&s)[D], int lane, float (&phi)[8][8]) {
+        FourierTables<DOMAIN, kWaveOrder> tb;
+        tb.build(s);
+        const int c1 = lane >> 3, c2 = lane & 7;
+        float e1r = tb.ct[1][0], e1i = tb.st[1][0], e2r = tb.ct[2][0], e2i = tb.st[2][0];
+#pragma unroll
+        for (int c = 1; c < N1; ++c) {
+            e1r = (c1 == c) ? tb.ct[1][c] : e1r; e1i = (c1 == c) ? tb.st[1][c] : e1i;
+            e2r = (c2 == c) ? tb.ct[2][c] : e2r; e2i = (c2 == c) ? tb.st[2][c] : e2i;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // ((E0[j] * E1[c1]) * E2[c2]) * E3[v], real part
+            float re = tb.ct[0][j], im = tb.st[0][j];
+            float nre = fmaf(-im, e1i, re * e1r), nim = fmaf(re, e1i, im * e1r);
+            re = nre; im = nim;
+            nre = fmaf(-im, e2i, re * e2r); nim = fmaf(re, e2i, im * e2r);
+            re = nre; im = nim;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) phi[j][v] = fmaf(-im, tb.st[3][v], re * tb.ct[3][v]);
+        }
+    }
+    // per-lane partial of <phi, w_b> (4 interleaved chains), then the wave total (uniform)
+    __device__ static __forceinline__ float dot(const float (&phi)[8][8], const float (&w)[8][8]) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi[j][v], w[j][v], acc[v & 3]);
+        return wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    }
+    template <class WT>
+    __device__ static __forceinline__ void load_w(const WT* __restrict__ Wi, int lane, float (&w)[A][8][8]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) WaveIO<WT>::load8(Wi, (int64_t)b * F + j * 512 + lane * 8, w[b][j]);
+    }
+    template <class WT>
+    __device__ static __forceinline__ void store_w(WT* __restrict__ Wi, int lane, const float (&w)[A][8][8]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) WaveIO<WT>::store8(Wi, (int64_t)b * F + j * 512 + lane * 8, w[b][j]);
+    }
+    // Q(s,.) with W streamed from memory (granular ops)
+    template <class WT>
+    __device__ static __forceinline__ void q_from_mem(const WT* __restrict__ Wi, int lane, const float (&phi)[8][8], float (&q)[A]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float w8[8];
+                WaveIO<WT>::load8(Wi, (int64_t)b * F + j * 512 + lane * 8, w8);
+#pragma unroll
+                for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi[j][v], w8[v], acc[v & 3]);
+            }
+            q[b] = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        }
+    }
+    // W[:,a] += scale*phi (one column, a is wave-uniform); bf16: stochastic rounding of every updated weight
+    template <class WT>
+    __device__ static __forceinline__ void update_col(float (&wa)[8][8], const float (&phi)[8][8], float scale, const U4& rnd) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                float x = fmaf(scale, phi[j][v], wa[j][v]);
+                if constexpr (WaveIO<WT>::kBf16) {
+                    const int e = j * 8 + v;
+                    const uint32_t word = (e & 3) == 0 ? rnd.x : (e & 3) == 1 ? rnd.y : (e & 3) == 2 ? rnd.z : rnd.w;
+                    x = round_bf16_sr(x, (word * (uint32_t)(2 * e + 1) * 0x9E3779B1u) >> 16);
+                }
+                wa[j][v] = x;
+            }
+    }
+};
+
+enum : uint32_t { BLK_SR_BASE = 16 };   // stochastic-rounding draws: block = 16 + lane
+
+// ---------------------------------------------------------------------------------------
+// fused driver loop, one wave per learner (semantics identical to k_train_reg)
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, class WT>
+__global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict__ Wbase, uint64_t t0, int n_steps,
+                                                       DevStats* __restrict__ stats) {
+    using WF = WaveFourier<DOMAIN>;
+    using Dom = Domain<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        WT* Wi = Wbase + i * (int64_t)(A * F);
+        float s[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+        int a = __builtin_amdgcn_readfirstlane(c.action[i]);
+        uint32_t ep = c.ep_step[i];
+        float w[A][8][8];
+        WF::template load_w<WT>(Wi, lane, w);
+        float phi_a[8][8], phi_b[8][8], q_s[A];
+        WF::project(s, lane, phi_a);
+#pragma unroll
+        for (int b = 0; b < A; ++b) q_s[b] = WF::dot(phi_a, w[b]);
+        float facc_abs = 0.0f, facc_r = 0.0f;
+
+        auto one_step = [&](const float (&phi_s)[8][8], float (&phi_n)[8][8], uint64_t t) {
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) Dom::reset(ns);
+            WF::project(ns, lane, phi_n);
+            float q_n[A];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = WF::dot(phi_n, w[b]);
+            const float qsa = select_a<A>(q_s, a);
+            U4 xin = U4{0, 0, 0, 0};
+            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            const float scale = c.alg.lr * e;
+            U4 rnd = U4{0, 0, 0, 0};
+            if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
+            // a is wave-uniform: a scalar branch picks the column, 64 fma per lane instead of A*64
+            float qa = 0.0f;
+            static_for<0, A>([&](auto Bb) {
+                constexpr int b = Bb;
+                if (a == b) {
+                    WF::template update_col<WT>(w[b], phi_s, scale, rnd);
+                    qa = WF::dot(phi_n, w[b]);                       // Q(s',a) with the UPDATED column
+                }
+            });
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
+            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            int na = policy_sample<A>(c.pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                WF::project(ns, lane, phi_n);
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = WF::dot(phi_n, w[b]);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(c.pol, q_n, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            a = __builtin_amdgcn_readfirstlane(na);
+        };
+        int k = 0;
+        for (; k + 1 < n_steps; k += 2) {
+            one_step(phi_a, phi_b, t0 + (uint64_t)k);
+            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+        }
+        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+
+        WF::template store_w<WT>(Wi, lane, w);
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+            c.action[i] = a;
+            c.ep_step[i] = ep;
+            sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+        } else {
+            n_ep = 0; n_trunc = 0; sum_len = 0;                      // the wave's statistics are counted once (lane 0)
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// trait-granular kernels, one wave per item
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, class WT>
+__global__ __launch_bounds__(kBlock) void k_wave_reset(Common c, const WT* __restrict__ Wbase, uint64_t t) {
+    using WF = WaveFourier<DOMAIN>; using Dom = Domain<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (i >= c.n_envs) return;
+    float s[D]; Dom::reset(s);
+    float phi[8][8], q[A];
+    WF::project(s, lane, phi);
+    WF::template q_from_mem<WT>(Wbase + i * (int64_t)(A * F), lane, phi, q);
+    const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
+    const int a = policy_sample<A>(c.pol, q, x);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = 0;
+    }
+}
+
+template <int DOMAIN, class WT>
+__global__ __launch_bounds__(kBlock) void k_wave_qop(Common c, const WT* __restrict__ Wbase, int op, const float* __restrict__ states,
+                                                     int64_t Mn, uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
+    using WF = WaveFourier<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (i >= Mn) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * Mn + i];
+    float phi[8][8];
+    WF::project(s, lane, phi);
+    if (op == QOP_FEATURES) {               // reference order: feature f = k - 1 for k >= 1, the constant (k = 0) last
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int k = j * 512 + lane * 8 + v;
+                fout[(int64_t)((k + F - 1) % F) * Mn + i] = phi[j][v];
+            }
+        return;
+    }
+    float q[A];
+    WF::template q_from_mem<WT>(Wbase + i * (int64_t)(A * F), lane, phi, q);
+    if (lane != 0 && op != QOP_SAMPLE) return;
+    if (op == QOP_EVALUATE) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
+    } else if (op == QOP_FIND_MAX) {
+        float v; const int bi = find_max<A>(q, v);
+        if (iout) iout[i] = bi;
+        if (fout) fout[i] = v;
+    } else if (op == QOP_SAMPLE) {
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+        const int a = policy_sample<A>(c.pol, q, x);
+        if (lane == 0) iout[i] = a;
+    } else if (op == QOP_MODE) {
+        iout[i] = policy_mode<A>(c.pol, q);
+    } else {
+        float p[A]; policy_probs<A>(c.pol, q, p);
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
+    }
+}
+
+template <int DOMAIN, class WT>
+__global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict__ Wbase, const float* __restrict__ from,
+                                                        const int32_t* __restrict__ act, const float* __restrict__ rew,
+                                                        const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                        int64_t Mn, uint64_t t, float* __restrict__ td_out) {
+    using WF = WaveFourier<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (i >= Mn) return;
+    WT* Wi = Wbase + i * (int64_t)(A * F);
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
+    const int a = __builtin_amdgcn_readfirstlane(act[i]);
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    float phi_s[8][8], phi_n[8][8], q_s[A], q_n[A];
+    WF::project(s, lane, phi_s);
+    WF::project(ns, lane, phi_n);
+    WF::template q_from_mem<WT>(Wi, lane, phi_s, q_s);
+    WF::template q_from_mem<WT>(Wi, lane, phi_n, q_n);
+    U4 xin = U4{0, 0, 0, 0};
+    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
+    float e;
+    const float delta = td_error<A>(c.alg, c.pol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+    const float scale = c.alg.lr * e;
+    U4 rnd = U4{0, 0, 0, 0};
+    if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_SR_BASE + (uint32_t)lane);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float w8[1][8];
+        const int64_t off = (int64_t)a * F + j * 512 + lane * 8;
+        WaveIO<WT>::load8(Wi, off, w8[0]);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            float x = fmaf(scale, phi_s[j][v], w8[0][v]);
+            if constexpr (WaveIO<WT>::kBf16) {
+                const int el = j * 8 + v;
+                const uint32_t word = (el & 3) == 0 ? rnd.x : (el & 3) == 1 ? rnd.y : (el & 3) == 2 ? rnd.z : rnd.w;
+                x = round_bf16_sr(x, (word * (uint32_t)(2 * el + 1) * 0x9E3779B1u) >> 16);
+            }
+            w8[0][v] = x;
+        }
+        WaveIO<WT>::store8(Wi, off, w8[0]);
+    }
+    if (td_out && lane == 0) td_out[i] = delta;
+}
+
+template <int DOMAIN, class WT>
+__global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __restrict__ Wbase, int64_t step_limit,
+                                                         uint32_t* __restrict__ n_states, float* __restrict__ total_reward) {
+    using WF = WaveFourier<DOMAIN>; using Dom = Domain<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (i >= c.n_envs) return;
+    float w[A][8][8];
+    WF::template load_w<WT>(Wbase + i * (int64_t)(A * F), lane, w);
+    float s[D]; Dom::reset(s);
+    float phi[8][8], q[A], r, tot = 0.0f;
+    WF::project(s, lane, phi);
+#pragma unroll
+    for (int b = 0; b < A; ++b) q[b] = WF::dot(phi, w[b]);
+    int a = policy_mode<A>(c.pol, q);
+    bool term = Dom::step(s, a, r);
+    int64_t steps = 0;
+    while (steps < step_limit - 1) {
+        steps += 1; tot += r;
+        if (term) break;
+        if (steps >= step_limit - 1) break;
+        WF::project(s, lane, phi);
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = WF::dot(phi, w[b]);
+        a = policy_mode<A>(c.pol, q);
+        term = Dom::step(s, a, r);
+    }
+    if (lane == 0) {
+        n_states[i] = (uint32_t)(steps + 1);
+        if (total_reward) total_reward[i] = tot;
+    }
+}
+
+// get / set of one learner's weights in the reference format f32[F][A] (feature f <-> k = (f+1) mod F)
+template <class WT>
+__global__ void k_wave_weights_get(const WT* __restrict__ Wi, int F, int A, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= F * A) return;
+    const int f = j / A, b = j % A, k = (f + 1) % F;
+    float tmp[8];
+    WaveIO<WT>::load8(Wi, (int64_t)b * F + (k & ~7), tmp);
+    float v = tmp[0];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) v = ((k & 7) == u) ? tmp[u] : v;
+    out[j] = v;
+}
+template <class WT>
+__global__ void k_wave_weights_set(WT* __restrict__ W, int64_t first, int64_t count, int F, int A, const float* __restrict__ in) {
+    // one thread per group of 8 consecutive k of one (learner, action); bf16: round to nearest even
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int groups = F / 8;
+    if (g >= count * A * groups) return;
+    const int64_t li = g / (A * groups);
+    const int b = (int)((g / groups) % A), k0 = (int)(g % groups) * 8;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u, f = (k + F - 1) % F;
+        float x = in[(int64_t)f * A + b];
+        if constexpr (WaveIO<WT>::kBf16) {
+            uint32_t bits = __builtin_bit_cast(uint32_t, x);
+            bits += 0x7fffu + ((bits >> 16) & 1u);
+            x = __builtin_bit_cast(float, bits & 0xffff0000u);
+        }
+        v[u] = x;
+    }
+    WaveIO<WT>::store8(W + (first + li) * (int64_t)(A * F), (int64_t)b * F + k0, v);
+}
+
+}  // namespace rsrl

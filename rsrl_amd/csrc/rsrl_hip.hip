@@ -16,6 +16,7 @@
 #include "../../include/rsrl_hip.h"
 #include "launch.hpp"
 #include "models.hpp"
+#include "kernels_wave.hpp"
 
 using namespace rsrl;
 
@@ -103,7 +104,7 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
-    size_t w_elems = 0; size_t dw_elems = 0;
+    size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
     int64_t w_stride = 0;
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
     size_t n_stat_slots = 0;
@@ -168,6 +169,19 @@ static bool for_model(const rsrl_hip_ctx* c, Fn&& fn) {
     return false;
 }
 static BasisGeom make_geom(const rsrl_hip_ctx* c) { return BasisGeom{c->F, c->cfg.tiles_per_dim}; }
+// wave family (one wavefront per learner): Fourier order 7 on the 4-D domains, f32 or bf16 weights
+template <int DM, class WT> struct WaveTag { static constexpr int domain = DM; using wt = WT; };
+static bool is_wave(const rsrl_hip_config& cfg) {
+    return cfg.basis == RSRL_FOURIER && cfg.order == kWaveOrder && (cfg.domain == RSRL_CART_POLE || cfg.domain == RSRL_ACROBOT);
+}
+template <class Fn>
+static bool for_wave(const rsrl_hip_ctx* c, Fn&& fn) {
+    const bool bf = c->cfg.weight_dtype == RSRL_W_BF16;
+    if (c->cfg.domain == RSRL_CART_POLE) { if (bf) fn(WaveTag<1, bf16_t>{}); else fn(WaveTag<1, float>{}); return true; }
+    if (c->cfg.domain == RSRL_ACROBOT) { if (bf) fn(WaveTag<2, bf16_t>{}); else fn(WaveTag<2, float>{}); return true; }
+    return false;
+}
+static inline unsigned wave_grid_for(int64_t items) { return (unsigned)((items + (kBlock / 64) - 1) / (kBlock / 64)); }
 #define NO_MODEL(c) fail(RSRL_HIP_EINVAL, "no kernel for basis %d domain %d order %d tilings %d", (c)->cfg.basis, (c)->cfg.domain, (c)->cfg.order, (c)->cfg.n_tilings)
 
 // ---- host/device pointer staging ---------------------------------------------------------
@@ -282,7 +296,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
         return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
-    if (cfg->weight_dtype != RSRL_W_F32) return fail(RSRL_HIP_EINVAL, "weight dtype %d not supported yet", cfg->weight_dtype);
+    if (cfg->weight_dtype != RSRL_W_F32 && cfg->weight_dtype != RSRL_W_BF16) return fail(RSRL_HIP_EINVAL, "unknown weight dtype %d", cfg->weight_dtype);
     if (cfg->basis == RSRL_FOURIER) {
         if (cfg->order < 1) return fail(RSRL_HIP_EINVAL, "Fourier order must be >= 1");
         c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
@@ -294,7 +308,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     } else {
         return fail(RSRL_HIP_EINVAL, "unknown basis %d", cfg->basis);
     }
-    if (!model_supported(*cfg))
+    if (is_wave(*cfg)) {
+        if (cfg->weight_mode == RSRL_W_SHARED) return fail(RSRL_HIP_EINVAL, "shared weights are not available for the order-7 wave family yet");
+    } else if (cfg->weight_dtype != RSRL_W_F32) {
+        return fail(RSRL_HIP_EINVAL, "bf16 weights are available for Fourier order 7 on CartPole / Acrobot only");
+    }
+    if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -308,11 +327,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     c->w_stride = shared ? 1 : N;
     c->w_elems = (size_t)c->A * c->F * (size_t)c->w_stride;
     c->dw_elems = (size_t)c->A * c->F;
-    c->n_stat_slots = grid_for(N);
+    c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
-    HIP_TRY(hipMalloc((void**)&c->W, sizeof(float) * c->w_elems));
+    c->w_bytes = c->w_elems * (cfg->weight_dtype == RSRL_W_BF16 ? 2 : 4);
+    HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
@@ -320,7 +340,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
-    HIP_TRY(hipMemsetAsync(c->W, 0, sizeof(float) * c->w_elems, c->stream));      // LFA::vector zero-initialises
+    HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
     HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
     HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
@@ -380,7 +400,12 @@ int rsrl_hip_reset(rsrl_hip_ctx* c) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (!for_model(c, [&](auto tag) {
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_reset<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, c->t);
+        });
+    } else if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             hipLaunchKernelGGL((k_reset<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, c->t);
         })) return NO_MODEL(c);
@@ -474,7 +499,12 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
-    if (!for_model(c, [&](auto tag) {
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_qop<T::domain, WT>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, op, d_states, M_, call, of.dev, oi.dev);
+        });
+    } else if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             hipLaunchKernelGGL((k_qop<M>), dim3(grid_for(M_)), dim3(kBlock), 0, c->stream, k, g, op, d_states, M_, call, of.dev, oi.dev);
         })) return NO_MODEL(c);
@@ -536,7 +566,12 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (!for_model(c, [&](auto tag) {
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_handle<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev);
+        });
+    } else if (!for_model(c, [&](auto tag) {
             using Mo = typename decltype(tag)::type;
             hipLaunchKernelGGL((k_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->dW);
         })) return NO_MODEL(c);
@@ -546,6 +581,8 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
+    c->t += 1;          // one handle call = one batch-step of learning: the agent-side draws (SARSA's inner sample,
+                        // bf16 stochastic rounding) advance exactly as they do inside rsrl_hip_train
     bool sync = true;   // inputs may be host memory staged asynchronously
     TRY(flush_out(c, &otd, &sync));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -559,6 +596,12 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; OutBuf<float> ow;
     TRY(stage_out(c, 0, w, (size_t)n, &ow));
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using WT = typename decltype(tag)::wt;
+            hipLaunchKernelGGL((k_wave_weights_get<WT>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const WT*)c->W + env_index * (int64_t)n, c->F, c->A, ow.dev);
+        });
+    } else
     hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, ow.dev);
     KCHECK();
     bool sync = false; TRY(flush_out(c, &ow, &sync));
@@ -572,6 +615,13 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using WT = typename decltype(tag)::wt;
+            const int64_t groups = (int64_t)c->A * (c->F / 8);
+            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, env_index, (int64_t)1, c->F, c->A, d_w);
+        });
+    } else
     hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -584,6 +634,13 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     const int n = c->F * c->A; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
     const int gy = n < 1024 ? n : 1024;
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using WT = typename decltype(tag)::wt;
+            const int64_t groups = c->cfg.n_envs * (int64_t)c->A * (c->F / 8);
+            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, (int64_t)0, c->cfg.n_envs, c->F, c->A, d_w);
+        });
+    } else
     hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->F, c->A, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -660,7 +717,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
-    const bool stream_k1 = !shared && fourier && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
+    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     int64_t done = 0;
     while (done < n_steps) {
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
@@ -668,6 +725,13 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         if (shared) {
             TRY(train_shared_step(c, k, g, d_stats));
             c->kernel_name = "k_shared_a";
+        } else if (is_wave(c->cfg)) {
+            for_wave(c, [&](auto tag) {
+                using T = decltype(tag); using WT = typename T::wt;
+                hipLaunchKernelGGL((k_train_wave<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
+            });
+            c->kernel_name = "k_train_wave";
+            KCHECK();
         } else if (fourier) {
             const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
             const dim3 gr(grid_for(k.n_envs)), b(kBlock);
@@ -721,7 +785,12 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_sta
     TRY(stage_out(c, 1, total_reward_out, (size_t)N, &ot));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (!for_model(c, [&](auto tag) {
+    if (is_wave(c->cfg)) {
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_rollout<T::domain, WT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, step_limit, on.dev, ot.dev);
+        });
+    } else if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             hipLaunchKernelGGL((k_rollout<M>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev);
         })) return NO_MODEL(c);
