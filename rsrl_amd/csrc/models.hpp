@@ -65,6 +65,11 @@ struct FourierModel {
             c.W[j] = fmaf(scale, ft.phi[f], c.W[j]);
         }
     }
+    __device__ static __forceinline__ void write_features(const BasisGeom&, const Feat& ft, int64_t Mn, int64_t i,
+                                                          float* __restrict__ fout, int32_t* __restrict__) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) fout[(int64_t)f * Mn + i] = ft.phi[f];
+    }
     // dW has the shared layout [A][F]
     // must be called by ALL lanes of the wave (uniform control flow); lanes without work pass valid = false
     __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
@@ -137,6 +142,11 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) c.W[widx(c, wi, g, ft.idx[t], a)] += scale;               // indices of distinct tilings never collide
     }
+    __device__ static __forceinline__ void write_features(const BasisGeom&, const Feat& ft, int64_t Mn, int64_t i,
+                                                          float* __restrict__, int32_t* __restrict__ iout) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) iout[(int64_t)t * Mn + i] = ft.idx[t];
+    }
     // dW has the shared layout [F][A].  Many learners sit in the same few tiles (all start at Domain::default()),
     // so before the f32 atomics the wave folds its heavy hitters: up to kRounds times the first pending lane's
     // key is broadcast, all lanes holding it are summed (DPP) and ONE atomic is issued for them.
@@ -161,6 +171,99 @@ struct TileModel {
             }
             if (pending) atomicAdd(&dW[key], scale);
         }
+    }
+};
+
+// Fourier basis of ANY order 1..7 on any domain, one thread per learner, features generated on the fly from the
+// per-dimension tables (runtime digits => the tables are indexed dynamically and live in scratch/LDS): the
+// catch-all for the (domain, order) pairs that have neither a register-family nor a wave-family kernel.
+// Same arithmetic as FourierReg (tables by the angle-addition chain, complex product in dimension order, the
+// 4-way interleaved dot product over the reference feature order).  W f32[A][F][Nw], learner index fastest.
+template <int DOMAIN>
+struct FourierGenericModel {
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = Dom::D, A = Dom::A;
+    static constexpr bool kDense = false;      // no register-resident phi: the shared-W block reduction is not available
+    struct Feat { float ct[D][8], st[D][8]; };
+    __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
+        const int order = g.tiles_per_dim;     // BasisGeom::tiles_per_dim carries the Fourier order for this model
+        static_for<0, D>([&](auto Dd) {
+            constexpr int d = Dd;
+            constexpr float lo = (float)Dom::lo_d(d), hi = (float)Dom::hi_d(d);
+            const float sc = (s[d] - lo) / (hi - lo);
+            ft.ct[d][0] = 1.0f; ft.st[d][0] = 0.0f;
+            sincospi01(sc, ft.st[d][1], ft.ct[d][1]);
+            for (int n = 2; n <= order; ++n) {
+                ft.ct[d][n] = fmaf(-ft.st[d][n - 1], ft.st[d][1], ft.ct[d][n - 1] * ft.ct[d][1]);
+                ft.st[d][n] = fmaf(ft.ct[d][n - 1], ft.st[d][1], ft.st[d][n - 1] * ft.ct[d][1]);
+            }
+        });
+    }
+    // phi of reference feature f (f = F-1 is the constant)
+    __device__ static __forceinline__ float phi_at(const BasisGeom& g, const Feat& ft, int f) {
+        if (f == g.F - 1) return 1.0f;
+        const int n1 = g.tiles_per_dim + 1;
+        int k = f + 1, c[D];
+#pragma unroll
+        for (int d = D - 1; d >= 0; --d) { c[d] = k % n1; k /= n1; }
+        float re = ft.ct[0][c[0]], im = ft.st[0][c[0]];
+#pragma unroll
+        for (int d = 1; d < D; ++d) {
+            const float cr = ft.ct[d][c[d]], sr = ft.st[d][c[d]];
+            const float nre = fmaf(-im, sr, re * cr), nim = fmaf(re, sr, im * cr);
+            re = nre; im = nim;
+        }
+        return re;
+    }
+    __device__ static __forceinline__ int64_t widx(const Common& c, int64_t wi, const BasisGeom& g, int b, int f) {
+        return ((int64_t)b * g.F + f) * c.w_stride + wi;
+    }
+    __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
+        float acc[A][4];
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[b][p] = 0.0f;
+        for (int f0 = 0; f0 < g.F; f0 += 4) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int f = f0 + p;
+                if (f < g.F) {
+                    const float ph = phi_at(g, ft, f);
+#pragma unroll
+                    for (int b = 0; b < A; ++b) acc[b][p] = fmaf(ph, c.W[widx(c, wi, g, b, f)], acc[b][p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = (acc[b][0] + acc[b][1]) + (acc[b][2] + acc[b][3]);
+    }
+    __device__ static __forceinline__ float q_index(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int f0 = 0; f0 < g.F; f0 += 4) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int f = f0 + p;
+                if (f < g.F) acc[p] = fmaf(phi_at(g, ft, f), c.W[widx(c, wi, g, a, f)], acc[p]);
+            }
+        }
+        return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    __device__ static __forceinline__ void update(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a, float scale) {
+        for (int f = 0; f < g.F; ++f) {
+            const int64_t j = widx(c, wi, g, a, f);
+            c.W[j] = fmaf(scale, phi_at(g, ft, f), c.W[j]);
+        }
+    }
+    __device__ static __forceinline__ void write_features(const BasisGeom& g, const Feat& ft, int64_t Mn, int64_t i,
+                                                          float* __restrict__ fout, int32_t* __restrict__) {
+        for (int f = 0; f < g.F; ++f) fout[(int64_t)f * Mn + i] = phi_at(g, ft, f);
+    }
+    // dW has the shared layout [A][F]; plain atomics (used by rsrl_hip_handle in shared mode only)
+    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom& g, const Feat& ft, int a, float scale,
+                                                      bool valid) {
+        if (valid)
+            for (int f = 0; f < g.F; ++f) atomicAdd(&dW[a * g.F + f], scale * phi_at(g, ft, f));
     }
 };
 
@@ -203,16 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_qop(Common c, BasisGeom g, int op, c
     float s[D]; load_state<M>(states, Mn, i, s);
     typename M::Feat ft;
     M::features(s, g, ft);
-    if (op == QOP_FEATURES) {
-        if constexpr (M::kDense) {
-#pragma unroll
-            for (int f = 0; f < M::F; ++f) fout[(int64_t)f * Mn + i] = ft.phi[f];
-        } else {
-#pragma unroll
-            for (int t = 0; t < (int)(sizeof(ft.idx) / sizeof(int)); ++t) iout[(int64_t)t * Mn + i] = ft.idx[t];
-        }
-        return;
-    }
+    if (op == QOP_FEATURES) { M::write_features(g, ft, Mn, i, fout, iout); return; }
     float q[A];
     M::q_all(c, c.shared ? 0 : i, g, ft, q);
     if (op == QOP_EVALUATE) {

@@ -147,12 +147,23 @@ static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) 
     X((FourierModel<1, 1>), RSRL_FOURIER, 1, 1) X((FourierModel<2, 1>), RSRL_FOURIER, 2, 1)  \
     X((TileModel<0, 4>), RSRL_TILE_CODING, 0, 4) X((TileModel<0, 8>), RSRL_TILE_CODING, 0, 8) X((TileModel<0, 16>), RSRL_TILE_CODING, 0, 16) \
     X((TileModel<1, 4>), RSRL_TILE_CODING, 1, 4) X((TileModel<1, 8>), RSRL_TILE_CODING, 1, 8) X((TileModel<1, 16>), RSRL_TILE_CODING, 1, 16) \
-    X((TileModel<2, 4>), RSRL_TILE_CODING, 2, 4) X((TileModel<2, 8>), RSRL_TILE_CODING, 2, 8) X((TileModel<2, 16>), RSRL_TILE_CODING, 2, 16)
+    X((TileModel<2, 4>), RSRL_TILE_CODING, 2, 4) X((TileModel<2, 8>), RSRL_TILE_CODING, 2, 8) X((TileModel<2, 16>), RSRL_TILE_CODING, 2, 16) \
+    X((FourierGenericModel<0>), RSRL_FOURIER, 0, -1) X((FourierGenericModel<1>), RSRL_FOURIER, 1, -1) X((FourierGenericModel<2>), RSRL_FOURIER, 2, -1)
 
 template <class T> struct Tag { using type = T; };
 #define RSRL_UNPAREN(...) __VA_ARGS__
+// param -1: the generic-order Fourier model (any order 1..7 without a specialised kernel; listed last)
 static bool model_match(const rsrl_hip_config& cfg, int basis, int domain, int param) {
-    return cfg.basis == basis && cfg.domain == domain && (basis == RSRL_FOURIER ? cfg.order : cfg.n_tilings) == param;
+    if (cfg.basis != basis || cfg.domain != domain) return false;
+    if (param == -1) return cfg.order >= 1 && cfg.order <= 7;
+    return (basis == RSRL_FOURIER ? cfg.order : cfg.n_tilings) == param;
+}
+static bool is_generic_fourier(const rsrl_hip_config& cfg) {
+    if (cfg.basis != RSRL_FOURIER) return false;
+#define X(TYPE, BS, DM, P) if (P != -1 && model_match(cfg, BS, DM, P)) return false;
+    RSRL_MODELS(X)
+#undef X
+    return true;
 }
 static bool model_supported(const rsrl_hip_config& cfg) {
 #define X(TYPE, BS, DM, P) if (model_match(cfg, BS, DM, P)) return true;
@@ -168,7 +179,9 @@ static bool for_model(const rsrl_hip_ctx* c, Fn&& fn) {
 #undef X
     return false;
 }
-static BasisGeom make_geom(const rsrl_hip_ctx* c) { return BasisGeom{c->F, c->cfg.tiles_per_dim}; }
+static BasisGeom make_geom(const rsrl_hip_ctx* c) {
+    return BasisGeom{c->F, c->cfg.basis == RSRL_FOURIER ? c->cfg.order : c->cfg.tiles_per_dim};
+}
 // wave family (one wavefront per learner): Fourier order 7 on the 4-D domains, f32 or bf16 weights
 template <int DM, class WT> struct WaveTag { static constexpr int domain = DM; using wt = WT; };
 static bool is_wave(const rsrl_hip_config& cfg) {
@@ -298,7 +311,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
     if (cfg->weight_dtype != RSRL_W_F32 && cfg->weight_dtype != RSRL_W_BF16) return fail(RSRL_HIP_EINVAL, "unknown weight dtype %d", cfg->weight_dtype);
     if (cfg->basis == RSRL_FOURIER) {
-        if (cfg->order < 1) return fail(RSRL_HIP_EINVAL, "Fourier order must be >= 1");
+        if (cfg->order < 1 || cfg->order > 7) return fail(RSRL_HIP_EINVAL, "Fourier order must be in [1, 7]");
         c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
     } else if (cfg->basis == RSRL_TILE_CODING) {
         if (cfg->tiles_per_dim < 1 || cfg->tiles_per_dim > 64) return fail(RSRL_HIP_EINVAL, "tiles_per_dim must be in [1, 64]");
@@ -308,6 +321,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     } else {
         return fail(RSRL_HIP_EINVAL, "unknown basis %d", cfg->basis);
     }
+    if (cfg->weight_mode == RSRL_W_SHARED && !is_wave(*cfg) && is_generic_fourier(*cfg))
+        return fail(RSRL_HIP_EINVAL, "shared weights need a register-family Fourier order (MountainCar 1-5, CartPole/Acrobot 1) or tile coding");
     if (is_wave(*cfg)) {
         if (cfg->weight_mode == RSRL_W_SHARED) return fail(RSRL_HIP_EINVAL, "shared weights are not available for the order-7 wave family yet");
     } else if (cfg->weight_dtype != RSRL_W_F32) {
@@ -336,7 +351,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
-        if (cfg->basis == RSRL_FOURIER) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
+        if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
     }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
@@ -717,7 +732,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
-    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
+    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     int64_t done = 0;
     while (done < n_steps) {
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
@@ -732,7 +747,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             });
             c->kernel_name = "k_train_wave";
             KCHECK();
-        } else if (fourier) {
+        } else if (fourier && !is_generic_fourier(c->cfg)) {
             const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
             const dim3 gr(grid_for(k.n_envs)), b(kBlock);
             const int kchunk = stream_k1 ? -1 : chunk;

@@ -169,3 +169,47 @@ def test_shared_handle_minibatch(ra, orc):
         dW += Wi - W
         assert abs(td[i] - d) <= 2e-5 * (1 + abs(d))
     assert np.max(np.abs(Wd - (W + dW))) <= 2e-6
+
+
+@pytest.mark.parametrize("domain,order", [(0, 7), (0, 6), (1, 2), (2, 3)])
+def test_generic_fourier_orders(ra, orc, domain, order):
+    # Fourier orders without a specialised kernel go through the generic on-the-fly model: same arithmetic
+    N, K = 40, 30
+    D = 2 if domain == 0 else 4
+    F = (order + 1) ** D
+    rng = np.random.default_rng(order)
+    s = rand_states(orc, domain, N, 40 + order, shrink=0.6)
+    kw = dict(gamma=0.95, lr=0.01, epsilon=0.1)
+    ag = orc.make_agent(domain=domain, order=order, policy=orc.EGREEDY, seed=31, max_episode_steps=20, **kw)
+    with ra.Context(domain=domain, order=order, policy=1, seed=31, max_episode_steps=20, n_envs=N, **kw) as c:
+        assert c.F == F
+        phi = c.project(s)
+        for m in range(0, N, 5):
+            assert np.max(np.abs(phi[:, m] - orc.fourier_project(domain, order, s[:, m], "f32"))) <= 2e-6
+            assert np.max(np.abs(phi[:, m] - orc.fourier_project(domain, order, s[:, m], "f64"))) <= 6e-6
+        A = c.A
+        Ws = [(rng.normal(size=(F, A)) * 0.1).astype(np.float32) for _ in range(N)]
+        for i in range(N):
+            c.set_weights(Ws[i], i)
+        q = c.q_evaluate(s)
+        for i in range(0, N, 3):
+            q32 = orc.q_evaluate(ag, Ws[i], s[:, i], "f32")
+            assert np.allclose(q[:, i], q32, rtol=0, atol=1e-5 * (1 + np.abs(q32).max()))
+        for i in range(N):
+            c.set_weights(np.zeros((F, A), dtype=np.float32), i)
+        run = orc.Run(ag, N, "f32")
+        run.reset()
+        run.train(K)
+        c.reset()
+        st = c.train(K)
+        tol = 2e-3 if domain == 2 else 1e-5
+        same = np.all(np.abs(c.states.T - run.state) <= tol * (1 + np.abs(run.state)), axis=1) & (c.actions == run.action)
+        assert same.mean() >= 0.85, same.mean()
+        for i in np.flatnonzero(same)[:5]:
+            assert np.max(np.abs(c.get_weights(i) - run.weights[i])) <= (5e-4 if domain == 2 else 5e-6)
+        n, _ = c.rollout_greedy(50)
+        assert n.shape == (N,) and st["env_steps"] == N * K
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(domain=domain, order=order, n_envs=4, weight_mode=ra.W_SHARED)
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(domain=domain, order=8, n_envs=4)
