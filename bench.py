@@ -81,6 +81,32 @@ def cpu_baseline(seconds=12.0):
                       f"eps-greedy, {total} env-steps in {dt:.1f} s (oracle/rsrl_oracle.c, gcc -O2)"}
 
 
+def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
+    """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg), i.e. the 608 B/env-step
+    streaming formulation the HBM roofline is defined on.  Never part of `value`."""
+    try:
+        ctx = rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, order=5, algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY,
+                               epsilon=0.1, gamma=0.9, lr=0.001, n_envs=envs, env_offset=rank * envs, seed=0,
+                               max_episode_steps=1000, steps_per_launch=1, device=device)
+        ctx.reset()
+        ctx.train(warmup, want_stats=False)
+        ctx.sync()
+        ctx.timing_enable(True)
+        t0 = time.perf_counter()
+        ctx.train(steps, want_stats=False)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ms, n, kn = ctx.timing_read()
+        ctx.close()
+        avg = ms * 1e-3 / max(1, n)
+        ach = BYTES_PER_ENV_STEP * envs / avg
+        return {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                "traffic": pmc_traffic(kn, envs, 1), "avg_launch_ms": avg * 1e3, "launches": n,
+                "env_steps_per_s_this_rank": envs * steps / dt}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def shared_w_leg(cp, rsrl_amd, make_sharded_context, envs_per_gpu=131072, steps=300, warmup=50):
     """Secondary measurement (BASELINE.json configs[3]): 131 072 MountainCar envs per GPU, ONE shared Fourier(5)
     approximator, per-batch-step all-reduce of the 432 B weight delta over RCCL.  Never part of `value`."""
@@ -119,6 +145,7 @@ def main():
     ap.add_argument("--envs", type=int, default=N_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared-leg", action="store_true", help="skip the secondary shared-W (RCCL) measurement")
+    ap.add_argument("--no-streaming-leg", action="store_true", help="skip the secondary 1-step-per-launch measurement")
     args = ap.parse_args()
 
     from rsrl_amd.distributed import ControlPlane, make_sharded_context
@@ -147,6 +174,7 @@ def main():
     ctx.timing_enable(False)
     n_states, _ = ctx.rollout_greedy(500)
     shared = shared_w_leg(cp, rsrl_amd, make_sharded_context) if not args.no_shared_leg else None
+    streaming = streaming_leg(rsrl_amd, args.envs, rank, device) if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
 
     if rank == 0:
         total_env_steps = args.steps * args.envs * world
@@ -176,6 +204,16 @@ def main():
                                  "and frac may exceed 1 (see DESIGN.md)"},
             "greedy_rollout_mean_n_states": float(n_states.mean()),
         }
+        if streaming is not None:
+            out["roofline_streaming"] = streaming
+        # the fused kernel is VALU-issue bound (profiles/r01_pmc_summary.md): instructions per env-step from the PMC pass
+        # (SQ_INSTS_VALU / env-steps) against the saturated issue rate measured by scripts/ubench/valu_issue.hip
+        if kname == "k_train_reg":
+            instr, cyc_per_instr, simds, clk = 635.0, 2.47, 1024, 2.4e9
+            peak_steps = simds * 64 * clk / (instr * cyc_per_instr)
+            out["valu_roofline"] = {"valu_instr_per_env_step": instr, "saturated_cycles_per_instr": cyc_per_instr,
+                                    "peak_env_steps_per_s_per_gpu": peak_steps, "frac": (value / world) / peak_steps,
+                                    "source": "profiles/r01_pmc_summary.md, profiles/r01_ubench_valu_issue.txt"}
         if shared is not None:
             out["shared_w"] = shared
         if world == 1 and not args.no_cpu_baseline:

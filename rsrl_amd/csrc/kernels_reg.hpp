@@ -29,6 +29,8 @@ struct Common {
     float* W;              // [A][F][Nw]
     int64_t w_stride;      // Nw: n_envs (per-env) or 1 (shared)
     int shared;            // one approximator for all learners (weight_mode == RSRL_W_SHARED)
+    float* qcache;         // [A][N] Q(s,.) of the CURRENT state with the current weights, carried between launches
+    int q_valid;           // 0: qcache is stale (weights/states were changed from outside) -> recompute from W
 };
 
 constexpr int kBlock = 256;
@@ -138,7 +140,7 @@ __device__ __forceinline__ float select_a(const float (&q)[A], int a) {
 // streaming formulation); otherwise all A columns are written once at the end.
 // ---------------------------------------------------------------------------------------
 #ifndef RSRL_RANK1_QPOST
-#define RSRL_RANK1_QPOST 0
+#define RSRL_RANK1_QPOST 1
 #endif
 #ifndef RSRL_K1_STORE_ALL
 #define RSRL_K1_STORE_ALL 1
@@ -174,7 +176,12 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 
         float phi_a[F], phi_b[F], q_s[A];
         Bas::project(s, phi_a);
-        q_from_reg<A, F>(w, phi_a, q_s);
+        if (c.q_valid) {                 // Q(s,.) carried from the previous launch (bit-identical to not having stopped)
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = c.qcache[(int64_t)b * N + i];
+        } else {
+            q_from_reg<A, F>(w, phi_a, q_s);
+        }
         int a_taken = a;
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
 
@@ -254,6 +261,8 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
+#pragma unroll
+        for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_s[b];
         if (store_col) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
@@ -301,7 +310,23 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
     unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
     double sum_abs = 0.0, sum_r = 0.0;
 
-    // all 108 loads in flight first (out-of-range lanes of the last block read in-bounds garbage or 0)
+    // Load order matters: vmcnt retires in issue order, so whatever the first arithmetic needs (state, action,
+    // the carried Q) is requested BEFORE the 108 weight loads -- the transition, both projections and the
+    // Philox rounds then run underneath the weight stream instead of behind it.
+    const int64_t il = i < N ? i : N - 1;                              // clamped: the loads are unconditional
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + il];
+    const int a = c.action[il];
+    uint32_t ep = c.ep_step[il] + 1;
+    float qc0 = 0.0f, qc1 = 0.0f, qc2 = 0.0f;
+    static_assert(A <= 3, "carried-Q registers are laid out for A <= 3");
+    if (c.q_valid) {
+        qc0 = c.qcache[il];
+        qc1 = c.qcache[N + il];
+        if constexpr (A > 2) qc2 = c.qcache[2 * N + il];
+    }
+    // all weight loads in flight (out-of-range lanes of the last block read in-bounds garbage or 0)
     float wv[A][F];
 #pragma unroll
     for (int b = 0; b < A; ++b)
@@ -314,11 +339,8 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         AlgoParams alg = c.alg; alg.kind = ALGO;
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
-        float s[D], ns[D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s[d] = c.state[(int64_t)d * N + i]; ns[d] = s[d]; }
-        const int a = c.action[i];
-        uint32_t ep = c.ep_step[i] + 1;
+        for (int d = 0; d < D; ++d) ns[d] = s[d];
         // ---- Domain::transition
         float r;
         const bool term = Dom::step(ns, a, r);
@@ -330,50 +352,34 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         U4 xin = U4{0, 0, 0, 0};
         if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
-        // ---- the touched column, Q(s,a) and Q(s',.) with the PRE-update weights
-        float wa[F];
+        // ---- Q(s,a): carried from the previous launch, or recomputed when the cache is stale
+        constexpr int P = RSRL_DOT_SPLIT;
+        float qsa;
+        if (c.q_valid) {
+            qsa = (a == 0) ? qc0 : ((a == 1) ? qc1 : qc2);
+        } else {
+            float qs[A];
+            q_from_reg<A, F>(wv, phi_s, qs);
+            qsa = select_a<A>(qs, a);
+        }
+        q_from_reg<A, F>(wv, phi_n, q_n);                              // Q(s',.) with the PRE-update weights
+        float e;
+        const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        // ---- W[:,a] += lr * e * phi(s); every (action, feature) row goes back as a FULL line (the untouched
+        //      columns are rewritten unchanged: the lane-dependent column would dirty all three lines anyway)
+        const float scale = alg.lr * e;
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             float v = wv[0][f];
 #pragma unroll
             for (int b = 1; b < A; ++b) v = (a == b) ? wv[b][f] : v;
-            wa[f] = v;
-        }
-        constexpr int P = RSRL_DOT_SPLIT;
-        float qsa;
-        {
-            float acc[P];
+            v = fmaf(scale, phi_s[f], v);
 #pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi_s[f], wa[f], acc[f % P]);
-            qsa = combine_partials<P>(acc);
-        }
-        q_from_reg<A, F>(wv, phi_n, q_n);
-        float e;
-        const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
-        // ---- W[:,a] += lr * e * phi(s), written straight back to its column
-        const float scale = alg.lr * e;
-        const int col_off = (int)((uint32_t)(a * F) * row_bytes) + voff;
-#if RSRL_K1_STORE_ALL
-        // write every (action, feature) row as a FULL line (the untouched columns are rewritten unchanged)
-#pragma unroll
-        for (int f = 0; f < F; ++f) wa[f] = fmaf(scale, phi_s[f], wa[f]);
-#pragma unroll
-        for (int b = 0; b < A; ++b)
-#pragma unroll
-            for (int f = 0; f < F; ++f) {
-                const float v = (a == b) ? wa[f] : wv[b][f];
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, (int)((uint32_t)(b * F + f) * row_bytes), 0);
+            for (int b = 0; b < A; ++b) {
+                wv[b][f] = (a == b) ? v : wv[b][f];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, wv[b][f]), rs, voff, (int)((uint32_t)(b * F + f) * row_bytes), 0);
             }
-        (void)col_off;
-#else
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            wa[f] = fmaf(scale, phi_s[f], wa[f]);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, wa[f]), rs, col_off, (int)((uint32_t)f * row_bytes), 0);
         }
-#endif
         // ---- Q(s',.) with the UPDATED weights: only column a changed
         {
 #if RSRL_RANK1_QPOST
@@ -382,27 +388,18 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
             for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
 #pragma unroll
             for (int f = 0; f < F; ++f) dacc[f % P] = fmaf(phi_s[f], phi_n[f], dacc[f % P]);
-            const float qa = fmaf(scale, combine_partials<P>(dacc), select_a<A>(q_n, a));
+            const float dot = combine_partials<P>(dacc);
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
 #else
-            float acc[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
-#pragma unroll
-            for (int f = 0; f < F; ++f) acc[f % P] = fmaf(phi_n[f], wa[f], acc[f % P]);
-            const float qa = combine_partials<P>(acc);
+            q_from_reg<A, F>(wv, phi_n, q_n);
 #endif
-#pragma unroll
-            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
         }
         int na = policy_sample<A>(pol, q_n, x);
         sum_abs = (double)fabsf(delta); sum_r = (double)r;
         if (term) { n_ep = 1; sum_len = ep; ep = 0; }
         if (trunc) {                               // step cap: new episode needs Q(s0) with the updated W
             n_ep = 1; n_trunc = 1; sum_len = ep; ep = 0;
-#pragma unroll
-            for (int b = 0; b < A; ++b)
-#pragma unroll
-                for (int f = 0; f < F; ++f) wv[b][f] = (a == b) ? wa[f] : wv[b][f];
             Dom::reset(ns);
             Bas::project(ns, phi_n);
             q_from_reg<A, F>(wv, phi_n, q_n);
@@ -413,6 +410,8 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
         c.action[i] = na;
         c.ep_step[i] = ep;
+#pragma unroll
+        for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }

@@ -103,6 +103,8 @@ struct rsrl_hip_ctx {
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
+    float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
+    bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
     size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
     int64_t w_stride = 0;
@@ -132,6 +134,7 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.alg.alpha = (float)c->cfg.alpha;
     k.max_episode_steps = c->cfg.max_episode_steps;
     k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
+    k.qcache = c->qcache; k.q_valid = c->q_valid ? 1 : 0;
     return k;
 }
 
@@ -284,6 +287,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->W) (void)hipFree(c->W);
     if (c->dW) (void)hipFree(c->dW);
     if (c->partials) (void)hipFree(c->partials);
+    if (c->qcache) (void)hipFree(c->qcache);
     if (c->flags) (void)hipFree(c->flags);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
@@ -349,6 +353,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     c->w_bytes = c->w_elems * (cfg->weight_dtype == RSRL_W_BF16 ? 2 : 4);
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
+    HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
         if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
@@ -412,6 +417,7 @@ int rsrl_hip_set_epsilon(rsrl_hip_ctx* c, double eps) {
 
 int rsrl_hip_reset(rsrl_hip_ctx* c) {
     CHECK_CTX(c);
+    c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
@@ -436,7 +442,8 @@ int rsrl_hip_get_states(rsrl_hip_ctx* c, float* states) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
-    CHECK_CTX(c); if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    c->q_valid = false; if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -460,6 +467,7 @@ int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
 int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_states, float* next_states,
                          float* rewards, uint8_t* terminal) {
     CHECK_CTX(c);
+    c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs; const size_t DN = (size_t)c->D * N;
     const int32_t* d_act; OutBuf<float> ofrom, onext, orew; OutBuf<uint8_t> oterm;
@@ -485,6 +493,7 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
 
 int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
     CHECK_CTX(c);
+    c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs;
     const uint8_t* d_mask;
@@ -596,6 +605,7 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
+    c->q_valid = false;
     c->t += 1;          // one handle call = one batch-step of learning: the agent-side draws (SARSA's inner sample,
                         // bf16 stochastic rounding) advance exactly as they do inside rsrl_hip_train
     bool sync = true;   // inputs may be host memory staged asynchronously
@@ -624,7 +634,8 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
-    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -643,7 +654,8 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
-    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     if (c->cfg.weight_mode == RSRL_W_SHARED) return rsrl_hip_set_weights(c, 0, w);
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A; const float* d_w;
@@ -726,7 +738,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     HIP_TRY(hipSetDevice(c->cfg.device));
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
-    const Common k = make_common(c);
+    Common k = make_common(c);
     const BasisGeom g = make_geom(c);
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
@@ -760,6 +772,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             if (!ok) return NO_MODEL(c);
             c->kernel_name = stream_k1 ? "k_step_reg" : "k_train_reg";
             KCHECK();
+            c->q_valid = true; k.q_valid = 1;       // the launch left Q(s,.) of its final state in qcache
         } else {
             if (!for_model(c, [&](auto tag) {
                     using M = typename decltype(tag)::type;
@@ -767,6 +780,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
                 })) return NO_MODEL(c);
             c->kernel_name = "k_train_mem";
             KCHECK();
+            c->q_valid = false;
         }
         TRY(timing_end(c));
         c->t += (uint64_t)chunk;
