@@ -465,15 +465,19 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
-// shared weights, phase A: transition + TD error against W_t + the learner's term lr*e*phi(s) of the
-// mini-batch delta.  The env state becomes s'; flags[i] bit0 = terminal, bit1 = truncated (phase C).
-//   dense basis : block-level reduction (DPP wave sums -> LDS -> one row of `partials` per block, fixed
-//                 order, no atomics => bitwise reproducible); k_dw_finalize sums the rows in block order.
+// shared weights, phases C(t-1) + A(t) in ONE launch.  Both read the same weights W_t: phase C finishes the previous
+// batch-step (policy.sample with the just-updated weights; finished episodes restart from Domain::default()), phase A
+// runs the transition and takes the TD error of this step against W_t and adds the learner's term lr*e*phi(s) to the
+// mini-batch delta.  phi(s) and Q(s,.) are computed once and serve both phases.  do_c = 0 on the first step of a
+// train call (the previous call already ran its phase C).  The env state becomes s'; flags[i] bit0 = terminal,
+// bit1 = truncated, consumed by the next phase C.
+//   dense basis : block-level reduction through LDS in a fixed order -> one row of `partials` per block (no atomics
+//                 => bitwise reproducible); k_dw_finalize sums the rows in block order.
 //   tile coding : f32 atomics straight into the dense delta table (sparse, 2*T entries per learner).
 template <class M>
-__global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint64_t t, float* __restrict__ dW,
-                                                     float* __restrict__ partials, uint8_t* __restrict__ flags,
-                                                     DevStats* __restrict__ stats) {
+__global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW,
+                                                      float* __restrict__ partials, uint8_t* __restrict__ flags,
+                                                      DevStats* __restrict__ stats) {
     constexpr int D = M::D, A = M::A;
     const int64_t N = c.n_envs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,19 +489,30 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
     if (i < N) {
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
-        float s[D], ns[D];
-        load_state<M>(c.state, N, i, s);
+        float s[D], ns[D], q_s[A];
+        uint32_t ep = c.ep_step[i];
+        bool done = false;
+        if (do_c) done = flags[i] != 0;
+        if (done) { M::Dom::reset(s); ep = 0; }
+        else load_state<M>(c.state, N, i, s);
+        M::features(s, g, fs);
+        M::q_all(c, 0, g, fs, q_s);
+        if (do_c) {                                                     // ---- phase C of batch-step t-1
+            const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
+            a = policy_sample<A>(c.pol, q_s, x);
+        } else {
+            a = c.action[i];
+        }
+        // ---- phase A of batch-step t
 #pragma unroll
         for (int d = 0; d < D; ++d) ns[d] = s[d];
-        a = c.action[i];
         float r;
         const bool term = M::Dom::step(ns, a, r);
-        const uint32_t ep = c.ep_step[i] + 1;
+        ep += 1;
         const bool trunc = !term && cap > 0 && ep >= cap;
         typename M::Feat fn;
-        M::features(s, g, fs);
         M::features(ns, g, fn);
-        const float qsa = M::q_index(c, 0, g, fs, a);
+        const float qsa = select_a<A>(q_s, a);
         float q_n[A];
         M::q_all(c, 0, g, fn, q_n);
         U4 xin = U4{0, 0, 0, 0};
@@ -507,6 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
         scale = c.alg.lr * e;
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+        c.action[i] = a;
         c.ep_step[i] = ep;
         flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
         sum_abs = (double)fabsf(delta); sum_r = (double)r;
@@ -533,7 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
         if (threadIdx.x < H * AF) {
             const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
             float acc = 0.0f;
-            for (int i = h * PER; i < (h + 1) * PER; ++i) acc += (act[i] == b) ? tile[i][f] : 0.0f;
+            for (int i2 = h * PER; i2 < (h + 1) * PER; ++i2) acc += (act[i2] == b) ? tile[i2][f] : 0.0f;
             part[h][j] = acc;
         }
         __syncthreads();
@@ -542,8 +558,8 @@ __global__ __launch_bounds__(kBlock) void k_shared_a(Common c, BasisGeom g, uint
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
-// shared weights, phase C (after W_{t+1} = W_t + dW): policy.sample with the updated weights; finished
-// episodes restart from Domain::default() with a fresh sample.
+// shared weights, stand-alone phase C (closes the last batch-step of a train call): policy.sample with the updated
+// weights; finished episodes restart from Domain::default() with a fresh sample.
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_shared_c(Common c, BasisGeom g, uint64_t t, const uint8_t* __restrict__ flags) {
     constexpr int D = M::D, A = M::A;

@@ -49,7 +49,8 @@ __global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, i
 }
 // shared-W dense basis: dW[j] = sum over blocks of partials[blk][j] in a FIXED order (reproducible):
 // 8 interleaved partial sums (blocks b = p mod 8, ascending) per element, combined p = 0..7.
-__global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW) {
+__global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW,
+                                                      float* __restrict__ W_apply) {
     __shared__ float part[8][128];
     const int jl = threadIdx.x & 127, p = threadIdx.x >> 7;
     const int j = blockIdx.x * 128 + jl;
@@ -69,7 +70,8 @@ __global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ 
         float tot = part[0][jl];
 #pragma unroll
         for (int q = 1; q < 8; ++q) tot += part[q][jl];
-        dW[j] = tot;
+        if (W_apply) W_apply[j] += tot;                          // single rank: W_{t+1} = W_t + delta right here
+        else dW[j] = tot;                                        // multi rank: the delta goes through the all-reduce first
     }
 }
 }  // namespace
@@ -706,29 +708,38 @@ static int timing_end(rsrl_hip_ctx* c) {
     return RSRL_HIP_OK;
 }
 
-// shared weights: one batch-step = phase A (errors against W_t, delta accumulation) -> [finalize] ->
-// [all-reduce over ranks] -> apply -> phase C (sample with W_{t+1}); SURVEY Appendix A.7.
-static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
+// shared weights: one batch-step = [phase C of the previous step + phase A] in one launch ->
+// delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
+// train call is closed by a stand-alone phase C.
+static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, bool first, bool last) {
     const dim3 grid(grid_for(k.n_envs)), block(kBlock);
     const bool dense = c->cfg.basis == RSRL_FOURIER;
+    const int do_c = first ? 0 : 1;
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_shared_a<M>), grid, block, 0, c->stream, k, g, c->t, c->dW, c->partials, c->flags, d_stats);
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, c->t, do_c, c->dW, c->partials, c->flags, d_stats);
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
+    const bool multi = c->comm && c->world_size > 1;
     if (dense) {
-        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(1024), 0, c->stream, c->partials, (int)grid.x, n, c->dW);
+        // single rank: the finalize kernel applies the summed delta itself (W += sum; one launch less)
+        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(1024), 0, c->stream, c->partials, (int)grid.x, n, c->dW,
+                           multi ? (float*)nullptr : c->W);
         KCHECK();
     }
-    TRY(comm_allreduce_dw(c));
-    hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
-    KCHECK();
-    if (!for_model(c, [&](auto tag) {
-            using M = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_shared_c<M>), grid, block, 0, c->stream, k, g, c->t, c->flags);
-        })) return NO_MODEL(c);
-    KCHECK();
+    if (multi || !dense) {
+        TRY(comm_allreduce_dw(c));
+        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+        KCHECK();
+    }
+    if (last) {
+        if (!for_model(c, [&](auto tag) {
+                using M = typename decltype(tag)::type;
+                hipLaunchKernelGGL((k_shared_c<M>), grid, block, 0, c->stream, k, g, c->t, c->flags);
+            })) return NO_MODEL(c);
+        KCHECK();
+    }
     return RSRL_HIP_OK;
 }
 
@@ -750,8 +761,8 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
         TRY(timing_begin(c));
         if (shared) {
-            TRY(train_shared_step(c, k, g, d_stats));
-            c->kernel_name = "k_shared_a";
+            TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
+            c->kernel_name = "k_shared_ca";
         } else if (is_wave(c->cfg)) {
             for_wave(c, [&](auto tag) {
                 using T = decltype(tag); using WT = typename T::wt;
