@@ -81,6 +81,21 @@ def cpu_baseline(seconds=12.0):
                       f"eps-greedy, {total} env-steps in {dt:.1f} s (oracle/rsrl_oracle.c, gcc -O2)"}
 
 
+def guarded(fn, timeout_s):
+    """Run a secondary measurement in a daemon thread; {"error": "timeout"} if it does not come back in time."""
+    box = {}
+
+    def run():
+        try:
+            box["r"] = fn()
+        except Exception as e:      # noqa: BLE001
+            box["r"] = {"error": repr(e)}
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    return box.get("r", {"error": "timeout"})
+
+
 def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
     """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg), i.e. the 608 B/env-step
     streaming formulation the HBM roofline is defined on.  Never part of `value`."""
@@ -173,8 +188,11 @@ def main():
     kernel_ms, launches, kname = ctx.timing_read()
     ctx.timing_enable(False)
     n_states, _ = ctx.rollout_greedy(500)
-    shared = shared_w_leg(cp, rsrl_amd, make_sharded_context) if not args.no_shared_leg else None
-    streaming = streaming_leg(rsrl_amd, args.envs, rank, device) if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
+    # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
+    streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
+        if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
+    shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context), 240) if not args.no_shared_leg else None
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared))
 
     if rank == 0:
         total_env_steps = args.steps * args.envs * world
@@ -218,7 +236,9 @@ def main():
             out["shared_w"] = shared
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)          # a secondary leg is stuck in a collective: do not wait for it in the destructors
     ctx.close()
     cp.close()
 

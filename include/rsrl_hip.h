@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 1
+#define RSRL_HIP_ABI_VERSION 2
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -57,8 +57,12 @@ typedef enum { RSRL_MOUNTAIN_CAR = 0, RSRL_CART_POLE = 1, RSRL_ACROBOT = 2 } rsr
 /* lfa::basis::{Fourier (+with_bias), TileCoding}  (re-exported by rsrl/src/fa/linear.rs:11-14) */
 typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
 /* rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}
- *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66 */
-typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2 } rsrl_algo;
+ *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66
+ * and the eligibility-trace agents {SARSALambda, QLambda}
+ *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights, register-family Fourier bases) */
+typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4 } rsrl_algo;
+/* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
+typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;
 /* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}
  *   greedy.rs:16-84, epsilon_greedy.rs:14-83, softmax.rs:55-143, random.rs:13-48 */
 typedef enum { RSRL_GREEDY = 0, RSRL_EPSILON_GREEDY = 1, RSRL_SOFTMAX = 2, RSRL_RANDOM = 3 } rsrl_policy;
@@ -98,8 +102,10 @@ typedef struct {
     double   epsilon;            /* EpsilonGreedy.epsilon (pub field, epsilon_greedy.rs:19)  */
     double   tau;                /* Softmax.tau (softmax.rs:52); |tau| < 1e-7 is rejected (:63-66) */
     uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default)       */
-    uint32_t reserved0;
+    int32_t  trace;              /* rsrl_trace (lambda agents)                                */
     void*    stream;             /* hipStream_t to run on; NULL = ctx-owned stream           */
+    double   lambda;             /* Trace::{accumulating,replacing,dutch}(dim, gamma, lambda) (examples/sarsa_lambda.rs:37);
+                                    the lambda agents step with `alpha` and bypass SGD(lr) (fa/linear.rs:184-196) */
 } rsrl_hip_config;
 
 /* per-call statistics of rsrl_hip_train (the println! / Response{error} of the
@@ -184,6 +190,10 @@ int rsrl_hip_set_epsilon(rsrl_hip_ctx* ctx, double epsilon);
  * ignored in shared mode.  Also the checkpoint hook. */
 int rsrl_hip_get_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* w /*[F][A]*/);
 int rsrl_hip_set_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* w /*[F][A]*/);
+/* the pub field `trace` of SARSALambda / QLambda (sarsa_lambda.rs:41, q_lambda.rs:40): one learner's eligibility trace,
+ * row-major f32[F][A] like the weights */
+int rsrl_hip_get_traces(rsrl_hip_ctx* ctx, int64_t env_index, float* z /*[F][A]*/);
+int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[F][A]*/);
 /* same weights broadcast to every learner (per-env mode) */
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 

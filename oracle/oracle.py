@@ -14,7 +14,8 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA = 0, 1, 2
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA = 0, 1, 2, 3, 4
+TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EGREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 BLK_STEP, BLK_RESET, BLK_INNER, BLK_INIT, BLK_API = 0, 1, 2, 3, 4
 
@@ -32,7 +33,8 @@ class Agent(C.Structure):
                 ("seed", C.c_uint64), ("env_offset", C.c_int64),
                 ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
                 ("epsilon", C.c_double), ("tau", C.c_double),
-                ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32)]
+                ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32),
+                ("lam", C.c_double), ("trace", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -126,6 +128,10 @@ def _declare(L):
         g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
         g("orc_run_reset").argtypes = [C.c_void_p]
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_handle_lambda").restype = R
+        g("orc_handle_lambda").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
+        g("orc_run_traces").restype = Rp
+        g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
         g("orc_run_rollout_greedy").restype = C.c_int
         g("orc_run_rollout_greedy").argtypes = [C.c_void_p, C.c_int64, u32p, Rp]
@@ -145,11 +151,13 @@ def _ptr(a, ct):
 
 def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
-               gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000):
+               gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000, lam=0.0,
+               trace=TRACE_ACCUMULATE):
     ag = Agent()
     lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
                          int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
                          max_episode_steps)
+    ag.lam, ag.trace = lam, trace
     return ag
 
 
@@ -285,6 +293,17 @@ def handle(ag, W, s, a, r, ns, term, x_inner=(0, 0, 0, 0), prec="f64"):
                                                       _ptr(ns, ct), int(term), xx))
 
 
+def handle_lambda(ag, W, Z, s, a, r, ns, term, x_inner=(0, 0, 0, 0), prec="f64"):
+    """SARSA(lambda) / Q(lambda) handle on one transition; W and Z (F,A) are updated in place; returns the TD error."""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    assert W.dtype == dt and Z.dtype == dt and W.flags.c_contiguous and Z.flags.c_contiguous
+    s = np.array(s, dtype=dt)
+    ns = np.array(ns, dtype=dt)
+    xx = (C.c_uint32 * 4)(*[int(v) for v in x_inner])
+    return float(getattr(lib(), f"orc_handle_lambda_{prec}")(C.byref(ag), _ptr(W, ct), _ptr(Z, ct), _ptr(s, ct), int(a),
+                                                             ct(r), _ptr(ns, ct), int(term), xx))
+
+
 class Run:
     """N independent (or shared-W) learners stepped by the oracle's driver loop."""
 
@@ -324,6 +343,10 @@ class Run:
     def weights(self):    # per-env (N, F, A) or shared (F, A) view
         shape = (self.F, self.A) if self.ag.shared_w else (self.n, self.F, self.A)
         return np.ctypeslib.as_array(self._f("orc_run_weights")(self._h), shape=shape)
+
+    @property
+    def traces(self):     # per-env (N, F, A) view (lambda agents only)
+        return np.ctypeslib.as_array(self._f("orc_run_traces")(self._h), shape=(self.n, self.F, self.A))
 
     @property
     def t(self):

@@ -13,7 +13,9 @@ extern "C" {
 
 enum { ORC_MOUNTAIN_CAR = 0, ORC_CART_POLE = 1, ORC_ACROBOT = 2 };
 enum { ORC_FOURIER = 0, ORC_TILE = 1 };
-enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2 };
+enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4 };
+/* eligibility-trace update rules (rsrl/src/traces.rs:188-240) */
+enum { ORC_TRACE_ACCUMULATE = 0, ORC_TRACE_SATURATE = 1, ORC_TRACE_DUTCH = 2 };
 enum { ORC_GREEDY = 0, ORC_EGREEDY = 1, ORC_SOFTMAX = 2, ORC_RANDOM = 3 };
 /* RNG draw blocks (counter word 3) */
 enum { ORC_BLK_STEP = 0, ORC_BLK_RESET = 1, ORC_BLK_INNER = 2, ORC_BLK_INIT = 3, ORC_BLK_API = 4 };
@@ -35,6 +37,8 @@ typedef struct {
     double gamma, lr, alpha, epsilon, tau;
     uint32_t eps_thr;
     uint32_t max_episode_steps;
+    double lambda;       /* eligibility traces */
+    int trace;
 } orc_agent;
 
 typedef struct {
@@ -88,6 +92,9 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     uint64_t  orc_run_t_##S(void* h);                                                                   \
     void  orc_run_set_epsilon_##S(void* h, double eps);                                                 \
     void  orc_run_reset_##S(void* h);                                                                   \
+    R     orc_handle_lambda_##S(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,   \
+                                const uint32_t x_inner[4]);                                             \
+    R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
                                  void (*dw_hook)(R* dW, int n, void* user), void* user);                \

@@ -445,6 +445,53 @@ R FN(orc_handle)(const orc_agent* ag, R* W, const R* s, int a, R r, const R* ns,
     return delta;
 }
 
+/* Eligibility-trace agents on per-env weights.  Z has the shape of W ((F, A) row-major).
+ *   SARSALambda::handle   control/td/sarsa_lambda.rs:53-98
+ *   QLambda::handle       control/td/q_lambda.rs:56-99   (Watkins: trace reset when the action taken was not
+ *                                                         argmax_first of Q(s,.), utils.rs:23-34)
+ *   trace update rules    traces.rs:188-240  Accumulate: z = gl*z + g;  Saturate: clip(gl*z + g, -1, 1);
+ *                                            Dutch: z = gl*(1-alpha)*z + g      (g = phi(s) in column a)
+ *   weight update         Handler<ScaledGradientUpdate>: W += (alpha*residual) * Z  -- bypasses the optimiser
+ *                         (fa/linear.rs:184-196)
+ * Dense (Fourier) bases only.  Returns the TD error. */
+R FN(orc_handle_lambda)(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,
+                        const uint32_t x_inner[4]) {
+    const orc_basis* b = &ag->basis; int A = ag->n_actions, F = orc_basis_nfeat(b), f, c;
+    R qs[ORC_MAX_ACTIONS], qsa, residual, rate, scale;
+    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+    FN(orc_q_evaluate)(b, W, A, s, qs);
+    qsa = qs[a];
+    if (ag->algo == ORC_Q_LAMBDA && a != FN(orc_argmax_first)(qs, A)) memset(Z, 0, sizeof(R) * (size_t)F * A);
+    FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+    rate = (R)ag->gamma * (R)ag->lambda;
+    if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+    for (f = 0; f < F; f++)
+        for (c = 0; c < A; c++) {
+            R g = (c == a) ? phi[f] : (R)0.0;
+            R z = FN(fma_)(rate, Z[(size_t)f * A + c], g);                     /* rate * x + y */
+            if (ag->trace == ORC_TRACE_SATURATE) { z = (z < (R)1.0) ? z : (R)1.0; z = (z > (R)-1.0) ? z : (R)-1.0; }
+            Z[(size_t)f * A + c] = z;
+        }
+    free(phi);
+    if (term) {
+        residual = r - qsa;
+    } else if (ag->algo == ORC_SARSA_LAMBDA) {
+        R qn[ORC_MAX_ACTIONS]; int na;
+        FN(orc_q_evaluate)(b, W, A, ns, qn);
+        na = FN(orc_policy_sample)(ag->policy, qn, A, ag->eps_thr, (R)ag->tau, x_inner);
+        residual = r + (R)ag->gamma * qn[na] - qsa;
+    } else {
+        R qn[ORC_MAX_ACTIONS], m;
+        FN(orc_q_evaluate)(b, W, A, ns, qn);
+        FN(orc_find_max)(qn, A, &m);
+        residual = r + (R)ag->gamma * m - qsa;
+    }
+    scale = (R)ag->alpha * residual;
+    for (f = 0; f < F * A; f++) W[f] = FN(fma_)(scale, Z[f], W[f]);
+    if (term) memset(Z, 0, sizeof(R) * (size_t)F * A);                        /* trace.reset() */
+    return residual;
+}
+
 /* ------------------------------------------------------------------ */
 /* Vectorised driver loop (examples/q_learning.rs:34-55 x N envs)      */
 /* ------------------------------------------------------------------ */
@@ -456,6 +503,7 @@ typedef struct {
     int32_t* action; /* [N]    */
     uint32_t* ep_step;
     R* W;            /* per-env: [N][F][A]; shared: [F][A] */
+    R* Z;            /* eligibility traces, per-env [N][F][A] (lambda agents only) */
     uint64_t t;      /* global batch-step counter */
 } FN(orc_run);
 
@@ -472,17 +520,19 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->action = (int32_t*)calloc((size_t)n_envs, sizeof(int32_t));
     run->ep_step = (uint32_t*)calloc((size_t)n_envs, sizeof(uint32_t));
     run->W = (R*)calloc(ag->shared_w ? FA : FA * (size_t)n_envs, sizeof(R));   /* LFA::vector zero-inits */
+    run->Z = (ag->algo >= ORC_SARSA_LAMBDA) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
     return run;
 }
 void FN(orc_run_destroy)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h;
-    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run);
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run);
 }
 R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
 int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
 uint32_t* FN(orc_run_ep_step)(void* h) { return ((FN(orc_run)*)h)->ep_step; }
 R* FN(orc_run_weights)(void* h) { return ((FN(orc_run)*)h)->W; }
+R* FN(orc_run_traces)(void* h) { return ((FN(orc_run)*)h)->Z; }
 uint64_t FN(orc_run_t)(void* h) { return ((FN(orc_run)*)h)->t; }
 void FN(orc_run_set_epsilon)(void* h, double eps) {
     FN(orc_run)* run = (FN(orc_run)*)h; run->ag.epsilon = eps; run->ag.eps_thr = orc_eps_threshold(eps);
@@ -526,7 +576,9 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
             term_all[i] = (uint8_t)term;
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
-            if (!ag->shared_w) {
+            if (ag->algo >= ORC_SARSA_LAMBDA) {
+                delta = FN(orc_handle_lambda)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term, xi);
+            } else if (!ag->shared_w) {
                 delta = FN(orc_handle)(ag, FN(run_W)(run, i), s, a, r, ns, term, xi);
             } else {
                 R e = FN(orc_td_error)(ag, run->W, s, a, r, ns, term, xi, &delta);

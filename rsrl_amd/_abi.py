@@ -16,7 +16,7 @@ class Config(C.Structure):
         ("max_episode_steps", C.c_uint32), ("n_envs", C.c_int64), ("env_offset", C.c_int64),
         ("seed", C.c_uint64), ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
         ("epsilon", C.c_double), ("tau", C.c_double), ("steps_per_launch", C.c_uint32),
-        ("reserved0", C.c_uint32), ("stream", C.c_void_p),
+        ("trace", C.c_int32), ("stream", C.c_void_p), ("lam", C.c_double),
     ]
 
 
@@ -61,6 +61,8 @@ SYMBOLS = {
     "rsrl_hip_get_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights_all": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsrl_hip_get_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "rsrl_hip_set_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_train": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     "rsrl_hip_step_count": (C.c_uint64, [C.c_void_p]),
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

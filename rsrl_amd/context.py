@@ -8,7 +8,8 @@ from . import _abi
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE_CODING = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA = 0, 1, 2
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA = 0, 1, 2, 3, 4
+TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
 W_F32, W_BF16 = 0, 1
@@ -44,7 +45,7 @@ class Context:
     def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
-                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None):
+                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -54,6 +55,7 @@ class Context:
         cfg.max_episode_steps, cfg.n_envs, cfg.env_offset, cfg.seed = max_episode_steps, n_envs, env_offset, seed
         cfg.gamma, cfg.lr, cfg.alpha, cfg.epsilon, cfg.tau = gamma, lr, alpha, epsilon, tau
         cfg.steps_per_launch = steps_per_launch
+        cfg.lam, cfg.trace = lam, trace
         cfg.stream = stream
         self.cfg = cfg
         self._h = C.c_void_p()
@@ -198,6 +200,14 @@ class Context:
 
     def set_weights(self, w, env_index=0):
         _abi.check(self._L.rsrl_hip_set_weights(self._h, int(env_index), _p(_in(w, np.float32, (self.F, self.A)))))
+
+    def get_traces(self, env_index=0):
+        out = np.empty((self.F, self.A), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_get_traces(self._h, int(env_index), _p(out)))
+        return out
+
+    def set_traces(self, z, env_index=0):
+        _abi.check(self._L.rsrl_hip_set_traces(self._h, int(env_index), _p(_in(z, np.float32, (self.F, self.A)))))
 
     def set_weights_all(self, w):
         _abi.check(self._L.rsrl_hip_set_weights_all(self._h, _p(_in(w, np.float32, (self.F, self.A)))))

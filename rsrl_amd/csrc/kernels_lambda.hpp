@@ -1,0 +1,190 @@
+// kernels_lambda.hpp -- eligibility-trace control on the register family:
+//   SARSALambda::handle   rsrl/src/control/td/sarsa_lambda.rs:53-98
+//   QLambda::handle       rsrl/src/control/td/q_lambda.rs:56-99  (Watkins: the trace is cut when the action taken was
+//                                                                not argmax_first of Q(s,.), utils.rs:23-34)
+//   trace update rules    rsrl/src/traces.rs:188-240   Accumulate z = gl*z + g | Saturate clip(gl*z + g, -1, 1) |
+//                                                      Dutch z = gl*(1-alpha)*z + g       (g = phi(s) in column a)
+//   weight update         Handler<ScaledGradientUpdate>: W += (alpha*residual)*Z, bypassing the optimiser
+//                         (rsrl/src/fa/linear.rs:184-196; examples/sarsa_lambda.rs:30 uses SGD(1.0))
+// The trace Z has the shape of W and the same HBM layout (f32[A][F][N], learner fastest).  In the fused driver loop W
+// AND Z stay in registers for the whole launch (2 x 108 for MountainCar Fourier(5)).  A step-cap truncation does not
+// reset the trace (the reference only resets on a terminal transition).
+#pragma once
+
+#include "models.hpp"
+
+namespace rsrl {
+
+enum : int { ALG_SARSA_LAMBDA = 3, ALG_Q_LAMBDA = 4 };
+enum : int { TRACE_ACCUMULATE = 0, TRACE_SATURATE = 1, TRACE_DUTCH = 2 };
+
+struct LambdaParams {
+    float* Z;          // [A][F][N]
+    float rate;        // gamma*lambda (Dutch: * (1 - alpha))
+    float alpha;       // step size of the lambda agents
+    int trace;         // TRACE_*
+};
+
+// z <- rule(rate_eff * z + g)
+__device__ __forceinline__ float trace_merge(int rule, float rate_eff, float z, float g) {
+    float v = fmaf(rate_eff, z, g);
+    if (rule == TRACE_SATURATE) v = fmaxf(-1.0f, fminf(1.0f, v));
+    return v;
+}
+
+template <int DOMAIN, int ORDER, int ALGO, int POLICY>
+__global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams lp, uint64_t t0, int n_steps,
+                                                         DevStats* __restrict__ stats) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    static_assert(ALGO == ALG_SARSA_LAMBDA || ALGO == ALG_Q_LAMBDA, "lambda agents only");
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = c.n_envs;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        PolicyParams pol = c.pol; pol.kind = POLICY;
+        AlgoParams alg = c.alg; alg.kind = (ALGO == ALG_SARSA_LAMBDA) ? ALG_SARSA : ALG_QLEARNING;   // the TD target formula
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+        int a = c.action[i];
+        uint32_t ep = c.ep_step[i];
+        float w[A][F], z[A][F];
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
+                z[b][f] = lp.Z[((int64_t)(b * F + f)) * N + i];
+            }
+        float phi_a[F], phi_b[F], q_s[A];
+        Bas::project(s, phi_a);
+        q_from_reg<A, F>(w, phi_a, q_s);
+        float facc_abs = 0.0f, facc_r = 0.0f;
+
+        auto one_step = [&](const float (&phi_s)[F], float (&phi_n)[F], uint64_t t) {
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) Dom::reset(ns);
+            float q_n[A];
+            Bas::project(ns, phi_n);
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const float qsa = select_a<A>(q_s, a);
+            // ---- trace: (Q(lambda): cut unless the action was the greedy one) then z = rule(rate*z + grad)
+            float rate_eff = lp.rate;
+            if constexpr (ALGO == ALG_Q_LAMBDA) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : lp.rate;
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int f = 0; f < F; ++f) z[b][f] = trace_merge(lp.trace, rate_eff, z[b][f], (a == b) ? phi_s[f] : 0.0f);
+            // ---- residual with the PRE-update weights
+            U4 xin = U4{0, 0, 0, 0};
+            if constexpr (ALGO == ALG_SARSA_LAMBDA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+            // ---- W += (alpha * residual) * Z ; a terminal transition then resets the trace
+            const float scale = lp.alpha * delta;
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    w[b][f] = fmaf(scale, z[b][f], w[b][f]);
+                    z[b][f] = term ? 0.0f : z[b][f];
+                }
+            // ---- policy.sample with the UPDATED weights (every column moved: recompute)
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            int na = policy_sample<A>(pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                Bas::project(ns, phi_n);
+                q_from_reg<A, F>(w, phi_n, q_n);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(pol, q_n, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            a = na;
+        };
+        int k = 0;
+        for (; k + 1 < n_steps; k += 2) {
+            one_step(phi_a, phi_b, t0 + (uint64_t)k);
+            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+        }
+        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = ep;
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                c.W[((int64_t)(b * F + f)) * N + i] = w[b][f];
+                lp.Z[((int64_t)(b * F + f)) * N + i] = z[b][f];
+            }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// Handler<&Transition>::handle of the lambda agents on caller-supplied transitions (W and Z in memory)
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_handle_lambda(Common c, LambdaParams lp, const float* __restrict__ from,
+                                                          const int32_t* __restrict__ act, const float* __restrict__ rew,
+                                                          const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                          int64_t Mn, uint64_t t, float* __restrict__ td_out) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    const int64_t N = c.n_envs;
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
+    const int a = act[i];
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    float phi_s[F], phi_n[F], q_s[A], q_n[A];
+    Bas::project(s, phi_s);
+    Bas::project(ns, phi_n);
+    q_from_mem<A, F>(c.W, N, i, phi_s, q_s);
+    q_from_mem<A, F>(c.W, N, i, phi_n, q_n);
+    AlgoParams alg = c.alg;
+    const bool sarsa = c.alg.kind == ALG_SARSA_LAMBDA;
+    alg.kind = sarsa ? ALG_SARSA : ALG_QLEARNING;
+    float rate_eff = lp.rate;
+    if (!sarsa) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : lp.rate;
+    U4 xin = U4{0, 0, 0, 0};
+    if (sarsa) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
+    float e;
+    const float delta = td_error<A>(alg, c.pol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+    const float scale = lp.alpha * delta;
+#pragma unroll
+    for (int b = 0; b < A; ++b)
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t j = ((int64_t)(b * F + f)) * N + i;
+            const float zz = trace_merge(lp.trace, rate_eff, lp.Z[j], (a == b) ? phi_s[f] : 0.0f);
+            c.W[j] = fmaf(scale, zz, c.W[j]);
+            lp.Z[j] = term ? 0.0f : zz;
+        }
+    if (td_out) td_out[i] = delta;
+}
+
+}  // namespace rsrl

@@ -14,6 +14,13 @@ bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block,
                          const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats);
 
 // chunk == -1 selects the single-step streaming kernel (k_step_reg)
+struct LambdaParams;
+bool launch_train_lambda(int domain, int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
+                         const Common& k, const LambdaParams& lp, uint64_t t, int chunk, DevStats* stats);
+bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const LambdaParams& lp,
+                          const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                          int64_t Mn, uint64_t t, float* td_out);
+
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
         if (chunk == -1)                                                                                    \

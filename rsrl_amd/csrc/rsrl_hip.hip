@@ -17,6 +17,7 @@
 #include "launch.hpp"
 #include "models.hpp"
 #include "kernels_wave.hpp"
+#include "kernels_lambda.hpp"
 
 using namespace rsrl;
 
@@ -106,6 +107,7 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
+    float* Z = nullptr;              // eligibility traces f32[A][F][N] (lambda agents)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
     size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
@@ -138,6 +140,15 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
     k.qcache = c->qcache; k.q_valid = c->q_valid ? 1 : 0;
     return k;
+}
+
+static LambdaParams make_lambda(const rsrl_hip_ctx* c) {
+    LambdaParams lp{};
+    lp.Z = c->Z;
+    double rate = c->cfg.gamma * c->cfg.lambda;
+    if (c->cfg.trace == RSRL_TRACE_DUTCH) rate *= (1.0 - c->cfg.alpha);       // traces.rs:233-239
+    lp.rate = (float)rate; lp.alpha = (float)c->cfg.alpha; lp.trace = c->cfg.trace;
+    return lp;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -274,6 +285,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->n_envs = 1; cfg->seed = 0;
     cfg->gamma = 0.9; cfg->lr = 0.001; cfg->alpha = 1.0; cfg->epsilon = 0.1; cfg->tau = 1.0;
     cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
+    cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0;
     return RSRL_HIP_OK;
 }
 
@@ -290,6 +302,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW) (void)hipFree(c->dW);
     if (c->partials) (void)hipFree(c->partials);
     if (c->qcache) (void)hipFree(c->qcache);
+    if (c->Z) (void)hipFree(c->Z);
     if (c->flags) (void)hipFree(c->flags);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
@@ -310,7 +323,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
     if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
-    if (cfg->algo < 0 || cfg->algo > RSRL_EXPECTED_SARSA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo < 0 || cfg->algo > RSRL_Q_LAMBDA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
@@ -336,6 +349,13 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
+    if (cfg->algo >= RSRL_SARSA_LAMBDA) {
+        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+            return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
+        if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
@@ -356,6 +376,10 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
+    if (cfg->algo >= RSRL_SARSA_LAMBDA) {
+        HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
+        HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
+    }
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
         if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
@@ -592,7 +616,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_wave(c->cfg)) {
+    if (c->cfg.algo >= RSRL_SARSA_LAMBDA) {
+        if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
+                                  d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
+    } else if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
             hipLaunchKernelGGL((k_wave_handle<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev);
@@ -655,6 +682,37 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
+static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in) {
+    CHECK_CTX(c);
+    if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
+    if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int n = c->F * c->A;
+    if (out) {
+        OutBuf<float> oz;
+        TRY(stage_out(c, 0, out, (size_t)n, &oz));
+        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->A, oz.dev);
+        KCHECK();
+        bool sync = false; TRY(flush_out(c, &oz, &sync));
+        if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        const float* d_z;
+        TRY(stage_in(c, 0, in, (size_t)n, &d_z));
+        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->A, d_z);
+        KCHECK();
+        if (!is_device_ptr(in)) HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_get_traces(rsrl_hip_ctx* c, int64_t env_index, float* z) {
+    if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
+    return traces_rw(c, env_index, z, nullptr);
+}
+int rsrl_hip_set_traces(rsrl_hip_ctx* c, int64_t env_index, const float* z) {
+    if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
+    return traces_rw(c, env_index, nullptr, z);
+}
+
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     CHECK_CTX(c);
     c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
@@ -763,6 +821,11 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         if (shared) {
             TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
             c->kernel_name = "k_shared_ca";
+        } else if (c->cfg.algo >= RSRL_SARSA_LAMBDA) {
+            if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),
+                                     c->stream, k, make_lambda(c), c->t, chunk, d_stats)) return NO_MODEL(c);
+            c->kernel_name = "k_train_lambda";
+            KCHECK();
         } else if (is_wave(c->cfg)) {
             for_wave(c, [&](auto tag) {
                 using T = decltype(tag); using WT = typename T::wt;

@@ -1,0 +1,32 @@
+// fused eligibility-trace driver loops (SARSA(lambda), Q(lambda)) for the register family
+#include "launch.hpp"
+#include "kernels_lambda.hpp"
+namespace rsrl {
+
+#define RSRL_LAMBDA_CASE(DM, OR, AL, PO)                                                                      \
+    if (domain == DM && order == OR && algo == AL && policy == PO) {                                          \
+        hipLaunchKernelGGL((k_train_lambda<DM, OR, AL, PO>), grid, block, 0, st, k, lp, t, chunk, stats);     \
+        return true;                                                                                          \
+    }
+#define RSRL_LAMBDA_POLICIES(DM, OR, AL) \
+    RSRL_LAMBDA_CASE(DM, OR, AL, 0) RSRL_LAMBDA_CASE(DM, OR, AL, 1) RSRL_LAMBDA_CASE(DM, OR, AL, 2) RSRL_LAMBDA_CASE(DM, OR, AL, 3)
+#define RSRL_LAMBDA_ALGOS(DM, OR) RSRL_LAMBDA_POLICIES(DM, OR, 3) RSRL_LAMBDA_POLICIES(DM, OR, 4)
+
+bool launch_train_lambda(int domain, int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
+                         const Common& k, const LambdaParams& lp, uint64_t t, int chunk, DevStats* stats) {
+    RSRL_LAMBDA_ALGOS(0, 1) RSRL_LAMBDA_ALGOS(0, 2) RSRL_LAMBDA_ALGOS(0, 3) RSRL_LAMBDA_ALGOS(0, 4) RSRL_LAMBDA_ALGOS(0, 5)
+    RSRL_LAMBDA_ALGOS(1, 1) RSRL_LAMBDA_ALGOS(2, 1)
+    return false;
+}
+#define RSRL_HL_CASE(DM, OR)                                                                                              \
+    if (domain == DM && order == OR) {                                                                                    \
+        hipLaunchKernelGGL((k_handle_lambda<DM, OR>), grid, block, 0, st, k, lp, from, act, rew, to, termf, Mn, t, td_out); \
+        return true;                                                                                                      \
+    }
+bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const LambdaParams& lp,
+                          const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                          int64_t Mn, uint64_t t, float* td_out) {
+    RSRL_HL_CASE(0, 1) RSRL_HL_CASE(0, 2) RSRL_HL_CASE(0, 3) RSRL_HL_CASE(0, 4) RSRL_HL_CASE(0, 5) RSRL_HL_CASE(1, 1) RSRL_HL_CASE(2, 1)
+    return false;
+}
+}  // namespace rsrl

@@ -336,3 +336,58 @@ def test_tile_indices_definition(orc):
                 lin += min(7, max(0, cell)) * 8 ** i
             assert idx[t] == t * 4096 + lin
     assert orc.n_features(ag) == 32768
+
+
+# ---------------------------------------------------------------------------- eligibility traces
+def test_trace_rules_reference_doctest(orc):
+    # rsrl/src/traces.rs:112-126 (doctest): Accumulate{gamma 0.95, lambda 0.7}: 1.0 -> 0.665 after an all-zero update.
+    # Driven through the agent: the constant feature (value 1) of column a is the probe.
+    ag = orc.make_agent(algo=orc.SARSA_LAMBDA, policy=orc.GREEDY, gamma=0.95, lam=0.7, alpha=0.0, trace=orc.TRACE_ACCUMULATE)
+    W, Z = np.zeros((36, 3)), np.zeros((36, 3))
+    s = np.array([-0.5, 0.0]); ns = np.array([-0.49, 0.001])
+    orc.handle_lambda(ag, W, Z, s, 0, -1.0, ns, False)
+    assert Z[35, 0] == 1.0 and Z[35, 1] == 0.0
+    orc.handle_lambda(ag, W, Z, s, 1, -1.0, ns, False)
+    assert abs(Z[35, 0] - 0.665) < 1e-12 and Z[35, 1] == 1.0        # column 0 received a zero gradient
+    orc.handle_lambda(ag, W, Z, s, 1, -1.0, ns, True)                # terminal: trace.reset()  (sarsa_lambda.rs:76)
+    assert np.all(Z == 0.0)
+    # Saturate (Trace::replacing) clips at +-1, Dutch multiplies the decay by (1 - alpha)   (traces.rs:205-240)
+    ag = orc.make_agent(algo=orc.SARSA_LAMBDA, policy=orc.GREEDY, gamma=1.0, lam=1.0, alpha=0.0, trace=orc.TRACE_SATURATE)
+    Z[:] = 0
+    for _ in range(3):
+        orc.handle_lambda(ag, W, Z, s, 2, -1.0, ns, False)
+    assert Z[35, 2] == 1.0 and np.all(np.abs(Z) <= 1.0)
+    ag = orc.make_agent(algo=orc.SARSA_LAMBDA, policy=orc.GREEDY, gamma=0.9, lam=0.5, alpha=0.2, trace=orc.TRACE_DUTCH)
+    Z[:] = 0
+    orc.handle_lambda(ag, W, Z, s, 0, -1.0, ns, False)
+    orc.handle_lambda(ag, W, Z, s, 1, -1.0, ns, False)
+    assert abs(Z[35, 0] - 0.9 * 0.5 * 0.8) < 1e-12
+
+
+def test_lambda_agents_hand_computation(orc):
+    # sarsa_lambda.rs:53-98 / q_lambda.rs:56-99 restated in numpy for one transition
+    rng = np.random.default_rng(5)
+    W0 = rng.normal(size=(36, 3)) * 0.1
+    Z0 = rng.normal(size=(36, 3)) * 0.05
+    s = np.array([-0.7, 0.02])
+    ns, r, term = orc.domain_step(0, s, 1)
+    phi, nphi = orc.fourier_project(0, 5, s), orc.fourier_project(0, 5, ns)
+    q, qn = phi @ W0, nphi @ W0
+    for algo in (orc.SARSA_LAMBDA, orc.Q_LAMBDA):
+        ag = orc.make_agent(algo=algo, policy=orc.EGREEDY, epsilon=0.3, gamma=0.97, alpha=0.05, lam=0.8, seed=2)
+        x = orc.draw(2, 0, 0, orc.BLK_INNER)
+        W, Z = W0.copy(), Z0.copy()
+        d = orc.handle_lambda(ag, W, Z, s, 1, r, ns, term, x)
+        Ze = Z0.copy()
+        if algo == orc.Q_LAMBDA and 1 != orc.argmax_first(q):
+            Ze[:] = 0
+        Ze = 0.97 * 0.8 * Ze
+        Ze[:, 1] += phi
+        if algo == orc.SARSA_LAMBDA:
+            na = orc.policy_sample(orc.EGREEDY, qn, x, eps=0.3)
+            de = r + 0.97 * qn[na] - q[1]
+        else:
+            de = r + 0.97 * qn.max() - q[1]
+        assert abs(d - de) < 1e-12
+        assert np.max(np.abs(Z - Ze)) < 1e-14
+        assert np.max(np.abs(W - (W0 + 0.05 * de * Ze))) < 1e-14
