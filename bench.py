@@ -227,11 +227,11 @@ def main():
         # the fused kernel is VALU-issue bound (profiles/r01_pmc_summary.md): instructions per env-step from the PMC pass
         # (SQ_INSTS_VALU / env-steps) against the saturated issue rate measured by scripts/ubench/valu_issue.hip
         if kname == "k_train_reg":
-            instr, cyc_per_instr, simds, clk = 635.0, 2.47, 1024, 2.4e9
+            instr, cyc_per_instr, simds, clk = 563.0, 2.47, 1024, 2.4e9
             peak_steps = simds * 64 * clk / (instr * cyc_per_instr)
             out["valu_roofline"] = {"valu_instr_per_env_step": instr, "saturated_cycles_per_instr": cyc_per_instr,
                                     "peak_env_steps_per_s_per_gpu": peak_steps, "frac": (value / world) / peak_steps,
-                                    "source": "profiles/r01_pmc_summary.md, profiles/r01_ubench_valu_issue.txt"}
+                                    "source": "profiles/r01_pmc_final_raw.json (SQ_INSTS_VALU / wave / 256 steps), profiles/r01_ubench_valu_issue.txt"}
         if shared is not None:
             out["shared_w"] = shared
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,8 @@ import rsrl_amd as ra  # noqa: E402
 CONFIGS = {
     "C2 65536 MountainCar QL Fourier(5) eps-greedy per-env W (fused 256)": (dict(n_envs=65536, policy=1, epsilon=0.1, max_episode_steps=1000), 5120, 512, 608),
     "C2 same, 1 step per launch": (dict(n_envs=65536, policy=1, epsilon=0.1, max_episode_steps=1000, steps_per_launch=1), 3000, 300, 608),
+    "L1 65536 MountainCar SARSA(lambda) Fourier(5) replacing traces (examples/sarsa_lambda.rs)": (dict(n_envs=65536, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.2, gamma=0.99, alpha=0.01,
+                                                                                                     lam=0.7, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 2560, 256, 1040),
     "C3 262144 CartPole SARSA tiles 8x8^4 shared W": (dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA, n_envs=262144, policy=1,
                                                           epsilon=0.1, gamma=0.99, lr=0.0125 / 262144, weight_mode=ra.W_SHARED, max_episode_steps=1000), 200, 20, 208),
     "C3' 16384 CartPole SARSA tiles 8x8^4 per-env W (4 GiB of tables)": (dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA, n_envs=16384, policy=1,
