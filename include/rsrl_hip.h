@@ -209,6 +209,11 @@ uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
 int rsrl_hip_rollout_greedy(rsrl_hip_ctx* ctx, int64_t step_limit,
                             uint32_t* n_states_out /*[N]*/, float* total_reward_out /*[N]*/);
 
+/* Order-independent 64-bit checksums of the ctx's device state (sum of the 32-bit words, each multiplied by an odd
+ * function of its index): out[0] weights (+traces), out[1] env states/actions/episode counters.  For determinism /
+ * sharding / fusion-invariance checks at sizes where copying the weights out is not practical. */
+int rsrl_hip_checksum(rsrl_hip_ctx* ctx, uint64_t out[2]);
+
 /* ---- multi-GPU (one process per GPU; no reference counterpart) -------------------------
  * Shared-W mode across ranks: every batch-step all-reduces the (F x A) f32 weight delta
  * over RCCL.  id_bytes is an ncclUniqueId (128 bytes) produced on rank 0 and distributed

@@ -66,6 +66,7 @@ SYMBOLS = {
     "rsrl_hip_train": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     "rsrl_hip_step_count": (C.c_uint64, [C.c_void_p]),
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rsrl_hip_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rsrl_hip_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -228,6 +228,12 @@ class Context:
         _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit), _p(n_states), _p(tot)))
         return n_states, tot
 
+    def checksum(self):
+        """(weights(+traces), env state) 64-bit checksums computed on the device"""
+        out = (C.c_uint64 * 2)()
+        _abi.check(self._L.rsrl_hip_checksum(self._h, out))
+        return int(out[0]), int(out[1])
+
     # ---- multi-GPU (shared weights): RCCL communicator, one process per GPU
     @staticmethod
     def comm_unique_id():

@@ -75,6 +75,15 @@ __global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ 
         else dW[j] = tot;                                        // multi rank: the delta goes through the all-reduce first
     }
 }
+// order-independent checksum: sum over words of bits * (2*index + 1)  (mod 2^64)
+__global__ void k_checksum(const uint32_t* __restrict__ p, size_t n, size_t index_offset, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)p[j] * (2ull * (j + index_offset) + 1ull);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------- errors
@@ -901,6 +910,33 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_sta
     bool sync = false;
     TRY(flush_out(c, &on, &sync)); TRY(flush_out(c, &ot, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
+    CHECK_CTX(c);
+    if (!out) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(scratch_reserve(c, 7, 2 * sizeof(unsigned long long)));
+    unsigned long long* d = (unsigned long long*)c->scratch[7].p;
+    HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), c->stream));
+    auto run = [&](const void* p, size_t bytes, size_t off, int slot) {
+        const size_t n = bytes / 4;
+        if (!p || n == 0) return;
+        const unsigned g = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(k_checksum, dim3(g), dim3(256), 0, c->stream, (const uint32_t*)p, n, off, d + slot);
+    };
+    const size_t N = (size_t)c->cfg.n_envs;
+    run(c->W, c->w_bytes, 0, 0);
+    run(c->Z, c->Z ? c->w_bytes : 0, (size_t)1 << 40, 0);
+    run(c->state, sizeof(float) * c->D * N, 0, 1);
+    run(c->action, sizeof(int32_t) * N, (size_t)1 << 36, 1);
+    run(c->ep_step, sizeof(uint32_t) * N, (size_t)1 << 37, 1);
+    KCHECK();
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    out[0] = h[0]; out[1] = h[1];
     return RSRL_HIP_OK;
 }
 

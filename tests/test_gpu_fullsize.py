@@ -1,0 +1,100 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot finish these in seconds):
+determinism, sharding invariance, fusion invariance (checksums of checksums computed on the device), index
+ranges, reward/episode bookkeeping identities."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+C2 = dict(policy=1, epsilon=0.1, gamma=0.9, lr=0.001, seed=0, max_episode_steps=1000)
+
+
+def test_c2_full_size_determinism_fusion_and_sharding(ra):
+    N, K = 65536, 192
+    sums = []
+    for spl in (64, 64, 1):                               # same seed twice, then one step per launch
+        with ra.Context(n_envs=N, steps_per_launch=spl, **C2) as c:
+            c.reset()
+            st = c.train(K)
+            sums.append(c.checksum())
+            assert st["env_steps"] == N * K
+            # MountainCar: reward -1 on every non-terminal transition, 0 on the terminal one (discrete.rs:84-95)
+            assert st["sum_reward"] == -(st["env_steps"] - (st["episodes"] - st["episodes_truncated"]))
+            assert st["sum_episode_steps"] <= st["env_steps"]
+    assert sums[0] == sums[1], "same seed must give bit-identical weights and states"
+    assert sums[0] == sums[2], "K-step fusion must not change a single bit"
+    # two half-size shards keyed by global env id == the full run (word-index-weighted checksums do not add up across
+    # shards, so compare the per-shard slices of the full run instead)
+    with ra.Context(n_envs=N, **C2) as full, ra.Context(n_envs=N // 2, env_offset=N // 2, **C2) as hi:
+        full.reset(), hi.reset()
+        full.train(K), hi.train(K)
+        assert np.array_equal(full.states[:, N // 2:], hi.states)
+        assert np.array_equal(full.actions[N // 2:], hi.actions)
+        for i in (0, 12345, N // 2 - 1):
+            assert np.array_equal(full.get_weights(N // 2 + i), hi.get_weights(i))
+
+
+def test_c3_full_size_tiles(ra):
+    N, T, B = 262144, 8, 8
+    with ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=B, algo=ra.SARSA, policy=1, epsilon=0.1, gamma=0.99,
+                    lr=0.0125 / N, weight_mode=ra.W_SHARED, n_envs=N, seed=3, max_episode_steps=200) as c:
+        c.reset()
+        st = c.train(40)
+        idx = c.tile_indices(c.states)
+        W = c.get_weights()
+    assert idx.shape == (T, N)
+    for t in range(T):                                    # tiling t owns the index block [t*B^4, (t+1)*B^4)
+        assert idx[t].min() >= t * B ** 4 and idx[t].max() < (t + 1) * B ** 4
+    assert np.all(np.isfinite(W)) and np.count_nonzero(W) > 0
+    assert st["env_steps"] == N * 40 and st["episodes"] > 0
+    # CartPole: reward -1 exactly on terminal transitions (cart_pole.rs:99-110)
+    assert st["sum_reward"] == -(st["episodes"] - st["episodes_truncated"])
+
+
+def test_c4_full_size_shared_weights_reproducible(ra):
+    N = 1048576                                            # the whole 8-GPU batch on one device: state is tiny
+    kw = dict(C2, n_envs=N, weight_mode=ra.W_SHARED, lr=0.001 / N)
+    out = []
+    for _ in range(2):
+        with ra.Context(**kw) as c:
+            c.reset()
+            st = c.train(25)
+            out.append((c.checksum(), c.get_weights().copy()))
+            assert st["env_steps"] == N * 25
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])     # fixed-order delta reduction
+    assert np.max(np.abs(out[0][1])) > 0
+
+
+def test_c5_full_size_bf16_wave_family(ra):
+    N = 65536                                              # 65 536 x 3 x 4096 bf16 = 1.6 GB of weights
+    kw = dict(domain=2, order=7, algo=ra.EXPECTED_SARSA, policy=ra.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0, n_envs=N,
+              weight_dtype=ra.W_BF16, seed=5, max_episode_steps=1000)
+    sums = []
+    for spl in (6, 1):
+        with ra.Context(steps_per_launch=spl, **kw) as c:
+            c.reset()
+            st = c.train(6)
+            sums.append(c.checksum())
+            w = c.get_weights(N - 1)
+            assert np.all((w.view(np.uint32) & 0xffff) == 0) and np.all(np.isfinite(w))
+            assert st["env_steps"] == N * 6
+    assert sums[0] == sums[1]
+
+
+def test_lambda_full_size_determinism(ra):
+    kw = dict(n_envs=65536, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.2, gamma=0.99, alpha=0.01, lam=0.7, trace=ra.TRACE_SATURATE,
+              seed=0, max_episode_steps=1000)
+    sums = []
+    for spl in (128, 16):
+        with ra.Context(steps_per_launch=spl, **kw) as c:
+            c.reset()
+            c.train(128)
+            sums.append(c.checksum())
+    assert sums[0] == sums[1]
