@@ -112,13 +112,30 @@ __device__ __forceinline__ void q_from_reg(const float (&w)[A][F], const float (
         q[b] = combine_partials<P>(acc);
     }
 }
+// q[a] by a compare/select chain.  Each compare sees its own opaque copy of the index: otherwise LLVM folds the
+// chain into a dynamic extractelement, which is legalised through a private array that promote-alloca moves to LDS
+// -- an exposed ds_write/ds_read round trip on the critical path of every step.
 template <int A>
 __device__ __forceinline__ float select_a(const float (&q)[A], int a) {
     float v = q[0];
 #pragma unroll
-    for (int i = 1; i < A; ++i) v = (a == i) ? q[i] : v;
+    for (int i = 1; i < A; ++i) {
+        int ai = a;
+        asm("" : "+v"(ai));
+        v = (ai == i) ? q[i] : v;
+    }
     return v;
 }
+
+// Q(s,.) carried across loop iterations as named scalars: as an array it stays an alloca (promote-alloca then puts it
+// in LDS and every step pays a ds_write/ds_read round trip on its critical path).
+struct QCarry {
+    float v0, v1, v2;
+    template <int A> __device__ __forceinline__ void set(const float (&q)[A]) {
+        v0 = q[0]; v1 = A > 1 ? q[A > 1 ? 1 : 0] : 0.0f; v2 = A > 2 ? q[A > 2 ? 2 : 0] : 0.0f;
+    }
+    __device__ __forceinline__ float at(int a) const { return (a == 1) ? v1 : ((a == 2) ? v2 : v0); }
+};
 
 // ---------------------------------------------------------------------------------------
 // The fused driver loop  (examples/q_learning.rs:40-52, order of operations SURVEY A.7)
@@ -174,13 +191,19 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 #pragma unroll
             for (int f = 0; f < F; ++f) w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
 
-        float phi_a[F], phi_b[F], q_s[A];
+        static_assert(A <= 3, "QCarry holds up to 3 actions");
+        float phi_a[F], phi_b[F];
+        QCarry q_s;
         Bas::project(s, phi_a);
-        if (c.q_valid) {                 // Q(s,.) carried from the previous launch (bit-identical to not having stopped)
+        {
+            float q0[A];
+            if (c.q_valid) {             // Q(s,.) carried from the previous launch (bit-identical to not having stopped)
 #pragma unroll
-            for (int b = 0; b < A; ++b) q_s[b] = c.qcache[(int64_t)b * N + i];
-        } else {
-            q_from_reg<A, F>(w, phi_a, q_s);
+                for (int b = 0; b < A; ++b) q0[b] = c.qcache[(int64_t)b * N + i];
+            } else {
+                q_from_reg<A, F>(w, phi_a, q0);
+            }
+            q_s.set<A>(q0);
         }
         int a_taken = a;
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             Bas::project(ns, phi_n);
             q_from_reg<A, F>(w, phi_n, q_n);
             // ---- handle: delta with the PRE-update weights
-            const float qsa = select_a<A>(q_s, a);
+            const float qsa = q_s.at(a);
             U4 xin = U4{0, 0, 0, 0};
             if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
@@ -244,8 +267,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
-#pragma unroll
-            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            q_s.set<A>(q_n);
             a = na;
         };
 
@@ -261,8 +283,9 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
-#pragma unroll
-        for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_s[b];
+        c.qcache[i] = q_s.v0;
+        if constexpr (A > 1) c.qcache[N + i] = q_s.v1;
+        if constexpr (A > 2) c.qcache[2 * N + i] = q_s.v2;
         if (store_col) {
 #pragma unroll
             for (int f = 0; f < F; ++f) {
