@@ -40,7 +40,7 @@ struct FourierModel {
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
     static constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
-    static constexpr bool kDense = true;
+    static constexpr bool kDense = true, kSparse = false;
     struct Feat { float phi[F]; };
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom&, Feat& ft) { Bas::project(s, ft.phi); }
     __device__ static __forceinline__ int64_t widx(const Common& c, int64_t wi, int b, int f) {
@@ -90,7 +90,7 @@ template <int DOMAIN, int T>
 struct TileModel {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, A = Dom::A;
-    static constexpr bool kDense = false;
+    static constexpr bool kDense = false, kSparse = true;
     struct Feat { int idx[T]; };
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
         const int B = g.tiles_per_dim;
@@ -172,6 +172,25 @@ struct TileModel {
             if (pending) atomicAdd(&dW[key], scale);
         }
     }
+    // Block-level form for the shared-W driver loop: the learners of a block sit in a handful of tiles, so each
+    // tiling's slice of the delta table (cells*A floats, 32 KiB at 8^4 x 2) is privatised in LDS -- ds_add_f32 from
+    // every learner, then ONE device atomic per touched entry instead of one per learner (2 M -> ~0.1 M atomics per
+    // batch-step at 262 144 CartPole learners: 335 -> see DESIGN.md).  `slice` is dynamic LDS of cells*A floats,
+    // zero on entry and left zero on exit.  All threads of the block must call.
+    __device__ static __forceinline__ void block_accumulate(float* __restrict__ dW, float* __restrict__ slice, const BasisGeom& g,
+                                                            const Feat& ft, int a, float scale, bool valid) {
+        const int S = (g.F / T) * A;                                    // entries per tiling
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (valid) atomicAdd(&slice[(ft.idx[t] - t * (g.F / T)) * A + a], scale);
+            __syncthreads();
+            for (int j = threadIdx.x; j < S; j += blockDim.x) {
+                const float v = slice[j];
+                if (v != 0.0f) { atomicAdd(&dW[(int64_t)t * S + j], v); slice[j] = 0.0f; }
+            }
+            __syncthreads();
+        }
+    }
 };
 
 // Fourier basis of ANY order 1..7 on any domain, one thread per learner, features generated on the fly from the
@@ -183,7 +202,7 @@ template <int DOMAIN>
 struct FourierGenericModel {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, A = Dom::A;
-    static constexpr bool kDense = false;      // no register-resident phi: the shared-W block reduction is not available
+    static constexpr bool kDense = false, kSparse = false;      // no register-resident phi: the shared-W block reduction is not available
     struct Feat { float ct[D][8], st[D][8]; };
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
         const int order = g.tiles_per_dim;     // BasisGeom::tiles_per_dim carries the Fourier order for this model
@@ -477,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW,
                                                       float* __restrict__ partials, uint8_t* __restrict__ flags,
-                                                      DevStats* __restrict__ stats) {
+                                                      DevStats* __restrict__ stats, int lds_slice_floats) {
     constexpr int D = M::D, A = M::A;
     const int64_t N = c.n_envs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,7 +552,20 @@ __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uin
             for (int f = 0; f < M::F; ++f) fs.phi[f] = 0.0f;
         }
     }
-    if constexpr (!M::kDense) M::accumulate(dW, g, fs, a, scale, i < N);      // all lanes call (DPP sums inside)
+    if constexpr (!M::kDense) {
+        if constexpr (M::kSparse) {
+            extern __shared__ float tile_slice[];                       // cells*A floats when the host could afford it
+            if (lds_slice_floats > 0) {
+                for (int j = threadIdx.x; j < lds_slice_floats; j += blockDim.x) tile_slice[j] = 0.0f;
+                __syncthreads();
+                M::block_accumulate(dW, tile_slice, g, fs, a, scale, i < N);
+            } else {
+                M::accumulate(dW, g, fs, a, scale, i < N);            // all lanes call (DPP sums inside)
+            }
+        } else {
+            M::accumulate(dW, g, fs, a, scale, i < N);
+        }
+    }
     if constexpr (M::kDense) {
         // block-level sum of the learners' terms through LDS, fixed order (reproducible):
         //   tile[i][f] = lr*e_i*phi_i[f], act[i] = a_i;  thread (h, b, f) sums the learners of half h with a_i == b.

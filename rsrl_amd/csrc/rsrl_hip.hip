@@ -784,7 +784,10 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     const int do_c = first ? 0 : 1;
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, c->t, do_c, c->dW, c->partials, c->flags, d_stats);
+            // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
+            int slice = 0;
+            if (!dense) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; if (f * 4 <= 64 * 1024) slice = (int)f; }
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, (size_t)slice * sizeof(float), c->stream, k, g, c->t, do_c, c->dW, c->partials, c->flags, d_stats, slice);
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
