@@ -194,6 +194,14 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* w /*
  * row-major f32[F][A] like the weights */
 int rsrl_hip_get_traces(rsrl_hip_ctx* ctx, int64_t env_index, float* z /*[F][A]*/);
 int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[F][A]*/);
+/* Checkpoint of the approximator(s) (the reference's only persistence story is the optional serde
+ * derive on the agents, rsrl/Cargo.toml:26).  File format, little-endian:
+ *   char magic[8] = "RSRLHIPW"; u32 version = 1; i32 domain, basis, order, n_tilings, tiles_per_dim, weight_mode;
+ *   i32 F, A; i64 n_learners (1 in shared mode); u64 step_count; then n_learners x f32[F][A] in the reference's
+ *   row-major (F, A) order (Parameterised::weights, params/mod.rs:118) -- independent of the device layout and dtype.
+ * load checks that the header matches the ctx's configuration.  Traces are not saved (they are reset state). */
+int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
+int rsrl_hip_load_weights(rsrl_hip_ctx* ctx, const char* path);
 /* same weights broadcast to every learner (per-env mode) */
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 

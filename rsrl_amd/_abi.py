@@ -61,6 +61,8 @@ SYMBOLS = {
     "rsrl_hip_get_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights_all": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsrl_hip_save_weights": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rsrl_hip_load_weights": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rsrl_hip_get_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_train": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(Stats)]),

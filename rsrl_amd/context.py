@@ -209,6 +209,12 @@ class Context:
     def set_traces(self, z, env_index=0):
         _abi.check(self._L.rsrl_hip_set_traces(self._h, int(env_index), _p(_in(z, np.float32, (self.F, self.A)))))
 
+    def save_weights(self, path):
+        _abi.check(self._L.rsrl_hip_save_weights(self._h, str(path).encode()))
+
+    def load_weights(self, path):
+        _abi.check(self._L.rsrl_hip_load_weights(self._h, str(path).encode()))
+
     def set_weights_all(self, w):
         _abi.check(self._L.rsrl_hip_set_weights_all(self._h, _p(_in(w, np.float32, (self.F, self.A)))))
 

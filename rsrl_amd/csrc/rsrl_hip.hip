@@ -722,6 +722,56 @@ int rsrl_hip_set_traces(rsrl_hip_ctx* c, int64_t env_index, const float* z) {
     return traces_rw(c, env_index, nullptr, z);
 }
 
+// ---- checkpoint: header + every learner's weights in the reference (F, A) order ---------------------------------
+struct CkptHeader {
+    char magic[8]; uint32_t version; int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A;
+    int64_t n_learners; uint64_t step_count;
+};
+static void ckpt_fill(const rsrl_hip_ctx* c, CkptHeader* h) {
+    memset(h, 0, sizeof(*h));
+    memcpy(h->magic, "RSRLHIPW", 8); h->version = 1;
+    h->domain = c->cfg.domain; h->basis = c->cfg.basis; h->order = c->cfg.order; h->n_tilings = c->cfg.n_tilings;
+    h->tiles_per_dim = c->cfg.tiles_per_dim; h->weight_mode = c->cfg.weight_mode; h->F = c->F; h->A = c->A;
+    h->n_learners = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : c->cfg.n_envs; h->step_count = c->t;
+}
+int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
+    CHECK_CTX(c);
+    if (!path) return fail(RSRL_HIP_EINVAL, "null path");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(RSRL_HIP_EINVAL, "cannot open %s for writing", path);
+    CkptHeader h; ckpt_fill(c, &h);
+    int rc = RSRL_HIP_OK;
+    if (fwrite(&h, sizeof(h), 1, f) != 1) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+    std::vector<float> w((size_t)c->F * c->A);
+    for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
+        rc = rsrl_hip_get_weights(c, i, w.data());
+        if (rc == RSRL_HIP_OK && fwrite(w.data(), sizeof(float), w.size(), f) != w.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+    }
+    fclose(f);
+    return rc;
+}
+int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
+    CHECK_CTX(c);
+    if (!path) return fail(RSRL_HIP_EINVAL, "null path");
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(RSRL_HIP_EINVAL, "cannot open %s", path);
+    CkptHeader h, want; ckpt_fill(c, &want);
+    int rc = RSRL_HIP_OK;
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RSRLHIPW", 8) != 0 || h.version != 1) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
+    else if (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
+             h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
+             h.n_learners != want.n_learners)
+        rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration", path);
+    std::vector<float> w((size_t)c->F * c->A);
+    for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
+        if (fread(w.data(), sizeof(float), w.size(), f) != w.size()) { rc = fail(RSRL_HIP_EINVAL, "%s is truncated", path); break; }
+        rc = rsrl_hip_set_weights(c, i, w.data());
+    }
+    fclose(f);
+    if (rc == RSRL_HIP_OK) c->t = h.step_count;
+    return rc;
+}
+
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     CHECK_CTX(c);
     c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");

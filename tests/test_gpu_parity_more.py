@@ -213,3 +213,36 @@ def test_generic_fourier_orders(ra, orc, domain, order):
         ra.Context(domain=domain, order=order, n_envs=4, weight_mode=ra.W_SHARED)
     with pytest.raises(ra.RsrlHipError):
         ra.Context(domain=domain, order=8, n_envs=4)
+
+
+def test_checkpoint_roundtrip_and_resume(ra, tmp_path):
+    # save -> load into a fresh ctx -> continue: identical to never having stopped (weights + step counter restored;
+    # env state is re-created by reset, so compare a run that also resets at the same point)
+    kw = dict(n_envs=300, policy=1, epsilon=0.1, seed=12, max_episode_steps=40)
+    path = tmp_path / "w.rsrlw"
+    with ra.Context(**kw) as a:
+        a.reset(); a.train(50)
+        a.save_weights(path)
+        wa = [a.get_weights(i) for i in (0, 150, 299)]
+        a.reset(); a.train(30)
+        ref = (a.states.copy(), [a.get_weights(i) for i in (0, 150, 299)])
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"RSRLHIPW" and len(raw) == 64 + 300 * 36 * 3 * 4
+    with ra.Context(**kw) as b:
+        b.load_weights(path)
+        assert b.step_count == 50
+        for w, i in zip(wa, (0, 150, 299)):
+            assert np.array_equal(b.get_weights(i), w)
+        b.reset(); b.train(30)
+        assert np.array_equal(b.states, ref[0])
+        for w, i in zip(ref[1], (0, 150, 299)):
+            assert np.array_equal(b.get_weights(i), w)
+    with ra.Context(n_envs=299, policy=1) as c:
+        with pytest.raises(ra.RsrlHipError):
+            c.load_weights(path)                      # different configuration
+    with ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=4, tiles_per_dim=4, weight_mode=ra.W_SHARED, n_envs=8) as t:
+        t.set_weights(np.arange(4 * 256 * 2, dtype=np.float32).reshape(1024, 2))
+        t.save_weights(tmp_path / "t.rsrlw")
+        t.set_weights(np.zeros((1024, 2), dtype=np.float32))
+        t.load_weights(tmp_path / "t.rsrlw")
+        assert np.array_equal(t.get_weights(), np.arange(2048, dtype=np.float32).reshape(1024, 2))
