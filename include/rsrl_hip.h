@@ -58,9 +58,11 @@ typedef enum { RSRL_MOUNTAIN_CAR = 0, RSRL_CART_POLE = 1, RSRL_ACROBOT = 2 } rsr
 typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
 /* rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}
  *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66
- * and the eligibility-trace agents {SARSALambda, QLambda}
- *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights, register-family Fourier bases) */
-typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4 } rsrl_algo;
+ * the eligibility-trace agents {SARSALambda, QLambda}
+ *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights, register-family Fourier bases)
+ * and PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`) */
+typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4,
+               RSRL_PAL = 5 } rsrl_algo;
 /* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
 typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;
 /* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}

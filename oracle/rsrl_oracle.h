@@ -13,7 +13,8 @@ extern "C" {
 
 enum { ORC_MOUNTAIN_CAR = 0, ORC_CART_POLE = 1, ORC_ACROBOT = 2 };
 enum { ORC_FOURIER = 0, ORC_TILE = 1 };
-enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4 };
+enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4, ORC_PAL = 5 };
+#define ORC_IS_LAMBDA(algo) ((algo) == ORC_SARSA_LAMBDA || (algo) == ORC_Q_LAMBDA)
 /* eligibility-trace update rules (rsrl/src/traces.rs:188-240) */
 enum { ORC_TRACE_ACCUMULATE = 0, ORC_TRACE_SATURATE = 1, ORC_TRACE_DUTCH = 2 };
 enum { ORC_GREEDY = 0, ORC_EGREEDY = 1, ORC_SOFTMAX = 2, ORC_RANDOM = 3 };

@@ -426,6 +426,17 @@ R FN(orc_td_error)(const orc_agent* ag, const R* W, const R* s, int a, R r, cons
         FN(orc_q_evaluate)(b, W, A, ns, q);
         na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x_inner);
         delta = r + (R)ag->gamma * q[na] - qsa;
+    } else if (ag->algo == ORC_PAL) {
+        /* PAL::handle  control/td/pal.rs:34-60: persistent advantage learning, the max of the advantage-learning error at
+         * s and at s'; a* / na* are argmax_first (utils.rs:23-34); the error sent on is alpha * residual (:57). */
+        R qs[ORC_MAX_ACTIONS], nqs[ORC_MAX_ACTIONS], td, al, alt; int as, nas;
+        FN(orc_q_evaluate)(b, W, A, s, qs);
+        FN(orc_q_evaluate)(b, W, A, ns, nqs);
+        as = FN(orc_argmax_first)(qs, A); nas = FN(orc_argmax_first)(nqs, A);
+        td = r + (R)ag->gamma * nqs[as] - qs[a];
+        al = td - (R)ag->alpha * (qs[as] - qs[a]);
+        alt = td - (R)ag->alpha * (nqs[nas] - nqs[a]);
+        delta = (al > alt) ? al : alt;                                   /* f64::max */
     } else {
         R q[ORC_MAX_ACTIONS], p[ORC_MAX_ACTIONS], ev = 0; int i;
         FN(orc_q_evaluate)(b, W, A, ns, q);
@@ -434,7 +445,7 @@ R FN(orc_td_error)(const orc_agent* ag, const R* W, const R* s, int a, R r, cons
         delta = r + (R)ag->gamma * ev - qsa;
     }
     if (delta_out) *delta_out = delta;
-    return (ag->algo == ORC_EXPECTED_SARSA) ? (R)ag->alpha * delta : delta;
+    return (ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL) ? (R)ag->alpha * delta : delta;
 }
 /* Full handle on per-env weights: error with pre-update W, then the column AXPY (projection #3). */
 R FN(orc_handle)(const orc_agent* ag, R* W, const R* s, int a, R r, const R* ns, int term,
@@ -520,7 +531,7 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->action = (int32_t*)calloc((size_t)n_envs, sizeof(int32_t));
     run->ep_step = (uint32_t*)calloc((size_t)n_envs, sizeof(uint32_t));
     run->W = (R*)calloc(ag->shared_w ? FA : FA * (size_t)n_envs, sizeof(R));   /* LFA::vector zero-inits */
-    run->Z = (ag->algo >= ORC_SARSA_LAMBDA) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
+    run->Z = ORC_IS_LAMBDA(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
     return run;
 }
@@ -576,7 +587,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
             term_all[i] = (uint8_t)term;
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
-            if (ag->algo >= ORC_SARSA_LAMBDA) {
+            if (ORC_IS_LAMBDA(ag->algo)) {
                 delta = FN(orc_handle_lambda)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term, xi);
             } else if (!ag->shared_w) {
                 delta = FN(orc_handle)(ag, FN(run_W)(run, i), s, a, r, ns, term, xi);

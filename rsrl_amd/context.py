@@ -8,7 +8,7 @@ from . import _abi
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE_CODING = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA = 0, 1, 2, 3, 4
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL = 0, 1, 2, 3, 4, 5
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1

@@ -319,7 +319,7 @@ __device__ __forceinline__ int sample_probs(const float (&p)[A], uint32_t x) {
     return res;
 }
 enum : int { POL_GREEDY = 0, POL_EGREEDY = 1, POL_SOFTMAX = 2, POL_RANDOM = 3 };
-enum : int { ALG_QLEARNING = 0, ALG_SARSA = 1, ALG_ESARSA = 2 };
+enum : int { ALG_QLEARNING = 0, ALG_SARSA = 1, ALG_ESARSA = 2, ALG_PAL = 5 };
 
 struct PolicyParams { int kind; uint32_t eps_thr; float eps; float tau; };
 
@@ -394,6 +394,40 @@ __device__ __forceinline__ float td_error(const AlgoParams& ap, const PolicyPara
     }
     e = (ap.kind == ALG_ESARSA) ? ap.alpha * delta : delta;
     return delta;
+}
+
+// PAL::handle  control/td/pal.rs:34-60 (persistent advantage learning): needs Q(s,.) in full.
+//   td = r + gamma*Q(s',a*) - Q(s,a);  residual = max(td - alpha*(Q(s,a*) - Q(s,a)), td - alpha*(Q(s',na*) - Q(s',a)))
+//   a* / na* = argmax_first (utils.rs:23-34); terminal: r - Q(s,a); the error sent on is alpha * residual (:57)
+template <int A>
+__device__ __forceinline__ float td_error_pal(const AlgoParams& ap, const float (&qs)[A], const float (&qn)[A], int a, float r,
+                                              bool term, float& e) {
+    float qsa = qs[0], qna = qn[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) { qsa = (a == i) ? qs[i] : qsa; qna = (a == i) ? qn[i] : qna; }
+    const int as = argmax_first<A>(qs), nas = argmax_first<A>(qn);
+    float qs_star = qs[0], qn_at_as = qn[0], qn_star = qn[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) {
+        qs_star = (as == i) ? qs[i] : qs_star; qn_at_as = (as == i) ? qn[i] : qn_at_as; qn_star = (nas == i) ? qn[i] : qn_star;
+    }
+    const float td = r + ap.gamma * qn_at_as - qsa;
+    const float al = td - ap.alpha * (qs_star - qsa);
+    const float alt = td - ap.alpha * (qn_star - qna);
+    const float delta = term ? (r - qsa) : fmaxf(al, alt);
+    e = ap.alpha * delta;
+    return delta;
+}
+
+// one entry point for all one-step agents: Q(s,.) in full, the action taken, Q(s',.) -> (delta, error sent on)
+template <int A>
+__device__ __forceinline__ float td_dispatch(const AlgoParams& ap, const PolicyParams& pp, const float (&qs)[A], int a,
+                                             const float (&qn)[A], float r, bool term, const U4& x_inner, float& e) {
+    if (ap.kind == ALG_PAL) return td_error_pal<A>(ap, qs, qn, a, r, term, e);
+    float qsa = qs[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) qsa = (a == i) ? qs[i] : qsa;
+    return td_error<A>(ap, pp, qsa, qn, r, term, x_inner, e);
 }
 
 // ---------------------------------------------------------------------------------------

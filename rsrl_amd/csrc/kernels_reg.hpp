@@ -223,10 +223,19 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             q_from_reg<A, F>(w, phi_n, q_n);
             // ---- handle: delta with the PRE-update weights
             const float qsa = q_s.at(a);
+            const float q_s_all[3] = {q_s.v0, q_s.v1, q_s.v2};
             U4 xin = U4{0, 0, 0, 0};
             if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+            float delta;
+            if constexpr (ALGO == ALG_PAL) {
+                float qs_arr[A];
+#pragma unroll
+                for (int b = 0; b < A; ++b) qs_arr[b] = q_s_all[b];
+                delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
+            } else {
+                delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+            }
             // ---- Handler<StateActionUpdate>: W[:,a] += lr * e * phi(s)     fa/linear.rs:379-391
             const float scale = alg.lr * e;
 #pragma unroll
@@ -377,17 +386,19 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
         // ---- Q(s,a): carried from the previous launch, or recomputed when the cache is stale
         constexpr int P = RSRL_DOT_SPLIT;
-        float qsa;
+        float qs_arr[A];
         if (c.q_valid) {
-            qsa = (a == 0) ? qc0 : ((a == 1) ? qc1 : qc2);
+            qs_arr[0] = qc0;
+            if constexpr (A > 1) qs_arr[1] = qc1;
+            if constexpr (A > 2) qs_arr[2] = qc2;
         } else {
-            float qs[A];
-            q_from_reg<A, F>(wv, phi_s, qs);
-            qsa = select_a<A>(qs, a);
+            q_from_reg<A, F>(wv, phi_s, qs_arr);
         }
+        const float qsa = (a == 0) ? qs_arr[0] : ((a == 1) ? qs_arr[A > 1 ? 1 : 0] : qs_arr[A > 2 ? 2 : 0]);
         q_from_reg<A, F>(wv, phi_n, q_n);                              // Q(s',.) with the PRE-update weights
-        float e;
-        const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        float e, delta;
+        if constexpr (ALGO == ALG_PAL) delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
+        else delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
         // ---- W[:,a] += lr * e * phi(s); every (action, feature) row goes back as a FULL line (the untouched
         //      columns are rewritten unchanged: the lane-dependent column would dirty all three lines anyway)
         const float scale = alg.lr * e;

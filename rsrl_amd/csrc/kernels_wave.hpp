@@ -213,7 +213,8 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+            (void)qsa;
             const float scale = c.alg.lr * e;
             U4 rnd = U4{0, 0, 0, 0};
             if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
     U4 xin = U4{0, 0, 0, 0};
     if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
     float e;
-    const float delta = td_error<A>(c.alg, c.pol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+    const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
     const float scale = c.alg.lr * e;
     U4 rnd = U4{0, 0, 0, 0};
     if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_SR_BASE + (uint32_t)lane);

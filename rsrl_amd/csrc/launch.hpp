@@ -31,6 +31,6 @@ bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStrea
     }
 #define RSRL_TRAIN_POLICIES(DM, OR, AL) \
     RSRL_TRAIN_CASE(DM, OR, AL, 0) RSRL_TRAIN_CASE(DM, OR, AL, 1) RSRL_TRAIN_CASE(DM, OR, AL, 2) RSRL_TRAIN_CASE(DM, OR, AL, 3)
-#define RSRL_TRAIN_ALGOS(DM, OR) RSRL_TRAIN_POLICIES(DM, OR, 0) RSRL_TRAIN_POLICIES(DM, OR, 1) RSRL_TRAIN_POLICIES(DM, OR, 2)
+#define RSRL_TRAIN_ALGOS(DM, OR) RSRL_TRAIN_POLICIES(DM, OR, 0) RSRL_TRAIN_POLICIES(DM, OR, 1) RSRL_TRAIN_POLICIES(DM, OR, 2) RSRL_TRAIN_POLICIES(DM, OR, 5)
 
 }  // namespace rsrl

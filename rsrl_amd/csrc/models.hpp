@@ -374,13 +374,13 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
         typename M::Feat fn;
         M::features(s, g, fs);
         M::features(ns, g, fn);
-        const float qsa = M::q_index(c, wi, g, fs, a);
-        float q_n[A];
+        float q_s[A], q_n[A];
+        M::q_all(c, wi, g, fs, q_s);
         M::q_all(c, wi, g, fn, q_n);
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
         float e;
-        const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+        const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
         if (!shared) M::update(c, wi, g, fs, a, scale);
         if (td_out) td_out[i] = delta;
@@ -449,13 +449,13 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) M::Dom::reset(ns);
             M::features(ns, g, fn);
-            const float qsa = M::q_index(c, i, g, fs, a);
-            float q_n[A];
+            float q_s[A], q_n[A];
+            M::q_all(c, i, g, fs, q_s);
             M::q_all(c, i, g, fn, q_n);
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
             M::update(c, i, g, fs, a, c.alg.lr * e);
             M::q_all(c, i, g, fn, q_n);                              // UPDATED weights
             const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
@@ -531,13 +531,12 @@ __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uin
         const bool trunc = !term && cap > 0 && ep >= cap;
         typename M::Feat fn;
         M::features(ns, g, fn);
-        const float qsa = select_a<A>(q_s, a);
         float q_n[A];
         M::q_all(c, 0, g, fn, q_n);
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         float e;
-        const float delta = td_error<A>(c.alg, c.pol, qsa, q_n, r, term, xin, e);
+        const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];

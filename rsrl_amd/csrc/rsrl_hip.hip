@@ -21,6 +21,8 @@
 
 using namespace rsrl;
 
+static inline bool is_lambda(int algo) { return algo == RSRL_SARSA_LAMBDA || algo == RSRL_Q_LAMBDA; }
+
 namespace {
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,7 +334,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
     if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
-    if (cfg->algo < 0 || cfg->algo > RSRL_Q_LAMBDA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo < 0 || cfg->algo > RSRL_PAL) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
@@ -358,7 +360,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
-    if (cfg->algo >= RSRL_SARSA_LAMBDA) {
+    if (is_lambda(cfg->algo)) {
         if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
             return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
                                          "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
@@ -385,7 +387,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
-    if (cfg->algo >= RSRL_SARSA_LAMBDA) {
+    if (is_lambda(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
         HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
     }
@@ -625,7 +627,7 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (c->cfg.algo >= RSRL_SARSA_LAMBDA) {
+    if (is_lambda(c->cfg.algo)) {
         if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
                                   d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
     } else if (is_wave(c->cfg)) {
@@ -883,7 +885,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         if (shared) {
             TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
             c->kernel_name = "k_shared_ca";
-        } else if (c->cfg.algo >= RSRL_SARSA_LAMBDA) {
+        } else if (is_lambda(c->cfg.algo)) {
             if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),
                                      c->stream, k, make_lambda(c), c->t, chunk, d_stats)) return NO_MODEL(c);
             c->kernel_name = "k_train_lambda";

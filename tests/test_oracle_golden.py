@@ -391,3 +391,32 @@ def test_lambda_agents_hand_computation(orc):
         assert abs(d - de) < 1e-12
         assert np.max(np.abs(Z - Ze)) < 1e-14
         assert np.max(np.abs(W - (W0 + 0.05 * de * Ze))) < 1e-14
+
+
+def test_pal_hand_computation(orc):
+    # control/td/pal.rs:34-60 restated in numpy: persistent advantage learning
+    ag = orc.make_agent(algo=orc.PAL, policy=orc.GREEDY, gamma=0.95, lr=0.002, alpha=0.3)
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        W = rng.normal(size=(36, 3)) * 0.3
+        s = np.array([rng.uniform(-1.2, 0.6), rng.uniform(-0.07, 0.07)])
+        a = int(rng.integers(0, 3))
+        ns, r, term = orc.domain_step(orc.MOUNTAIN_CAR, s, a)
+        phi, nphi = orc.fourier_project(0, 5, s), orc.fourier_project(0, 5, ns)
+        qs, nqs = phi @ W, nphi @ W
+        a_star, na_star = int(np.argmax(qs)), int(np.argmax(nqs))       # distinct values: first == any
+        td = r + 0.95 * nqs[a_star] - qs[a]
+        al = td - 0.3 * (qs[a_star] - qs[a])
+        res = max(al, td - 0.3 * (nqs[na_star] - nqs[a]))
+        W_exp = W.copy()
+        W_exp[:, a] += 0.002 * (0.3 * res) * phi                        # error sent on = alpha * residual (pal.rs:57)
+        W2 = W.copy()
+        d = orc.handle(ag, W2, s, a, r, ns, False)
+        assert abs(d - res) < 1e-12
+        assert np.max(np.abs(W2 - W_exp)) < 1e-14
+        W3 = W.copy()
+        d = orc.handle(ag, W3, s, a, r, ns, True)                       # terminal: r - Q(s,a)  (pal.rs:39-40)
+        assert abs(d - (r - qs[a])) < 1e-12
+        assert np.max(np.abs(W3[:, a] - (W[:, a] + 0.002 * 0.3 * d * phi))) < 1e-14
+    # PAL's residual never exceeds the plain TD(a*) residual (both corrections are <= 0)  -- the action-gap property
+    assert res <= td + 1e-15
