@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 2
+#define RSRL_HIP_ABI_VERSION 3
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -60,9 +60,11 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66
  * the eligibility-trace agents {SARSALambda, QLambda}
  *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights, register-family Fourier bases)
- * and PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`) */
+ * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
+ * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
+ *   rsrl_hip_get/set_td_weights); per-learner weights, register-family Fourier bases */
 typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4,
-               RSRL_PAL = 5 } rsrl_algo;
+               RSRL_PAL = 5, RSRL_GREEDY_GQ = 6 } rsrl_algo;
 /* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
 typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;
 /* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}
@@ -108,6 +110,7 @@ typedef struct {
     void*    stream;             /* hipStream_t to run on; NULL = ctx-owned stream           */
     double   lambda;             /* Trace::{accumulating,replacing,dutch}(dim, gamma, lambda) (examples/sarsa_lambda.rs:37);
                                     the lambda agents step with `alpha` and bypass SGD(lr) (fa/linear.rs:184-196) */
+    double   lr_td;              /* GreedyGQ: SGD rate of fa_td (examples/greedy_gq.rs:27 uses 0.001 next to SGD(0.1) for fa_q) */
 } rsrl_hip_config;
 
 /* per-call statistics of rsrl_hip_train (the println! / Response{error} of the
@@ -196,6 +199,9 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* w /*
  * row-major f32[F][A] like the weights */
 int rsrl_hip_get_traces(rsrl_hip_ctx* ctx, int64_t env_index, float* z /*[F][A]*/);
 int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[F][A]*/);
+/* the pub field `fa_td` of GreedyGQ (greedy_gq.rs:52): one learner's second approximator, row-major f32[F][A] */
+int rsrl_hip_get_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* v /*[F][A]*/);
+int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v /*[F][A]*/);
 /* Checkpoint of the approximator(s) (the reference's only persistence story is the optional serde
  * derive on the agents, rsrl/Cargo.toml:26).  File format, little-endian:
  *   char magic[8] = "RSRLHIPW"; u32 version = 1; i32 domain, basis, order, n_tilings, tiles_per_dim, weight_mode;

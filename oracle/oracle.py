@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL = 0, 1, 2, 3, 4, 5
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ = 0, 1, 2, 3, 4, 5, 6
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EGREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 BLK_STEP, BLK_RESET, BLK_INNER, BLK_INIT, BLK_API = 0, 1, 2, 3, 4
@@ -34,7 +34,7 @@ class Agent(C.Structure):
                 ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
                 ("epsilon", C.c_double), ("tau", C.c_double),
                 ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32),
-                ("lam", C.c_double), ("trace", C.c_int)]
+                ("lam", C.c_double), ("trace", C.c_int), ("lr_td", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -130,6 +130,8 @@ def _declare(L):
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_handle_lambda").restype = R
         g("orc_handle_lambda").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
+        g("orc_handle_gq").restype = R
+        g("orc_handle_gq").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int]
         g("orc_run_traces").restype = Rp
         g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
@@ -152,12 +154,12 @@ def _ptr(a, ct):
 def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
                gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000, lam=0.0,
-               trace=TRACE_ACCUMULATE):
+               trace=TRACE_ACCUMULATE, lr_td=0.0):
     ag = Agent()
     lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
                          int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
                          max_episode_steps)
-    ag.lam, ag.trace = lam, trace
+    ag.lam, ag.trace, ag.lr_td = lam, trace, lr_td
     return ag
 
 
@@ -302,6 +304,16 @@ def handle_lambda(ag, W, Z, s, a, r, ns, term, x_inner=(0, 0, 0, 0), prec="f64")
     xx = (C.c_uint32 * 4)(*[int(v) for v in x_inner])
     return float(getattr(lib(), f"orc_handle_lambda_{prec}")(C.byref(ag), _ptr(W, ct), _ptr(Z, ct), _ptr(s, ct), int(a),
                                                              ct(r), _ptr(ns, ct), int(term), xx))
+
+
+def handle_gq(ag, W, V, s, a, r, ns, term, prec="f64"):
+    """GreedyGQ handle on one transition; W (fa_q) and V (fa_td), both (F,A), are updated in place; returns td_error."""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    assert W.dtype == dt and V.dtype == dt and W.flags.c_contiguous and V.flags.c_contiguous
+    s = np.array(s, dtype=dt)
+    ns = np.array(ns, dtype=dt)
+    return float(getattr(lib(), f"orc_handle_gq_{prec}")(C.byref(ag), _ptr(W, ct), _ptr(V, ct), _ptr(s, ct), int(a),
+                                                         ct(r), _ptr(ns, ct), int(term)))
 
 
 class Run:

@@ -154,7 +154,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     ag->gamma = gamma; ag->lr = lr; ag->alpha = alpha; ag->epsilon = epsilon; ag->tau = tau;
     ag->eps_thr = orc_eps_threshold(epsilon);
     ag->max_episode_steps = max_episode_steps;
-    ag->lambda = 0.0; ag->trace = ORC_TRACE_ACCUMULATE;
+    ag->lambda = 0.0; ag->trace = ORC_TRACE_ACCUMULATE; ag->lr_td = 0.0;
 }
 
 /* ------------------------------------------------------------------ */

@@ -13,8 +13,11 @@ extern "C" {
 
 enum { ORC_MOUNTAIN_CAR = 0, ORC_CART_POLE = 1, ORC_ACROBOT = 2 };
 enum { ORC_FOURIER = 0, ORC_TILE = 1 };
-enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4, ORC_PAL = 5 };
+enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4, ORC_PAL = 5,
+       ORC_GREEDY_GQ = 6 };
 #define ORC_IS_LAMBDA(algo) ((algo) == ORC_SARSA_LAMBDA || (algo) == ORC_Q_LAMBDA)
+/* agents with a second per-learner matrix of W's shape: the trace Z (lambda agents) or fa_td's weights (GreedyGQ) */
+#define ORC_HAS_AUX(algo) (ORC_IS_LAMBDA(algo) || (algo) == ORC_GREEDY_GQ)
 /* eligibility-trace update rules (rsrl/src/traces.rs:188-240) */
 enum { ORC_TRACE_ACCUMULATE = 0, ORC_TRACE_SATURATE = 1, ORC_TRACE_DUTCH = 2 };
 enum { ORC_GREEDY = 0, ORC_EGREEDY = 1, ORC_SOFTMAX = 2, ORC_RANDOM = 3 };
@@ -40,6 +43,7 @@ typedef struct {
     uint32_t max_episode_steps;
     double lambda;       /* eligibility traces */
     int trace;
+    double lr_td;        /* GreedyGQ: SGD rate of fa_td (examples/greedy_gq.rs:27) */
 } orc_agent;
 
 typedef struct {
@@ -95,6 +99,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     void  orc_run_reset_##S(void* h);                                                                   \
     R     orc_handle_lambda_##S(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,   \
                                 const uint32_t x_inner[4]);                                             \
+    R     orc_handle_gq_##S(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, const R* ns, int term);              \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \

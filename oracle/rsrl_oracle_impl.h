@@ -503,6 +503,31 @@ R FN(orc_handle_lambda)(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r,
     return residual;
 }
 
+/* GreedyGQ::handle   control/td/greedy_gq.rs:73-141.  W = fa_q's weights (SGD(lr)), V = fa_td's weights (SGD(lr_td)),
+ * both (F, A) row-major.  Order of the reference: qsa and td_est with the pre-update matrices; (na, max) =
+ * fa_q.find_max(s') BEFORE any update; fa_q: column a moves by lr*td_error*phi(s), THEN column na by
+ * lr*(-gamma*td_est)*phi(s') (non-terminal only); fa_td: column a moves by lr_td*(td_error - td_est)*phi(s).
+ * Returns td_error. */
+R FN(orc_handle_gq)(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, const R* ns, int term) {
+    const orc_basis* b = &ag->basis; int A = ag->n_actions;
+    R qsa = FN(orc_q_evaluate_index)(b, W, A, s, a);
+    R td_est = FN(orc_q_evaluate_index)(b, V, A, s, a);
+    R td_error;
+    if (term) {
+        td_error = r - qsa;
+        FN(orc_q_update_index)(b, W, A, s, a, (R)ag->lr, td_error);
+    } else {
+        R q[ORC_MAX_ACTIONS], m; int na;
+        FN(orc_q_evaluate)(b, W, A, ns, q);
+        na = FN(orc_find_max)(q, A, &m);
+        td_error = r + (R)ag->gamma * m - qsa;
+        FN(orc_q_update_index)(b, W, A, s, a, (R)ag->lr, td_error);
+        FN(orc_q_update_index)(b, W, A, ns, na, (R)ag->lr, -(R)ag->gamma * td_est);
+    }
+    FN(orc_q_update_index)(b, V, A, s, a, (R)ag->lr_td, td_error - td_est);
+    return td_error;
+}
+
 /* ------------------------------------------------------------------ */
 /* Vectorised driver loop (examples/q_learning.rs:34-55 x N envs)      */
 /* ------------------------------------------------------------------ */
@@ -514,7 +539,7 @@ typedef struct {
     int32_t* action; /* [N]    */
     uint32_t* ep_step;
     R* W;            /* per-env: [N][F][A]; shared: [F][A] */
-    R* Z;            /* eligibility traces, per-env [N][F][A] (lambda agents only) */
+    R* Z;            /* per-env [N][F][A]: eligibility traces (lambda agents) or fa_td weights (GreedyGQ) */
     uint64_t t;      /* global batch-step counter */
 } FN(orc_run);
 
@@ -531,7 +556,7 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->action = (int32_t*)calloc((size_t)n_envs, sizeof(int32_t));
     run->ep_step = (uint32_t*)calloc((size_t)n_envs, sizeof(uint32_t));
     run->W = (R*)calloc(ag->shared_w ? FA : FA * (size_t)n_envs, sizeof(R));   /* LFA::vector zero-inits */
-    run->Z = ORC_IS_LAMBDA(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
+    run->Z = ORC_HAS_AUX(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
     return run;
 }
@@ -589,6 +614,8 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
             if (ORC_IS_LAMBDA(ag->algo)) {
                 delta = FN(orc_handle_lambda)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term, xi);
+            } else if (ag->algo == ORC_GREEDY_GQ) {
+                delta = FN(orc_handle_gq)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term);
             } else if (!ag->shared_w) {
                 delta = FN(orc_handle)(ag, FN(run_W)(run, i), s, a, r, ns, term, xi);
             } else {

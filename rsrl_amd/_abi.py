@@ -17,6 +17,7 @@ class Config(C.Structure):
         ("seed", C.c_uint64), ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
         ("epsilon", C.c_double), ("tau", C.c_double), ("steps_per_launch", C.c_uint32),
         ("trace", C.c_int32), ("stream", C.c_void_p), ("lam", C.c_double),
+        ("lr_td", C.c_double),
     ]
 
 
@@ -65,6 +66,8 @@ SYMBOLS = {
     "rsrl_hip_load_weights": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rsrl_hip_get_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_traces": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "rsrl_hip_get_td_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "rsrl_hip_set_td_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_train": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     "rsrl_hip_step_count": (C.c_uint64, [C.c_void_p]),
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

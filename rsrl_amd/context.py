@@ -8,7 +8,7 @@ from . import _abi
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE_CODING = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL = 0, 1, 2, 3, 4, 5
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ = 0, 1, 2, 3, 4, 5, 6
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
@@ -45,7 +45,7 @@ class Context:
     def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
-                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE):
+                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -55,7 +55,7 @@ class Context:
         cfg.max_episode_steps, cfg.n_envs, cfg.env_offset, cfg.seed = max_episode_steps, n_envs, env_offset, seed
         cfg.gamma, cfg.lr, cfg.alpha, cfg.epsilon, cfg.tau = gamma, lr, alpha, epsilon, tau
         cfg.steps_per_launch = steps_per_launch
-        cfg.lam, cfg.trace = lam, trace
+        cfg.lam, cfg.trace, cfg.lr_td = lam, trace, lr_td
         cfg.stream = stream
         self.cfg = cfg
         self._h = C.c_void_p()
@@ -208,6 +208,15 @@ class Context:
 
     def set_traces(self, z, env_index=0):
         _abi.check(self._L.rsrl_hip_set_traces(self._h, int(env_index), _p(_in(z, np.float32, (self.F, self.A)))))
+
+    def get_td_weights(self, env_index=0):
+        """GreedyGQ.fa_td's weights of one learner (greedy_gq.rs:52)"""
+        out = np.empty((self.F, self.A), dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_get_td_weights(self._h, int(env_index), _p(out)))
+        return out
+
+    def set_td_weights(self, v, env_index=0):
+        _abi.check(self._L.rsrl_hip_set_td_weights(self._h, int(env_index), _p(_in(v, np.float32, (self.F, self.A)))))
 
     def save_weights(self, path):
         _abi.check(self._L.rsrl_hip_save_weights(self._h, str(path).encode()))

@@ -1,0 +1,183 @@
+// kernels_gq.hpp -- GreedyGQ on the register family:
+//   GreedyGQ::handle   rsrl/src/control/td/greedy_gq.rs:73-141      driver rsrl/examples/greedy_gq.rs:21-58
+// Two approximators per learner: fa_q (weights W, SGD(lr)) and fa_td (weights V, SGD(lr_td)), both f32[A][F][N].
+// Per transition, all against the PRE-update matrices:
+//     qsa = <phi(s), W[:,a]>,  td_est = <phi(s), V[:,a]>,  (na, qmax) = find_max(Q(s',.))      (ties -> last, core.rs:96-105)
+//     td_error = r - qsa                         (terminal)          | r + gamma*qmax - qsa    (otherwise)
+//     W[:,a]  += lr * td_error * phi(s);   then (non-terminal)  W[:,na] += lr * (-gamma*td_est) * phi(s')
+//     V[:,a]  += lr_td * (td_error - td_est) * phi(s)
+// In the fused driver loop W AND V stay in registers for the whole launch (the layout of the eligibility-trace kernels,
+// kernels_lambda.hpp); V lives in the ctx's auxiliary matrix (the one the lambda agents use for the trace).
+#pragma once
+
+#include "models.hpp"
+
+namespace rsrl {
+
+enum : int { ALG_GREEDY_GQ = 6 };
+
+struct GqParams {
+    float* V;          // fa_td weights [A][F][N]
+    float lr_td;       // SGD rate of fa_td
+};
+
+// column-select dot product: <phi, m[a][:]> with the family's 4-chain summation order
+template <int A, int F>
+__device__ __forceinline__ float dot_col_reg(const float (&m)[A][F], const float (&phi)[F], int a) {
+    float q[A];
+    q_from_reg<A, F>(m, phi, q);
+    return select_a<A>(q, a);
+}
+
+template <int DOMAIN, int ORDER, int POLICY>
+__global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = c.n_envs;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        PolicyParams pol = c.pol; pol.kind = POLICY;
+        const float gamma = c.alg.gamma, lr = c.alg.lr;
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+        int a = c.action[i];
+        uint32_t ep = c.ep_step[i];
+        float w[A][F], v[A][F];
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
+                v[b][f] = gp.V[((int64_t)(b * F + f)) * N + i];
+            }
+        float phi_a[F], phi_b[F], q_s[A];
+        Bas::project(s, phi_a);
+        q_from_reg<A, F>(w, phi_a, q_s);
+        float facc_abs = 0.0f, facc_r = 0.0f;
+
+        auto one_step = [&](const float (&phi_s)[F], float (&phi_n)[F], uint64_t t) {
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) Dom::reset(ns);                       // a terminal transition never reads Q(s',.): go straight to the restart state
+            float q_n[A];
+            Bas::project(ns, phi_n);
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const float qsa = select_a<A>(q_s, a);
+            const float td_est = dot_col_reg<A, F>(v, phi_s, a);
+            float qmax;
+            const int na_star = find_max<A>(q_n, qmax);
+            const float delta = term ? (r - qsa) : (r + gamma * qmax - qsa);
+            const float sc1 = lr * delta;
+            const float sc2 = term ? 0.0f : lr * (-gamma * td_est);
+            const float sc3 = gp.lr_td * (delta - td_est);
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    float wv = w[b][f];
+                    wv = (a == b) ? fmaf(sc1, phi_s[f], wv) : wv;
+                    wv = (!term && na_star == b) ? fmaf(sc2, phi_n[f], wv) : wv;
+                    w[b][f] = wv;
+                    v[b][f] = (a == b) ? fmaf(sc3, phi_s[f], v[b][f]) : v[b][f];
+                }
+            // ---- behaviour_policy.sample with the UPDATED fa_q (two columns may have moved: recompute)
+            q_from_reg<A, F>(w, phi_n, q_n);
+            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            int na = policy_sample<A>(pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                Bas::project(ns, phi_n);
+                q_from_reg<A, F>(w, phi_n, q_n);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(pol, q_n, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            a = na;
+        };
+        int k = 0;
+        for (; k + 1 < n_steps; k += 2) {
+            one_step(phi_a, phi_b, t0 + (uint64_t)k);
+            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+        }
+        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = ep;
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                c.W[((int64_t)(b * F + f)) * N + i] = w[b][f];
+                gp.V[((int64_t)(b * F + f)) * N + i] = v[b][f];
+            }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// Handler<&Transition>::handle of GreedyGQ on caller-supplied transitions (W and V in memory)
+template <int DOMAIN, int ORDER>
+__global__ __launch_bounds__(kBlock) void k_handle_gq(Common c, GqParams gp, const float* __restrict__ from,
+                                                      const int32_t* __restrict__ act, const float* __restrict__ rew,
+                                                      const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                      int64_t Mn, float* __restrict__ td_out) {
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    const int64_t N = c.n_envs;
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
+    const int a = act[i];
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    float phi_s[F], phi_n[F], q_s[A], q_n[A], e_s[A];
+    Bas::project(s, phi_s);
+    Bas::project(ns, phi_n);
+    q_from_mem<A, F>(c.W, N, i, phi_s, q_s);
+    q_from_mem<A, F>(c.W, N, i, phi_n, q_n);
+    q_from_mem<A, F>(gp.V, N, i, phi_s, e_s);
+    const float qsa = select_a<A>(q_s, a), td_est = select_a<A>(e_s, a);
+    float qmax;
+    const int na_star = find_max<A>(q_n, qmax);
+    const float delta = term ? (r - qsa) : (r + c.alg.gamma * qmax - qsa);
+    const float sc1 = c.alg.lr * delta;
+    const float sc2 = c.alg.lr * (-c.alg.gamma * td_est);
+    const float sc3 = gp.lr_td * (delta - td_est);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int64_t ja = ((int64_t)(a * F + f)) * N + i;
+        c.W[ja] = fmaf(sc1, phi_s[f], c.W[ja]);
+        gp.V[ja] = fmaf(sc3, phi_s[f], gp.V[ja]);
+    }
+    if (!term) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int64_t jn = ((int64_t)(na_star * F + f)) * N + i;
+            c.W[jn] = fmaf(sc2, phi_n[f], c.W[jn]);
+        }
+    }
+    if (td_out) td_out[i] = delta;
+}
+
+}  // namespace rsrl

@@ -21,6 +21,13 @@ bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStrea
                           const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                           int64_t Mn, uint64_t t, float* td_out);
 
+struct GqParams;
+bool launch_train_gq(int domain, int order, int policy, dim3 grid, dim3 block, hipStream_t st, const Common& k,
+                     const GqParams& gp, uint64_t t, int chunk, DevStats* stats);
+bool launch_handle_gq(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const GqParams& gp,
+                      const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                      int64_t Mn, float* td_out);
+
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
         if (chunk == -1)                                                                                    \

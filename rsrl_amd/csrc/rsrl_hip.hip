@@ -18,10 +18,12 @@
 #include "models.hpp"
 #include "kernels_wave.hpp"
 #include "kernels_lambda.hpp"
+#include "kernels_gq.hpp"
 
 using namespace rsrl;
 
 static inline bool is_lambda(int algo) { return algo == RSRL_SARSA_LAMBDA || algo == RSRL_Q_LAMBDA; }
+static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ; }   // second matrix of W's shape
 
 namespace {
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
@@ -118,7 +120,7 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
-    float* Z = nullptr;              // eligibility traces f32[A][F][N] (lambda agents)
+    float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
     size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
@@ -160,6 +162,12 @@ static LambdaParams make_lambda(const rsrl_hip_ctx* c) {
     if (c->cfg.trace == RSRL_TRACE_DUTCH) rate *= (1.0 - c->cfg.alpha);       // traces.rs:233-239
     lp.rate = (float)rate; lp.alpha = (float)c->cfg.alpha; lp.trace = c->cfg.trace;
     return lp;
+}
+
+static GqParams make_gq(const rsrl_hip_ctx* c) {
+    GqParams gp{};
+    gp.V = c->Z; gp.lr_td = (float)c->cfg.lr_td;
+    return gp;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -296,7 +304,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->n_envs = 1; cfg->seed = 0;
     cfg->gamma = 0.9; cfg->lr = 0.001; cfg->alpha = 1.0; cfg->epsilon = 0.1; cfg->tau = 1.0;
     cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
-    cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0;
+    cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0; cfg->lr_td = 0.0;
     return RSRL_HIP_OK;
 }
 
@@ -334,7 +342,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
     if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
-    if (cfg->algo < 0 || cfg->algo > RSRL_PAL) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo < 0 || cfg->algo > RSRL_GREEDY_GQ) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
@@ -360,6 +368,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
+    if (cfg->algo == RSRL_GREEDY_GQ) {
+        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights on a register-family Fourier basis "
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (!(cfg->lr_td >= 0.0)) return fail(RSRL_HIP_EINVAL, "lr_td must be >= 0");
+    }
     if (is_lambda(cfg->algo)) {
         if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
             return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
@@ -387,7 +401,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
-    if (is_lambda(cfg->algo)) {
+    if (has_aux(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
         HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
     }
@@ -627,7 +641,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_lambda(c->cfg.algo)) {
+    if (c->cfg.algo == RSRL_GREEDY_GQ) {
+        if (!launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
+                              d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+    } else if (is_lambda(c->cfg.algo)) {
         if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
                                   d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
     } else if (is_wave(c->cfg)) {
@@ -695,7 +712,7 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
 }
 static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in) {
     CHECK_CTX(c);
-    if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
+    if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no auxiliary matrix (eligibility trace / fa_td weights)");
     if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->A;
@@ -717,11 +734,27 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
 }
 int rsrl_hip_get_traces(rsrl_hip_ctx* c, int64_t env_index, float* z) {
     if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    if (!is_lambda(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
     return traces_rw(c, env_index, z, nullptr);
 }
 int rsrl_hip_set_traces(rsrl_hip_ctx* c, int64_t env_index, const float* z) {
     if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    if (!is_lambda(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
     return traces_rw(c, env_index, nullptr, z);
+}
+int rsrl_hip_get_td_weights(rsrl_hip_ctx* c, int64_t env_index, float* v) {
+    if (!v) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    if (c->cfg.algo != RSRL_GREEDY_GQ) return fail(RSRL_HIP_ESTATE, "only GreedyGQ has a second approximator (fa_td)");
+    return traces_rw(c, env_index, v, nullptr);
+}
+int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) {
+    if (!v) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c);
+    if (c->cfg.algo != RSRL_GREEDY_GQ) return fail(RSRL_HIP_ESTATE, "only GreedyGQ has a second approximator (fa_td)");
+    return traces_rw(c, env_index, nullptr, v);
 }
 
 // ---- checkpoint: header + every learner's weights in the reference (F, A) order ---------------------------------
@@ -885,6 +918,11 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         if (shared) {
             TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
             c->kernel_name = "k_shared_ca";
+        } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
+            if (!launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
+                                 make_gq(c), c->t, chunk, d_stats)) return NO_MODEL(c);
+            c->kernel_name = "k_train_gq";
+            KCHECK();
         } else if (is_lambda(c->cfg.algo)) {
             if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),
                                      c->stream, k, make_lambda(c), c->t, chunk, d_stats)) return NO_MODEL(c);

@@ -420,3 +420,40 @@ def test_pal_hand_computation(orc):
         assert np.max(np.abs(W3[:, a] - (W[:, a] + 0.002 * 0.3 * d * phi))) < 1e-14
     # PAL's residual never exceeds the plain TD(a*) residual (both corrections are <= 0)  -- the action-gap property
     assert res <= td + 1e-15
+
+
+def test_greedy_gq_hand_computation(orc):
+    # control/td/greedy_gq.rs:73-141 restated in numpy; examples/greedy_gq.rs:25-27 rates (fa_q SGD(0.1), fa_td SGD(0.001))
+    ag = orc.make_agent(algo=orc.GREEDY_GQ, order=3, policy=orc.EGREEDY, gamma=0.99, lr=0.1, lr_td=0.001)
+    rng = np.random.default_rng(8)
+    F = 16
+    for trial in range(20):
+        W, V = rng.normal(size=(F, 3)) * 0.3, rng.normal(size=(F, 3)) * 0.2
+        s = np.array([rng.uniform(-1.2, 0.6), rng.uniform(-0.07, 0.07)])
+        a = int(rng.integers(0, 3))
+        ns, r, _ = orc.domain_step(orc.MOUNTAIN_CAR, s, a)
+        phi, nphi = orc.fourier_project(0, 3, s), orc.fourier_project(0, 3, ns)
+        qsa, td_est, nq = phi @ W[:, a], phi @ V[:, a], nphi @ W
+        na = int(np.argmax(nq))
+        td = r + 0.99 * nq[na] - qsa
+        W_exp, V_exp = W.copy(), V.copy()
+        W_exp[:, a] += 0.1 * td * phi
+        W_exp[:, na] += 0.1 * (-0.99 * td_est) * nphi          # second fa_q update at (s', na)   greedy_gq.rs:113-119
+        V_exp[:, a] += 0.001 * (td - td_est) * phi
+        W2, V2 = W.copy(), V.copy()
+        d = orc.handle_gq(ag, W2, V2, s, a, r, ns, False)
+        assert abs(d - td) < 1e-12
+        assert np.max(np.abs(W2 - W_exp)) < 1e-14 and np.max(np.abs(V2 - V_exp)) < 1e-14
+        # terminal: td_error = r - qsa, no second fa_q update   greedy_gq.rs:79-96
+        W3, V3 = W.copy(), V.copy()
+        d = orc.handle_gq(ag, W3, V3, s, a, r, ns, True)
+        assert abs(d - (r - qsa)) < 1e-12
+        W_t, V_t = W.copy(), V.copy()
+        W_t[:, a] += 0.1 * d * phi
+        V_t[:, a] += 0.001 * (d - td_est) * phi
+        assert np.max(np.abs(W3 - W_t)) < 1e-14 and np.max(np.abs(V3 - V_t)) < 1e-14
+    # the driver loop keeps fa_td in the run's auxiliary matrix
+    run = orc.Run(ag, 3, "f64")
+    run.reset()
+    run.train(50)
+    assert np.abs(run.weights).max() > 0 and np.abs(run.traces).max() > 0
