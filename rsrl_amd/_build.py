@@ -11,9 +11,16 @@ LIB_PATH = os.path.join(LIB_DIR, "librsrl_hip.so")
 # -ffp-contract=off: fused multiply-adds are written out as fmaf in the sources, nothing else is fused,
 # so the fp32 op order is explicit (bit-exact tile indices; tight parity with the f32 oracle).
 # -fno-slp-vectorize: SLP packing of adjacent f32 FMAs into v_pk_fma_f32 costs ~250 v_mov per step to build
-# register pairs and pushes the fused kernel into scratch; plain v_fmac_f32 already issues at the fp32 peak.
+# register pairs and pushes the fused kernel into scratch; the W-sized loops are packed BY HAND instead (f2 storage in
+# kernels_reg.hpp: no shuffles, +14 % on the fused kernel at one wave per SIMD).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
                "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+# per-source flags: the fused register-family loops run at ONE wave per SIMD (65 536 learners = 1024 waves), where
+# single-wave ILP is all there is -- LLVM's max-ILP scheduling strategy is worth +2..3 % there (A/B on MI355X, round 1)
+PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+                    for name in ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip")}
 
 
 def hipcc():
@@ -29,7 +36,7 @@ def sources():
 
 def deps():
     inc = os.path.join(os.path.dirname(HERE), "include", "rsrl_hip.h")
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc]
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc, os.path.abspath(__file__)]
 
 
 def is_stale():
@@ -42,7 +49,8 @@ def is_stale():
 def _compile_one(args):
     src, obj, verbose, extra = args
     flags = [f for f in HIPCC_FLAGS if f != "-shared" and not (f == "-fno-slp-vectorize" and "-fslp-vectorize" in extra)]
-    cmd = [hipcc()] + flags + list(extra) + ["-c", src, "-o", obj]
+    per_src = [] if any("amdgpu-sched-strategy" in e for e in extra) else PER_SOURCE_FLAGS.get(os.path.basename(src), [])
+    cmd = [hipcc()] + flags + per_src + list(extra) + ["-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

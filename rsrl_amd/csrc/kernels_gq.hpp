@@ -21,14 +21,6 @@ struct GqParams {
     float lr_td;       // SGD rate of fa_td
 };
 
-// column-select dot product: <phi, m[a][:]> with the family's 4-chain summation order
-template <int A, int F>
-__device__ __forceinline__ float dot_col_reg(const float (&m)[A][F], const float (&phi)[F], int a) {
-    float q[A];
-    q_from_reg<A, F>(m, phi, q);
-    return select_a<A>(q, a);
-}
-
 template <int DOMAIN, int ORDER, int POLICY>
 __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
     using Dom = Domain<DOMAIN>;
@@ -48,20 +40,23 @@ __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint
         for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
         int a = c.action[i];
         uint32_t ep = c.ep_step[i];
-        float w[A][F], v[A][F];
+        constexpr bool PK = (RSRL_PK != 0) && (F % 4 == 0);
+        using Phi = PhiBuf<F, PK>;
+        WBuf<A, F, PK> w, v;
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
-                v[b][f] = gp.V[((int64_t)(b * F + f)) * N + i];
+                w.put(b, f, c.W[((int64_t)(b * F + f)) * N + i]);
+                v.put(b, f, gp.V[((int64_t)(b * F + f)) * N + i]);
             }
-        float phi_a[F], phi_b[F], q_s[A];
-        Bas::project(s, phi_a);
-        q_from_reg<A, F>(w, phi_a, q_s);
+        Phi phi_a, phi_b;
+        float q_s[A];
+        { float ph[F]; Bas::project(s, ph); phi_a.set(ph); }
+        w.q(phi_a, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
 
-        auto one_step = [&](const float (&phi_s)[F], float (&phi_n)[F], uint64_t t) {
+        auto one_step = [&](const Phi& phi_s, Phi& phi_n, uint64_t t) {
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
@@ -70,29 +65,30 @@ __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint
             ep += 1;
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);                       // a terminal transition never reads Q(s',.): go straight to the restart state
-            float q_n[A];
-            Bas::project(ns, phi_n);
-            q_from_reg<A, F>(w, phi_n, q_n);
+            float q_n[A], e_s[A];
+            { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
+            w.q(phi_n, q_n);
+            v.q(phi_s, e_s);                                // all A columns, then select: no per-element column select
             const float qsa = select_a<A>(q_s, a);
-            const float td_est = dot_col_reg<A, F>(v, phi_s, a);
+            const float td_est = select_a<A>(e_s, a);
             float qmax;
             const int na_star = find_max<A>(q_n, qmax);
             const float delta = term ? (r - qsa) : (r + gamma * qmax - qsa);
             const float sc1 = lr * delta;
-            const float sc2 = term ? 0.0f : lr * (-gamma * td_est);
+            const float sc2 = lr * (-gamma * td_est);
             const float sc3 = gp.lr_td * (delta - td_est);
+            float sb1[A], sb2[A], sb3[A];
 #pragma unroll
-            for (int b = 0; b < A; ++b)
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    float wv = w[b][f];
-                    wv = (a == b) ? fmaf(sc1, phi_s[f], wv) : wv;
-                    wv = (!term && na_star == b) ? fmaf(sc2, phi_n[f], wv) : wv;
-                    w[b][f] = wv;
-                    v[b][f] = (a == b) ? fmaf(sc3, phi_s[f], v[b][f]) : v[b][f];
-                }
+            for (int b = 0; b < A; ++b) {
+                sb1[b] = (a == b) ? sc1 : 0.0f;
+                sb2[b] = (!term && na_star == b) ? sc2 : 0.0f;
+                sb3[b] = (a == b) ? sc3 : 0.0f;
+            }
+            w.axpy(sb1, phi_s);
+            w.axpy(sb2, phi_n);
+            v.axpy(sb3, phi_s);
             // ---- behaviour_policy.sample with the UPDATED fa_q (two columns may have moved: recompute)
-            q_from_reg<A, F>(w, phi_n, q_n);
+            w.q(phi_n, q_n);
             const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
@@ -100,8 +96,8 @@ __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint
             if (trunc) {
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
-                Bas::project(ns, phi_n);
-                q_from_reg<A, F>(w, phi_n, q_n);
+                { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
+                w.q(phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
                 na = policy_sample<A>(pol, q_n, xr);
             }
@@ -126,8 +122,8 @@ __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint
         for (int b = 0; b < A; ++b)
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                c.W[((int64_t)(b * F + f)) * N + i] = w[b][f];
-                gp.V[((int64_t)(b * F + f)) * N + i] = v[b][f];
+                c.W[((int64_t)(b * F + f)) * N + i] = w.get(b, f);
+                gp.V[((int64_t)(b * F + f)) * N + i] = v.get(b, f);
             }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);

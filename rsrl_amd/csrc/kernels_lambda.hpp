@@ -53,20 +53,24 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
         for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
         int a = c.action[i];
         uint32_t ep = c.ep_step[i];
-        float w[A][F], z[A][F];
+        constexpr bool PK = (RSRL_PK != 0) && (F % 4 == 0);
+        using Phi = PhiBuf<F, PK>;
+        WBuf<A, F, PK> w, z;
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                w[b][f] = c.W[((int64_t)(b * F + f)) * N + i];
-                z[b][f] = lp.Z[((int64_t)(b * F + f)) * N + i];
+                w.put(b, f, c.W[((int64_t)(b * F + f)) * N + i]);
+                z.put(b, f, lp.Z[((int64_t)(b * F + f)) * N + i]);
             }
-        float phi_a[F], phi_b[F], q_s[A];
-        Bas::project(s, phi_a);
-        q_from_reg<A, F>(w, phi_a, q_s);
+        Phi phi_a, phi_b;
+        float q_s[A];
+        { float ph[F]; Bas::project(s, ph); phi_a.set(ph); }
+        w.q(phi_a, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
+        bool cut = false;          // trace.reset() of a terminal transition, applied as a zero decay rate at the next update
 
-        auto one_step = [&](const float (&phi_s)[F], float (&phi_n)[F], uint64_t t) {
+        auto one_step = [&](const Phi& phi_s, Phi& phi_n, uint64_t t) {
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
@@ -76,32 +80,29 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);
             float q_n[A];
-            Bas::project(ns, phi_n);
-            q_from_reg<A, F>(w, phi_n, q_n);
+            { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
+            w.q(phi_n, q_n);
             const float qsa = select_a<A>(q_s, a);
             // ---- trace: (Q(lambda): cut unless the action was the greedy one) then z = rule(rate*z + grad)
-            float rate_eff = lp.rate;
-            if constexpr (ALGO == ALG_Q_LAMBDA) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : lp.rate;
+            float rate_eff = cut ? 0.0f : lp.rate;
+            if constexpr (ALGO == ALG_Q_LAMBDA) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : rate_eff;
+            {
+                float ind[A];
 #pragma unroll
-            for (int b = 0; b < A; ++b)
-#pragma unroll
-                for (int f = 0; f < F; ++f) z[b][f] = trace_merge(lp.trace, rate_eff, z[b][f], (a == b) ? phi_s[f] : 0.0f);
+                for (int b = 0; b < A; ++b) ind[b] = (a == b) ? 1.0f : 0.0f;
+                z.decay_add(rate_eff, ind, phi_s);
+                if (lp.trace == TRACE_SATURATE) z.clip(-1.0f, 1.0f);
+            }
             // ---- residual with the PRE-update weights
             U4 xin = U4{0, 0, 0, 0};
             if constexpr (ALGO == ALG_SARSA_LAMBDA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
             const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
             // ---- W += (alpha * residual) * Z ; a terminal transition then resets the trace
-            const float scale = lp.alpha * delta;
-#pragma unroll
-            for (int b = 0; b < A; ++b)
-#pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    w[b][f] = fmaf(scale, z[b][f], w[b][f]);
-                    z[b][f] = term ? 0.0f : z[b][f];
-                }
+            w.axpy_buf(lp.alpha * delta, z);
+            cut = term;
             // ---- policy.sample with the UPDATED weights (every column moved: recompute)
-            q_from_reg<A, F>(w, phi_n, q_n);
+            w.q(phi_n, q_n);
             const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
             if (trunc) {
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
-                Bas::project(ns, phi_n);
-                q_from_reg<A, F>(w, phi_n, q_n);
+                { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
+                w.q(phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
                 na = policy_sample<A>(pol, q_n, xr);
             }
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
         for (int b = 0; b < A; ++b)
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                c.W[((int64_t)(b * F + f)) * N + i] = w[b][f];
-                lp.Z[((int64_t)(b * F + f)) * N + i] = z[b][f];
+                c.W[((int64_t)(b * F + f)) * N + i] = w.get(b, f);
+                lp.Z[((int64_t)(b * F + f)) * N + i] = cut ? 0.0f : z.get(b, f);
             }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
