@@ -224,14 +224,25 @@ def main():
         }
         if streaming is not None:
             out["roofline_streaming"] = streaming
-        # the fused kernel is VALU-issue bound (profiles/r01_pmc_summary.md): instructions per env-step from the PMC pass
-        # (SQ_INSTS_VALU / env-steps) against the saturated issue rate measured by scripts/ubench/valu_issue.hip
+        # the fused kernel is VALU-issue bound (profiles/r01_pmc_summary.md).  Issue cost of one env-step at SATURATED occupancy:
+        # VALU instructions per env-step from the PMC pass (SQ_INSTS_VALU / wave / steps, profiles/pmc_traffic.json), of which the
+        # static ISA mix has 180 v_pk_fma_f32, 31 v_mad_u64_u32 and 17 v_cndmask (scripts/isa_stats.py); cycles per instruction at
+        # 8 waves/SIMD from scripts/ubench/valu_issue.hip (profiles/r01_ubench_valu_issue.txt): pk_fma 4.47, mad_u64 4.96,
+        # cndmask 4.13, everything else 2.46.  The launch itself runs at ONE wave per SIMD (65 536 learners = 1024 waves).
         if kname == "k_train_reg":
-            instr, cyc_per_instr, simds, clk = 563.0, 2.47, 1024, 2.4e9
-            peak_steps = simds * 64 * clk / (instr * cyc_per_instr)
-            out["valu_roofline"] = {"valu_instr_per_env_step": instr, "saturated_cycles_per_instr": cyc_per_instr,
-                                    "peak_env_steps_per_s_per_gpu": peak_steps, "frac": (value / world) / peak_steps,
-                                    "source": "profiles/r01_pmc_final_raw.json (SQ_INSTS_VALU / wave / 256 steps), profiles/r01_ubench_valu_issue.txt"}
+            try:
+                instr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k_train_reg"]["valu_instr_per_env_step"]
+            except Exception:
+                instr = None
+            if instr:
+                n_pk, n_mad, n_cnd = 180.0, 31.0, 17.0
+                cyc = n_pk * 4.47 + n_mad * 4.96 + n_cnd * 4.13 + max(0.0, instr - n_pk - n_mad - n_cnd) * 2.46
+                simds, clk = 1024, 2.4e9
+                peak_steps = simds * 64 * clk / cyc
+                out["valu_roofline"] = {"valu_instr_per_env_step": instr, "saturated_issue_cycles_per_env_step": cyc,
+                                        "peak_env_steps_per_s_per_gpu": peak_steps, "frac": (value / world) / peak_steps,
+                                        "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU / wave / steps), scripts/isa_stats.py (static mix), "
+                                                  "profiles/r01_ubench_valu_issue.txt (cycles per instruction at 8 waves/SIMD)"}
         if shared is not None:
             out["shared_w"] = shared
         if world == 1 and not args.no_cpu_baseline:
