@@ -99,11 +99,44 @@ struct Softmax : Policy {                 // Softmax::new(fa, tau) panics for |t
 
 // ---- rsrl::control::td -----------------------------------------------------------------------------
 namespace control { namespace td {
-struct Agent { int algo; Shared<fa::linear::LFA> q_func; double gamma; double alpha = 1.0; };
+struct Agent {
+    int algo; Shared<fa::linear::LFA> q_func; double gamma; double alpha = 1.0;
+    int trace = RSRL_TRACE_ACCUMULATE; double lambda = 0.0;      // SARSALambda / QLambda
+    double lr_td = 0.0;                                          // GreedyGQ: SGD rate of fa_td
+};
 struct QLearning : Agent { QLearning(Shared<fa::linear::LFA> q, double gamma) : Agent{RSRL_QLEARNING, std::move(q), gamma} {} };
 struct SARSA : Agent { SARSA(Shared<fa::linear::LFA> q, double gamma) : Agent{RSRL_SARSA, std::move(q), gamma} {} };
 struct ExpectedSARSA : Agent {
     ExpectedSARSA(Shared<fa::linear::LFA> q, double alpha_, double gamma) : Agent{RSRL_EXPECTED_SARSA, std::move(q), gamma, alpha_} {}
+};
+// PAL { q_func, alpha, gamma }                                                    (control/td/pal.rs:18-24)
+struct PAL : Agent { PAL(Shared<fa::linear::LFA> q, double alpha_, double gamma) : Agent{RSRL_PAL, std::move(q), gamma, alpha_} {} };
+}}  // namespace control::td
+
+// ---- rsrl::traces: Trace::{accumulating, replacing, dutch}(dim, gamma, lambda)       (traces.rs:38-70)
+namespace traces {
+struct Trace {
+    int rule; double gamma, lambda;
+    static Trace accumulating(double gamma, double lambda) { return Trace{RSRL_TRACE_ACCUMULATE, gamma, lambda}; }
+    static Trace replacing(double gamma, double lambda) { return Trace{RSRL_TRACE_SATURATE, gamma, lambda}; }
+    static Trace dutch(double gamma, double lambda) { return Trace{RSRL_TRACE_DUTCH, gamma, lambda}; }
+};
+}  // namespace traces
+
+namespace control { namespace td {
+// SARSALambda { q_func, policy, trace, alpha, gamma } / QLambda                   (sarsa_lambda.rs:37-51, q_lambda.rs:37-54)
+struct SARSALambda : Agent {
+    SARSALambda(Shared<fa::linear::LFA> q, const traces::Trace& tr, double alpha_, double gamma)
+        : Agent{RSRL_SARSA_LAMBDA, std::move(q), gamma, alpha_, tr.rule, tr.lambda} {}
+};
+struct QLambda : Agent {
+    QLambda(Shared<fa::linear::LFA> q, const traces::Trace& tr, double alpha_, double gamma)
+        : Agent{RSRL_Q_LAMBDA, std::move(q), gamma, alpha_, tr.rule, tr.lambda} {}
+};
+// GreedyGQ { fa_q, fa_td, behaviour_policy, gamma }                                (greedy_gq.rs:49-58)
+struct GreedyGQ : Agent {
+    GreedyGQ(Shared<fa::linear::LFA> fa_q, const fa::linear::LFA& fa_td, double gamma)
+        : Agent{RSRL_GREEDY_GQ, std::move(fa_q), gamma, 1.0, RSRL_TRACE_ACCUMULATE, 0.0, fa_td.lr} {}
 };
 }}  // namespace control::td
 
@@ -119,6 +152,7 @@ public:
         cfg.basis = q.basis_kind; cfg.order = q.order; cfg.n_tilings = q.n_tilings; cfg.tiles_per_dim = q.tiles_per_dim;
         cfg.lr = q.lr; cfg.weight_mode = q.shared_weights ? RSRL_W_SHARED : RSRL_W_PER_ENV;
         cfg.algo = agent.algo; cfg.gamma = agent.gamma; cfg.alpha = agent.alpha;
+        cfg.trace = agent.trace; cfg.lambda = agent.lambda; cfg.lr_td = agent.lr_td;
         cfg.policy = policy.kind; cfg.epsilon = policy.epsilon; cfg.tau = policy.tau;
         cfg.seed = seed; cfg.max_episode_steps = max_episode_steps;
         check(rsrl_hip_create(&cfg, &ctx_));
@@ -167,6 +201,17 @@ public:
     std::vector<float> weights(int64_t env = 0) {
         std::vector<float> w((size_t)F_ * A_); check(rsrl_hip_get_weights(ctx_, env, w.data())); return w;
     }
+    // the pub field `trace` of SARSALambda / QLambda                                (sarsa_lambda.rs:41)
+    std::vector<float> trace(int64_t env = 0) {
+        std::vector<float> z((size_t)F_ * A_); check(rsrl_hip_get_traces(ctx_, env, z.data())); return z;
+    }
+    // the pub field `fa_td` of GreedyGQ                                             (greedy_gq.rs:52)
+    std::vector<float> td_weights(int64_t env = 0) {
+        std::vector<float> v((size_t)F_ * A_); check(rsrl_hip_get_td_weights(ctx_, env, v.data())); return v;
+    }
+    // serde analogue: checkpoint of every learner's approximator(s)                  (rsrl/Cargo.toml:26)
+    void save_weights(const std::string& path) { check(rsrl_hip_save_weights(ctx_, path.c_str())); }
+    void load_weights(const std::string& path) { check(rsrl_hip_load_weights(ctx_, path.c_str())); }
     // the fused driver loop: n_steps of {transition, handle, sample} for every env, auto-reset
     rsrl_hip_stats train(int64_t n_steps) { rsrl_hip_stats st; check(rsrl_hip_train(ctx_, n_steps, &st)); return st; }
     // Domain::rollout(|s| policy.mode(s), Some(limit)).n_states()                 (lib.rs:448-479, :340)

@@ -337,3 +337,21 @@ def test_cpp_example_runs_on_gpu(tmp_path):
     out = subprocess.run([str(exe), "256", "3000"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "OOS:" in out.stdout and "fused: 768000 env-steps" in out.stdout
+
+
+@pytest.mark.parametrize("name,args,expect", [("sarsa_lambda", ["128", "6", "400"], "max |trace|"), ("greedy_gq", ["128", "4", "500"], "max |fa_td weight|")])
+def test_cpp_examples_of_the_next_rows_run_on_gpu(tmp_path, name, args, expect):
+    # examples/sarsa_lambda.cpp / greedy_gq.cpp: the reference's examples of the same names through the C++ mirror
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "rsrl_amd", "lib")
+    exe = tmp_path / name
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "examples", name + ".cpp"),
+                           "-L" + lib_dir, "-lrsrl_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + lib_dir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "OOS:" in out.stdout and expect in out.stdout
+    val = float(out.stdout.split(expect)[1].split(":")[1].split()[0])
+    assert val > 0
