@@ -50,8 +50,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 __device__ __forceinline__ void block_stats_accumulate(DevStats* __restrict__ stats, unsigned long long n_ep,
                                                        unsigned long long n_trunc, unsigned long long sum_len,
                                                        double sum_abs, double sum_r) {
-    __shared__ unsigned long long sh_u[3][kBlock / 64];
-    __shared__ double sh_d[2][kBlock / 64];
+    __shared__ unsigned long long sh_u[3][16];          // up to 1024 threads per block
+    __shared__ double sh_d[2][16];
     n_ep = wave_sum(n_ep); n_trunc = wave_sum(n_trunc); sum_len = wave_sum(sum_len);
     sum_abs = wave_sum(sum_abs); sum_r = wave_sum(sum_r);
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -153,30 +153,28 @@ struct TileModel {
     // Must be called by ALL lanes of the wave (the DPP sum needs full exec); lanes without work pass valid = false.
     __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
                                                       bool valid) {
-        constexpr int kRounds = 3;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int key = valid ? ft.idx[t] * A + a : -1;
             bool pending = valid;
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
+            // one round per distinct key of the wave (learners crowd into few tiles: typically a handful of rounds)
+            while (true) {
                 const unsigned long long todo = __ballot(pending);
                 if (todo == 0ull) break;
                 const int leader = __ffsll((long long)todo) - 1;
                 const int lkey = __shfl(key, leader, 64);
                 const bool mine = pending && key == lkey;
                 const float tot = wave_sum_all(mine ? scale : 0.0f);
-                if (mine && (int)(threadIdx.x & 63) == leader) atomicAdd(&dW[lkey], tot);
+                if (mine && (int)(threadIdx.x & 63) == leader && tot != 0.0f) atomicAdd(&dW[lkey], tot);
                 pending = pending && !mine;
             }
-            if (pending) atomicAdd(&dW[key], scale);
         }
     }
-    // Block-level form for the shared-W driver loop: the learners of a block sit in a handful of tiles, so each
-    // tiling's slice of the delta table (cells*A floats, 32 KiB at 8^4 x 2) is privatised in LDS -- ds_add_f32 from
-    // every learner, then ONE device atomic per touched entry instead of one per learner (2 M -> ~0.1 M atomics per
-    // batch-step at 262 144 CartPole learners: 335 -> see DESIGN.md).  `slice` is dynamic LDS of cells*A floats,
-    // zero on entry and left zero on exit.  All threads of the block must call.
+    // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A floats, 32 KiB at
+    // 8^4 x 2) is privatised in LDS -- ds_add_f32 from every learner of the block, a sweep of the slice, then ONE device
+    // atomic per touched entry instead of one per learner.  The sweep is paid per block and tiling whatever the number of
+    // learners, so the shared-W driver runs this with 1024-learner blocks (DESIGN.md 4.3b has the measured ladder).
+    // `slice` is dynamic LDS of cells*A floats, zero on entry and left zero on exit.  All threads of the block must call.
     __device__ static __forceinline__ void block_accumulate(float* __restrict__ dW, float* __restrict__ slice, const BasisGeom& g,
                                                             const Feat& ft, int a, float scale, bool valid) {
         const int S = (g.F / T) * A;                                    // entries per tiling
@@ -492,11 +490,15 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
 // bit1 = truncated, consumed by the next phase C.
 //   dense basis : block-level reduction through LDS in a fixed order -> one row of `partials` per block (no atomics
 //                 => bitwise reproducible); k_dw_finalize sums the rows in block order.
-//   tile coding : f32 atomics straight into the dense delta table (sparse, 2*T entries per learner).
-template <class M>
-__global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW,
+//   tile coding : per-tiling slice of the delta table privatised in LDS, one device atomic per touched entry into one of
+//                 n_rep copies of the table (k_apply_rep sums them).
+template <class M, int BLOCK = kBlock>
+__global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW_base,
                                                       float* __restrict__ partials, uint8_t* __restrict__ flags,
-                                                      DevStats* __restrict__ stats, int lds_slice_floats) {
+                                                      DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride) {
+    // tile coding: the delta table is replicated n_rep times and block b adds into copy b % n_rep -- device atomics on one
+    // 128-B line serialise at ~11 ns each and the learners crowd into a few lines; k_apply_rep sums the copies
+    float* __restrict__ dW = dW_base + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride;
     constexpr int D = M::D, A = M::A;
     const int64_t N = c.n_envs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -26,6 +26,27 @@ static inline bool is_lambda(int algo) { return algo == RSRL_SARSA_LAMBDA || alg
 static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ; }   // second matrix of W's shape
 
 namespace {
+// tile coding, shared W: sum the n_rep copies of the delta table (and clear them); single rank: W += sum, otherwise the sum
+// goes to dW for the all-reduce.  n is a multiple of 4 (A * cells * T with even cells).
+__global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float* __restrict__ dW, float* __restrict__ rep, int n_rep, int n) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (j >= n) return;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int r = 0; r < n_rep; ++r) {
+        float4* p = reinterpret_cast<float4*>(rep + (int64_t)r * n + j);
+        const float4 v = *p;
+        if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            *p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    if (W) {
+        float4* w = reinterpret_cast<float4*>(W + j);
+        float4 x = *w; x.x += acc.x; x.y += acc.y; x.z += acc.z; x.w += acc.w; *w = x;
+    } else {
+        *reinterpret_cast<float4*>(dW + j) = acc;
+    }
+}
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) { W[j] += dW[j]; dW[j] = 0.0f; }
@@ -118,6 +139,7 @@ struct rsrl_hip_ctx {
     bool own_stream = false;
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
+    float* dW_rep = nullptr; int n_rep = 1;      // shared tile coding: replicated delta tables (contention relief)
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
@@ -319,6 +341,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->ep_step) (void)hipFree(c->ep_step);
     if (c->W) (void)hipFree(c->W);
     if (c->dW) (void)hipFree(c->dW);
+    if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->partials) (void)hipFree(c->partials);
     if (c->qcache) (void)hipFree(c->qcache);
     if (c->Z) (void)hipFree(c->Z);
@@ -413,6 +436,15 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
+    if (shared && cfg->basis == RSRL_TILE_CODING && c->dw_elems % 4 == 0) {
+        const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob; 2 copies measured best with 1024-learner blocks
+        int r = e ? atoi(e) : 2;
+        c->n_rep = r < 1 ? 1 : (r > 64 ? 64 : r);
+        if (c->n_rep > 1) {
+            HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(float) * c->dw_elems * c->n_rep));
+            HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(float) * c->dw_elems * c->n_rep, c->stream));
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
     HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
     return RSRL_HIP_OK;
@@ -870,9 +902,20 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
-            int slice = 0;
-            if (!dense) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; if (f * 4 <= 64 * 1024) slice = (int)f; }
-            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, (size_t)slice * sizeof(float), c->stream, k, g, c->t, do_c, c->dW, c->partials, c->flags, d_stats, slice);
+            int slice = 0; size_t lds = 0;
+            if (!dense) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; if (f * 4 <= 64 * 1024) { slice = (int)f; lds = (size_t)f * 4; } }
+            float* dwp = c->dW_rep ? c->dW_rep : c->dW;
+            const int nrep = c->dW_rep ? c->n_rep : 1;
+            if constexpr (M::kSparse) {
+                // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
+                if (slice > 0) {
+                    hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, c->t, do_c, dwp,
+                                       c->partials, c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, c->t, do_c, dwp, c->partials, c->flags, d_stats, slice, nrep,
+                               (int64_t)c->dw_elems);
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
@@ -883,7 +926,11 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
                            multi ? (float*)nullptr : c->W);
         KCHECK();
     }
-    if (multi || !dense) {
+    if (!dense && c->dW_rep) {
+        hipLaunchKernelGGL(k_apply_rep, dim3((n / 4 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n);
+        KCHECK();
+    }
+    if (multi || (!dense && !c->dW_rep)) {
         TRY(comm_allreduce_dw(c));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
