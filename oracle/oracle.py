@@ -132,6 +132,8 @@ def _declare(L):
         g("orc_handle_lambda").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
         g("orc_handle_gq").restype = R
         g("orc_handle_gq").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int]
+        g("orc_run_train_fast").restype = C.c_int
+        g("orc_run_train_fast").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_run_traces").restype = Rp
         g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
@@ -373,6 +375,14 @@ class Run:
     def train(self, n_steps):
         st = Stats()
         self._f("orc_run_train")(self._h, int(n_steps), C.byref(st))
+        return st.as_dict()
+
+    def train_fast(self, n_steps):
+        """Same results as train() with the repeated projections / heap traffic of the reference's call pattern removed
+        (QLearning + Fourier + per-env W only): the 'optimised CPU' baseline."""
+        st = Stats()
+        if self._f("orc_run_train_fast")(self._h, int(n_steps), C.byref(st)) != 0:
+            raise ValueError("train_fast: QLearning on a Fourier basis with per-env weights only")
         return st.as_dict()
 
     def train_with_dw_hook(self, n_steps, hook):

@@ -100,6 +100,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     R     orc_handle_lambda_##S(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,   \
                                 const uint32_t x_inner[4]);                                             \
     R     orc_handle_gq_##S(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, const R* ns, int term);              \
+    int   orc_run_train_fast_##S(void* h, int64_t n_steps, orc_stats* st);                                        \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \

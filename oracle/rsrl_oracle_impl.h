@@ -241,24 +241,29 @@ void FN(orc_fourier_project)(int order, int D, const R* lo, const R* hi, const R
 /*   (fa/linear.rs:293-301, weights.ncols() = A at :358)               */
 /* ------------------------------------------------------------------ */
 
+/* q[a] = <phi, W[:,a]> for every column of the row-major (F, A) matrix */
+static void FN(dot_columns)(const R* phi, const R* W, int A, int F, R* q) {
+    int a, f;
+    for (a = 0; a < A; a++) {
+#ifdef ORC_SEPARABLE
+        /* device order: 4 interleaved partial sums, q = (acc0 + acc1) + (acc2 + acc3) */
+        R acc[4] = { 0, 0, 0, 0 };
+        for (f = 0; f < F; f++) acc[f & 3] = FN(fma_)(phi[f], W[(size_t)f * A + a], acc[f & 3]);
+        q[a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#else
+        R acc = 0;
+        for (f = 0; f < F; f++) acc = FN(fma_)(phi[f], W[(size_t)f * A + a], acc);
+        q[a] = acc;
+#endif
+    }
+}
 /* Function<(S,)>::evaluate -> Q(s,.) = W^T phi      fa/linear.rs:303-311 */
 void FN(orc_q_evaluate)(const orc_basis* b, const R* W, int A, const R* s, R* q) {
-    int F = orc_basis_nfeat(b), a, f;
+    int F = orc_basis_nfeat(b), a;
     if (b->kind == ORC_FOURIER) {
         R* phi = (R*)malloc(sizeof(R) * (size_t)F);             /* reference allocs a feature array per call */
         FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
-        for (a = 0; a < A; a++) {
-#ifdef ORC_SEPARABLE
-            /* device order: 4 interleaved partial sums, q = (acc0 + acc1) + (acc2 + acc3) */
-            R acc[4] = { 0, 0, 0, 0 };
-            for (f = 0; f < F; f++) acc[f & 3] = FN(fma_)(phi[f], W[(size_t)f * A + a], acc[f & 3]);
-            q[a] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#else
-            R acc = 0;
-            for (f = 0; f < F; f++) acc = FN(fma_)(phi[f], W[(size_t)f * A + a], acc);
-            q[a] = acc;
-#endif
-        }
+        FN(dot_columns)(phi, W, A, F, q);
         free(phi);
     } else {
         int idx[ORC_MAX_TILINGS], t;
@@ -654,6 +659,64 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
 }
 
 void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) { FN(orc_run_train_hook)(h, n_steps, st, NULL, NULL); }
+
+/* The same driver loop with the work the reference repeats removed -- phi(s) and Q(s,.) carried over from the previous
+ * step, phi(s') projected once, no heap traffic, learners walked one after the other (they are independent): the
+ * "optimised CPU" figure of SURVEY 8(d), so that the GPU/CPU ratio is not inflated by the reference's call pattern.
+ * Same feature values and dot-product order as orc_run_train => identical states, actions and weights (tested).
+ * QLearning on a Fourier basis with per-env weights only; returns -1 otherwise. */
+int FN(orc_run_train_fast)(void* h, int64_t n_steps, orc_stats* st) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), f, d;
+    int64_t N = run->n_envs, i, k;
+    R *phi_s, *phi_n, *tmp;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (ag->algo != ORC_QLEARNING || b->kind != ORC_FOURIER || ag->shared_w) return -1;
+    phi_s = (R*)malloc(sizeof(R) * (size_t)F); phi_n = (R*)malloc(sizeof(R) * (size_t)F);
+    for (i = 0; i < N; i++) {
+        R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
+        R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
+        int a = run->action[i]; uint32_t ep = run->ep_step[i];
+        FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), s, phi_s);
+        FN(dot_columns)(phi_s, W, A, F, q_s);
+        for (k = 0; k < n_steps; k++) {
+            R r, m, delta, scale; int term, na, done; uint32_t x[4];
+            for (d = 0; d < D; d++) ns[d] = s[d];
+            term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+            ep += 1;
+            done = term || (ag->max_episode_steps > 0 && ep >= ag->max_episode_steps);
+            if (!term) {
+                FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi_n);
+                FN(dot_columns)(phi_n, W, A, F, q_n);
+                FN(orc_find_max)(q_n, A, &m);
+                delta = r + (R)ag->gamma * m - q_s[a];
+            } else {
+                delta = r - q_s[a];
+            }
+            scale = (R)ag->lr * delta;
+            for (f = 0; f < F; f++) W[(size_t)f * A + a] = FN(fma_)(scale, phi_s[f], W[(size_t)f * A + a]);
+            acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
+            if (done) {
+                acc.episodes += 1; if (!term) acc.episodes_truncated += 1; acc.sum_episode_steps += ep;
+                FN(orc_domain_reset)(ag->domain, ns);
+                FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi_n);
+                ep = 0;
+            }
+            FN(dot_columns)(phi_n, W, A, F, q_n);                          /* policy.sample sees the UPDATED weights */
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t + (uint64_t)k, done ? ORC_BLK_RESET : ORC_BLK_STEP, x);
+            na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
+            for (d = 0; d < D; d++) s[d] = ns[d];
+            for (d = 0; d < A; d++) q_s[d] = q_n[d];
+            tmp = phi_s; phi_s = phi_n; phi_n = tmp;
+            a = na;
+        }
+        run->action[i] = a; run->ep_step[i] = ep;
+    }
+    run->t += (uint64_t)n_steps;
+    free(phi_s); free(phi_n);
+    if (st) *st = acc;
+    return 0;
+}
 
 /* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340
  * One fresh default env per learner i, evaluated with learner i's weights. */

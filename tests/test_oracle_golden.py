@@ -457,3 +457,21 @@ def test_greedy_gq_hand_computation(orc):
     run.reset()
     run.train(50)
     assert np.abs(run.weights).max() > 0 and np.abs(run.traces).max() > 0
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_optimised_cpu_loop_is_the_same_computation(orc, prec):
+    # bench.py's "optimised CPU" baseline (1 projection per step, no heap traffic) must be the reference-pattern loop
+    # with the redundancy removed, nothing else: identical states, actions, weights
+    kw = dict(policy=orc.EGREEDY, epsilon=0.1, gamma=0.9, lr=0.001, seed=3, max_episode_steps=120)
+    a, b = orc.Run(orc.make_agent(**kw), 12, prec), orc.Run(orc.make_agent(**kw), 12, prec)
+    a.reset(); b.reset()
+    sa = a.train(700)
+    sb = b.train_fast(300)
+    sb2 = b.train_fast(400)          # split calls: the step counter carries over
+    assert np.array_equal(a.state, b.state) and np.array_equal(a.action, b.action)
+    assert np.array_equal(a.weights, b.weights)
+    assert sa["episodes"] == sb["episodes"] + sb2["episodes"] and sa["env_steps"] == 8400
+    assert abs(sa["sum_abs_td_error"] - sb["sum_abs_td_error"] - sb2["sum_abs_td_error"]) < 1e-6 * sa["sum_abs_td_error"]
+    with pytest.raises(ValueError):
+        orc.Run(orc.make_agent(algo=orc.SARSA), 2, prec).train_fast(1)
