@@ -64,7 +64,10 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights, register-family Fourier bases */
 typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4,
-               RSRL_PAL = 5, RSRL_GREEDY_GQ = 6 } rsrl_algo;
+               RSRL_PAL = 5, RSRL_GREEDY_GQ = 6,
+               /* prediction (state-value function on a ScalarLFA, ONE weight column; behaviour policy RSRL_RANDOM):
+                *   TD prediction/td/td.rs:25-59 (SGD(lr)), TDLambda prediction/td/td_lambda.rs:25-78 (step = the TD error) */
+               RSRL_TD = 7, RSRL_TD_LAMBDA = 8 } rsrl_algo;
 /* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
 typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;
 /* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}
@@ -139,6 +142,9 @@ int rsrl_hip_sync(rsrl_hip_ctx* ctx);
  *   (examples/q_learning.rs:20; Parameterised::weights_dim, params/mod.rs:128) */
 int rsrl_hip_state_dim(const rsrl_hip_ctx* ctx);
 int rsrl_hip_n_actions(const rsrl_hip_ctx* ctx);
+/* columns of the weight matrix: n_actions for the control agents (VectorLFA), 1 for TD / TDLambda (ScalarLFA,
+ * Parameterised::weights_dim = (F, 1), fa/linear.rs:201-203) */
+int rsrl_hip_n_outputs(const rsrl_hip_ctx* ctx);
 int rsrl_hip_n_features(const rsrl_hip_ctx* ctx);
 int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* ctx);
 /* state_space() bounds: mountain_car/discrete.rs:97-99, cart_pole.rs:112-118, acrobot.rs:143-149 */
@@ -165,6 +171,8 @@ int rsrl_hip_domain_reset(rsrl_hip_ctx* ctx, const uint8_t* mask);
 /* Function<(S,)>::evaluate for VectorLFA: Q(s,.) = W^T phi(s)      rsrl/src/fa/linear.rs:303-311
  * state m is evaluated with learner m's weights (or the shared weights). */
 int rsrl_hip_q_evaluate(rsrl_hip_ctx* ctx, const float* states /*[D][M]*/, int64_t M, float* q_out /*[A][M]*/);
+/*   prediction agents: the same call is Function<(S,)>::evaluate of the ScalarLFA (fa/linear.rs:213-221), q_out = V f32[1][M];
+ *   find_max / policy_mode / policy_probs / policy_sample / rollout_greedy return RSRL_HIP_ESTATE for them (no Q function). */
 /* Enumerable::find_max (ties -> last index)                         rsrl/src/core.rs:96-105 */
 int rsrl_hip_q_find_max(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* idx_out, float* val_out);
 /* basis.project(s): dense features phi f32[F][M] (Fourier) -- lfa Basis::project */

@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ = 0, 1, 2, 3, 4, 5, 6
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EGREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 BLK_STEP, BLK_RESET, BLK_INNER, BLK_INIT, BLK_API = 0, 1, 2, 3, 4
@@ -132,6 +132,10 @@ def _declare(L):
         g("orc_handle_lambda").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
         g("orc_handle_gq").restype = R
         g("orc_handle_gq").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int]
+        g("orc_v_evaluate").restype = R
+        g("orc_v_evaluate").argtypes = [C.POINTER(Basis), Rp, Rp]
+        g("orc_handle_td").restype = R
+        g("orc_handle_td").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, R, Rp, C.c_int]
         g("orc_run_train_fast").restype = C.c_int
         g("orc_run_train_fast").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_run_traces").restype = Rp
@@ -308,6 +312,25 @@ def handle_lambda(ag, W, Z, s, a, r, ns, term, x_inner=(0, 0, 0, 0), prec="f64")
                                                              ct(r), _ptr(ns, ct), int(term), xx))
 
 
+def v_evaluate(ag, w, s, prec="f64"):
+    """V(s) = <phi(s), w> of a prediction agent (ScalarLFA); w has F entries"""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    w = np.ascontiguousarray(w, dtype=dt).reshape(-1)
+    s = np.array(s, dtype=dt)
+    return float(getattr(lib(), f"orc_v_evaluate_{prec}")(C.byref(ag.basis), _ptr(w, ct), _ptr(s, ct)))
+
+
+def handle_td(ag, w, z, s, r, ns, term, prec="f64"):
+    """TD / TDLambda handle on one transition; w (and the trace z, TDLambda only) with F entries are updated in place;
+    returns the TD error."""
+    dt, ct = _np_dtype(prec), _ct(prec)
+    assert w.dtype == dt and w.flags.c_contiguous and (z is None or (z.dtype == dt and z.flags.c_contiguous))
+    s = np.array(s, dtype=dt)
+    ns = np.array(ns, dtype=dt)
+    zp = _ptr(z, ct) if z is not None else None
+    return float(getattr(lib(), f"orc_handle_td_{prec}")(C.byref(ag), _ptr(w, ct), zp, _ptr(s, ct), ct(r), _ptr(ns, ct), int(term)))
+
+
 def handle_gq(ag, W, V, s, a, r, ns, term, prec="f64"):
     """GreedyGQ handle on one transition; W (fa_q) and V (fa_td), both (F,A), are updated in place; returns td_error."""
     dt, ct = _np_dtype(prec), _ct(prec)
@@ -327,7 +350,7 @@ class Run:
         self._L = lib()
         self._h = C.c_void_p(getattr(self._L, f"orc_run_create_{prec}")(C.byref(ag), self.n))
         self.D = ag.basis.dim
-        self.A = ag.n_actions
+        self.A = 1 if ag.algo in (TD, TD_LAMBDA) else ag.n_actions       # columns of the weight matrix
         self.F = n_features(ag)
 
     def _f(self, name):

@@ -14,10 +14,14 @@ extern "C" {
 enum { ORC_MOUNTAIN_CAR = 0, ORC_CART_POLE = 1, ORC_ACROBOT = 2 };
 enum { ORC_FOURIER = 0, ORC_TILE = 1 };
 enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4, ORC_PAL = 5,
-       ORC_GREEDY_GQ = 6 };
+       ORC_GREEDY_GQ = 6, ORC_TD = 7, ORC_TD_LAMBDA = 8 };
 #define ORC_IS_LAMBDA(algo) ((algo) == ORC_SARSA_LAMBDA || (algo) == ORC_Q_LAMBDA)
 /* agents with a second per-learner matrix of W's shape: the trace Z (lambda agents) or fa_td's weights (GreedyGQ) */
-#define ORC_HAS_AUX(algo) (ORC_IS_LAMBDA(algo) || (algo) == ORC_GREEDY_GQ)
+/* prediction agents: ONE weight column (ScalarLFA, the state-value function); the behaviour policy must be Random */
+#define ORC_IS_PRED(algo) ((algo) == ORC_TD || (algo) == ORC_TD_LAMBDA)
+#define ORC_HAS_AUX(algo) (ORC_IS_LAMBDA(algo) || (algo) == ORC_GREEDY_GQ || (algo) == ORC_TD_LAMBDA)
+/* columns of the weight matrix */
+#define ORC_N_OUT(ag) (ORC_IS_PRED((ag)->algo) ? 1 : (ag)->n_actions)
 /* eligibility-trace update rules (rsrl/src/traces.rs:188-240) */
 enum { ORC_TRACE_ACCUMULATE = 0, ORC_TRACE_SATURATE = 1, ORC_TRACE_DUTCH = 2 };
 enum { ORC_GREEDY = 0, ORC_EGREEDY = 1, ORC_SOFTMAX = 2, ORC_RANDOM = 3 };
@@ -100,6 +104,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     R     orc_handle_lambda_##S(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,   \
                                 const uint32_t x_inner[4]);                                             \
     R     orc_handle_gq_##S(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, const R* ns, int term);              \
+    R     orc_v_evaluate_##S(const orc_basis* b, const R* w, const R* s);                                         \
+    R     orc_handle_td_##S(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* ns, int term);             \
     int   orc_run_train_fast_##S(void* h, int64_t n_steps, orc_stats* st);                                        \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \

@@ -533,6 +533,49 @@ R FN(orc_handle_gq)(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, con
     return td_error;
 }
 
+/* Prediction: TD::handle (prediction/td/td.rs:31-59) and TDLambda::handle (prediction/td/td_lambda.rs:41-78) on a
+ * ScalarLFA (fa/linear.rs:201-251: V(s) = <phi(s), w>, grad = phi(s), StateUpdate -> SGD: w += lr*error*phi(s)).
+ *   TD        : td = r + gamma*V(s') - V(s)  (terminal: r - V(s));  w += lr * td * phi(s)
+ *   TDLambda  : trace.update(phi(s)) FIRST (traces.rs:188-240, same rules as the control agents), then
+ *               w += td * trace  -- `ScaledGradientUpdate { alpha: td_error, jacobian: &trace }` (td_lambda.rs:59-62, :71-74):
+ *               the step is the TD error itself, no learning rate (fa/linear.rs:184-196 bypasses the optimiser);
+ *               a terminal transition then resets the trace (:64).
+ * Dense (Fourier) bases only.  w, z: F values.  Returns the TD error. */
+R FN(orc_v_evaluate)(const orc_basis* b, const R* w, const R* s) {
+    int F = orc_basis_nfeat(b); R v;
+    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+    FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+    FN(dot_columns)(phi, w, 1, F, &v);
+    free(phi);
+    return v;
+}
+R FN(orc_handle_td)(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* ns, int term) {
+    const orc_basis* b = &ag->basis; int F = orc_basis_nfeat(b), f;
+    R pred, td, rate;
+    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+    FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+    FN(dot_columns)(phi, w, 1, F, &pred);
+    if (ag->algo == ORC_TD_LAMBDA) {
+        rate = (R)ag->gamma * (R)ag->lambda;
+        if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+        for (f = 0; f < F; f++) {
+            R v = FN(fma_)(rate, z[f], phi[f]);
+            if (ag->trace == ORC_TRACE_SATURATE) { v = (v < (R)1.0) ? v : (R)1.0; v = (v > (R)-1.0) ? v : (R)-1.0; }
+            z[f] = v;
+        }
+    }
+    td = term ? r - pred : r + (R)ag->gamma * FN(orc_v_evaluate)(b, w, ns) - pred;
+    if (ag->algo == ORC_TD_LAMBDA) {
+        for (f = 0; f < F; f++) w[f] = FN(fma_)(td, z[f], w[f]);
+        if (term) memset(z, 0, sizeof(R) * (size_t)F);
+    } else {
+        R scale = (R)ag->lr * td;
+        for (f = 0; f < F; f++) w[f] = FN(fma_)(scale, phi[f], w[f]);
+    }
+    free(phi);
+    return td;
+}
+
 /* ------------------------------------------------------------------ */
 /* Vectorised driver loop (examples/q_learning.rs:34-55 x N envs)      */
 /* ------------------------------------------------------------------ */
@@ -549,13 +592,20 @@ typedef struct {
 } FN(orc_run);
 
 static R* FN(run_W)(FN(orc_run)* run, int64_t i) {
-    size_t FA = (size_t)orc_basis_nfeat(&run->ag.basis) * (size_t)run->ag.n_actions;
+    size_t FA = (size_t)orc_basis_nfeat(&run->ag.basis) * (size_t)ORC_N_OUT(&run->ag);
     return run->ag.shared_w ? run->W : run->W + (size_t)i * FA;
+}
+
+/* Q(s,.) of learner i for the behaviour policy; prediction agents have no Q (their policy is Random, which ignores it) */
+static void FN(run_q)(FN(orc_run)* run, int64_t i, const R* s, R* q) {
+    int A = run->ag.n_actions, k;
+    if (ORC_IS_PRED(run->ag.algo)) { for (k = 0; k < A; k++) q[k] = (R)0.0; return; }
+    FN(orc_q_evaluate)(&run->ag.basis, FN(run_W)(run, i), A, s, q);
 }
 
 void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     FN(orc_run)* run = (FN(orc_run)*)calloc(1, sizeof(*run));
-    size_t FA = (size_t)orc_basis_nfeat(&ag->basis) * (size_t)ag->n_actions;
+    size_t FA = (size_t)orc_basis_nfeat(&ag->basis) * (size_t)ORC_N_OUT(ag);
     run->ag = *ag; run->n_envs = n_envs;
     run->state = (R*)calloc((size_t)n_envs * (size_t)ag->basis.dim, sizeof(R));
     run->action = (int32_t*)calloc((size_t)n_envs, sizeof(int32_t));
@@ -587,7 +637,7 @@ void FN(orc_run_reset)(void* h) {
         R q[ORC_MAX_ACTIONS]; uint32_t x[4];
         R* s = run->state + (size_t)i * D;
         FN(orc_domain_reset)(ag->domain, s);
-        FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, s, q);
+        FN(run_q)(run, i, s, q);
         orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INIT, x);
         run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
         run->ep_step[i] = 0;
@@ -617,7 +667,9 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
             term_all[i] = (uint8_t)term;
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
-            if (ORC_IS_LAMBDA(ag->algo)) {
+            if (ORC_IS_PRED(ag->algo)) {
+                delta = FN(orc_handle_td)(ag, FN(run_W)(run, i), run->Z ? run->Z + (size_t)i * F : NULL, s, r, ns, term);
+            } else if (ORC_IS_LAMBDA(ag->algo)) {
                 delta = FN(orc_handle_lambda)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term, xi);
             } else if (ag->algo == ORC_GREEDY_GQ) {
                 delta = FN(orc_handle_gq)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term);
@@ -635,7 +687,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
         for (i = 0; i < N; i++) {
             R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
             R q[ORC_MAX_ACTIONS]; uint32_t x[4]; int na;
-            FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, ns, q);     /* projection #4, UPDATED W */
+            FN(run_q)(run, i, ns, q);                                       /* projection #4, UPDATED W */
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_STEP, x);
             na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
             run->ep_step[i] += 1;
@@ -645,7 +697,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
                 if (!term_all[i]) acc.episodes_truncated += 1;
                 acc.sum_episode_steps += run->ep_step[i];
                 FN(orc_domain_reset)(ag->domain, ns);
-                FN(orc_q_evaluate)(&ag->basis, FN(run_W)(run, i), A, ns, q);
+                FN(run_q)(run, i, ns, q);
                 orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_RESET, x);
                 na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
                 run->ep_step[i] = 0;
@@ -723,7 +775,7 @@ int FN(orc_run_train_fast)(void* h, int64_t n_steps, orc_stats* st) {
 int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
     int A = ag->n_actions; int64_t i;
-    if (step_limit < 1 || ag->policy == ORC_RANDOM) return -1;
+    if (step_limit < 1 || ag->policy == ORC_RANDOM || ORC_IS_PRED(ag->algo)) return -1;
     for (i = 0; i < run->n_envs; i++) {
         R s[8], q[ORC_MAX_ACTIONS], r, tot = 0; int a, term; int64_t steps = 0;
         const R* W = FN(run_W)(run, i);

@@ -40,6 +40,7 @@ SYMBOLS = {
     "rsrl_hip_sync": (C.c_int, [C.c_void_p]),
     "rsrl_hip_state_dim": (C.c_int, [C.c_void_p]),
     "rsrl_hip_n_actions": (C.c_int, [C.c_void_p]),
+    "rsrl_hip_n_outputs": (C.c_int, [C.c_void_p]),
     "rsrl_hip_n_features": (C.c_int, [C.c_void_p]),
     "rsrl_hip_n_envs": (C.c_int64, [C.c_void_p]),
     "rsrl_hip_state_bounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

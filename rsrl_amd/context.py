@@ -8,7 +8,7 @@ from . import _abi
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE_CODING = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ = 0, 1, 2, 3, 4, 5, 6
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
@@ -63,6 +63,7 @@ class Context:
         self.N = int(n_envs)
         self.D = self._L.rsrl_hip_state_dim(self._h)
         self.A = self._L.rsrl_hip_n_actions(self._h)
+        self.n_out = self._L.rsrl_hip_n_outputs(self._h)      # weight columns: A, or 1 for TD / TDLambda
         self.F = self._L.rsrl_hip_n_features(self._h)
         self.shared = weight_mode == W_SHARED
 
@@ -139,7 +140,7 @@ class Context:
 
     def q_evaluate(self, states):
         states, M = self._batch(states)
-        out = np.empty((self.A, M), dtype=np.float32)
+        out = np.empty((self.n_out, M), dtype=np.float32)
         _abi.check(self._L.rsrl_hip_q_evaluate(self._h, _p(states), M, _p(out)))
         return out
 
@@ -194,20 +195,20 @@ class Context:
 
     # ---- Parameterised
     def get_weights(self, env_index=0):
-        out = np.empty((self.F, self.A), dtype=np.float32)
+        out = np.empty((self.F, self.n_out), dtype=np.float32)
         _abi.check(self._L.rsrl_hip_get_weights(self._h, int(env_index), _p(out)))
         return out
 
     def set_weights(self, w, env_index=0):
-        _abi.check(self._L.rsrl_hip_set_weights(self._h, int(env_index), _p(_in(w, np.float32, (self.F, self.A)))))
+        _abi.check(self._L.rsrl_hip_set_weights(self._h, int(env_index), _p(_in(w, np.float32, (self.F, self.n_out)))))
 
     def get_traces(self, env_index=0):
-        out = np.empty((self.F, self.A), dtype=np.float32)
+        out = np.empty((self.F, self.n_out), dtype=np.float32)
         _abi.check(self._L.rsrl_hip_get_traces(self._h, int(env_index), _p(out)))
         return out
 
     def set_traces(self, z, env_index=0):
-        _abi.check(self._L.rsrl_hip_set_traces(self._h, int(env_index), _p(_in(z, np.float32, (self.F, self.A)))))
+        _abi.check(self._L.rsrl_hip_set_traces(self._h, int(env_index), _p(_in(z, np.float32, (self.F, self.n_out)))))
 
     def get_td_weights(self, env_index=0):
         """GreedyGQ.fa_td's weights of one learner (greedy_gq.rs:52)"""
@@ -225,7 +226,7 @@ class Context:
         _abi.check(self._L.rsrl_hip_load_weights(self._h, str(path).encode()))
 
     def set_weights_all(self, w):
-        _abi.check(self._L.rsrl_hip_set_weights_all(self._h, _p(_in(w, np.float32, (self.F, self.A)))))
+        _abi.check(self._L.rsrl_hip_set_weights_all(self._h, _p(_in(w, np.float32, (self.F, self.n_out)))))
 
     # ---- driver loop
     def train(self, n_steps, want_stats=True):

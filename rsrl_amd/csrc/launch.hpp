@@ -28,6 +28,14 @@ bool launch_handle_gq(int domain, int order, dim3 grid, dim3 block, hipStream_t 
                       const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                       int64_t Mn, float* td_out);
 
+struct TdParams;
+bool launch_train_td(int domain, int order, bool lambda, dim3 grid, dim3 block, hipStream_t st, const Common& k, const TdParams& tp,
+                     uint64_t t, int chunk, DevStats* stats);
+bool launch_handle_td(int domain, int order, bool lambda, dim3 grid, dim3 block, hipStream_t st, const Common& k, const TdParams& tp,
+                      const float* from, const float* rew, const float* to, const uint8_t* termf, int64_t Mn, float* td_out);
+bool launch_v_evaluate(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const float* states, int64_t Mn, float* out);
+bool launch_reset_td(int domain, dim3 grid, dim3 block, hipStream_t st, const Common& k, uint64_t t);
+
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
         if (chunk == -1)                                                                                    \

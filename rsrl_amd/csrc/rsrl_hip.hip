@@ -19,11 +19,13 @@
 #include "kernels_wave.hpp"
 #include "kernels_lambda.hpp"
 #include "kernels_gq.hpp"
+#include "kernels_td.hpp"
 
 using namespace rsrl;
 
 static inline bool is_lambda(int algo) { return algo == RSRL_SARSA_LAMBDA || algo == RSRL_Q_LAMBDA; }
-static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ; }   // second matrix of W's shape
+static inline bool is_pred(int algo) { return algo == RSRL_TD || algo == RSRL_TD_LAMBDA; }        // one weight column (V function)
+static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ || algo == RSRL_TD_LAMBDA; }   // second matrix of W's shape
 
 namespace {
 // tile coding, shared W: sum the n_rep copies of the delta table (and clear them); single rank: W += sum, otherwise the sum
@@ -139,6 +141,7 @@ struct rsrl_hip_ctx {
     bool own_stream = false;
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
+    int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
     float* dW_rep = nullptr; int n_rep = 1;      // shared tile coding: replicated delta tables (contention relief)
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
@@ -190,6 +193,15 @@ static GqParams make_gq(const rsrl_hip_ctx* c) {
     GqParams gp{};
     gp.V = c->Z; gp.lr_td = (float)c->cfg.lr_td;
     return gp;
+}
+
+static TdParams make_td(const rsrl_hip_ctx* c) {
+    TdParams tp{};
+    tp.Z = c->Z;
+    double rate = c->cfg.gamma * c->cfg.lambda;
+    if (c->cfg.trace == RSRL_TRACE_DUTCH) rate *= (1.0 - c->cfg.alpha);
+    tp.rate = (float)rate; tp.trace = c->cfg.trace;
+    return tp;
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
@@ -365,7 +377,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
     if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
-    if (cfg->algo < 0 || cfg->algo > RSRL_GREEDY_GQ) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo < 0 || cfg->algo > RSRL_TD_LAMBDA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
@@ -391,6 +403,16 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
+    if (is_pred(cfg->algo)) {
+        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a register-family Fourier basis "
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (cfg->policy != RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "prediction agents have no Q function: the behaviour policy must be RSRL_RANDOM");
+        if (cfg->algo == RSRL_TD_LAMBDA) {
+            if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
+            if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
+        }
+    }
     if (cfg->algo == RSRL_GREEDY_GQ) {
         if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
             return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights on a register-family Fourier basis "
@@ -414,8 +436,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     const int64_t N = cfg->n_envs;
     const bool shared = cfg->weight_mode == RSRL_W_SHARED;
     c->w_stride = shared ? 1 : N;
-    c->w_elems = (size_t)c->A * c->F * (size_t)c->w_stride;
-    c->dw_elems = (size_t)c->A * c->F;
+    c->Aw = is_pred(cfg->algo) ? 1 : c->A;
+    c->w_elems = (size_t)c->Aw * c->F * (size_t)c->w_stride;
+    c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
@@ -474,6 +497,7 @@ int rsrl_hip_sync(rsrl_hip_ctx* c) {
 
 int rsrl_hip_state_dim(const rsrl_hip_ctx* c) { return c ? c->D : RSRL_HIP_EINVAL; }
 int rsrl_hip_n_actions(const rsrl_hip_ctx* c) { return c ? c->A : RSRL_HIP_EINVAL; }
+int rsrl_hip_n_outputs(const rsrl_hip_ctx* c) { return c ? c->Aw : RSRL_HIP_EINVAL; }
 int rsrl_hip_n_features(const rsrl_hip_ctx* c) { return c ? c->F : RSRL_HIP_EINVAL; }
 int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* c) { return c ? c->cfg.n_envs : RSRL_HIP_EINVAL; }
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* c) { return c ? c->t : 0; }
@@ -504,7 +528,9 @@ int rsrl_hip_reset(rsrl_hip_ctx* c) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_wave(c->cfg)) {
+    if (is_pred(c->cfg.algo)) {
+        if (!launch_reset_td(c->cfg.domain, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, c->t)) return NO_MODEL(c);
+    } else if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
             hipLaunchKernelGGL((k_wave_reset<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, c->t);
@@ -597,6 +623,8 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
                size_t icount = 0) {
     CHECK_CTX(c);
     if (!states || M_ < 1 || M_ > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M_, (long long)c->cfg.n_envs);
+    if (is_pred(c->cfg.algo) && op != QOP_EVALUATE && op != QOP_FEATURES)
+        return fail(RSRL_HIP_ESTATE, "a prediction agent has a state-value function only (use rsrl_hip_q_evaluate for V(s))");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const float* d_states; OutBuf<float> of; OutBuf<int32_t> oi;
     TRY(stage_in(c, 0, states, (size_t)c->D * M_, &d_states));
@@ -606,7 +634,9 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
-    if (is_wave(c->cfg)) {
+    if (is_pred(c->cfg.algo) && op == QOP_EVALUATE) {
+        if (!launch_v_evaluate(c->cfg.domain, c->cfg.order, dim3(grid_for(M_)), dim3(kBlock), c->stream, k, d_states, M_, of.dev)) return NO_MODEL(c);
+    } else if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
             hipLaunchKernelGGL((k_wave_qop<T::domain, WT>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, op, d_states, M_, call, of.dev, oi.dev);
@@ -624,7 +654,7 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
 
 int rsrl_hip_q_evaluate(rsrl_hip_ctx* c, const float* states, int64_t M, float* q_out) {
     if (!q_out) return fail(RSRL_HIP_EINVAL, "null argument");
-    return qop(c, QOP_EVALUATE, states, M, q_out, c ? (size_t)c->A * M : 0, nullptr);
+    return qop(c, QOP_EVALUATE, states, M, q_out, c ? (size_t)c->Aw * M : 0, nullptr);
 }
 int rsrl_hip_q_find_max(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* idx_out, float* val_out) {
     return qop(c, QOP_FIND_MAX, states, M, val_out, (size_t)M, idx_out);
@@ -673,7 +703,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (c->cfg.algo == RSRL_GREEDY_GQ) {
+    if (is_pred(c->cfg.algo)) {
+        if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
+                              d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+    } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
         if (!launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
                               d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
     } else if (is_lambda(c->cfg.algo)) {
@@ -708,7 +741,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const int n = c->F * c->A; OutBuf<float> ow;
+    const int n = c->F * c->Aw; OutBuf<float> ow;
     TRY(stage_out(c, 0, w, (size_t)n, &ow));
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
@@ -716,7 +749,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
             hipLaunchKernelGGL((k_wave_weights_get<WT>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const WT*)c->W + env_index * (int64_t)n, c->F, c->A, ow.dev);
         });
     } else
-    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, ow.dev);
+    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->Aw, ow.dev);
     KCHECK();
     bool sync = false; TRY(flush_out(c, &ow, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -728,7 +761,7 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const int n = c->F * c->A; const float* d_w;
+    const int n = c->F * c->Aw; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
@@ -737,7 +770,7 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
             hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, env_index, (int64_t)1, c->F, c->A, d_w);
         });
     } else
-    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->A, d_w);
+    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->Aw, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
@@ -747,18 +780,18 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
     if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no auxiliary matrix (eligibility trace / fa_td weights)");
     if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const int n = c->F * c->A;
+    const int n = c->F * c->Aw;
     if (out) {
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
-        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->A, oz.dev);
+        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->Aw, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
         if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
         const float* d_z;
         TRY(stage_in(c, 0, in, (size_t)n, &d_z));
-        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->A, d_z);
+        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->Aw, d_z);
         KCHECK();
         if (!is_device_ptr(in)) HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -767,13 +800,13 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
 int rsrl_hip_get_traces(rsrl_hip_ctx* c, int64_t env_index, float* z) {
     if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
     CHECK_CTX(c);
-    if (!is_lambda(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
+    if (!is_lambda(c->cfg.algo) && c->cfg.algo != RSRL_TD_LAMBDA) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
     return traces_rw(c, env_index, z, nullptr);
 }
 int rsrl_hip_set_traces(rsrl_hip_ctx* c, int64_t env_index, const float* z) {
     if (!z) return fail(RSRL_HIP_EINVAL, "null argument");
     CHECK_CTX(c);
-    if (!is_lambda(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
+    if (!is_lambda(c->cfg.algo) && c->cfg.algo != RSRL_TD_LAMBDA) return fail(RSRL_HIP_ESTATE, "this agent has no eligibility trace");
     return traces_rw(c, env_index, nullptr, z);
 }
 int rsrl_hip_get_td_weights(rsrl_hip_ctx* c, int64_t env_index, float* v) {
@@ -798,7 +831,7 @@ static void ckpt_fill(const rsrl_hip_ctx* c, CkptHeader* h) {
     memset(h, 0, sizeof(*h));
     memcpy(h->magic, "RSRLHIPW", 8); h->version = 1;
     h->domain = c->cfg.domain; h->basis = c->cfg.basis; h->order = c->cfg.order; h->n_tilings = c->cfg.n_tilings;
-    h->tiles_per_dim = c->cfg.tiles_per_dim; h->weight_mode = c->cfg.weight_mode; h->F = c->F; h->A = c->A;
+    h->tiles_per_dim = c->cfg.tiles_per_dim; h->weight_mode = c->cfg.weight_mode; h->F = c->F; h->A = c->Aw;
     h->n_learners = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : c->cfg.n_envs; h->step_count = c->t;
 }
 int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
@@ -809,7 +842,7 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
     CkptHeader h; ckpt_fill(c, &h);
     int rc = RSRL_HIP_OK;
     if (fwrite(&h, sizeof(h), 1, f) != 1) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
-    std::vector<float> w((size_t)c->F * c->A);
+    std::vector<float> w((size_t)c->F * c->Aw);
     for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
         rc = rsrl_hip_get_weights(c, i, w.data());
         if (rc == RSRL_HIP_OK && fwrite(w.data(), sizeof(float), w.size(), f) != w.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
@@ -829,7 +862,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
              h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
              h.n_learners != want.n_learners)
         rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration", path);
-    std::vector<float> w((size_t)c->F * c->A);
+    std::vector<float> w((size_t)c->F * c->Aw);
     for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
         if (fread(w.data(), sizeof(float), w.size(), f) != w.size()) { rc = fail(RSRL_HIP_EINVAL, "%s is truncated", path); break; }
         rc = rsrl_hip_set_weights(c, i, w.data());
@@ -844,7 +877,7 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     if (c->cfg.weight_mode == RSRL_W_SHARED) return rsrl_hip_set_weights(c, 0, w);
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const int n = c->F * c->A; const float* d_w;
+    const int n = c->F * c->Aw; const float* d_w;
     TRY(stage_in(c, 0, w, (size_t)n, &d_w));
     const int gy = n < 1024 ? n : 1024;
     if (is_wave(c->cfg)) {
@@ -854,7 +887,7 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
             hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, (int64_t)0, c->cfg.n_envs, c->F, c->A, d_w);
         });
     } else
-    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->F, c->A, d_w);
+    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->F, c->Aw, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
@@ -965,6 +998,11 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         if (shared) {
             TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
             c->kernel_name = "k_shared_ca";
+        } else if (is_pred(c->cfg.algo)) {
+            if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
+                                 make_td(c), c->t, chunk, d_stats)) return NO_MODEL(c);
+            c->kernel_name = "k_train_td";
+            KCHECK();
         } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
             if (!launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_gq(c), c->t, chunk, d_stats)) return NO_MODEL(c);

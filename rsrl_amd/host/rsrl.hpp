@@ -140,6 +140,18 @@ struct GreedyGQ : Agent {
 };
 }}  // namespace control::td
 
+// ---- rsrl::prediction::td: TD { v_func, gamma } / TDLambda { fa_theta, trace, gamma }   (td.rs:25-30, td_lambda.rs:25-32)
+// The value function is a ScalarLFA (one weight column); drive these with policies::Random.
+namespace prediction { namespace td {
+struct TD : control::td::Agent {
+    TD(Shared<fa::linear::LFA> v_func, double gamma) : control::td::Agent{RSRL_TD, std::move(v_func), gamma} {}
+};
+struct TDLambda : control::td::Agent {
+    TDLambda(Shared<fa::linear::LFA> fa_theta, const traces::Trace& tr, double gamma)
+        : control::td::Agent{RSRL_TD_LAMBDA, std::move(fa_theta), gamma, 1.0, tr.rule, tr.lambda} {}
+};
+}}  // namespace prediction::td
+
 // ---- the bound object graph: env + agent + policy sharing one q_func on one MI355X -------------------
 class Session {
 public:
@@ -157,6 +169,7 @@ public:
         cfg.seed = seed; cfg.max_episode_steps = max_episode_steps;
         check(rsrl_hip_create(&cfg, &ctx_));
         D_ = rsrl_hip_state_dim(ctx_); A_ = rsrl_hip_n_actions(ctx_); F_ = rsrl_hip_n_features(ctx_); N_ = env.n_envs;
+        O_ = rsrl_hip_n_outputs(ctx_);
     }
     ~Session() { rsrl_hip_destroy(ctx_); }
     Session(const Session&) = delete;
@@ -194,16 +207,16 @@ public:
     }
     // Function<(S,)>::evaluate                                                    (fa/linear.rs:303-311)
     std::vector<float> evaluate(const std::vector<float>& states) {
-        std::vector<float> q((size_t)A_ * N_); check(rsrl_hip_q_evaluate(ctx_, states.data(), N_, q.data())); return q;
+        std::vector<float> q((size_t)O_ * N_); check(rsrl_hip_q_evaluate(ctx_, states.data(), N_, q.data())); return q;
     }
     void set_epsilon(double eps) { check(rsrl_hip_set_epsilon(ctx_, eps)); }      // pub field EpsilonGreedy.epsilon
     // Parameterised::weights()                                                    (params/mod.rs:118)
     std::vector<float> weights(int64_t env = 0) {
-        std::vector<float> w((size_t)F_ * A_); check(rsrl_hip_get_weights(ctx_, env, w.data())); return w;
+        std::vector<float> w((size_t)F_ * O_); check(rsrl_hip_get_weights(ctx_, env, w.data())); return w;
     }
     // the pub field `trace` of SARSALambda / QLambda                                (sarsa_lambda.rs:41)
     std::vector<float> trace(int64_t env = 0) {
-        std::vector<float> z((size_t)F_ * A_); check(rsrl_hip_get_traces(ctx_, env, z.data())); return z;
+        std::vector<float> z((size_t)F_ * O_); check(rsrl_hip_get_traces(ctx_, env, z.data())); return z;
     }
     // the pub field `fa_td` of GreedyGQ                                             (greedy_gq.rs:52)
     std::vector<float> td_weights(int64_t env = 0) {
@@ -222,7 +235,7 @@ public:
 
 private:
     rsrl_hip_ctx* ctx_ = nullptr;
-    int D_ = 0, A_ = 0, F_ = 0;
+    int D_ = 0, A_ = 0, F_ = 0, O_ = 0;      // O_: weight columns (A_, or 1 for the prediction agents)
     int64_t N_ = 0;
 };
 

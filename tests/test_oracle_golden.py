@@ -475,3 +475,39 @@ def test_optimised_cpu_loop_is_the_same_computation(orc, prec):
     assert abs(sa["sum_abs_td_error"] - sb["sum_abs_td_error"] - sb2["sum_abs_td_error"]) < 1e-6 * sa["sum_abs_td_error"]
     with pytest.raises(ValueError):
         orc.Run(orc.make_agent(algo=orc.SARSA), 2, prec).train_fast(1)
+
+
+def test_td_prediction_hand_computation(orc):
+    # prediction/td/td.rs:31-59 and td_lambda.rs:41-78 on a ScalarLFA (fa/linear.rs:201-251), restated in numpy
+    rng = np.random.default_rng(12)
+    F = 36
+    for trace, lam in ((orc.TRACE_ACCUMULATE, 0.6), (orc.TRACE_SATURATE, 0.9), (orc.TRACE_DUTCH, 0.5)):
+        ag0 = orc.make_agent(algo=orc.TD, policy=orc.RANDOM, gamma=0.95, lr=0.01)
+        agl = orc.make_agent(algo=orc.TD_LAMBDA, policy=orc.RANDOM, gamma=0.95, alpha=0.2, lam=lam, trace=trace)
+        for term in (False, True):
+            w, z = rng.normal(size=F) * 0.2, rng.normal(size=F) * 0.7
+            s = np.array([rng.uniform(-1.2, 0.6), rng.uniform(-0.07, 0.07)])
+            ns, r, _ = orc.domain_step(orc.MOUNTAIN_CAR, s, int(rng.integers(0, 3)))
+            phi, nphi = orc.fourier_project(0, 5, s), orc.fourier_project(0, 5, ns)
+            pred = phi @ w
+            assert abs(orc.v_evaluate(ag0, w, s) - pred) < 1e-13
+            td = (r - pred) if term else (r + 0.95 * (nphi @ w) - pred)
+            # TD(0): w += lr * td * phi(s)
+            w2 = w.copy()
+            d = orc.handle_td(ag0, w2, None, s, r, ns, term)
+            assert abs(d - td) < 1e-12 and np.max(np.abs(w2 - (w + 0.01 * td * phi))) < 1e-14
+            # TD(lambda): the trace moves first, then w += td * trace (no learning rate), terminal resets the trace
+            rate = 0.95 * lam * ((1 - 0.2) if trace == orc.TRACE_DUTCH else 1.0)
+            z_exp = rate * z + phi
+            if trace == orc.TRACE_SATURATE:
+                z_exp = np.clip(z_exp, -1.0, 1.0)
+            w3, z3 = w.copy(), z.copy()
+            d = orc.handle_td(agl, w3, z3, s, r, ns, term)
+            assert abs(d - td) < 1e-12
+            assert np.max(np.abs(w3 - (w + td * z_exp))) < 1e-13
+            assert np.max(np.abs(z3 - (0 * z_exp if term else z_exp))) < 1e-14
+    # driver loop: Random behaviour policy, one weight column per learner
+    run = orc.Run(orc.make_agent(algo=orc.TD, policy=orc.RANDOM, gamma=0.99, lr=0.01, max_episode_steps=50), 5, "f64")
+    run.reset()
+    st = run.train(120)
+    assert run.weights.shape == (5, 36, 1) and np.abs(run.weights).max() > 0 and st["episodes"] == 10
