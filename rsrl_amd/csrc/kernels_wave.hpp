@@ -30,6 +30,14 @@ constexpr int kWaveN1 = 8;
 struct bf16_t { uint16_t bits; };
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+// 16 rounding bits for element e (0..63) of a lane from the lane's 128-bit Philox block: the 16-bit window at bit (e >> 2) of
+// word (e & 3) -- one v_bfe_u32 per weight.  Windows of neighbouring elements overlap (their roundings are correlated), each
+// element's own bits are uniform, which is all unbiasedness needs; the previous multiplicative hash cost a quarter-rate
+// v_mul_lo_u32 per weight (~8 % of the wave-step).
+__device__ __forceinline__ uint32_t sr_bits(const U4& rnd, int e) {
+    const uint32_t word = (e & 3) == 0 ? rnd.x : (e & 3) == 1 ? rnd.y : (e & 3) == 2 ? rnd.z : rnd.w;
+    return (word >> (e >> 2)) & 0xffffu;
+}
 // stochastic rounding f32 -> bf16-representable f32: add 16 random bits below the kept mantissa, truncate
 __device__ __forceinline__ float round_bf16_sr(float x, uint32_t rnd16) {
     uint32_t b = __builtin_bit_cast(uint32_t, x);
@@ -154,9 +162,7 @@ struct WaveFourier {
             for (int v = 0; v < 8; ++v) {
                 float x = fmaf(scale, phi[j][v], wa[j][v]);
                 if constexpr (WaveIO<WT>::kBf16) {
-                    const int e = j * 8 + v;
-                    const uint32_t word = (e & 3) == 0 ? rnd.x : (e & 3) == 1 ? rnd.y : (e & 3) == 2 ? rnd.z : rnd.w;
-                    x = round_bf16_sr(x, (word * (uint32_t)(2 * e + 1) * 0x9E3779B1u) >> 16);
+                    x = round_bf16_sr(x, sr_bits(rnd, j * 8 + v));
                 }
                 wa[j][v] = x;
             }
@@ -377,9 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
         for (int v = 0; v < 8; ++v) {
             float x = fmaf(scale, phi_s[j][v], w8[0][v]);
             if constexpr (WaveIO<WT>::kBf16) {
-                const int el = j * 8 + v;
-                const uint32_t word = (el & 3) == 0 ? rnd.x : (el & 3) == 1 ? rnd.y : (el & 3) == 2 ? rnd.z : rnd.w;
-                x = round_bf16_sr(x, (word * (uint32_t)(2 * el + 1) * 0x9E3779B1u) >> 16);
+                x = round_bf16_sr(x, sr_bits(rnd, j * 8 + v));
             }
             w8[0][v] = x;
         }
