@@ -19,7 +19,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 # per-source flags: the fused register-family loops run at ONE wave per SIMD (65 536 learners = 1024 waves), where
 # single-wave ILP is all there is -- LLVM's max-ILP scheduling strategy is worth +2..3 % there (A/B on MI355X, round 1)
-PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get("RSRL_SCHED_STRATEGY", "max-ilp")]
                     for name in ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip")}
 
 

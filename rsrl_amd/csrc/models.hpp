@@ -70,6 +70,20 @@ struct FourierModel {
 #pragma unroll
         for (int f = 0; f < F; ++f) fout[(int64_t)f * Mn + i] = ft.phi[f];
     }
+    __host__ __device__ static constexpr int F_or_1() { return F; }
+    // Q(s,.) from a copy of the shared W[A][F] in LDS (uniform addresses: broadcast reads); same summation order as q_from_mem
+    __device__ static __forceinline__ void q_all_lds(const float* __restrict__ shw, const Feat& ft, float (&q)[A]) {
+        constexpr int P = RSRL_DOT_SPLIT;
+#pragma unroll
+        for (int b = 0; b < A; ++b) {
+            float acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f % P] = fmaf(ft.phi[f], shw[b * F + f], acc[f % P]);
+            q[b] = combine_partials<P>(acc);
+        }
+    }
     // dW has the shared layout [A][F]
     // must be called by ALL lanes of the wave (uniform control flow); lanes without work pass valid = false
     __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
@@ -92,6 +106,8 @@ struct TileModel {
     static constexpr int D = Dom::D, A = Dom::A;
     static constexpr bool kDense = false, kSparse = true;
     struct Feat { int idx[T]; };
+    __host__ __device__ static constexpr int F_or_1() { return 1; }
+    __device__ static __forceinline__ void q_all_lds(const float*, const Feat&, float (&)[A]) {}
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
         const int B = g.tiles_per_dim;
         int BD = 1;
@@ -201,7 +217,9 @@ struct FourierGenericModel {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, A = Dom::A;
     static constexpr bool kDense = false, kSparse = false;      // no register-resident phi: the shared-W block reduction is not available
+    __host__ __device__ static constexpr int F_or_1() { return 1; }
     struct Feat { float ct[D][8], st[D][8]; };
+    __device__ static __forceinline__ void q_all_lds(const float*, const Feat&, float (&)[A]) {}
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom& g, Feat& ft) {
         const int order = g.tiles_per_dim;     // BasisGeom::tiles_per_dim carries the Fourier order for this model
         static_for<0, D>([&](auto Dd) {
@@ -504,6 +522,13 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
     double sum_abs = 0.0, sum_r = 0.0;
+    // dense basis: the shared W (A*F floats) is staged in LDS once per block -- with W in global memory every lane issues
+    // the same 2*A*F uniform-address loads per step and the kernel is bound by VMEM issue, not arithmetic
+    __shared__ __attribute__((aligned(16))) float sh_w[M::A * M::F_or_1()];
+    if constexpr (M::kDense) {
+        for (int j = threadIdx.x; j < M::A * M::F_or_1(); j += blockDim.x) sh_w[j] = c.W[j];
+        __syncthreads();
+    }
     typename M::Feat fs;
     int a = 0;
     float scale = 0.0f;
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         if (done) { M::Dom::reset(s); ep = 0; }
         else load_state<M>(c.state, N, i, s);
         M::features(s, g, fs);
-        M::q_all(c, 0, g, fs, q_s);
+        if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s); else M::q_all(c, 0, g, fs, q_s);
         if (do_c) {                                                     // ---- phase C of batch-step t-1
             const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
@@ -534,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         typename M::Feat fn;
         M::features(ns, g, fn);
         float q_n[A];
-        M::q_all(c, 0, g, fn, q_n);
+        if constexpr (M::kDense) M::q_all_lds(sh_w, fn, q_n); else M::q_all(c, 0, g, fn, q_n);
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         float e;
@@ -587,6 +612,10 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         }
         __syncthreads();
         if (threadIdx.x < AF) partials[(int64_t)blockIdx.x * AF + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
+        // ---- the LAST block to arrive sums the rows (fixed order: bitwise reproducible whichever block it is) and applies
+        // them -- one launch per batch-step instead of two (a dependent launch costs ~4 us + a ~4 us gap on this part).
+        // Publish / acquire as in cdna_hip_programming.md Guideline 16: stores drained, block barrier, ONE release fence,
+        // the ticket; the last arriver takes ONE acquire fence before plain loads of the other blocks' rows.
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
