@@ -456,7 +456,8 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 // Precondition (checked by the host): A*F*N*4 < 2^32.
 // ---------------------------------------------------------------------------------------
 template <int DOMAIN, int ORDER, int ALGO, int POLICY>
-__global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevStats* __restrict__ stats) {
+__global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
     constexpr int D = Dom::D, A = Dom::A, F = Bas::F;

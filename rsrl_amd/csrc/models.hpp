@@ -169,21 +169,23 @@ struct TileModel {
     // Must be called by ALL lanes of the wave (the DPP sum needs full exec); lanes without work pass valid = false.
     __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
                                                       bool valid) {
+        constexpr int kRounds = 3;         // more rounds cost more than the atomics they save: a wave holds tens of distinct keys
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int key = valid ? ft.idx[t] * A + a : -1;
             bool pending = valid;
-            // one round per distinct key of the wave (learners crowd into few tiles: typically a handful of rounds)
-            while (true) {
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
                 const unsigned long long todo = __ballot(pending);
                 if (todo == 0ull) break;
                 const int leader = __ffsll((long long)todo) - 1;
                 const int lkey = __shfl(key, leader, 64);
                 const bool mine = pending && key == lkey;
                 const float tot = wave_sum_all(mine ? scale : 0.0f);
-                if (mine && (int)(threadIdx.x & 63) == leader && tot != 0.0f) atomicAdd(&dW[lkey], tot);
+                if (mine && (int)(threadIdx.x & 63) == leader) atomicAdd(&dW[lkey], tot);
                 pending = pending && !mine;
             }
+            if (pending) atomicAdd(&dW[key], scale);
         }
     }
     // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A floats, 32 KiB at
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
 template <class M, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW_base,
                                                       float* __restrict__ partials, uint8_t* __restrict__ flags,
-                                                      DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride) {
+                                                      DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride,
+                                                      const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
     // tile coding: the delta table is replicated n_rep times and block b adds into copy b % n_rep -- device atomics on one
     // 128-B line serialise at ~11 ns each and the learners crowd into a few lines; k_apply_rep sums the copies
     float* __restrict__ dW = dW_base + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride;

@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
         *reinterpret_cast<float4*>(dW + j) = acc;
     }
 }
+__global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
+__global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) { W[j] += dW[j]; dW[j] = 0.0f; }
@@ -158,7 +160,14 @@ struct rsrl_hip_ctx {
     // timing of train launches
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<uint32_t> event_launches;      // batch-step launches bracketed by each event pair (a graph replay brackets many)
     size_t events_used = 0;
+    // launch-bound inner loops (one batch-step per launch: the streaming kernel, the shared-W phases) replayed as a hipGraph
+    uint64_t* d_t = nullptr;                   // device copy of the batch-step counter: graph nodes carry offsets to it
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_graph_exec = nullptr;
+    Common step_graph_key{};                   // kernel arguments the graph was captured with
+    int step_graph_kind = 0;                   // 1 = k_step_reg, 2 = shared-W batch-step
     const char* kernel_name = "";
     // multi-GPU shared-W: one RCCL communicator per ctx (one process per GPU)
     ncclComm_t comm = nullptr;
@@ -355,6 +364,9 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW) (void)hipFree(c->dW);
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->partials) (void)hipFree(c->partials);
+    if (c->step_graph_exec) (void)hipGraphExecDestroy(c->step_graph_exec);
+    if (c->step_graph) (void)hipGraphDestroy(c->step_graph);
+    if (c->d_t) (void)hipFree(c->d_t);
     if (c->qcache) (void)hipFree(c->qcache);
     if (c->Z) (void)hipFree(c->Z);
     if (c->flags) (void)hipFree(c->flags);
@@ -456,6 +468,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
     }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
+    HIP_TRY(hipMalloc((void**)&c->d_t, sizeof(uint64_t)));
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
@@ -918,20 +931,23 @@ static int timing_begin(rsrl_hip_ctx* c) {
     HIP_TRY(hipEventRecord(c->events[c->events_used].first, c->stream));
     return RSRL_HIP_OK;
 }
-static int timing_end(rsrl_hip_ctx* c) {
+static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
     if (!c->timing) return RSRL_HIP_OK;
     HIP_TRY(hipEventRecord(c->events[c->events_used].second, c->stream));
+    if (c->event_launches.size() <= c->events_used) c->event_launches.resize(c->events_used + 1);
+    c->event_launches[c->events_used] = launches;
     c->events_used++;
     return RSRL_HIP_OK;
 }
 
 // shared weights: one batch-step = [phase C of the previous step + phase A] in one launch ->
 // delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
-// train call is closed by a stand-alone phase C.
-static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, bool first, bool last) {
+// train call is closed by a stand-alone phase C (enqueue_shared_c).
+// t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
+static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int do_c, uint64_t t,
+                               const uint64_t* t_dev) {
     const dim3 grid(grid_for(k.n_envs)), block(kBlock);
     const bool dense = c->cfg.basis == RSRL_FOURIER;
-    const int do_c = first ? 0 : 1;
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
@@ -942,13 +958,13 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
             if constexpr (M::kSparse) {
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
                 if (slice > 0) {
-                    hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, c->t, do_c, dwp,
-                                       c->partials, c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems);
+                    hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, t, do_c, dwp,
+                                       c->partials, c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems, t_dev);
                     return;
                 }
             }
-            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, c->t, do_c, dwp, c->partials, c->flags, d_stats, slice, nrep,
-                               (int64_t)c->dw_elems);
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, t, do_c, dwp, c->partials, c->flags, d_stats, slice, nrep,
+                               (int64_t)c->dw_elems, t_dev);
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
@@ -968,13 +984,54 @@ static int train_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
-    if (last) {
-        if (!for_model(c, [&](auto tag) {
-                using M = typename decltype(tag)::type;
-                hipLaunchKernelGGL((k_shared_c<M>), grid, block, 0, c->stream, k, g, c->t, c->flags);
-            })) return NO_MODEL(c);
-        KCHECK();
+    return RSRL_HIP_OK;
+}
+static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
+    if (!for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_shared_c<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, t_last, c->flags);
+        })) return NO_MODEL(c);
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+// the single-step streaming kernel (register family, steps_per_launch = 1)
+static int enqueue_k1_step(rsrl_hip_ctx* c, const Common& k, DevStats* d_stats, uint64_t t, const uint64_t* t_dev) {
+    const dim3 gr(grid_for(k.n_envs)), b(kBlock);
+    bool ok;
+    switch (c->cfg.domain) {
+    case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
+    case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
+    default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
     }
+    if (!ok) return NO_MODEL(c);
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+
+// ---- hipGraph replay of the launch-bound loops ------------------------------------------------------------------------
+// One batch-step per launch costs ~4 us of launch gap per dependent kernel on top of the kernels themselves; kStepsPerGraph
+// steady-state batch-steps (no statistics, single rank, ctx-owned stream) are captured once and replayed.  The nodes carry
+// their step offset; the counter itself lives on the device (k_set_t before the first replay of a train call, k_advance_t
+// as the graph's last node), so one executable graph serves every replay.  Any change of the kernel arguments (epsilon,
+// pointers) re-captures.
+constexpr int kStepsPerGraph = 32;
+static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int kind) {
+    if (c->step_graph_exec && c->step_graph_kind == kind && memcmp(&c->step_graph_key, &k, sizeof(Common)) == 0) return RSRL_HIP_OK;
+    if (c->step_graph_exec) { (void)hipGraphExecDestroy(c->step_graph_exec); c->step_graph_exec = nullptr; }
+    if (c->step_graph) { (void)hipGraphDestroy(c->step_graph); c->step_graph = nullptr; }
+    HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = RSRL_HIP_OK;
+    for (int j = 0; j < kStepsPerGraph && rc == RSRL_HIP_OK; ++j)
+        rc = kind == 1 ? enqueue_k1_step(c, k, nullptr, (uint64_t)j, c->d_t) : enqueue_shared_step(c, k, g, nullptr, 1, (uint64_t)j, c->d_t);
+    if (rc == RSRL_HIP_OK) hipLaunchKernelGGL(k_advance_t, dim3(1), dim3(1), 0, c->stream, c->d_t, (uint64_t)kStepsPerGraph);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc != RSRL_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess) return fail(RSRL_HIP_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    c->step_graph = graph;
+    HIP_TRY(hipGraphInstantiate(&c->step_graph_exec, c->step_graph, nullptr, nullptr, 0));
+    memcpy(&c->step_graph_key, &k, sizeof(Common));
+    c->step_graph_kind = kind;
     return RSRL_HIP_OK;
 }
 
@@ -991,12 +1048,28 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
     const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
+    // launch-bound loops go through a captured graph (RSRL_NO_GRAPH=1 keeps the plain launches, for A/B runs)
+    const bool graph_ok = (stream_k1 || shared) && c->own_stream && !stats_out && !(c->comm && c->world_size > 1) && !getenv("RSRL_NO_GRAPH");
+    bool t_dev_set = false;
     int64_t done = 0;
     while (done < n_steps) {
+        if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? done > 0 : c->q_valid)) {
+            Common kg = k; kg.q_valid = stream_k1 ? 1 : k.q_valid;
+            TRY(ensure_step_graph(c, kg, g, stream_k1 ? 1 : 2));
+            if (!t_dev_set) { hipLaunchKernelGGL(k_set_t, dim3(1), dim3(1), 0, c->stream, c->d_t, c->t); KCHECK(); t_dev_set = true; }
+            TRY(timing_begin(c));
+            HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
+            TRY(timing_end(c, kStepsPerGraph));
+            c->kernel_name = stream_k1 ? "k_step_reg" : "k_shared_ca";
+            c->t += (uint64_t)kStepsPerGraph;
+            done += kStepsPerGraph;
+            continue;
+        }
+        t_dev_set = false;                  // plain launches advance the host counter only
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
         TRY(timing_begin(c));
         if (shared) {
-            TRY(train_shared_step(c, k, g, d_stats, done == 0, done + chunk >= n_steps));
+            TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
             c->kernel_name = "k_shared_ca";
         } else if (is_pred(c->cfg.algo)) {
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
@@ -1020,10 +1093,14 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             });
             c->kernel_name = "k_train_wave";
             KCHECK();
+        } else if (stream_k1) {
+            TRY(enqueue_k1_step(c, k, d_stats, c->t, nullptr));
+            c->kernel_name = "k_step_reg";
+            c->q_valid = true; k.q_valid = 1;
         } else if (fourier && !is_generic_fourier(c->cfg)) {
             const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
             const dim3 gr(grid_for(k.n_envs)), b(kBlock);
-            const int kchunk = stream_k1 ? -1 : chunk;
+            const int kchunk = chunk;
             bool ok;
             switch (c->cfg.domain) {
             case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
@@ -1031,7 +1108,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
             }
             if (!ok) return NO_MODEL(c);
-            c->kernel_name = stream_k1 ? "k_step_reg" : "k_train_reg";
+            c->kernel_name = "k_train_reg";
             KCHECK();
             c->q_valid = true; k.q_valid = 1;       // the launch left Q(s,.) of its final state in qcache
         } else {
@@ -1047,6 +1124,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
         c->t += (uint64_t)chunk;
         done += chunk;
     }
+    if (shared && n_steps > 0) TRY(enqueue_shared_c(c, k, g, c->t - 1));     // phase C of the last batch-step
     if (stats_out) {
         HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1156,7 +1234,7 @@ int rsrl_hip_timing_read(rsrl_hip_ctx* c, double* ms_total, uint64_t* launches, 
         tot += ms;
     }
     if (ms_total) *ms_total = tot;
-    if (launches) *launches = c->events_used;
+    if (launches) { uint64_t n = 0; for (size_t i = 0; i < c->events_used; ++i) n += c->event_launches[i]; *launches = n; }
     if (kernel_name) *kernel_name = c->kernel_name;
     return RSRL_HIP_OK;
 }

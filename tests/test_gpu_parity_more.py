@@ -246,3 +246,33 @@ def test_checkpoint_roundtrip_and_resume(ra, tmp_path):
         t.set_weights(np.zeros((1024, 2), dtype=np.float32))
         t.load_weights(tmp_path / "t.rsrlw")
         assert np.array_equal(t.get_weights(), np.arange(2048, dtype=np.float32).reshape(1024, 2))
+
+
+@pytest.mark.parametrize("name,kw,bitwise", [
+    ("k1", dict(n_envs=5000, policy=1, epsilon=0.1, seed=2, max_episode_steps=60, steps_per_launch=1), True),
+    ("shared-dense", dict(n_envs=5000, policy=1, epsilon=0.1, seed=2, max_episode_steps=60, weight_mode=1, lr=1e-5), True),
+    ("shared-tile", dict(domain=1, basis=1, algo=1, n_envs=5000, policy=1, epsilon=0.1, seed=2, max_episode_steps=60, weight_mode=1, lr=1e-4), False),
+])
+def test_graph_replay_equals_plain_launches(ra, monkeypatch, name, kw, bitwise):
+    # the launch-bound loops (one batch-step per launch) are replayed as a captured hipGraph of 32 steps whose nodes read
+    # the step counter from the device; RSRL_NO_GRAPH=1 keeps plain launches.  Same results either way, including across
+    # a change of the kernel arguments (set_epsilon re-captures) and chunk sizes that are not multiples of 32.
+    def run(no_graph):
+        if no_graph:
+            monkeypatch.setenv("RSRL_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("RSRL_NO_GRAPH", raising=False)
+        with ra.Context(**kw) as c:
+            c.reset()
+            c.train(100, want_stats=False)
+            c.train(7, want_stats=False)
+            c.set_epsilon(0.05)
+            c.train(77, want_stats=False)
+            st = c.train(40)                   # statistics requested: plain launches
+            assert c.step_count == 224
+            return c.get_weights(3), c.states, c.actions, st["episodes"]
+    a, b = run(False), run(True)
+    if bitwise:
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    else:                                      # f32 atomics: the order of the adds is not fixed
+        assert np.allclose(a[0], b[0], rtol=0, atol=1e-6) and (np.abs(a[1] - b[1]) <= 1e-5).mean() > 0.98
