@@ -202,7 +202,7 @@ template <int A, int F, bool PK> struct WBuf {
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
-            for (int f = 0; f < F; ++f) w[b][f] = fmaxf(lo, fminf(hi, w[b][f]));
+            for (int f = 0; f < F; ++f) w[b][f] = __builtin_amdgcn_fmed3f(w[b][f], lo, hi);      // one v_med3_f32, not min + max + canonicalise
     }
 };
 template <int A, int F> struct WBuf<A, F, true> {
@@ -239,8 +239,8 @@ template <int A, int F> struct WBuf<A, F, true> {
         for (int b = 0; b < A; ++b)
 #pragma unroll
             for (int j = 0; j < F / 2; ++j) {
-                w[b][j].x = fmaxf(lo, fminf(hi, w[b][j].x));
-                w[b][j].y = fmaxf(lo, fminf(hi, w[b][j].y));
+                w[b][j].x = __builtin_amdgcn_fmed3f(w[b][j].x, lo, hi);      // one v_med3_f32, not min + max + canonicalise
+                w[b][j].y = __builtin_amdgcn_fmed3f(w[b][j].y, lo, hi);
             }
     }
 };
