@@ -339,10 +339,15 @@ def test_cpp_example_runs_on_gpu(tmp_path):
     assert "OOS:" in out.stdout and "fused: 768000 env-steps" in out.stdout
 
 
-@pytest.mark.parametrize("name,args,expect", [("sarsa_lambda", ["128", "6", "400"], "max |trace|"), ("greedy_gq", ["128", "4", "500"], "max |fa_td weight|")])
-def test_cpp_examples_of_the_next_rows_run_on_gpu(tmp_path, name, args, expect):
-    # examples/sarsa_lambda.cpp / greedy_gq.cpp: the reference's examples of the same names through the C++ mirror
+@pytest.mark.parametrize("name,args,pattern", [
+    ("sarsa_lambda", ["128", "6", "400"], r"max \|trace\| of learner 0: ([0-9.eE+-]+)"),
+    ("greedy_gq", ["128", "4", "500"], r"max \|fa_td weight\| of learner 0: ([0-9.eE+-]+)"),
+    ("pal", ["128", "3", "500"], r"mean \|residual\| ([0-9.eE+-]+)"),
+])
+def test_cpp_examples_of_the_next_rows_run_on_gpu(tmp_path, name, args, pattern):
+    # examples/sarsa_lambda.cpp / greedy_gq.cpp / pal.cpp: the reference's examples of the same names through the C++ mirror
     import os
+    import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib_dir = os.path.join(root, "rsrl_amd", "lib")
@@ -352,6 +357,6 @@ def test_cpp_examples_of_the_next_rows_run_on_gpu(tmp_path, name, args, expect):
                            "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     out = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert "OOS:" in out.stdout and expect in out.stdout
-    val = float(out.stdout.split(expect)[1].split(":")[1].split()[0])
-    assert val > 0
+    m = re.search(pattern, out.stdout)
+    assert "OOS:" in out.stdout and m, out.stdout
+    assert float(m.group(1)) > 0
