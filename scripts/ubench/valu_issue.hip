@@ -11,7 +11,8 @@
 constexpr int ITER = 2000;
 
 template <int KIND>
-__global__ void k(float* out, int iters) {
+__global__ void k(float* out, int iters, int half_exec) {
+    if (half_exec && (threadIdx.x & 32)) return;      // only lanes 0..31 of every wave stay active
     float a[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) a[i] = (float)threadIdx.x * 1e-3f + i;
@@ -62,15 +63,15 @@ __global__ void k(float* out, int iters) {
 }
 
 template <int KIND>
-int run(const char* name, int ops_per_iter, float* d_out) {
+int run(const char* name, int ops_per_iter, float* d_out, int half_exec = 0) {
     for (int wps : {1, 2, 4, 8}) {
         const int blocks = 256 * wps;     // 256 threads = 4 waves per block = one wave per SIMD per block
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, 10, half_exec);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, ITER);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, d_out, ITER, half_exec);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -91,5 +92,8 @@ int main() {
     run<2>("pk_fma x8 independent", 64, d_out);
     run<3>("mad_u64_u32 x4 (+xor)", 64 * 2, d_out);
     run<5>("cndmask x16", 64 * 2, d_out);
+    // does a wave with half of its lanes masked off issue faster?  (it does not: see profiles/r01_ubench_valu_issue.txt)
+    run<0>("fma x16 indep, 32 lanes", 64, d_out, 1);
+    run<2>("pk_fma x8 indep, 32 lanes", 64, d_out, 1);
     return 0;
 }
