@@ -196,7 +196,14 @@ int FN(orc_domain_step)(int domain, R* s, int a, R* reward) {
 void FN(orc_fourier_project)(int order, int D, const R* lo, const R* hi, const R* s, R* phi) {
     int n1 = order + 1, F = 1, i, k, c[8];
     R sc[8];
-    for (i = 0; i < D; i++) { F *= n1; sc[i] = (s[i] - lo[i]) / (hi[i] - lo[i]); }
+    for (i = 0; i < D; i++) {
+        F *= n1;
+#ifdef ORC_SEPARABLE
+        sc[i] = (s[i] - lo[i]) * ((R)1.0 / (hi[i] - lo[i]));      /* device op order: multiply by the rounded reciprocal */
+#else
+        sc[i] = (s[i] - lo[i]) / (hi[i] - lo[i]);
+#endif
+    }
 #ifdef ORC_SEPARABLE
     {
         R ct[8][16], st[8][16];

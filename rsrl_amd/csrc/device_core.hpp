@@ -446,7 +446,10 @@ struct FourierTables {
         static_for<0, D>([&](auto Dd) {
             constexpr int d = Dd;
             constexpr float lo = (float)Dom::lo_d(d), hi = (float)Dom::hi_d(d);
-            const float sc = (s[d] - lo) / (hi - lo);
+            // s~ = (s - lo) * fl(1/(hi - lo)): a true division is a ~10-deep dependent sequence on the critical path of every
+            // step; the f32 oracle mirrors the multiply, the f64 oracle keeps the reference's division (<= 1.5 ulp apart)
+            constexpr float inv = 1.0f / (hi - lo);
+            const float sc = (s[d] - lo) * inv;
             ct[d][0] = 1.0f; st[d][0] = 0.0f;
             if constexpr (ORDER >= 1) sincospi01(sc, st[d][1], ct[d][1]);
             static_for<2, N1>([&](auto Nn) {

@@ -227,7 +227,8 @@ struct FourierGenericModel {
         static_for<0, D>([&](auto Dd) {
             constexpr int d = Dd;
             constexpr float lo = (float)Dom::lo_d(d), hi = (float)Dom::hi_d(d);
-            const float sc = (s[d] - lo) / (hi - lo);
+            constexpr float inv = 1.0f / (hi - lo);                 // as FourierTables::build
+            const float sc = (s[d] - lo) * inv;
             ft.ct[d][0] = 1.0f; ft.st[d][0] = 0.0f;
             sincospi01(sc, ft.st[d][1], ft.ct[d][1]);
             for (int n = 2; n <= order; ++n) {
