@@ -130,9 +130,14 @@ template <> struct Domain<0> {
     __device__ static __forceinline__ void reset(float (&s)[D]) { s[0] = -0.5f; s[1] = 0.0f; }   // :68-70
     __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) { return s[0] >= 0.6f; }  // :76-82
     // update_state + dv (:58-65): v first, the NEW v moves x; no velocity reset at the left wall
-    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
+    // the action-independent part of the transition: the fused loop evaluates it as soon as the state is known, long before
+    // the next action is chosen, which takes the cos chain off the step's critical path (policy -> action -> transition)
+    struct Pre { float cos3x; };
+    __device__ static __forceinline__ Pre pre(const float (&s)[D]) { return Pre{cos_cw(3.0f * s[0])}; }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) { return step(s, a, r, pre(s)); }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r, const Pre& p) {
         const float act = (float)(a - 1);                              // ALL_ACTIONS [-1,0,1] (:22)
-        const float dv = 0.001f * act + -0.0025f * cos_cw(3.0f * s[0]);
+        const float dv = 0.001f * act + -0.0025f * p.cos3x;
         const float v = clipf(-0.07f, s[1] + dv, 0.07f);
         const float x = clipf(-1.2f, s[0] + v, 0.6f);
         s[0] = x; s[1] = v;
@@ -175,6 +180,9 @@ template <> struct Domain<1> {
         constexpr float TW = (float)(kPi / 15.0);
         return s[0] <= -2.4f || s[0] >= 2.4f || s[2] <= -TW || s[2] >= TW;
     }
+    struct Pre {};                                                    // nothing of the RK4 step is action-independent
+    __device__ static __forceinline__ Pre pre(const float (&)[D]) { return Pre{}; }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r, const Pre&) { return step(s, a, r); }
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         constexpr float TW = (float)(kPi / 15.0);
         const float force = (a == 0) ? -10.0f : 10.0f;                 // ALL_ACTIONS (:26)
@@ -214,6 +222,9 @@ template <> struct Domain<2> {
     __device__ static __forceinline__ bool is_terminal(const float (&s)[D]) {                          // :56-58
         return cos_cw(s[0]) + cos_cw(s[0] + s[1]) < -1.0f;
     }
+    struct Pre {};
+    __device__ static __forceinline__ Pre pre(const float (&)[D]) { return Pre{}; }
+    __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r, const Pre&) { return step(s, a, r); }
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         constexpr float PI_ = (float)kPi;
         const float torque = (float)(a - 1);                           // ALL_ACTIONS (:35-36)

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             q_s.set<A>(q0);
         }
         int a_taken = a;
+        typename Dom::Pre pre_s = Dom::pre(s);
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
 
         auto one_step = [&](const Phi& phi_s, Phi& phi_n, uint64_t t) {
@@ -349,10 +350,11 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
             float r;
-            const bool term = Dom::step(ns, a, r);
+            const bool term = Dom::step(ns, a, r, pre_s);
             ep += 1;
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);              // select, not a branch: phi/Q of s0 take the s' slot
+            pre_s = Dom::pre(ns);                  // action-independent part of the NEXT transition, off the critical path
             float q_n[A];
             { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
             w.q(phi_n, q_n);
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             if (trunc) {                           // step cap: Q(s') was needed above, now the new episode
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
+                pre_s = Dom::pre(ns);
                 { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
                 w.q(phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
