@@ -27,7 +27,8 @@ struct Common {
     int32_t* action;       // [N]
     uint32_t* ep_step;     // [N]
     float* W;              // [A][F][Nw]
-    int64_t w_stride;      // Nw: n_envs (per-env) or 1 (shared)
+    int64_t w_stride;      // stride between consecutive (action, feature) rows: n_envs (feature-major), 1 (shared, learner-major)
+    int64_t w_ls;          // stride between learners: 1 (feature-major / shared), A*F (learner-major, the single-step layout)
     int shared;            // one approximator for all learners (weight_mode == RSRL_W_SHARED)
     float* qcache;         // [A][N] Q(s,.) of the CURRENT state with the current weights, carried between launches
     int q_valid;           // 0: qcache is stale (weights/states were changed from outside) -> recompute from W
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
-            for (int f = 0; f < F; ++f) w.put(b, f, c.W[((int64_t)(b * F + f)) * N + i]);
+            for (int f = 0; f < F; ++f) w.put(b, f, c.W[((int64_t)(b * F + f)) * c.w_stride + i * c.w_ls]);
 
         static_assert(A <= 3, "QCarry holds up to 3 actions");
         Phi phi_a, phi_b;
@@ -433,13 +434,13 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
                 float v = w.get(0, f);
 #pragma unroll
                 for (int b = 1; b < A; ++b) v = (a_taken == b) ? w.get(b, f) : v;
-                c.W[((int64_t)(a_taken * F + f)) * N + i] = v;
+                c.W[((int64_t)(a_taken * F + f)) * c.w_stride + i * c.w_ls] = v;
             }
         } else {
 #pragma unroll
             for (int b = 0; b < A; ++b)
 #pragma unroll
-                for (int f = 0; f < F; ++f) c.W[((int64_t)(b * F + f)) * N + i] = w.get(b, f);
+                for (int f = 0; f < F; ++f) c.W[((int64_t)(b * F + f)) * c.w_stride + i * c.w_ls] = w.get(b, f);
         }
     }
 
@@ -570,6 +571,172 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
             Dom::reset(ns);
             Bas::project(ns, phi_n);
             q_from_reg<A, F>(wv, phi_n, q_n);
+            const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+            na = policy_sample<A>(pol, q_n, xr);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+        c.action[i] = na;
+        c.ep_step[i] = ep;
+#pragma unroll
+        for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// The single-step streaming kernel on the LEARNER-MAJOR layout W[N][A][F] (what a ctx created with steps_per_launch = 1
+// uses when A*F is a multiple of 4).  With the feature-major layout every (action, feature) row is a full line per wave and
+// the lane-dependent column dirties all A lines of every feature: 432 B written per learner for 144 B changed.  Here a
+// learner's weights are contiguous:
+//   read : the wave's 64 learners = one contiguous 64*A*F*4 B image, coalesced 16 B per lane, transposed through LDS
+//          (ds_write_b128 linear, ds_read_b128 at lane*A*F*4 + 16k: with A*F = 108 dwords the 16 lanes of a pass hit
+//          disjoint banks);
+//   write: ONLY the touched column, F*4 contiguous bytes per learner (16 B stores); the column's old values are re-read
+//          from the LDS image at a lane-dependent address, so no select chains.
+// => 432 B read + 144 B written per learner-step, the 608 B/env-step accounting of SURVEY 8(d), instead of 432 + 432.
+// Arithmetic is bit-identical to k_step_reg / k_train_reg (same helpers, same op order).
+// Precondition (host): per-env weights, (A*F) % 4 == 0, F % 4 == 0, A*F*N*4 < 2^32.
+// ---------------------------------------------------------------------------------------
+template <int DOMAIN, int ORDER, int ALGO, int POLICY>
+__global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;
+    using Dom = Domain<DOMAIN>;
+    using Bas = FourierReg<DOMAIN, ORDER>;
+    constexpr int D = Dom::D, A = Dom::A, F = Bas::F, AF = A * F;
+    static_assert(AF % 4 == 0 && F % 4 == 0, "16-byte rows");
+    constexpr int AF4 = AF / 4, F4 = F / 4;
+    __shared__ __attribute__((aligned(16))) float lds[kBlock * AF];
+    const int64_t N = c.n_envs;
+    const int lane = (int)(threadIdx.x & 63), wv_id = (int)(threadIdx.x >> 6);
+    const int64_t wbase = (int64_t)blockIdx.x * kBlock + wv_id * 64;    // first learner of this wave
+    const int64_t i = wbase + lane;
+    float* __restrict__ img = lds + wv_id * 64 * AF;                    // this wave's 64 x A x F image
+    // buffer descriptor over the wave's image: loads beyond the end of W return 0, stores are dropped (last, partial wave)
+    const int64_t remain = N - wbase;
+    const uint32_t img_bytes = (uint32_t)((remain < 64 ? (remain < 0 ? 0 : remain) : 64) * AF * 4);
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(c.W + wbase * AF), 0, (int)img_bytes, 0x00020000);
+
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+
+    // the small loads the first arithmetic needs go out BEFORE the weight stream (vmcnt retires in issue order)
+    const int64_t il = i < N ? i : N - 1;
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + il];
+    const int a = c.action[il];
+    uint32_t ep = c.ep_step[il] + 1;
+    float qc0 = 0.0f, qc1 = 0.0f, qc2 = 0.0f;
+    static_assert(A <= 3, "carried-Q registers are laid out for A <= 3");
+    if (c.q_valid) {
+        qc0 = c.qcache[il];
+        qc1 = c.qcache[N + il];
+        if constexpr (A > 2) qc2 = c.qcache[2 * N + il];
+    }
+    // the image: AF4 coalesced 16-B loads per lane, all in flight ...
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    f4 ld[AF4];
+#pragma unroll
+    for (int m = 0; m < AF4; ++m)
+        ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * m) * 16, 0, 0));
+
+    // ... and everything that needs only the state runs underneath them: the transition, both projections, the draws
+    PolicyParams pol = c.pol; pol.kind = POLICY;
+    AlgoParams alg = c.alg; alg.kind = ALGO;
+    const uint32_t gid = (uint32_t)(c.env_offset + il);
+    const uint32_t cap = c.max_episode_steps;
+#pragma unroll
+    for (int d = 0; d < D; ++d) ns[d] = s[d];
+    float r;
+    const bool term = Dom::step(ns, a, r);
+    const bool trunc = !term && cap > 0 && ep >= cap;
+    if (term) Dom::reset(ns);
+    float phi_s[F], phi_n[F], q_n[A];
+    Bas::project(s, phi_s);
+    Bas::project(ns, phi_n);
+    U4 xin = U4{0, 0, 0, 0};
+    if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+    const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+
+    // transpose through LDS: linear 16-B writes, then each lane reads its own learner's A*F weights
+#pragma unroll
+    for (int m = 0; m < AF4; ++m) *reinterpret_cast<f4*>(img + (lane + 64 * m) * 4) = ld[m];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // the image is private to this wave: no block barrier
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float wv[A][F];
+#pragma unroll
+    for (int k = 0; k < AF4; ++k) {
+        const f4 v = *reinterpret_cast<const f4*>(img + lane * AF + 4 * k);
+        wv[(4 * k) / F][(4 * k) % F] = v.x; wv[(4 * k + 1) / F][(4 * k + 1) % F] = v.y;
+        wv[(4 * k + 2) / F][(4 * k + 2) % F] = v.z; wv[(4 * k + 3) / F][(4 * k + 3) % F] = v.w;
+    }
+
+    if (i < N) {
+        constexpr int P = RSRL_DOT_SPLIT;
+        float qs_arr[A];
+        if (c.q_valid) {
+            qs_arr[0] = qc0;
+            if constexpr (A > 1) qs_arr[1] = qc1;
+            if constexpr (A > 2) qs_arr[2] = qc2;
+        } else {
+            q_from_reg<A, F>(wv, phi_s, qs_arr);
+        }
+        const float qsa = (a == 0) ? qs_arr[0] : ((a == 1) ? qs_arr[A > 1 ? 1 : 0] : qs_arr[A > 2 ? 2 : 0]);
+        q_from_reg<A, F>(wv, phi_n, q_n);                              // Q(s',.) with the PRE-update weights
+        float e, delta;
+        if constexpr (ALGO == ALG_PAL) delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
+        else delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        // ---- W[:,a] += lr * e * phi(s): old column from the LDS image (lane-dependent address), new column to memory
+        const float scale = alg.lr * e;
+        float vcol[F];
+        const float* __restrict__ colp = img + lane * AF + a * F;
+        const int col_off = (lane * AF + a * F) * 4;
+#pragma unroll
+        for (int k = 0; k < F4; ++k) {
+            const f4 o = *reinterpret_cast<const f4*>(colp + 4 * k);
+            f4 v;
+            v.x = fmaf(scale, phi_s[4 * k], o.x); v.y = fmaf(scale, phi_s[4 * k + 1], o.y);
+            v.z = fmaf(scale, phi_s[4 * k + 2], o.z); v.w = fmaf(scale, phi_s[4 * k + 3], o.w);
+            vcol[4 * k] = v.x; vcol[4 * k + 1] = v.y; vcol[4 * k + 2] = v.z; vcol[4 * k + 3] = v.w;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, 0);
+        }
+        // ---- Q(s',.) with the UPDATED weights: only column a changed
+        {
+#if RSRL_RANK1_QPOST
+            float dacc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < F; ++f) dacc[f % P] = fmaf(phi_s[f], phi_n[f], dacc[f % P]);
+            const float dot = combine_partials<P>(dacc);
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
+#else
+            { float one[1][F]; float qa[1];
+#pragma unroll
+              for (int f = 0; f < F; ++f) one[0][f] = vcol[f];
+              q_from_reg<1, F>(one, phi_n, qa);
+#pragma unroll
+              for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa[0] : q_n[b]; }
+#endif
+        }
+        int na = policy_sample<A>(pol, q_n, x);
+        sum_abs = (double)fabsf(delta); sum_r = (double)r;
+        if (term) { n_ep = 1; sum_len = ep; ep = 0; }
+        if (trunc) {                               // step cap: new episode needs Q(s0) with the updated W
+            n_ep = 1; n_trunc = 1; sum_len = ep; ep = 0;
+            Dom::reset(ns);
+            Bas::project(ns, phi_n);
+            q_from_reg<A, F>(wv, phi_n, q_n);      // untouched columns: old == new
+            float one[1][F], qa[1];
+#pragma unroll
+            for (int f = 0; f < F; ++f) one[0][f] = vcol[f];
+            q_from_reg<1, F>(one, phi_n, qa);      // the touched column, same dot-product order
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa[0] : q_n[b];
             const U4 xr = draw(c.seed, gid, t, BLK_RESET);
             na = policy_sample<A>(pol, q_n, xr);
         }

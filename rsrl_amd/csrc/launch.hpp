@@ -13,7 +13,7 @@ bool launch_train_reg_d1(int order, int algo, int policy, dim3 grid, dim3 block,
 bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
                          const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats, const uint64_t* t_dev = nullptr);
 
-// chunk == -1 selects the single-step streaming kernel (k_step_reg)
+// chunk == -1 selects the single-step streaming kernel (k_step_reg), -2 its learner-major form (k_step_reg_lm)
 struct LambdaParams;
 bool launch_train_lambda(int domain, int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
                          const Common& k, const LambdaParams& lp, uint64_t t, int chunk, DevStats* stats);
@@ -38,7 +38,11 @@ bool launch_reset_td(int domain, dim3 grid, dim3 block, hipStream_t st, const Co
 
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
-        if (chunk == -1)                                                                                    \
+        if (chunk == -2) {                                                                                  \
+            if constexpr ((Domain<DM>::A * FourierReg<DM, OR>::F) % 4 == 0 && FourierReg<DM, OR>::F % 4 == 0)     \
+                hipLaunchKernelGGL((k_step_reg_lm<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats, t_dev);       \
+            else return false;                                                                              \
+        } else if (chunk == -1)                                                                             \
             hipLaunchKernelGGL((k_step_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats, t_dev);              \
         else                                                                                                \
             hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, chunk, store_col, stats); \

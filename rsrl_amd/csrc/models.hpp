@@ -44,10 +44,10 @@ struct FourierModel {
     struct Feat { float phi[F]; };
     __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom&, Feat& ft) { Bas::project(s, ft.phi); }
     __device__ static __forceinline__ int64_t widx(const Common& c, int64_t wi, int b, int f) {
-        return ((int64_t)(b * F + f)) * c.w_stride + wi;
+        return ((int64_t)(b * F + f)) * c.w_stride + wi * c.w_ls;
     }
     __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom&, const Feat& ft, float (&q)[A]) {
-        q_from_mem<A, F>(c.W, c.w_stride, wi, ft.phi, q);
+        q_from_mem<A, F>(c.W, c.w_stride, wi * c.w_ls, ft.phi, q);
     }
     __device__ static __forceinline__ float q_index(const Common& c, int64_t wi, const BasisGeom&, const Feat& ft, int a) {
         constexpr int P = RSRL_DOT_SPLIT;

@@ -72,10 +72,10 @@ __global__ void k_weights_set(float* __restrict__ W, bool tile, int64_t stride, 
     W[w_index(tile, stride, wi, F, A, j / A, j % A)] = in[j];
 }
 // grid.x covers the learners, grid.y strides over the F*A weights
-__global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, int F, int A, const float* __restrict__ in) {
+__global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, int64_t stride, int64_t ls, int F, int A, const float* __restrict__ in) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    for (int j = blockIdx.y; j < F * A; j += gridDim.y) W[w_index(tile, N, i, F, A, j / A, j % A)] = in[j];
+    for (int j = blockIdx.y; j < F * A; j += gridDim.y) W[w_index(tile, stride, i * ls, F, A, j / A, j % A)] = in[j];
 }
 // shared-W dense basis: dW[j] = sum over blocks of partials[blk][j] in a FIXED order (reproducible):
 // 8 interleaved partial sums (blocks b = p mod 8, ascending) per element, combined p = 0..7.
@@ -103,6 +103,19 @@ __global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ 
         if (W_apply) W_apply[j] += tot;                          // single rank: W_{t+1} = W_t + delta right here
         else dW[j] = tot;                                        // multi rank: the delta goes through the all-reduce first
     }
+}
+// the same sum for a learner-major W[N][AF], with every word weighted by the index it has in the feature-major layout
+// ((row)*N + learner): the checksum of the weights does not depend on the layout the ctx chose
+__global__ void k_checksum_lm(const uint32_t* __restrict__ p, int64_t N, int AF, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    const size_t n = (size_t)N * AF;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t learner = j / AF, row = j % AF;
+        acc += (unsigned long long)p[j] * (2ull * (row * (size_t)N + learner) + 1ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 // order-independent checksum: sum over words of bits * (2*index + 1)  (mod 2^64)
 __global__ void k_checksum(const uint32_t* __restrict__ p, size_t n, size_t index_offset, unsigned long long* __restrict__ out) {
@@ -151,7 +164,8 @@ struct rsrl_hip_ctx {
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
     size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
-    int64_t w_stride = 0;
+    int64_t w_stride = 0;            // stride between (action, feature) rows of W
+    int64_t w_ls = 1;                // stride between learners (A*F in the learner-major single-step layout, else 1)
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
     size_t n_stat_slots = 0;
     uint64_t t = 0;          // batch-steps executed (RNG counter)
@@ -184,7 +198,7 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.alg.kind = c->cfg.algo; k.alg.gamma = (float)c->cfg.gamma; k.alg.lr = (float)c->cfg.lr;
     k.alg.alpha = (float)c->cfg.alpha;
     k.max_episode_steps = c->cfg.max_episode_steps;
-    k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
+    k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.w_ls = c->w_ls; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
     k.qcache = c->qcache; k.q_valid = c->q_valid ? 1 : 0;
     return k;
 }
@@ -449,7 +463,15 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     const bool shared = cfg->weight_mode == RSRL_W_SHARED;
     c->w_stride = shared ? 1 : N;
     c->Aw = is_pred(cfg->algo) ? 1 : c->A;
-    c->w_elems = (size_t)c->Aw * c->F * (size_t)c->w_stride;
+    c->w_elems = (size_t)c->Aw * c->F * (size_t)(shared ? 1 : N);
+    // a ctx that steps one batch-step per launch streams W every step: learner-major rows (W[N][A][F]) let k_step_reg_lm
+    // write back only the touched column (RSRL_K1_FEATURE_MAJOR=1 keeps the feature-major layout, for A/B runs)
+    if (!shared && cfg->steps_per_launch == 1 && cfg->basis == RSRL_FOURIER && !is_wave(*cfg) && !is_generic_fourier(*cfg) &&
+        !has_aux(cfg->algo) && !is_pred(cfg->algo) && (c->A * c->F) % 4 == 0 && c->F % 4 == 0 &&
+        (uint64_t)c->w_elems * 4ull < (1ull << 32) && !getenv("RSRL_K1_FEATURE_MAJOR")) {
+        c->w_stride = 1;
+        c->w_ls = (int64_t)c->A * c->F;
+    }
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
@@ -762,7 +784,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
             hipLaunchKernelGGL((k_wave_weights_get<WT>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const WT*)c->W + env_index * (int64_t)n, c->F, c->A, ow.dev);
         });
     } else
-    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->Aw, ow.dev);
+    hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, (shared ? 0 : env_index) * c->w_ls, c->F, c->Aw, ow.dev);
     KCHECK();
     bool sync = false; TRY(flush_out(c, &ow, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -783,7 +805,7 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
             hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, env_index, (int64_t)1, c->F, c->A, d_w);
         });
     } else
-    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, shared ? 0 : env_index, c->F, c->Aw, d_w);
+    hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, (shared ? 0 : env_index) * c->w_ls, c->F, c->Aw, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
@@ -900,7 +922,8 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
             hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, (int64_t)0, c->cfg.n_envs, c->F, c->A, d_w);
         });
     } else
-    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->F, c->Aw, d_w);
+    hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->cfg.basis == RSRL_TILE_CODING ? c->cfg.n_envs : c->w_stride, c->w_ls,
+                       c->F, c->Aw, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
@@ -998,10 +1021,11 @@ static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g
 static int enqueue_k1_step(rsrl_hip_ctx* c, const Common& k, DevStats* d_stats, uint64_t t, const uint64_t* t_dev) {
     const dim3 gr(grid_for(k.n_envs)), b(kBlock);
     bool ok;
+    const int kind = c->w_ls != 1 ? -2 : -1;              // learner-major rows: k_step_reg_lm
     switch (c->cfg.domain) {
-    case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
-    case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
-    default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, -1, 1, d_stats, t_dev); break;
+    case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
+    case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
+    default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
     }
     if (!ok) return NO_MODEL(c);
     KCHECK();
@@ -1060,7 +1084,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             TRY(timing_begin(c));
             HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
             TRY(timing_end(c, kStepsPerGraph));
-            c->kernel_name = stream_k1 ? "k_step_reg" : "k_shared_ca";
+            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg") : "k_shared_ca";
             c->t += (uint64_t)kStepsPerGraph;
             done += kStepsPerGraph;
             continue;
@@ -1095,7 +1119,7 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             KCHECK();
         } else if (stream_k1) {
             TRY(enqueue_k1_step(c, k, d_stats, c->t, nullptr));
-            c->kernel_name = "k_step_reg";
+            c->kernel_name = c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg";
             c->q_valid = true; k.q_valid = 1;
         } else if (fourier && !is_generic_fourier(c->cfg)) {
             const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
@@ -1183,7 +1207,8 @@ int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
         hipLaunchKernelGGL(k_checksum, dim3(g), dim3(256), 0, c->stream, (const uint32_t*)p, n, off, d + slot);
     };
     const size_t N = (size_t)c->cfg.n_envs;
-    run(c->W, c->w_bytes, 0, 0);
+    if (c->w_ls != 1) hipLaunchKernelGGL(k_checksum_lm, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->W, (int64_t)N, c->A * c->F, d);
+    else run(c->W, c->w_bytes, 0, 0);
     run(c->Z, c->Z ? c->w_bytes : 0, (size_t)1 << 40, 0);
     run(c->state, sizeof(float) * c->D * N, 0, 1);
     run(c->action, sizeof(int32_t) * N, (size_t)1 << 36, 1);

@@ -276,3 +276,44 @@ def test_graph_replay_equals_plain_launches(ra, monkeypatch, name, kw, bitwise):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
     else:                                      # f32 atomics: the order of the adds is not fixed
         assert np.allclose(a[0], b[0], rtol=0, atol=1e-6) and (np.abs(a[1] - b[1]) <= 1e-5).mean() > 0.98
+
+
+def test_single_step_layout_is_invisible_through_the_abi(ra, orc, tmp_path, monkeypatch):
+    # a ctx created with steps_per_launch = 1 keeps W learner-major (k_step_reg_lm writes back only the touched column);
+    # nothing of that may show through the ABI: weights in/out, Q, handle, checkpoints, checksums, training results
+    kw = dict(n_envs=777, policy=1, epsilon=0.1, seed=5, max_episode_steps=70)
+    rng = np.random.default_rng(3)
+    Ws = {i: (rng.normal(size=(36, 3)) * 0.1).astype(np.float32) for i in (0, 1, 63, 64, 500, 776)}
+    s = (np.array([[-0.5], [0.0]]) + rng.normal(size=(2, 777)) * np.array([[0.3], [0.02]])).astype(np.float32)
+    with ra.Context(steps_per_launch=1, **kw) as lm, ra.Context(**kw) as fm:
+        for i, W in Ws.items():
+            lm.set_weights(W, i); fm.set_weights(W, i)
+            assert np.array_equal(lm.get_weights(i), W)
+        assert np.array_equal(lm.q_evaluate(s), fm.q_evaluate(s))
+        assert lm.checksum() == fm.checksum()
+        lm.reset(); fm.reset()
+        lm.train(150); fm.train(150)                      # 150 single-step launches (graph + plain) vs one fused launch
+        assert np.array_equal(lm.states, fm.states) and np.array_equal(lm.actions, fm.actions)
+        for i in (0, 63, 64, 776):
+            assert np.array_equal(lm.get_weights(i), fm.get_weights(i))
+        assert lm.checksum() == fm.checksum()
+        a = lm.actions.copy()
+        frm, nxt, rew, term = lm.domain_step(a)
+        fm.states = frm
+        fm.domain_step(a)
+        td1, td2 = lm.handle(frm, a, rew, nxt, term), fm.handle(frm, a, rew, nxt, term)
+        assert np.array_equal(td1, td2) and np.array_equal(lm.get_weights(64), fm.get_weights(64))
+        path = tmp_path / "w.rsrl"
+        lm.save_weights(path)
+        fm.set_weights_all(np.zeros((36, 3), np.float32))
+        fm.load_weights(path)
+        assert np.array_equal(lm.get_weights(500), fm.get_weights(500)) and lm.checksum()[0] == fm.checksum()[0]
+    # the feature-major single-step kernel stays available and gives the same bits
+    monkeypatch.setenv("RSRL_K1_FEATURE_MAJOR", "1")
+    with ra.Context(steps_per_launch=1, **kw) as c1:
+        monkeypatch.delenv("RSRL_K1_FEATURE_MAJOR")
+        with ra.Context(steps_per_launch=1, **kw) as c2:
+            c1.reset(); c2.reset()
+            c1.train(90); c2.train(90)
+            assert np.array_equal(c1.get_weights(5), c2.get_weights(5)) and np.array_equal(c1.states, c2.states)
+            assert c1.checksum() == c2.checksum()
