@@ -15,10 +15,10 @@ CONFIGS = {
     "L1 65536 MountainCar SARSA(lambda) Fourier(5) replacing traces (examples/sarsa_lambda.rs)": (dict(n_envs=65536, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.2, gamma=0.99, alpha=0.01,
                                                                                                      lam=0.7, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 2560, 256, 1040),
     "C3 262144 CartPole SARSA tiles 8x8^4 shared W": (dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA, n_envs=262144, policy=1,
-                                                          epsilon=0.1, gamma=0.99, lr=0.0125 / 262144, weight_mode=ra.W_SHARED, max_episode_steps=1000), 200, 20, 208),
+                                                          epsilon=0.1, gamma=0.99, lr=0.0125 / 262144, weight_mode=ra.W_SHARED, max_episode_steps=1000), 256, 64, 208),
     "C3' 16384 CartPole SARSA tiles 8x8^4 per-env W (4 GiB of tables)": (dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA, n_envs=16384, policy=1,
                                                                               epsilon=0.1, gamma=0.99, lr=0.0125, max_episode_steps=1000, steps_per_launch=64), 512, 64, 208),
-    "C4/8 131072 MountainCar shared-W QL Fourier(5) (one GPU's share)": (dict(n_envs=131072, policy=1, epsilon=0.1, lr=0.001 / 131072, weight_mode=ra.W_SHARED, max_episode_steps=1000), 300, 30, 32),
+    "C4/8 131072 MountainCar shared-W QL Fourier(5) (one GPU's share)": (dict(n_envs=131072, policy=1, epsilon=0.1, lr=0.001 / 131072, weight_mode=ra.W_SHARED, max_episode_steps=1000), 320, 64, 32),
     "C5/2 32768 Acrobot ExpectedSARSA Fourier(7) Softmax bf16 W (one GPU's share)": (dict(domain=2, order=7, algo=ra.EXPECTED_SARSA, policy=ra.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,
                                                                                           n_envs=32768, weight_dtype=ra.W_BF16, max_episode_steps=1000, steps_per_launch=64), 256, 64, 32816),
     "C5' 32768 Acrobot ExpectedSARSA Fourier(7) Softmax f32 W": (dict(domain=2, order=7, algo=ra.EXPECTED_SARSA, policy=ra.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,
