@@ -108,7 +108,9 @@ typedef struct {
     double   alpha;              /* ExpectedSARSA.alpha (expected_sarsa.rs:26,64)             */
     double   epsilon;            /* EpsilonGreedy.epsilon (pub field, epsilon_greedy.rs:19)  */
     double   tau;                /* Softmax.tau (softmax.rs:52); |tau| < 1e-7 is rejected (:63-66) */
-    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default)       */
+    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default = 256). 1 = one batch-step per launch:
+                                    the ctx then keeps W learner-major and streams it once per step (the 608 B/env-step
+                                    formulation), replayed as a hipGraph; results are bit-identical for every depth */
     int32_t  trace;              /* rsrl_trace (lambda agents)                                */
     void*    stream;             /* hipStream_t to run on; NULL = ctx-owned stream           */
     double   lambda;             /* Trace::{accumulating,replacing,dutch}(dim, gamma, lambda) (examples/sarsa_lambda.rs:37);
