@@ -23,6 +23,12 @@ PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get(
                     for name in ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip")}
 
 
+# rsrl_hip.hip (generic / shared-W kernels): the runtime dispatch over agents and policies leaves a few 3-float arrays
+# (Q(s,.), Q(s',.)) as allocas; promoted to LDS next to the 37 KiB reduction tile of k_shared_ca they made the kernel 2-4x
+# slower (measured 7.7 us with the arrays in scratch, 21-34 us promoted) -- keep them out of LDS in this translation unit.
+PER_SOURCE_FLAGS["rsrl_hip.hip"] = ["-mllvm", "-disable-promote-alloca-to-lds"]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

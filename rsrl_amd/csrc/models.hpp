@@ -599,20 +599,30 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     }
     if constexpr (M::kDense) {
         // block-level sum of the learners' terms through LDS, fixed order (reproducible):
-        //   tile[i][f] = lr*e_i*phi_i[f], act[i] = a_i;  thread (h, b, f) sums the learners of half h with a_i == b.
-        constexpr int F = M::F, AF = A * F, H = 2, PER = kBlock / H;
-        static_assert(H * AF <= kBlock, "dense shared-W reduction needs A*F*2 <= block size");
-        __shared__ float tile[kBlock][F + 1];          // +1: conflict-free rows
-        __shared__ int act[kBlock];
+        //   tile_t[f][i] = lr*e_i*phi_i[f] (feature-major rows, padded: conflict-free both ways), ind[b][i] = [a_i == b];
+        //   thread (h, b, f) sums the learners of half h in ascending order as ONE fma chain acc = ind*v + acc (ind in
+        //   {0, 1}: exactly "acc += v" or "acc += 0"), reading 4 learners per 16-B LDS access.  The first version walked
+        //   tile[i][f] one learner per iteration with a compare/select: latency-bound, 5.9 of the kernel's 11.9 us.
+        constexpr int F = M::F, AF = A * F, H = 2, PER = kBlock / H, LP = kBlock + 4;
+        static_assert(H * AF <= kBlock && PER % 4 == 0, "dense shared-W reduction needs A*F*2 <= block size");
+        __shared__ __attribute__((aligned(16))) float tile_t[F][LP];
+        __shared__ __attribute__((aligned(16))) float ind[A][kBlock];
         __shared__ float part[H][AF];
 #pragma unroll
-        for (int f = 0; f < F; ++f) tile[threadIdx.x][f] = scale * fs.phi[f];
-        act[threadIdx.x] = a;
+        for (int f = 0; f < F; ++f) tile_t[f][threadIdx.x] = scale * fs.phi[f];
+#pragma unroll
+        for (int b = 0; b < A; ++b) ind[b][threadIdx.x] = (a == b) ? 1.0f : 0.0f;
         __syncthreads();
         if (threadIdx.x < H * AF) {
             const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
+            const float4* __restrict__ vrow = reinterpret_cast<const float4*>(&tile_t[f][h * PER]);
+            const float4* __restrict__ drow = reinterpret_cast<const float4*>(&ind[b][h * PER]);
             float acc = 0.0f;
-            for (int i2 = h * PER; i2 < (h + 1) * PER; ++i2) acc += (act[i2] == b) ? tile[i2][f] : 0.0f;
+#pragma unroll 8
+            for (int q = 0; q < PER / 4; ++q) {
+                const float4 v = vrow[q], d = drow[q];
+                acc = fmaf(d.x, v.x, acc); acc = fmaf(d.y, v.y, acc); acc = fmaf(d.z, v.z, acc); acc = fmaf(d.w, v.w, acc);
+            }
             part[h][j] = acc;
         }
         __syncthreads();
