@@ -627,10 +627,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         }
         __syncthreads();
         if (threadIdx.x < AF) partials[(int64_t)blockIdx.x * AF + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
-        // ---- the LAST block to arrive sums the rows (fixed order: bitwise reproducible whichever block it is) and applies
-        // them -- one launch per batch-step instead of two (a dependent launch costs ~4 us + a ~4 us gap on this part).
-        // Publish / acquire as in cdna_hip_programming.md Guideline 16: stores drained, block barrier, ONE release fence,
-        // the ticket; the last arriver takes ONE acquire fence before plain loads of the other blocks' rows.
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
