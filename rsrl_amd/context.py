@@ -42,6 +42,22 @@ def device_count():
 
 
 class Context:
+    """One object graph of the reference on one GPU, times `n_envs` independent environments in lock-step:
+
+        env    = MountainCar | CartPole | Acrobot ::default()                      (domain)
+        basis  = Fourier::from_space(order, ..).with_bias() | TileCoding           (basis, order | n_tilings, tiles_per_dim)
+        q_func = make_shared(LFA::vector(basis, SGD(lr), n_actions))               (lr; weight_mode: one per env or one shared)
+        policy = Greedy | EpsilonGreedy(epsilon) | Softmax(tau) | Random           (policy, epsilon, tau)
+        agent  = QLearning{gamma} | SARSA | ExpectedSARSA{alpha} | PAL{alpha}      (algo, gamma, alpha)
+                 | SARSALambda / QLambda {trace(gamma, lam), alpha}                (lam, trace)
+                 | GreedyGQ {fa_td = LFA(SGD(lr_td))} | TD | TDLambda              (lr_td; TD/TDLambda need policy=RANDOM)
+
+    (rsrl/examples/q_learning.rs:19-32 and the other examples).  `seed` keys the per-env Philox streams by GLOBAL env id
+    (`env_offset` + local index), so a sharded run reproduces the unsharded one bit for bit.  `steps_per_launch`: fuse
+    depth of `train` (0 = 256; 1 = one batch-step per launch).  Arrays are SoA: states `(D, M)`, actions `(M,)`; weights
+    `(F, n_out)` row-major like the reference's `Parameterised::weights()`.  Every method raises `RsrlHipError` with the
+    ABI's message on failure; there is no CPU fallback."""
+
     def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
