@@ -180,6 +180,14 @@ def main():
     import rsrl_amd
     device = local_rank % max(1, rsrl_amd.device_count())     # one rank per GPU; modulo only matters on under-sized test boxes
 
+    # one-off costs that are not steps (loading the kernels' code object on first use) are paid by a throw-away 64-env ctx
+    # of the same configuration, so that --warmup 0 still times steps and nothing else
+    with rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, basis=rsrl_amd.FOURIER, order=5, algo=rsrl_amd.QLEARNING,
+                          policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.9, lr=0.001, n_envs=64, seed=0,
+                          max_episode_steps=1000, steps_per_launch=args.steps_per_launch, device=device) as prime:
+        prime.reset()
+        prime.train(2, want_stats=False)
+        prime.sync()
     ctx = rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, basis=rsrl_amd.FOURIER, order=5,
                            algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1,
                            gamma=0.9, lr=0.001, n_envs=args.envs, env_offset=rank * args.envs, seed=0,
