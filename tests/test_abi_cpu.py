@@ -91,3 +91,16 @@ def test_cpp_host_mirror_compiles_against_the_abi(abi, tmp_path):
                                "-L" + lib_dir, "-lrsrl_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + lib_dir,
                                "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
         assert exe.exists()
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu():
+    # bench.py's cpu_baseline object (the oracle timed on the host cores: reference call pattern + optimised loop)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline(0.4, 0.3)
+    assert out["unit"] == "env-steps/s" and out["kind"] == "port" and out["cores"] >= 1
+    assert out["value"] > 0 and out["optimised"]["value"] > out["value"]           # fewer projections, no heap traffic
+    assert "sample" in out and abs(out["per_core"] * out["cores"] - out["value"]) < 1e-6 * out["value"]
+    assert bench.BYTES_PER_ENV_STEP == 2 * 2 * 4 + 8 + 8 + 36 * 3 * 4 + 36 * 4   # 608 B per env-step
