@@ -317,3 +317,27 @@ def test_single_step_layout_is_invisible_through_the_abi(ra, orc, tmp_path, monk
             c1.train(90); c2.train(90)
             assert np.array_equal(c1.get_weights(5), c2.get_weights(5)) and np.array_equal(c1.states, c2.states)
             assert c1.checksum() == c2.checksum()
+
+
+@pytest.mark.parametrize("name,okw,dkw,K", [
+    ("cartpole-sarsa-tiles", dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=1, policy=1, epsilon=0.1, gamma=0.99, lr=0.0125),
+     dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=1, policy=1, epsilon=0.1, gamma=0.99, lr=0.0125), 5000),
+    ("acrobot-esarsa-softmax", dict(domain=2, order=1, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.01, alpha=0.5),
+     dict(domain=2, order=1, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.01, alpha=0.5), 3000),
+])
+def test_long_run_population_statistics_other_configs(ra, orc, name, okw, dkw, K):
+    # the other agents / bases / policies over thousands of steps: individual trajectories part ways (fp32 vs f64, chaotic
+    # dynamics), the learner population must not -- episodes finished, TD error mass and weight magnitude within 2-3 %
+    N = 128
+    ag = orc.make_agent(seed=21, max_episode_steps=200, **okw)
+    run = orc.Run(ag, N, "f64")
+    run.reset()
+    ost = run.train(K)
+    with ra.Context(n_envs=N, seed=21, max_episode_steps=200, **dkw) as c:
+        c.reset()
+        st = c.train(K)
+        Wd = np.stack([c.get_weights(i) for i in range(N)])
+        assert abs(st["episodes"] - ost["episodes"]) <= 0.03 * ost["episodes"] + 3, (st["episodes"], ost["episodes"])
+        assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 0.03 * ost["sum_abs_td_error"]
+        assert abs(np.abs(Wd).mean() - np.abs(run.weights).mean()) <= 0.03 * np.abs(run.weights).mean()
+        assert abs(st["sum_reward"] - ost["sum_reward"]) <= 0.03 * abs(ost["sum_reward"]) + 3
