@@ -213,6 +213,28 @@ def test_train_fused_equals_stepwise_bitwise(ra):
         assert sa["env_steps"] == 96 * 1000 and a.step_count == 96
 
 
+@pytest.mark.parametrize("kw", [
+    dict(domain=0, order=5, algo=1, policy=1, epsilon=0.2),                 # SARSA: the inner draw block
+    dict(domain=0, order=3, algo=2, policy=2, tau=0.7, alpha=0.6),          # ExpectedSARSA + Softmax, F = 16
+    dict(domain=0, order=5, algo=5, policy=1, epsilon=0.1, alpha=0.5),      # PAL
+    dict(domain=0, order=4, algo=0, policy=1, epsilon=0.1),                 # A*F = 75: not a multiple of 4 -> feature-major kernel
+    dict(domain=1, order=1, algo=0, policy=1, epsilon=0.1),                 # CartPole, A*F = 32
+    dict(domain=2, order=1, algo=1, policy=0),                              # Acrobot SARSA Greedy, A*F = 48
+])
+def test_single_step_kernels_equal_the_fused_kernel_for_every_agent(ra, kw):
+    # both single-step kernels (learner-major k_step_reg_lm, feature-major k_step_reg), plain and graph-replayed, against
+    # the fused kernel: 70 batch-steps, bit for bit, with episode restarts and step-cap truncations on the way
+    base = dict(n_envs=333, seed=7, max_episode_steps=25, gamma=0.95, lr=0.01)
+    with ra.Context(steps_per_launch=70, **base, **kw) as a, ra.Context(steps_per_launch=1, **base, **kw) as b:
+        a.reset(); b.reset()
+        sa, sb = a.train(70), b.train(35)
+        b.train(35, want_stats=False)                      # second half through the captured graph (32) + plain launches (3)
+        assert np.array_equal(a.states, b.states) and np.array_equal(a.actions, b.actions)
+        for i in (0, 63, 64, 332):
+            assert np.array_equal(a.get_weights(i), b.get_weights(i))
+        assert a.checksum() == b.checksum() and sa["env_steps"] == 2 * sb["env_steps"]
+
+
 def test_train_sharding_invariance(ra):
     # RNG streams are keyed by the GLOBAL env id: two half-size ctxs == one full-size ctx
     kw = dict(policy=1, epsilon=0.2, seed=3, max_episode_steps=30)
