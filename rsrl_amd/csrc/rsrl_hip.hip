@@ -1071,7 +1071,8 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
-    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
+    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && !has_aux(c->cfg.algo) && !is_pred(c->cfg.algo) &&
+                           spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     // launch-bound loops go through a captured graph (RSRL_NO_GRAPH=1 keeps the plain launches, for A/B runs)
     const bool graph_ok = (stream_k1 || shared) && c->own_stream && !stats_out && !(c->comm && c->world_size > 1) && !getenv("RSRL_NO_GRAPH");
     bool t_dev_set = false;
