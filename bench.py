@@ -8,12 +8,19 @@ A "step" = one pass of the hot path (transition -> handle -> sample) over the wh
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1: launched by torch.distributed.run, one rank per GPU; envs are sharded by global id with NO
-data-path collective (independent learners) => weak scaling; value = all ranks' env-steps / max-over-ranks time.
+N > 1 without a launcher (WORLD_SIZE unset): bench.py starts the N ranks itself (torch.distributed.run, one rank per
+GPU, rendezvous on 127.0.0.1).  Under a launcher it is one of the ranks.  Envs are sharded by global id with NO
+data-path collective (independent learners) => weak scaling.
+
+Timed region: a K-step call is short (K = 20 is ~40 us of GPU work), so the call is repeated R times back to back
+between ONE pair of barrier + synchronize (R is chosen so that the region lasts >= ~0.25 s and is reported in
+config.repeats); ms_per_step = region / (K * R), value = all ranks' env-steps / max-over-ranks region time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -24,6 +31,12 @@ sys.path.insert(0, ROOT)
 N_ENVS = 65536
 BYTES_PER_ENV_STEP = 608            # 2*D*4 + 8 + 8 + F*A*4 (W read) + F*4 (W column write)
 HBM_PEAK = 8.0e12                   # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_VECTOR_PEAK = 157.3e12         # MI355X_MICROARCH.md: peak FP32 (vector), spec
+N_SIMD, CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs, max clock
+# HBM bytes one launch of the fused kernel must move per learner, whatever its depth: W in + W out (2 x 432), state in/out
+# (2 x 8), action in/out (2 x 4), episode counter in/out (2 x 4), carried Q in/out (2 x 12)
+FUSED_BYTES_PER_LEARNER_LAUNCH = 2 * (432 + 8 + 4 + 4 + 12)
+TARGET_REGION_S = 0.25
 
 
 def usable_cores():
@@ -38,16 +51,22 @@ def usable_cores():
     return n
 
 
-def pmc_traffic(kernel, envs, steps_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None
-    when no pass was collected for this kernel/configuration.  bench.py cannot run rocprofv3 on itself."""
+def _profiles_json(name):
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[kernel]
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
-    if rec["envs"] != envs or abs(rec["steps_per_launch"] - steps_per_launch) > 1e-9:
-        return None
-    return rec["traffic_bytes_per_launch"]
+
+
+def pmc_traffic(kernel, envs, steps_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), or None when no pass was collected for this
+    kernel / configuration.  bench.py cannot run rocprofv3 on itself."""
+    rec = (_profiles_json("pmc_traffic.json") or {}).get(kernel)
+    for r in (rec if isinstance(rec, list) else [rec] if rec else []):
+        if r.get("envs") == envs and abs(r.get("steps_per_launch", -1) - steps_per_launch) < 1e-9:
+            return r["traffic_bytes_per_launch"]
+    return None
 
 
 def cpu_baseline(seconds=9.0, seconds_optimised=5.0):
@@ -92,6 +111,27 @@ def cpu_baseline(seconds=9.0, seconds_optimised=5.0):
                       f"{dt_o:.1f} s (optimised), oracle/rsrl_oracle.c, gcc -O2"}
 
 
+def greedy_rollout_check(ctx, sample=256, limit=500):
+    """north_star: "the 1-GPU greedy rollout length matching the CPU reference".  The device's greedy rollout
+    (Domain::rollout with policy.mode, lib.rs:448-479) over ALL learners, and -- for the first `sample` learners -- the f64
+    CPU oracle's rollout from the very same weights, side by side."""
+    import numpy as np
+    from oracle import oracle as orc
+    n_dev, _ = ctx.rollout_greedy(limit)
+    m = min(sample, ctx.N)
+    ag = orc.make_agent(policy=orc.EGREEDY, epsilon=0.1, seed=0, gamma=0.9, lr=0.001, max_episode_steps=1000)
+    run = orc.Run(ag, m, "f64")
+    for i in range(m):
+        run.weights[i] = ctx.get_weights(i).astype(np.float64)
+    n_cpu, _ = run.rollout_greedy(limit)
+    run.close()
+    return {"limit": limit, "device_mean_n_states_all_learners": float(n_dev.mean()), "sample_learners": m,
+            "device_mean_n_states": float(n_dev[:m].mean()), "cpu_reference_mean_n_states": float(n_cpu.mean()),
+            "identical_n_states_frac": float((n_dev[:m] == n_cpu).mean()),
+            "note": "CPU = f64 oracle (oracle/rsrl_oracle.c orc_run_rollout_greedy) from the same weights; a learner can "
+                    "differ only where an argmax margin is below fp32 resolution"}
+
+
 def guarded(fn, timeout_s):
     """Run a secondary measurement in a daemon thread; {"error": "timeout"} if it does not come back in time."""
     box = {}
@@ -108,8 +148,8 @@ def guarded(fn, timeout_s):
 
 
 def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
-    """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg), i.e. the 608 B/env-step
-    streaming formulation the HBM roofline is defined on.  Never part of `value`."""
+    """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg_lm), i.e. the 608 B/env-step
+    streaming formulation the HBM roofline of SURVEY 8(d) is defined on -- every byte of it really moves.  Never part of `value`."""
     try:
         ctx = rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, order=5, algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY,
                                epsilon=0.1, gamma=0.9, lr=0.001, n_envs=envs, env_offset=rank * envs, seed=0,
@@ -128,19 +168,21 @@ def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
         ach = BYTES_PER_ENV_STEP * envs / avg
         return {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
                 "traffic": pmc_traffic(kn, envs, 1), "avg_launch_ms": avg * 1e3, "launches": n,
+                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 "env_steps_per_s_this_rank": envs * steps / dt}
     except Exception as e:
         return {"error": repr(e)}
 
 
-def shared_w_leg(cp, rsrl_amd, make_sharded_context, envs_per_gpu=131072, steps=300, warmup=50):
+def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=131072, steps=320, warmup=64):
     """Secondary measurement (BASELINE.json configs[3]): 131 072 MountainCar envs per GPU, ONE shared Fourier(5)
-    approximator, per-batch-step all-reduce of the 432 B weight delta over RCCL.  Never part of `value`."""
+    approximator, per-batch-step exchange of the 432 B weight delta (RCCL all-reduce, or the one-hop peer-write).  The
+    exchange is attached for a single rank too (communicator of size 1: same sequence).  Never part of `value`."""
     try:
-        ctx = make_sharded_context(envs_per_gpu * cp.world, cp, domain=rsrl_amd.MOUNTAIN_CAR, order=5,
+        ctx = make_sharded_context(envs_per_gpu * cp.world, cp, force_exchange=True, domain=rsrl_amd.MOUNTAIN_CAR, order=5,
                                    algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.9,
                                    lr=0.001 / (envs_per_gpu * cp.world), weight_mode=rsrl_amd.W_SHARED, seed=0,
-                                   max_episode_steps=1000)
+                                   max_episode_steps=1000, exchange=exchange)
         ctx.reset()
         ctx.train(warmup, want_stats=False)
         ctx.sync()
@@ -151,34 +193,77 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, envs_per_gpu=131072, steps=
         dt = cp.max_over_ranks(time.perf_counter() - t0)
         w = ctx.get_weights()
         import numpy as np
-        chk = np.array([float(np.abs(w).sum())])
-        lo, hi = -cp.max_over_ranks(-chk[0]), cp.max_over_ranks(chk[0])
+        chk = float(np.abs(w).sum())
+        lo, hi = -cp.max_over_ranks(-chk), cp.max_over_ranks(chk)
         ctx.close()
-        return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step RCCL "
-                            f"all-reduce of the 432 B delta", "n_gpus": cp.world, "steps": steps,
+        return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step "
+                            f"{'peer-write' if exchange else 'RCCL all-reduce'} exchange of the 432 B delta", "ranks": cp.world, "steps": steps,
                 "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
                 "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
     except Exception as e:                       # never let the secondary leg take the headline down
         return {"error": repr(e)}
 
 
+def valu_roofline(kname, per_gpu_steps_per_s):
+    """The fused kernel is VALU-issue bound (profiles/r0*_pmc_summary.md: W sits in the register file, HBM is idle).  Ceiling =
+    every SIMD issuing this kernel's own instruction mix at the SATURATED per-instruction issue cost measured by
+    scripts/ubench/valu_issue.hip (profiles/r01_ubench_valu_issue.txt, 8 waves/SIMD).  Mix: profiles/isa_mix.json (static
+    count of the steady-state loop body by scripts/isa_stats.py, cross-checked against SQ_INSTS_VALU)."""
+    mix = (_profiles_json("isa_mix.json") or {}).get(kname)
+    if not mix:
+        return None
+    cost = {"pk": 4.47, "mad_u64": 4.96, "cndmask": 4.13, "other": 2.46}
+    cyc = sum(mix[k] * cost[k] for k in cost)
+    flop = mix["pk"] * 4 + mix.get("fp_fma", 0) * 2 + mix.get("fp_other", 0)
+    peak = N_SIMD * 64 * CLOCK_HZ / cyc
+    return {"bound": "valu", "achieved": per_gpu_steps_per_s, "peak": peak, "unit": "env-steps/s per GPU", "frac": per_gpu_steps_per_s / peak,
+            "valu_instr_per_env_step": sum(mix[k] for k in cost), "saturated_issue_cycles_per_env_step": cyc,
+            "fp32": {"flop_per_env_step": flop, "achieved_tflops": flop * per_gpu_steps_per_s / 1e12, "peak_tflops": FP32_VECTOR_PEAK / 1e12,
+                     "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK},
+            "source": "profiles/isa_mix.json (instruction mix of the loop body), profiles/r01_ubench_valu_issue.txt (issue cycles per "
+                      "instruction class at 8 waves/SIMD); peak = 1024 SIMDs x 64 lanes x 2.4 GHz / cycles per env-step"}
+
+
+def spawn_ranks(n):
+    """--gpus N without a launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON line through."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20480)
-    ap.add_argument("--warmup", type=int, default=2048)
+    ap.add_argument("--steps", type=int, default=2560)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--repeats", type=int, default=0, help="back-to-back repetitions of the K-step call inside the timed region (0 = auto: >= 0.25 s)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="fuse depth (0 = library default)")
     ap.add_argument("--envs", type=int, default=N_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-shared-leg", action="store_true", help="skip the secondary shared-W (RCCL) measurement")
+    ap.add_argument("--no-shared-leg", action="store_true", help="skip the secondary shared-W (exchange) measurements")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the secondary 1-step-per-launch measurement")
+    ap.add_argument("--allow-oversubscribe", action="store_true", help="let several ranks share a device (test boxes only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     from rsrl_amd.distributed import ControlPlane, make_sharded_context
     cp = ControlPlane()          # gloo control plane (rendezvous / barrier / max over ranks); no-op for one rank
     rank, local_rank, world = cp.rank, cp.info.local_rank, cp.world
     import rsrl_amd
-    device = local_rank % max(1, rsrl_amd.device_count())     # one rank per GPU; modulo only matters on under-sized test boxes
+    ndev = rsrl_amd.device_count()
+    if world > ndev and not args.allow_oversubscribe:
+        if rank == 0:
+            print(f"bench.py: {world} ranks but {ndev} visible GPU(s); one rank per GPU is the contract "
+                  "(--allow-oversubscribe shares devices on a test box)", file=sys.stderr)
+        sys.exit(2)
+    device = local_rank % max(1, ndev)
 
     # one-off costs that are not steps (loading the kernels' code object on first use) are paid by a throw-away 64-env ctx
     # of the same configuration, so that --warmup 0 still times steps and nothing else
@@ -196,74 +281,96 @@ def main():
     if args.warmup > 0:
         ctx.train(args.warmup, want_stats=False)
     ctx.sync()
+    # R: how many K-step calls make a >= 0.25 s region (one untimed calibration call; the same R on every rank)
+    repeats = args.repeats
+    if repeats <= 0:
+        t0 = time.perf_counter()
+        ctx.train(args.steps, want_stats=False)
+        ctx.sync()
+        t_call = cp.max_over_ranks(time.perf_counter() - t0)
+        repeats = int(min(200000, max(3, -(-TARGET_REGION_S // max(t_call, 1e-7)))))
     cp.barrier()
+    ctx.sync()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
-    ctx.train(args.steps, want_stats=False)
+    for _ in range(repeats):
+        ctx.train(args.steps, want_stats=False)
     ctx.sync()
     dt = time.perf_counter() - t0
     dt = cp.max_over_ranks(dt)
     cp.barrier()
     kernel_ms, launches, kname = ctx.timing_read()
     ctx.timing_enable(False)
-    n_states, _ = ctx.rollout_greedy(500)
+    rollout = guarded(lambda: greedy_rollout_check(ctx), 120) if rank == 0 else None
     # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
     streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
-    shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context), 240) if not args.no_shared_leg else None
-    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared))
+    shared = shared_peer = None
+    if not args.no_shared_leg:
+        shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
+        if not (isinstance(shared, dict) and shared.get("error") == "timeout"):
+            shared_peer = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_PEER), 240)
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared, shared_peer))
 
     if rank == 0:
-        total_env_steps = args.steps * args.envs * world
+        total_steps = args.steps * repeats
+        total_env_steps = total_steps * args.envs * world
         value = total_env_steps / dt
         avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
-        steps_per_launch = args.steps / max(1, launches)   # exact: --steps is a multiple of the fuse depth by default
-        algo_bytes_per_launch = BYTES_PER_ENV_STEP * args.envs * steps_per_launch
-        achieved = algo_bytes_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        steps_per_launch = total_steps / max(1, launches)
+        per_gpu_kernel_rate = args.envs * steps_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+        n_gpus = min(world, ndev)
+        fused = kname == "k_train_reg"
+        traffic = pmc_traffic(kname, args.envs, round(steps_per_launch))
+        traffic_src = "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json)"
+        if traffic is None and fused:
+            traffic = float(FUSED_BYTES_PER_LEARNER_LAUNCH * args.envs)
+            traffic_src = ("analytic: 920 B per learner per launch (W in + out, state, action, episode counter, carried Q), independent of the "
+                           "depth; the PMC pass at 256 steps per launch measured 1.006x this figure (profiles/pmc_traffic.json)")
         out = {
             "metric": "env-steps/sec (whole node), MountainCar Q-learning Fourier-5",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timed_region_s": dt,
             "config": {"workload": f"{args.envs} vectorised MountainCar envs per GPU, QLearning + Fourier(5), "
                                    "eps-greedy(0.1), gamma 0.9, SGD(0.001), per-env W, 1xMI355X per rank "
                                    "(BASELINE.json configs[1])",
-                       "envs_per_gpu": args.envs, "steps_per_launch": steps_per_launch,
+                       "envs_per_gpu": args.envs, "steps_per_launch": steps_per_launch, "repeats": repeats,
+                       "timed": f"{repeats} back-to-back calls of {args.steps} batch-steps between one barrier+synchronize pair",
+                       "ranks": world,
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK,
-                         "traffic": pmc_traffic(kname, args.envs, round(steps_per_launch)),
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
-                         "kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
-                         "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "note": "algorithmic bytes = 608 B/env-step (unfused streaming formulation) x env-steps "
-                                 "per launch; the fused launch keeps W in VGPRs so real HBM traffic is far lower "
-                                 "and frac may exceed 1 (see DESIGN.md)"},
-            "greedy_rollout_mean_n_states": float(n_states.mean()),
         }
+        if world > ndev:
+            out["oversubscribed"] = f"{world} ranks share {ndev} device(s): not a scaling measurement"
+        common = {"kernel": kname, "avg_launch_ms": avg_launch_s * 1e3, "launches": launches,
+                  "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src}
+        if fused:
+            # the fused kernel keeps W in the register file for the whole launch: the bytes of the streaming formulation are not
+            # moved, so the HBM "roofline" of SURVEY 8(d) does not bound it.  Its bound is VALU issue.
+            rl = valu_roofline(kname, per_gpu_kernel_rate) or {"bound": "valu", "error": "profiles/isa_mix.json missing"}
+            rl.update(common)
+            if traffic and avg_launch_s > 0:
+                rl["hbm"] = {"achieved": traffic / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": traffic / avg_launch_s / HBM_PEAK, "what": "REAL traffic of the launch / its duration"}
+            rl["streaming_formulation_equivalent"] = {
+                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+                "equivalent_GBps": BYTES_PER_ENV_STEP * per_gpu_kernel_rate / 1e9,
+                "note": "608 B/env-step x rate: what an unfused implementation would have to stream; NOT a bandwidth this kernel "
+                        "moves and not a roofline fraction (see roofline_streaming for the kernel that does move them)"}
+            out["roofline"] = rl
+        else:
+            ach = BYTES_PER_ENV_STEP * args.envs * steps_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
+            out["roofline"] = dict({"bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                                    "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}, **common)
+        if rollout is not None:
+            out["greedy_rollout"] = rollout
         if streaming is not None:
             out["roofline_streaming"] = streaming
-        # the fused kernel is VALU-issue bound (profiles/r01_pmc_summary.md).  Issue cost of one env-step at SATURATED occupancy:
-        # VALU instructions per env-step from the PMC pass (SQ_INSTS_VALU / wave / steps, profiles/pmc_traffic.json), of which the
-        # static ISA mix has 180 v_pk_fma_f32, 31 v_mad_u64_u32 and 17 v_cndmask (scripts/isa_stats.py); cycles per instruction at
-        # 8 waves/SIMD from scripts/ubench/valu_issue.hip (profiles/r01_ubench_valu_issue.txt): pk_fma 4.47, mad_u64 4.96,
-        # cndmask 4.13, everything else 2.46.  The launch itself runs at ONE wave per SIMD (65 536 learners = 1024 waves).
-        if kname == "k_train_reg":
-            try:
-                instr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["k_train_reg"]["valu_instr_per_env_step"]
-            except Exception:
-                instr = None
-            if instr:
-                n_pk, n_mad, n_cnd = 180.0, 31.0, 17.0
-                cyc = n_pk * 4.47 + n_mad * 4.96 + n_cnd * 4.13 + max(0.0, instr - n_pk - n_mad - n_cnd) * 2.46
-                simds, clk = 1024, 2.4e9
-                peak_steps = simds * 64 * clk / cyc
-                out["valu_roofline"] = {"valu_instr_per_env_step": instr, "saturated_issue_cycles_per_env_step": cyc,
-                                        "peak_env_steps_per_s_per_gpu": peak_steps, "frac": (value / world) / peak_steps,
-                                        "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU / wave / steps), scripts/isa_stats.py (static mix), "
-                                                  "profiles/r01_ubench_valu_issue.txt (cycles per instruction at 8 waves/SIMD)"}
         if shared is not None:
             out["shared_w"] = shared
+        if shared_peer is not None:
+            out["shared_w_peer"] = shared_peer
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

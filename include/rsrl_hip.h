@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 3
+#define RSRL_HIP_ABI_VERSION 4
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -77,6 +77,12 @@ typedef enum { RSRL_GREEDY = 0, RSRL_EPSILON_GREEDY = 1, RSRL_SOFTMAX = 2, RSRL_
  * (synchronous mini-batch rule; N=1 == the reference rule) */
 typedef enum { RSRL_W_PER_ENV = 0, RSRL_W_SHARED = 1 } rsrl_weight_mode;
 typedef enum { RSRL_W_F32 = 0, RSRL_W_BF16 = 1 } rsrl_weight_dtype;
+/* multi-rank shared-W: the per-batch-step exchange of the (F x A) weight delta (no reference counterpart)
+ *   RCCL : ncclAllReduce(sum) on the ctx's stream (one process per GPU, any topology)
+ *   PEER : one-hop peer-write -- every rank stores its delta into a slot of every other rank's receive buffer
+ *          (hipIpc-mapped memory: xGMI stores across GPUs) and each rank sums the slots in rank order: deterministic,
+ *          ring-free, one fabric hop (single node) */
+typedef enum { RSRL_EXCHANGE_RCCL = 0, RSRL_EXCHANGE_PEER = 1 } rsrl_exchange;
 
 typedef struct rsrl_hip_ctx rsrl_hip_ctx;
 
@@ -116,7 +122,19 @@ typedef struct {
     double   lambda;             /* Trace::{accumulating,replacing,dutch}(dim, gamma, lambda) (examples/sarsa_lambda.rs:37);
                                     the lambda agents step with `alpha` and bypass SGD(lr) (fa/linear.rs:184-196) */
     double   lr_td;              /* GreedyGQ: SGD rate of fa_td (examples/greedy_gq.rs:27 uses 0.001 next to SGD(0.1) for fa_q) */
+    /* ---- ABI 4 (struct_size-versioned: a caller built against ABI 3 passes the shorter struct and gets the defaults) ---- */
+    int32_t  agent_policy;       /* the policy OWNED BY THE AGENT: SARSA{q_func, policy, gamma} draws its inner a' from it
+                                    (sarsa.rs:35-41,61), ExpectedSARSA{.., policy, ..} takes its expectation under it
+                                    (expected_sarsa.rs:22-29,52-58), SARSALambda likewise (sarsa_lambda.rs:37-44).
+                                    -1 (default) = the behaviour policy object itself (the examples share one policy through
+                                    make_shared); otherwise an rsrl_policy with its own parameters below, e.g. a Greedy
+                                    target under an EpsilonGreedy behaviour = off-policy ExpectedSARSA                   */
+    int32_t  exchange;           /* rsrl_exchange: how ranks exchange the shared-W delta (rsrl_hip_comm_init)            */
+    double   agent_epsilon;      /* EpsilonGreedy.epsilon of the agent's policy                                          */
+    double   agent_tau;          /* Softmax.tau of the agent's policy                                                    */
 } rsrl_hip_config;
+/* size of the ABI 3 struct: the oldest layout rsrl_hip_create accepts */
+#define RSRL_HIP_CONFIG_SIZE_V3 ((uint32_t)offsetof(rsrl_hip_config, agent_policy))
 
 /* per-call statistics of rsrl_hip_train (the println! / Response{error} of the
  * reference drivers, examples/q_learning.rs:54, control/td/q_learning.rs:17-20) */
@@ -213,11 +231,18 @@ int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[
 int rsrl_hip_get_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* v /*[F][A]*/);
 int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v /*[F][A]*/);
 /* Checkpoint of the approximator(s) (the reference's only persistence story is the optional serde
- * derive on the agents, rsrl/Cargo.toml:26).  File format, little-endian:
- *   char magic[8] = "RSRLHIPW"; u32 version = 1; i32 domain, basis, order, n_tilings, tiles_per_dim, weight_mode;
- *   i32 F, A; i64 n_learners (1 in shared mode); u64 step_count; then n_learners x f32[F][A] in the reference's
- *   row-major (F, A) order (Parameterised::weights, params/mod.rs:118) -- independent of the device layout and dtype.
- * load checks that the header matches the ctx's configuration.  Traces are not saved (they are reset state). */
+ * derive on the agents, rsrl/Cargo.toml:26).  File format version 2, little-endian, serialised field by field (no padding):
+ *   offset  0  char magic[8] = "RSRLHIPW"
+ *           8  u32  version = 2
+ *          12  i32  domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A (weight columns),
+ *                   algo, weight_dtype, aux_kind (0 none, 1 eligibility traces, 2 GreedyGQ's fa_td weights)     [11 x i32]
+ *          56  i64  n_learners (1 in shared mode)
+ *          64  u64  step_count
+ *          72  n_learners x f32[F][A] weights in the reference's row-major (F, A) order (Parameterised::weights,
+ *              params/mod.rs:118), independent of the device layout and storage dtype;
+ *              then, if aux_kind != 0, n_learners x f32[F][A] of the auxiliary matrix (traces / fa_td).
+ * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header
+ * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run resumes bit-identically. */
 int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
 int rsrl_hip_load_weights(rsrl_hip_ctx* ctx, const char* path);
 /* same weights broadcast to every learner (per-env mode) */
@@ -246,6 +271,17 @@ int rsrl_hip_checksum(rsrl_hip_ctx* ctx, uint64_t out[2]);
  * by the caller's control plane (torch.distributed / MPI / files). */
 int rsrl_hip_comm_unique_id(uint8_t* id_bytes /*[128]*/);
 int rsrl_hip_comm_init(rsrl_hip_ctx* ctx, const uint8_t* id_bytes, int world_size, int rank);
+/* A communicator of size 1 is valid and runs the SAME finalize -> all-reduce -> apply sequence as world_size > 1.
+ *
+ * RSRL_EXCHANGE_PEER (config.exchange): the one-hop peer-write exchange instead of RCCL.  Every rank calls
+ * rsrl_hip_peer_export (allocates its receive buffer for world_size ranks and describes it in a 128-byte handle: an
+ * hipIpcMemHandle plus the owner's pid), the caller's control plane all-gathers the handles, then every rank calls
+ * rsrl_hip_peer_connect with all of them in rank order.  Ranks may live in different processes (one per GPU; the
+ * buffers are mapped with hipIpcOpenMemHandle) or in one process (several ctxs, any devices).  A rank that waits more
+ * than ~4 s for a peer's delta gives up: the next rsrl_hip_sync returns RSRL_HIP_ERCCL. */
+#define RSRL_HIP_PEER_HANDLE_BYTES 128
+int rsrl_hip_peer_export(rsrl_hip_ctx* ctx, int world_size, uint8_t* handle_out /*[128]*/);
+int rsrl_hip_peer_connect(rsrl_hip_ctx* ctx, const uint8_t* handles /*[world_size][128]*/, int world_size, int rank);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------
  * HIP-event timing of the kernels launched by train since the last reset, on the ctx's

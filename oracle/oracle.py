@@ -1,5 +1,8 @@
 """ctypes binding of the CPU oracle (TEST INFRASTRUCTURE ONLY).
 
+Precisions: "f64" (the reference's), "f32" (the device's arithmetic type and op order, libm transcendentals rounded
+once) and "f32d" (f32 with the device's own sincos / exp polynomials restated: bitwise comparison with the HIP path).
+
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  See oracle/rsrl_oracle.c for scope and pinning status.
 """
@@ -34,7 +37,8 @@ class Agent(C.Structure):
                 ("gamma", C.c_double), ("lr", C.c_double), ("alpha", C.c_double),
                 ("epsilon", C.c_double), ("tau", C.c_double),
                 ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32),
-                ("lam", C.c_double), ("trace", C.c_int), ("lr_td", C.c_double)]
+                ("lam", C.c_double), ("trace", C.c_int), ("lr_td", C.c_double),
+                ("apolicy", C.c_int), ("aepsilon", C.c_double), ("atau", C.c_double), ("aeps_thr", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -81,7 +85,7 @@ def _declare(L):
     L.orc_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, u32p]
     L.orc_agent_init.argtypes = [C.POINTER(Agent)] + [C.c_int] * 8 + [C.c_uint64, C.c_int64] + \
         [C.c_double] * 5 + [C.c_uint32]
-    for S, R in (("f64", C.c_double), ("f32", C.c_float)):
+    for S, R in (("f64", C.c_double), ("f32", C.c_float), ("f32d", C.c_float)):
         Rp = C.POINTER(R)
         g = lambda n: getattr(L, f"{n}_{S}")
         g("orc_domain_step").restype = C.c_int
@@ -138,6 +142,9 @@ def _declare(L):
         g("orc_handle_td").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, R, Rp, C.c_int]
         g("orc_run_train_fast").restype = C.c_int
         g("orc_run_train_fast").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_train_dev").restype = C.c_int
+        g("orc_run_train_dev").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_invalidate_q").argtypes = [C.c_void_p]
         g("orc_run_traces").restype = Rp
         g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
@@ -160,12 +167,15 @@ def _ptr(a, ct):
 def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
                gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000, lam=0.0,
-               trace=TRACE_ACCUMULATE, lr_td=0.0):
+               trace=TRACE_ACCUMULATE, lr_td=0.0, agent_policy=None, agent_epsilon=0.1, agent_tau=1.0):
     ag = Agent()
     lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
                          int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
                          max_episode_steps)
     ag.lam, ag.trace, ag.lr_td = lam, trace, lr_td
+    if agent_policy is not None:      # the agent's own policy object (sarsa.rs:35-41, expected_sarsa.rs:22-29); default: the behaviour policy
+        ag.apolicy, ag.aepsilon, ag.atau = agent_policy, agent_epsilon, agent_tau
+        ag.aeps_thr = lib().orc_eps_threshold(agent_epsilon)
     return ag
 
 
@@ -407,6 +417,18 @@ class Run:
         if self._f("orc_run_train_fast")(self._h, int(n_steps), C.byref(st)) != 0:
             raise ValueError("train_fast: QLearning on a Fourier basis with per-env weights only")
         return st.as_dict()
+
+    def train_dev(self, n_steps):
+        """The driver loop in the DEVICE's evaluation order (carried phi / Q, rank-1 post-update Q): with prec="f32d" this is
+        what the HIP path must reproduce bit for bit.  QLearning / SARSA / ExpectedSARSA / PAL, Fourier, per-env W."""
+        st = Stats()
+        if self._f("orc_run_train_dev")(self._h, int(n_steps), C.byref(st)) != 0:
+            raise ValueError("train_dev: one-step control agents on a Fourier basis with per-env weights only")
+        return st.as_dict()
+
+    def invalidate_q(self):
+        """Q(s,.) carried between train_dev calls is stale (weights / states were written from outside)"""
+        self._f("orc_run_invalidate_q")(self._h)
 
     def train_with_dw_hook(self, n_steps, hook):
         """Shared-W training; hook(dW: np.ndarray view of the local delta) runs once per batch-step before the

@@ -155,6 +155,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     ag->eps_thr = orc_eps_threshold(epsilon);
     ag->max_episode_steps = max_episode_steps;
     ag->lambda = 0.0; ag->trace = ORC_TRACE_ACCUMULATE; ag->lr_td = 0.0;
+    ag->apolicy = policy; ag->aepsilon = epsilon; ag->atau = tau; ag->aeps_thr = ag->eps_thr;
 }
 
 /* ------------------------------------------------------------------ */
@@ -176,6 +177,23 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
 #define RMAX FLT_MAX
 #define ORC_SEPARABLE 1
 #include "rsrl_oracle_impl.h"
+#undef ORC_SEPARABLE
+#undef R
+#undef FN
+#undef RC
+#undef RMAX
+
+/* f32 again with the device's own sincos / exp polynomials restated (bitwise comparison with the HIP path) */
+static const float*  basis_lo_f32d(const orc_basis* b) { return b->lo_f; }
+static const float*  basis_hi_f32d(const orc_basis* b) { return b->hi_f; }
+#define R float
+#define FN(name) name##_f32d
+#define RC(name) name##f
+#define RMAX FLT_MAX
+#define ORC_SEPARABLE 1
+#define ORC_DEVTRIG 1
+#include "rsrl_oracle_impl.h"
+#undef ORC_DEVTRIG
 #undef ORC_SEPARABLE
 #undef R
 #undef FN

@@ -48,6 +48,11 @@ typedef struct {
     double lambda;       /* eligibility traces */
     int trace;
     double lr_td;        /* GreedyGQ: SGD rate of fa_td (examples/greedy_gq.rs:27) */
+    /* the policy OWNED BY THE AGENT (SARSA{q_func, policy, gamma} sarsa.rs:35-41; ExpectedSARSA expected_sarsa.rs:22-29;
+     * SARSALambda sarsa_lambda.rs:37-44): orc_agent_init copies the behaviour policy (the examples share one object) */
+    int apolicy;
+    double aepsilon, atau;
+    uint32_t aeps_thr;
 } orc_agent;
 
 typedef struct {
@@ -107,6 +112,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     R     orc_v_evaluate_##S(const orc_basis* b, const R* w, const R* s);                                         \
     R     orc_handle_td_##S(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* ns, int term);             \
     int   orc_run_train_fast_##S(void* h, int64_t n_steps, orc_stats* st);                                        \
+    int   orc_run_train_dev_##S(void* h, int64_t n_steps, orc_stats* st);                                         \
+    void  orc_run_invalidate_q_##S(void* h);                                                                      \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
@@ -115,6 +122,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
 
 ORC_DECLARE(double, f64)
 ORC_DECLARE(float, f32)
+/* f32 with the device's sincos / exp polynomials restated: bitwise comparison with the HIP path (rsrl_oracle_impl.h) */
+ORC_DECLARE(float, f32d)
 
 #ifdef __cplusplus
 }

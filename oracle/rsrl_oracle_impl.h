@@ -20,9 +20,77 @@
 /* ------------------------------------------------------------------ */
 /* transcendental helpers: evaluate in double, round once to R         */
 /* ------------------------------------------------------------------ */
+#ifdef ORC_DEVTRIG
+/* Third instantiation (suffix _f32d): the f32 body with the DEVICE's own branch-free polynomials restated operation by
+ * operation (rsrl_amd/csrc/device_core.hpp: sincospi01, sincos_cw, exp_dev), so that the HIP path can be checked BITWISE
+ * against a CPU run for arbitrarily many steps instead of "97 % of the trajectories".  Everything else (fma chains, op
+ * order, integer decision logic, Philox) is already shared with the _f32 instantiation.  The polynomials themselves are
+ * checked against libm in tests/test_oracle_golden.py (<= 2 ulp on the ranges the path uses). */
+static inline void FN(sincospi01_dev)(R x, R* sn, R* cs) {       /* sin(pi x), cos(pi x), x in [0, 1] */
+    const R q = rintf(x * 2.0f);
+    const R r = fmaf(q, -0.5f, x);
+    const R u = r * r;
+    R ps = 0.08100174367427826f, pc = 0.23132924735546112f, s, c;
+    int qi;
+    ps = fmaf(ps, u, -0.5992020964622498f);
+    ps = fmaf(ps, u, 2.5501625537872314f);
+    ps = fmaf(ps, u, -5.167712688446045f);
+    ps = fmaf(ps, u, 3.1415927410125732f);
+    s = ps * r;
+    pc = fmaf(pc, u, -1.335044503211975f);
+    pc = fmaf(pc, u, 4.058707237243652f);
+    pc = fmaf(pc, u, -4.934802055358887f);
+    c = fmaf(pc, u, 1.0f);
+    qi = (int)q;
+    *sn = (qi == 1) ? c : ((qi == 2) ? -s : s);
+    *cs = (qi == 1) ? -s : ((qi == 2) ? -c : c);
+}
+static inline void FN(sincos_cw_dev)(R x, R* sn, R* cs) {        /* sin(x), cos(x), |x| <= 100 */
+    const R n = rintf(x * 0.6366197466850281f);
+    R r = fmaf(n, -1.5707963705062866f, x), u, ps, pc, s, c;
+    int q;
+    r = fmaf(n, 4.371138828673793e-08f, r);
+    u = r * r;
+    ps = 2.715809387154877e-06f;
+    ps = fmaf(ps, u, -0.00019839033484458923f);
+    ps = fmaf(ps, u, 0.008333328180015087f);
+    ps = fmaf(ps, u, -0.1666666716337204f);
+    ps = fmaf(ps, u, 1.0f);
+    s = ps * r;
+    pc = 2.4362980184378102e-05f;
+    pc = fmaf(pc, u, -0.001388643286190927f);
+    pc = fmaf(pc, u, 0.04166661202907562f);
+    pc = fmaf(pc, u, -0.5f);
+    c = fmaf(pc, u, 1.0f);
+    q = ((int)n) & 3;
+    *sn = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
+    *cs = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
+}
+static inline R FN(cos_)(R x) { R s, c; FN(sincos_cw_dev)(x, &s, &c); return c; }
+static inline R FN(sin_)(R x) { R s, c; FN(sincos_cw_dev)(x, &s, &c); return s; }
+/* exp_dev: n = rint(x log2 e), two-term Cody-Waite reduction, degree-5 polynomial in r on top of 1 + r, scaled by 2^n;
+ * below -87 the result is 0 (no denormals), above 88.5 +inf */
+static inline R FN(exp_)(R x) {
+    const R n = rintf(x * 1.4426950216293335f);
+    R r = fmaf(n, -0.693145751953125f, x), p;
+    r = fmaf(n, -1.4286067653302337e-06f, r);
+    p = 1.9875691e-4f;
+    p = fmaf(p, r, 1.3981999e-3f);
+    p = fmaf(p, r, 8.3334519e-3f);
+    p = fmaf(p, r, 4.1665795e-2f);
+    p = fmaf(p, r, 1.6666665e-1f);
+    p = fmaf(p, r, 5.0000001e-1f);
+    p = fmaf(p, r * r, r);
+    p = p + 1.0f;
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.5f) return INFINITY;
+    return ldexpf(p, (int)n);
+}
+#else
 static inline R FN(cos_)(R x) { return (R)cos((double)x); }
 static inline R FN(sin_)(R x) { return (R)sin((double)x); }
 static inline R FN(exp_)(R x) { return (R)exp((double)x); }
+#endif
 /* cos(pi * x): reference computes (PI * cx).cos() in f64 (lfa Fourier, recalled).
  * For R = double this is literally that; for R = float it is the correctly
  * rounded cospi of the f32 argument, i.e. what a good cospif approximates. */
@@ -210,7 +278,11 @@ void FN(orc_fourier_project)(int order, int D, const R* lo, const R* hi, const R
         int n;
         for (i = 0; i < D; i++) {
             ct[i][0] = (R)1.0; st[i][0] = (R)0.0;
+#ifdef ORC_DEVTRIG
+            FN(sincospi01_dev)(sc[i], &st[i][1], &ct[i][1]);
+#else
             ct[i][1] = (R)cos(M_PI * (double)sc[i]); st[i][1] = (R)sin(M_PI * (double)sc[i]);
+#endif
             for (n = 2; n <= order; n++) {
                 ct[i][n] = FN(fma_)(-st[i][n - 1], st[i][1], ct[i][n - 1] * ct[i][1]);
                 st[i][n] = FN(fma_)(ct[i][n - 1], st[i][1], st[i][n - 1] * ct[i][1]);
@@ -375,6 +447,8 @@ static int FN(greedy_sample)(const R* q, int A, uint32_t x_tie) {
     int ixs[ORC_MAX_ACTIONS], n;
     n = FN(orc_argmaxima)(q, A, ixs, NULL);
     if (n == 1) return ixs[0];
+    if (n == 0) return (int)orc_mulhi(x_tie, (uint32_t)A);   /* all Q NaN / -inf: the reference panics ("No valid maxima",
+                                                                utils.rs:70-76); the build keeps the action in [0, A) */
     return ixs[orc_mulhi(x_tie, (uint32_t)n)];
 }
 /* sample_probs_with_rng                               policies/mod.rs:45-61 */
@@ -436,7 +510,7 @@ R FN(orc_td_error)(const orc_agent* ag, const R* W, const R* s, int a, R r, cons
     } else if (ag->algo == ORC_SARSA) {
         R q[ORC_MAX_ACTIONS]; int na;
         FN(orc_q_evaluate)(b, W, A, ns, q);
-        na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x_inner);
+        na = FN(orc_policy_sample)(ag->apolicy, q, A, ag->aeps_thr, (R)ag->atau, x_inner);
         delta = r + (R)ag->gamma * q[na] - qsa;
     } else if (ag->algo == ORC_PAL) {
         /* PAL::handle  control/td/pal.rs:34-60: persistent advantage learning, the max of the advantage-learning error at
@@ -452,7 +526,7 @@ R FN(orc_td_error)(const orc_agent* ag, const R* W, const R* s, int a, R r, cons
     } else {
         R q[ORC_MAX_ACTIONS], p[ORC_MAX_ACTIONS], ev = 0; int i;
         FN(orc_q_evaluate)(b, W, A, ns, q);
-        FN(orc_policy_probs)(ag->policy, q, A, (R)ag->epsilon, (R)ag->tau, p);
+        FN(orc_policy_probs)(ag->apolicy, q, A, (R)ag->aepsilon, (R)ag->atau, p);
         for (i = 0; i < A; i++) ev = ev + q[i] * p[i];                 /* fold(0.0, acc + q*p) */
         delta = r + (R)ag->gamma * ev - qsa;
     }
@@ -501,7 +575,7 @@ R FN(orc_handle_lambda)(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r,
     } else if (ag->algo == ORC_SARSA_LAMBDA) {
         R qn[ORC_MAX_ACTIONS]; int na;
         FN(orc_q_evaluate)(b, W, A, ns, qn);
-        na = FN(orc_policy_sample)(ag->policy, qn, A, ag->eps_thr, (R)ag->tau, x_inner);
+        na = FN(orc_policy_sample)(ag->apolicy, qn, A, ag->aeps_thr, (R)ag->atau, x_inner);
         residual = r + (R)ag->gamma * qn[na] - qsa;
     } else {
         R qn[ORC_MAX_ACTIONS], m;
@@ -596,6 +670,8 @@ typedef struct {
     R* W;            /* per-env: [N][F][A]; shared: [F][A] */
     R* Z;            /* per-env [N][F][A]: eligibility traces (lambda agents) or fa_td weights (GreedyGQ) */
     uint64_t t;      /* global batch-step counter */
+    R* qc;           /* [N][A] Q(s,.) of the current state carried between orc_run_train_dev calls (the device's qcache) */
+    int q_valid;     /* 0: qc is stale -> recompute from W at the next orc_run_train_dev call */
 } FN(orc_run);
 
 static R* FN(run_W)(FN(orc_run)* run, int64_t i) {
@@ -620,11 +696,12 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->W = (R*)calloc(ag->shared_w ? FA : FA * (size_t)n_envs, sizeof(R));   /* LFA::vector zero-inits */
     run->Z = ORC_HAS_AUX(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
+    run->qc = (R*)calloc((size_t)n_envs * ORC_MAX_ACTIONS, sizeof(R)); run->q_valid = 0;
     return run;
 }
 void FN(orc_run_destroy)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h;
-    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run);
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run);
 }
 R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
 int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
@@ -640,6 +717,7 @@ void FN(orc_run_set_epsilon)(void* h, double eps) {
 void FN(orc_run_reset)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
     int D = ag->basis.dim, A = ag->n_actions; int64_t i;
+    run->q_valid = 0;
     for (i = 0; i < run->n_envs; i++) {
         R q[ORC_MAX_ACTIONS]; uint32_t x[4];
         R* s = run->state + (size_t)i * D;
@@ -772,6 +850,99 @@ int FN(orc_run_train_fast)(void* h, int64_t n_steps, orc_stats* st) {
         run->action[i] = a; run->ep_step[i] = ep;
     }
     run->t += (uint64_t)n_steps;
+    free(phi_s); free(phi_n);
+    if (st) *st = acc;
+    return 0;
+}
+
+/* The driver loop in the DEVICE's evaluation order (rsrl_amd/csrc/kernels_reg.hpp: k_train_reg / k_step_reg_lm), for bitwise
+ * comparison with the HIP path (instantiation _f32d) and as a CPU cross-check of that order against orc_run_train
+ * (_f32 / _f64: same trajectories up to rounding).  Differences from orc_run_train, all value-preserving up to rounding:
+ *   - phi(s) and Q(s,.) are carried from the previous step instead of being projected / evaluated again;
+ *   - a TERMINAL transition needs no Q(s') (delta = r - Q(s,a)): the projection slot takes s0 = Domain::default();
+ *   - Q(s',.) with the UPDATED weights = Q(s',.) with the old ones + (lr*e) * <phi(s), phi(s')> in column a (the update
+ *     is rank-1 in that column); only a step-cap truncation re-evaluates Q(s0,.) from W;
+ *   - Q(s,.) is carried across calls (qc / q_valid), as the device carries it across launches.
+ * QLearning / SARSA / ExpectedSARSA / PAL on a Fourier basis with per-env weights; returns -1 otherwise. */
+void FN(orc_run_invalidate_q)(void* h) { ((FN(orc_run)*)h)->q_valid = 0; }
+int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), f, d, j;
+    int64_t N = run->n_envs, i, k;
+    R *phi_s, *phi_n, *tmp;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (b->kind != ORC_FOURIER || ag->shared_w ||
+        !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
+    phi_s = (R*)malloc(sizeof(R) * (size_t)F); phi_n = (R*)malloc(sizeof(R) * (size_t)F);
+    for (i = 0; i < N; i++) {
+        R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i); R* qc = run->qc + (size_t)i * ORC_MAX_ACTIONS;
+        R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
+        int a = run->action[i]; uint32_t ep = run->ep_step[i];
+        FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), s, phi_s);
+        if (run->q_valid) { for (j = 0; j < A; j++) q_s[j] = qc[j]; }
+        else FN(dot_columns)(phi_s, W, A, F, q_s);
+        for (k = 0; k < n_steps; k++) {
+            const uint64_t t = run->t + (uint64_t)k;
+            R r, delta, e, scale, dot; int term, trunc, na; uint32_t x[4], xin[4] = { 0, 0, 0, 0 };
+            for (d = 0; d < D; d++) ns[d] = s[d];
+            term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+            ep += 1;
+            trunc = !term && ag->max_episode_steps > 0 && ep >= ag->max_episode_steps;
+            if (term) FN(orc_domain_reset)(ag->domain, ns);
+            FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi_n);
+            FN(dot_columns)(phi_n, W, A, F, q_n);                          /* PRE-update weights */
+            if (ag->algo == ORC_SARSA) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+            if (term) {
+                delta = r - q_s[a];
+            } else if (ag->algo == ORC_QLEARNING) {
+                R m; FN(orc_find_max)(q_n, A, &m);
+                delta = r + (R)ag->gamma * m - q_s[a];
+            } else if (ag->algo == ORC_SARSA) {
+                int ia = FN(orc_policy_sample)(ag->apolicy, q_n, A, ag->aeps_thr, (R)ag->atau, xin);
+                delta = r + (R)ag->gamma * q_n[ia] - q_s[a];
+            } else if (ag->algo == ORC_PAL) {
+                int as = FN(orc_argmax_first)(q_s, A), nas = FN(orc_argmax_first)(q_n, A);
+                R td = r + (R)ag->gamma * q_n[as] - q_s[a];
+                R al = td - (R)ag->alpha * (q_s[as] - q_s[a]);
+                R alt = td - (R)ag->alpha * (q_n[nas] - q_n[a]);
+                delta = (al > alt) ? al : alt;
+            } else {
+                R p[ORC_MAX_ACTIONS], ev = 0;
+                FN(orc_policy_probs)(ag->apolicy, q_n, A, (R)ag->aepsilon, (R)ag->atau, p);
+                for (j = 0; j < A; j++) ev = ev + q_n[j] * p[j];
+                delta = r + (R)ag->gamma * ev - q_s[a];
+            }
+            e = (ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL) ? (R)ag->alpha * delta : delta;
+            scale = (R)ag->lr * e;
+            for (f = 0; f < F; f++) W[(size_t)f * A + a] = FN(fma_)(scale, phi_s[f], W[(size_t)f * A + a]);
+            {   /* <phi(s), phi(s')> in the 4-way interleaved order of every dot product on this path */
+                R pa[4] = { 0, 0, 0, 0 };
+                for (f = 0; f < F; f++) pa[f & 3] = FN(fma_)(phi_s[f], phi_n[f], pa[f & 3]);
+                dot = (pa[0] + pa[1]) + (pa[2] + pa[3]);
+            }
+            q_n[a] = FN(fma_)(scale, dot, q_n[a]);
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, term ? ORC_BLK_RESET : ORC_BLK_STEP, x);
+            na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
+            acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
+            if (term) { acc.episodes += 1; acc.sum_episode_steps += ep; ep = 0; }
+            if (trunc) {
+                acc.episodes += 1; acc.episodes_truncated += 1; acc.sum_episode_steps += ep; ep = 0;
+                FN(orc_domain_reset)(ag->domain, ns);
+                FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi_n);
+                FN(dot_columns)(phi_n, W, A, F, q_n);                      /* UPDATED weights */
+                orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_RESET, x);
+                na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
+            }
+            for (d = 0; d < D; d++) s[d] = ns[d];
+            for (j = 0; j < A; j++) q_s[j] = q_n[j];
+            tmp = phi_s; phi_s = phi_n; phi_n = tmp;
+            a = na;
+        }
+        run->action[i] = a; run->ep_step[i] = ep;
+        for (j = 0; j < A; j++) qc[j] = q_s[j];
+    }
+    run->t += (uint64_t)n_steps;
+    run->q_valid = 1;
     free(phi_s); free(phi_n);
     if (st) *st = acc;
     return 0;

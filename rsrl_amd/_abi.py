@@ -18,6 +18,7 @@ class Config(C.Structure):
         ("epsilon", C.c_double), ("tau", C.c_double), ("steps_per_launch", C.c_uint32),
         ("trace", C.c_int32), ("stream", C.c_void_p), ("lam", C.c_double),
         ("lr_td", C.c_double),
+        ("agent_policy", C.c_int32), ("exchange", C.c_int32), ("agent_epsilon", C.c_double), ("agent_tau", C.c_double),
     ]
 
 
@@ -75,6 +76,8 @@ SYMBOLS = {
     "rsrl_hip_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rsrl_hip_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rsrl_hip_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "rsrl_hip_peer_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rsrl_hip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_char_p)]),

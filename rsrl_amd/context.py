@@ -13,6 +13,8 @@ TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
 W_F32, W_BF16 = 0, 1
+EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1
+PEER_HANDLE_BYTES = 128
 
 
 def _p(a):
@@ -51,6 +53,8 @@ class Context:
         agent  = QLearning{gamma} | SARSA | ExpectedSARSA{alpha} | PAL{alpha}      (algo, gamma, alpha)
                  | SARSALambda / QLambda {trace(gamma, lam), alpha}                (lam, trace)
                  | GreedyGQ {fa_td = LFA(SGD(lr_td))} | TD | TDLambda              (lr_td; TD/TDLambda need policy=RANDOM)
+                 SARSA / ExpectedSARSA / SARSALambda own a policy of their own       (agent_policy, agent_epsilon, agent_tau;
+                                                                                     None = the behaviour policy object)
 
     (rsrl/examples/q_learning.rs:19-32 and the other examples).  `seed` keys the per-env Philox streams by GLOBAL env id
     (`env_offset` + local index), so a sharded run reproduces the unsharded one bit for bit.  `steps_per_launch`: fuse
@@ -61,7 +65,8 @@ class Context:
     def __init__(self, domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
-                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0):
+                 max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0,
+                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -73,6 +78,9 @@ class Context:
         cfg.steps_per_launch = steps_per_launch
         cfg.lam, cfg.trace, cfg.lr_td = lam, trace, lr_td
         cfg.stream = stream
+        # the policy owned by the agent (SARSA's inner draw, ExpectedSARSA's expectation); None = the behaviour policy itself
+        cfg.agent_policy = -1 if agent_policy is None else int(agent_policy)
+        cfg.agent_epsilon, cfg.agent_tau, cfg.exchange = agent_epsilon, agent_tau, exchange
         self.cfg = cfg
         self._h = C.c_void_p()
         _abi.check(self._L.rsrl_hip_create(C.byref(cfg), C.byref(self._h)))
@@ -277,6 +285,19 @@ class Context:
     def comm_init(self, id_bytes, world_size, rank):
         buf = (C.c_uint8 * 128)(*id_bytes)
         _abi.check(self._L.rsrl_hip_comm_init(self._h, buf, int(world_size), int(rank)))
+
+    # ---- multi-GPU (shared weights): one-hop peer-write exchange (exchange=EXCHANGE_PEER)
+    def peer_export(self, world_size):
+        """this rank's receive buffer described in a 128-byte handle -- all-gather the handles through the control plane"""
+        buf = (C.c_uint8 * PEER_HANDLE_BYTES)()
+        _abi.check(self._L.rsrl_hip_peer_export(self._h, int(world_size), buf))
+        return bytes(buf)
+
+    def peer_connect(self, handles, rank):
+        """handles: the world_size handles in rank order"""
+        blob = b"".join(handles)
+        buf = (C.c_uint8 * len(blob))(*blob)
+        _abi.check(self._L.rsrl_hip_peer_connect(self._h, buf, len(handles), int(rank)))
 
     # ---- measurement
     def timing_enable(self, on=True):

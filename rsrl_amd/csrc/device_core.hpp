@@ -119,6 +119,25 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     cs = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
 }
 __device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
+// exp(x) for the softmax policy: n = rint(x log2 e), two-term Cody-Waite reduction by ln 2, degree-5 polynomial on top of
+// 1 + r, scaled by 2^n (v_ldexp_f32).  Below -87 the result is 0 (no denormals), above 88.5 +inf.  Written out (instead
+// of expf -> v_exp_f32, whose bits are unspecified) so that the test oracle can restate it and compare the softmax paths
+// bitwise; <= 1.5 ulp.
+__device__ __forceinline__ float exp_dev(float x) {
+    const float n = rintf(x * 1.4426950216293335f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.4286067653302337e-06f, r);
+    float p = 1.9875691e-4f;
+    p = fmaf(p, r, 1.3981999e-3f);
+    p = fmaf(p, r, 8.3334519e-3f);
+    p = fmaf(p, r, 4.1665795e-2f);
+    p = fmaf(p, r, 1.6666665e-1f);
+    p = fmaf(p, r, 5.0000001e-1f);
+    p = fmaf(p, r * r, r);
+    p = p + 1.0f;
+    const float y = ldexpf(p, (int)n);
+    return (x < -87.0f) ? 0.0f : ((x > 88.5f) ? __builtin_inff() : y);
+}
 
 template <int DOMAIN> struct Domain;
 
@@ -303,8 +322,14 @@ __device__ __forceinline__ int greedy_sample(const float (&q)[A], uint32_t x_tie
     const uint32_t mask = argmaxima_mask<A>(q);
     const int n = __popc(mask);
     if (n == 1) return __ffs((int)mask) - 1;
+    // no maximum at all (every Q is NaN or -inf: a diverged learner; the reference panics with "No valid maxima",
+    // utils.rs:70-76): the action indexes a weight column, so it must stay in [0, A) -- a uniform pick
+    if (n == 0) return (int)mulhi_u32(x_tie, (uint32_t)A);
     return kth_set_bit(mask, (int)mulhi_u32(x_tie, (uint32_t)n));
 }
+// caller-supplied actions index weight columns: keep them in [0, A) whatever the caller passed
+template <int A>
+__device__ __forceinline__ int clamp_action(int a) { return a < 0 ? 0 : (a > A - 1 ? A - 1 : a); }
 // softmax_stable + softmax                                                   softmax.rs:15-37
 template <int A>
 __device__ __forceinline__ void softmax_probs(const float (&q)[A], float tau, float (&p)[A]) {
@@ -313,7 +338,7 @@ __device__ __forceinline__ void softmax_probs(const float (&q)[A], float tau, fl
     for (int i = 1; i < A; ++i) m = (q[i] > m) ? q[i] : m;
     float z = 0.0f;
 #pragma unroll
-    for (int i = 0; i < A; ++i) { p[i] = expf((q[i] - m) / tau); z += p[i]; }
+    for (int i = 0; i < A; ++i) { p[i] = exp_dev((q[i] - m) / tau); z += p[i]; }
 #pragma unroll
     for (int i = 0; i < A; ++i) p[i] = fminf(p[i] / z, FLT_MAX);
 }
@@ -366,7 +391,7 @@ __device__ __forceinline__ void policy_probs(const PolicyParams& pp, const float
         return;
     }
     const uint32_t mask = argmaxima_mask<A>(q);
-    const float pg = 1.0f / (float)__popc(mask);
+    const float pg = 1.0f / (float)max(1, __popc(mask));      // empty set (all Q NaN / -inf): all-zero greedy part
 #pragma unroll
     for (int i = 0; i < A; ++i) p[i] = ((mask >> i) & 1u) ? pg : 0.0f;
     if (pp.kind == POL_EGREEDY) {

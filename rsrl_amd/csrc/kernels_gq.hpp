@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_handle_gq(Common c, GqParams gp, con
     float s[D], ns[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
-    const int a = act[i];
+    const int a = clamp_action<Dom::A>(act[i]);
     const float r = rew[i];
     const bool term = termf[i] != 0;
     float phi_s[F], phi_n[F], q_s[A], q_n[A], e_s[A];

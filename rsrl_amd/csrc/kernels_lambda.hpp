@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
             U4 xin = U4{0, 0, 0, 0};
             if constexpr (ALGO == ALG_SARSA_LAMBDA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+            float delta;          // SARSALambda owns its policy (sarsa_lambda.rs:37-44): the inner draw comes from it
+            if (ALGO == ALG_SARSA_LAMBDA && !c.apol_same) delta = td_error<A>(alg, c.apol, qsa, q_n, r, term, xin, e);
+            else delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
             // ---- W += (alpha * residual) * Z ; a terminal transition then resets the trace
             w.axpy_buf(lp.alpha * delta, z);
             cut = term;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_handle_lambda(Common c, LambdaParams
     float s[D], ns[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
-    const int a = act[i];
+    const int a = clamp_action<Dom::A>(act[i]);
     const float r = rew[i];
     const bool term = termf[i] != 0;
     float phi_s[F], phi_n[F], q_s[A], q_n[A];
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_handle_lambda(Common c, LambdaParams
     U4 xin = U4{0, 0, 0, 0};
     if (sarsa) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
     float e;
-    const float delta = td_error<A>(alg, c.pol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+    const float delta = td_error<A>(alg, c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
     const float scale = lp.alpha * delta;
 #pragma unroll
     for (int b = 0; b < A; ++b)

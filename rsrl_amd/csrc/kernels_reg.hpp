@@ -20,7 +20,9 @@ struct Common {
     int64_t n_envs;        // learners in this ctx
     int64_t env_offset;    // global id of learner 0
     uint64_t seed;
-    PolicyParams pol;
+    PolicyParams pol;      // behaviour policy (the driver's policy.sample / mode)
+    PolicyParams apol;     // the policy owned by the agent (SARSA's inner draw, ExpectedSARSA's expectation): sarsa.rs:35-41, expected_sarsa.rs:22-29
+    int apol_same;         // apol is the behaviour policy object itself (what the reference examples build with make_shared)
     AlgoParams alg;
     uint32_t max_episode_steps;
     float* state;          // [D][N]
@@ -246,6 +248,17 @@ template <int A, int F> struct WBuf<A, F, true> {
     }
 };
 
+// td_error with the agent's own policy: a wave-uniform branch keeps the common case (the agent shares the behaviour
+// policy: compile-time kind, folded switch) exactly as it was
+template <int A, int ALGO>
+__device__ __forceinline__ float td_error_ap(const AlgoParams& alg, const PolicyParams& pol, const Common& c, float qsa,
+                                             const float (&qn)[A], float r, bool term, const U4& xin, float& e) {
+    if constexpr (ALGO == ALG_SARSA || ALGO == ALG_ESARSA) {
+        if (!c.apol_same) return td_error<A>(alg, c.apol, qsa, qn, r, term, xin, e);
+    }
+    return td_error<A>(alg, pol, qsa, qn, r, term, xin, e);
+}
+
 // q[a] by a compare/select chain.  Each compare sees its own opaque copy of the index: otherwise LLVM folds the
 // chain into a dynamic extractelement, which is legalised through a private array that promote-alloca moves to LDS
 // -- an exposed ds_write/ds_read round trip on the critical path of every step.
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
                 for (int b = 0; b < A; ++b) qs_arr[b] = q_s_all[b];
                 delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
             } else {
-                delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+                delta = td_error_ap<A, ALGO>(alg, pol, c, qsa, q_n, r, term, xin, e);
             }
             // ---- Handler<StateActionUpdate>: W[:,a] += lr * e * phi(s)     fa/linear.rs:379-391
             const float scale = alg.lr * e;
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         q_from_reg<A, F>(wv, phi_n, q_n);                              // Q(s',.) with the PRE-update weights
         float e, delta;
         if constexpr (ALGO == ALG_PAL) delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
-        else delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        else delta = td_error_ap<A, ALGO>(alg, pol, c, qsa, q_n, r, term, xin, e);
         // ---- W[:,a] += lr * e * phi(s); every (action, feature) row goes back as a FULL line (the untouched
         //      columns are rewritten unchanged: the lane-dependent column would dirty all three lines anyway)
         const float scale = alg.lr * e;
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         q_from_reg<A, F>(wv, phi_n, q_n);                              // Q(s',.) with the PRE-update weights
         float e, delta;
         if constexpr (ALGO == ALG_PAL) delta = td_error_pal<A>(alg, qs_arr, q_n, a, r, term, e);
-        else delta = td_error<A>(alg, pol, qsa, q_n, r, term, xin, e);
+        else delta = td_error_ap<A, ALGO>(alg, pol, c, qsa, q_n, r, term, xin, e);
         // ---- W[:,a] += lr * e * phi(s): old column from the LDS image (lane-dependent address), new column to memory
         const float scale = alg.lr * e;
         float vcol[F];

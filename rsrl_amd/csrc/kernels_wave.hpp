@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
             (void)qsa;
             const float scale = c.alg.lr * e;
             U4 rnd = U4{0, 0, 0, 0};
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
     float s[D], ns[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
-    const int a = __builtin_amdgcn_readfirstlane(act[i]);
+    const int a = clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i]));
     const float r = rew[i];
     const bool term = termf[i] != 0;
     float phi_s[8][8], phi_n[8][8], q_s[A], q_n[A];
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
     U4 xin = U4{0, 0, 0, 0};
     if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
     float e;
-    const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+    const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
     const float scale = c.alg.lr * e;
     U4 rnd = U4{0, 0, 0, 0};
     if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_SR_BASE + (uint32_t)lane);

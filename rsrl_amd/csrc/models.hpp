@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
         float s[D], ns[D];
         load_state<M>(from, Mn, i, s);
         load_state<M>(to, Mn, i, ns);
-        a = act[i];
+        a = clamp_action<A>(act[i]);
         const float r = rew[i];
         const bool term = termf[i] != 0;
         typename M::Feat fn;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
         float e;
-        const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+        const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
         if (!shared) M::update(c, wi, g, fs, a, scale);
         if (td_out) td_out[i] = delta;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
             M::update(c, i, g, fs, a, c.alg.lr * e);
             M::q_all(c, i, g, fn, q_n);                              // UPDATED weights
             const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         float e;
-        const float delta = td_dispatch<A>(c.alg, c.pol, q_s, a, q_n, r, term, xin, e);
+        const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];

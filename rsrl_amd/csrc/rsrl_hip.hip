@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,51 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
     } else {
         *reinterpret_cast<float4*>(dW + j) = acc;
     }
+}
+// actions index weight columns: whatever a caller stored through a DEVICE pointer is brought into [0, A)
+__global__ void k_clamp_actions(int32_t* __restrict__ a, int64_t n, int A) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = a[i]; a[i] = v < 0 ? 0 : (v > A - 1 ? A - 1 : v); }
+}
+// ---- RSRL_EXCHANGE_PEER: one-hop peer-write exchange of the shared-W delta ------------------------------
+// Every rank stores its delta into slot [parity][rank] of EVERY rank's receive buffer (hipIpc-mapped: xGMI stores across
+// GPUs), as naturally aligned 8-byte granules {value bits, tag = low 32 bits of (batch-step + 1)} written by one
+// system-scope store each -- the tag travels with the value, so there is no separate flag, no fence and no second hop
+// (MI355X_MICROARCH.md, hand-off price list: "granules for latency").  Each rank then sums the world slots in RANK order:
+// every replica adds the same numbers in the same order => the replicas of W stay bit-identical, whatever the arrival
+// order.  Two parities: a rank can be at most one exchange ahead of the slowest one (it cannot pass exchange t+1 before
+// every peer has pushed t+1, i.e. finished reading t).
+__global__ __launch_bounds__(256) void k_peer_push(const float* __restrict__ dW, int n, uint2* const* __restrict__ peers, int world, int rank,
+                                                   uint64_t t, const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t g = (uint64_t)__float_as_uint(dW[j]) | ((uint64_t)(uint32_t)(t + 1) << 32);
+    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
+    for (int r = 0; r < world; ++r)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// dW[j] = sum over ranks (ascending) of slot [parity][r][j], each polled until its tag says "batch-step t".  The spin is
+// bounded (~4 s of the 100 MHz wall clock): a missing peer sets *err instead of hanging the GPU.
+__global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int n, const uint2* __restrict__ recv, int world, uint64_t t,
+                                                     const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
+    if (t_dev) t += *t_dev;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t want = (uint32_t)(t + 1);
+    const uint64_t t_start = wall_clock64();
+    float acc = 0.0f;
+    for (int r = 0; r < world; ++r) {
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(t & 1) * world + r) * (size_t)n + j);
+        uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while ((uint32_t)(g >> 32) != want) {
+            if (wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
+            __builtin_amdgcn_s_sleep(8);
+            g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        acc += __uint_as_float((uint32_t)g);
+    }
+    dW[j] = acc;
 }
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
 __global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
@@ -183,9 +229,16 @@ struct rsrl_hip_ctx {
     Common step_graph_key{};                   // kernel arguments the graph was captured with
     int step_graph_kind = 0;                   // 1 = k_step_reg, 2 = shared-W batch-step
     const char* kernel_name = "";
-    // multi-GPU shared-W: one RCCL communicator per ctx (one process per GPU)
-    ncclComm_t comm = nullptr;
+    // multi-rank shared-W (one process per GPU): the per-batch-step exchange of the weight delta
+    ncclComm_t comm = nullptr;                 // RSRL_EXCHANGE_RCCL
     int world_size = 1, rank = 0;
+    bool multi = false;                        // an exchange is attached (a communicator of size 1 included: same sequence)
+    // RSRL_EXCHANGE_PEER: one-hop peer-write.  recv = this rank's receive buffer, granules {value bits, step tag}
+    // [2 (step parity)][world][dw_elems]; peers[r] = rank r's receive buffer mapped into this process (hipIpc), own included
+    uint2* peer_recv = nullptr; size_t peer_recv_bytes = 0; int peer_world = 0;
+    std::vector<void*> peer_ptrs; std::vector<char> peer_opened;
+    uint2** d_peer_ptrs = nullptr;             // device copy of peer_ptrs
+    uint32_t* d_peer_err = nullptr;            // set by a rank that waited too long for a peer
 };
 
 static Common make_common(const rsrl_hip_ctx* c) {
@@ -195,6 +248,14 @@ static Common make_common(const rsrl_hip_ctx* c) {
     double v = c->cfg.epsilon * 16777216.0;
     k.pol.eps_thr = v <= 0.0 ? 0u : (v >= 16777216.0 ? 16777216u : (uint32_t)v);
     k.pol.eps = (float)c->cfg.epsilon; k.pol.tau = (float)c->cfg.tau;
+    if (c->cfg.agent_policy < 0) { k.apol = k.pol; k.apol_same = 1; }
+    else {
+        k.apol.kind = c->cfg.agent_policy;
+        v = c->cfg.agent_epsilon * 16777216.0;
+        k.apol.eps_thr = v <= 0.0 ? 0u : (v >= 16777216.0 ? 16777216u : (uint32_t)v);
+        k.apol.eps = (float)c->cfg.agent_epsilon; k.apol.tau = (float)c->cfg.agent_tau;
+        k.apol_same = 0;
+    }
     k.alg.kind = c->cfg.algo; k.alg.gamma = (float)c->cfg.gamma; k.alg.lr = (float)c->cfg.lr;
     k.alg.alpha = (float)c->cfg.alpha;
     k.max_episode_steps = c->cfg.max_episode_steps;
@@ -336,8 +397,48 @@ static int flush_out(rsrl_hip_ctx* c, OutBuf<T>* ob, bool* need_sync) {
     }
     return RSRL_HIP_OK;
 }
+// caller-supplied actions index weight columns (W[:,a]): a HOST array is validated (EINVAL, where the reference would
+// panic on the out-of-range column); a DEVICE array cannot be inspected from here and is clamped by the kernels instead
+static int check_host_actions(const int32_t* a, size_t n, int A) {
+    if (!a || is_device_ptr(a)) return RSRL_HIP_OK;
+    for (size_t i = 0; i < n; ++i)
+        if (a[i] < 0 || a[i] >= A) return fail(RSRL_HIP_EINVAL, "action[%zu] = %d is outside [0, %d)", i, a[i], A);
+    return RSRL_HIP_OK;
+}
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define KCHECK() HIP_TRY(hipGetLastError())
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess) return fail(RSRL_HIP_ERCCL, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+// The one exchange step of the path: sum the (F x A) f32 weight delta over the ranks so that every rank applies the
+// identical update and the replicas of W stay bit-identical.  In place on c->dW, on the ctx's stream, no host
+// synchronisation, capturable into the step graph.  A communicator of size 1 runs the same sequence (that is how the
+// multi-rank path is exercised on a one-GPU box).  At 432 B (MountainCar Fourier(5)) this is latency-bound, not link-bound.
+//   t / t_dev: the batch-step this exchange belongs to (PEER: slot parity and granule tag); t_dev != nullptr inside a graph.
+static int exchange_dw(rsrl_hip_ctx* c, uint64_t t, const uint64_t* t_dev = nullptr) {
+    if (!c->multi) return RSRL_HIP_OK;
+    const int n = (int)c->dw_elems;
+    if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {
+        hipLaunchKernelGGL(k_peer_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->d_peer_ptrs, c->world_size, c->rank, t, t_dev);
+        hipLaunchKernelGGL(k_peer_reduce, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->peer_recv, c->world_size, t, t_dev, c->d_peer_err);
+        KCHECK();
+        return RSRL_HIP_OK;
+    }
+    NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+    return RSRL_HIP_OK;
+}
+// a rank that waited too long for a peer left a mark: report it at the next synchronising call
+static int peer_check(rsrl_hip_ctx* c) {
+    if (!c->d_peer_err) return RSRL_HIP_OK;
+    uint32_t e = 0;
+    HIP_TRY(hipMemcpyAsync(&e, c->d_peer_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (e) return fail(RSRL_HIP_ERCCL, "peer exchange timed out: a rank did not deliver its weight delta (rank %d of %d)", c->rank, c->world_size);
+    return RSRL_HIP_OK;
+}
 
 // ------------------------------------------------------------------------------- API
 extern "C" {
@@ -362,6 +463,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->gamma = 0.9; cfg->lr = 0.001; cfg->alpha = 1.0; cfg->epsilon = 0.1; cfg->tau = 1.0;
     cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
     cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0; cfg->lr_td = 0.0;
+    cfg->agent_policy = -1; cfg->agent_epsilon = 0.1; cfg->agent_tau = 1.0; cfg->exchange = RSRL_EXCHANGE_RCCL;
     return RSRL_HIP_OK;
 }
 
@@ -387,6 +489,10 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    for (size_t r = 0; r < c->peer_ptrs.size(); ++r) if (c->peer_opened[r] && c->peer_ptrs[r]) (void)hipIpcCloseMemHandle(c->peer_ptrs[r]);
+    if (c->peer_recv) (void)hipFree(c->peer_recv);
+    if (c->d_peer_ptrs) (void)hipFree(c->d_peer_ptrs);
+    if (c->d_peer_err) (void)hipFree(c->d_peer_err);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSRL_HIP_OK;
@@ -409,6 +515,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
         return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
     if (cfg->weight_dtype != RSRL_W_F32 && cfg->weight_dtype != RSRL_W_BF16) return fail(RSRL_HIP_EINVAL, "unknown weight dtype %d", cfg->weight_dtype);
+    if (cfg->agent_policy < -1 || cfg->agent_policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown agent policy %d", cfg->agent_policy);
+    if (cfg->agent_policy == RSRL_SOFTMAX && std::fabs(cfg->agent_tau) < 1e-7)
+        return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
+    if (cfg->agent_policy == RSRL_EPSILON_GREEDY && !(cfg->agent_epsilon >= 0.0 && cfg->agent_epsilon <= 1.0))
+        return fail(RSRL_HIP_EINVAL, "agent_epsilon must be in [0,1]");
+    if (cfg->exchange != RSRL_EXCHANGE_RCCL && cfg->exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_EINVAL, "unknown exchange %d", cfg->exchange);
     if (cfg->basis == RSRL_FOURIER) {
         if (cfg->order < 1 || cfg->order > 7) return fail(RSRL_HIP_EINVAL, "Fourier order must be in [1, 7]");
         c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
@@ -512,8 +624,16 @@ int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask);
 
 int rsrl_hip_create(const rsrl_hip_config* cfg, rsrl_hip_ctx** out) {
     if (!cfg || !out) return fail(RSRL_HIP_EINVAL, "null argument");
-    if (cfg->struct_size != sizeof(rsrl_hip_config))
-        return fail(RSRL_HIP_EINVAL, "config struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(rsrl_hip_config));
+    // struct_size-versioned: a caller built against an older header passes a shorter struct; the fields it does not know
+    // keep the defaults of rsrl_hip_config_init
+    if (cfg->struct_size < RSRL_HIP_CONFIG_SIZE_V3 || cfg->struct_size > sizeof(rsrl_hip_config))
+        return fail(RSRL_HIP_EINVAL, "config struct_size %u not in [%u, %zu] (ABI mismatch)", cfg->struct_size,
+                    RSRL_HIP_CONFIG_SIZE_V3, sizeof(rsrl_hip_config));
+    rsrl_hip_config full;
+    rsrl_hip_config_init(&full);
+    memcpy(&full, cfg, cfg->struct_size);
+    full.struct_size = (uint32_t)sizeof(full);
+    cfg = &full;
     rsrl_hip_ctx* c = new rsrl_hip_ctx();
     int rc = create_impl(cfg, c);
     if (rc == RSRL_HIP_OK) rc = rsrl_hip_domain_reset(c, nullptr);     // envs start at Domain::default()
@@ -527,7 +647,7 @@ int rsrl_hip_sync(rsrl_hip_ctx* c) {
     CHECK_CTX(c);
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return RSRL_HIP_OK;
+    return peer_check(c);
 }
 
 int rsrl_hip_state_dim(const rsrl_hip_ctx* c) { return c ? c->D : RSRL_HIP_EINVAL; }
@@ -603,7 +723,10 @@ int rsrl_hip_get_actions(rsrl_hip_ctx* c, int32_t* actions) {
 int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
     CHECK_CTX(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(check_host_actions(actions, (size_t)c->cfg.n_envs, c->A));
     HIP_TRY(hipMemcpyAsync(c->action, actions, sizeof(int32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    hipLaunchKernelGGL(k_clamp_actions, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->action, c->cfg.n_envs, c->A);
+    KCHECK();
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
@@ -615,6 +738,7 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs; const size_t DN = (size_t)c->D * N;
     const int32_t* d_act; OutBuf<float> ofrom, onext, orew; OutBuf<uint8_t> oterm;
+    TRY(check_host_actions(actions, (size_t)N, c->A));
     TRY(stage_in(c, 0, actions, (size_t)N, &d_act));
     TRY(stage_out(c, 1, from_states, DN, &ofrom));
     TRY(stage_out(c, 2, next_states, DN, &onext));
@@ -729,6 +853,7 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     if (!from_states || !actions || !rewards || !to_states || !terminal) return fail(RSRL_HIP_EINVAL, "null argument");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch size");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    TRY(check_host_actions(actions, (size_t)M, c->A));
     const float *d_from, *d_rew, *d_to; const int32_t* d_act; const uint8_t* d_term; OutBuf<float> otd;
     TRY(stage_in(c, 0, from_states, (size_t)c->D * M, &d_from));
     TRY(stage_in(c, 1, actions, (size_t)M, &d_act));
@@ -758,6 +883,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         })) return NO_MODEL(c);
     KCHECK();
     if (c->cfg.weight_mode == RSRL_W_SHARED) {
+        // the mini-batch delta of ALL ranks is applied by every rank (replicas of W stay bit-identical): same exchange step
+        // as inside rsrl_hip_train
+        TRY(exchange_dw(c, c->t));
         const int n = (int)c->dw_elems;
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
@@ -857,53 +985,119 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) 
     return traces_rw(c, env_index, nullptr, v);
 }
 
-// ---- checkpoint: header + every learner's weights in the reference (F, A) order ---------------------------------
-struct CkptHeader {
-    char magic[8]; uint32_t version; int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A;
+// ---- checkpoint: header + every learner's weights in the reference (F, A) order -----------------------------------
+// The header is serialised FIELD BY FIELD (little-endian, no implicit padding); layout in include/rsrl_hip.h.
+namespace {
+constexpr uint32_t kCkptVersion = 2;
+constexpr size_t kCkptHeaderBytes = 72;
+struct Ckpt {
+    int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A, algo, weight_dtype, aux_kind;
     int64_t n_learners; uint64_t step_count;
 };
-static void ckpt_fill(const rsrl_hip_ctx* c, CkptHeader* h) {
-    memset(h, 0, sizeof(*h));
-    memcpy(h->magic, "RSRLHIPW", 8); h->version = 1;
-    h->domain = c->cfg.domain; h->basis = c->cfg.basis; h->order = c->cfg.order; h->n_tilings = c->cfg.n_tilings;
-    h->tiles_per_dim = c->cfg.tiles_per_dim; h->weight_mode = c->cfg.weight_mode; h->F = c->F; h->A = c->Aw;
-    h->n_learners = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : c->cfg.n_envs; h->step_count = c->t;
+int aux_kind_of(const rsrl_hip_ctx* c) { return !c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1); }   // 1 = eligibility traces, 2 = fa_td weights
+Ckpt ckpt_of(const rsrl_hip_ctx* c) {
+    Ckpt h{};
+    h.domain = c->cfg.domain; h.basis = c->cfg.basis; h.order = c->cfg.order; h.n_tilings = c->cfg.n_tilings;
+    h.tiles_per_dim = c->cfg.tiles_per_dim; h.weight_mode = c->cfg.weight_mode; h.F = c->F; h.A = c->Aw;
+    h.algo = c->cfg.algo; h.weight_dtype = c->cfg.weight_dtype; h.aux_kind = aux_kind_of(c);
+    h.n_learners = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : c->cfg.n_envs; h.step_count = c->t;
+    return h;
 }
+void put32(uint8_t*& p, uint32_t v) { for (int i = 0; i < 4; ++i) *p++ = (uint8_t)(v >> (8 * i)); }
+void put64(uint8_t*& p, uint64_t v) { for (int i = 0; i < 8; ++i) *p++ = (uint8_t)(v >> (8 * i)); }
+uint32_t get32(const uint8_t*& p) { uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)*p++ << (8 * i); return v; }
+uint64_t get64(const uint8_t*& p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v |= (uint64_t)*p++ << (8 * i); return v; }
+void ckpt_encode(const Ckpt& h, uint8_t (&buf)[kCkptHeaderBytes]) {
+    uint8_t* p = buf;
+    memcpy(p, "RSRLHIPW", 8); p += 8;
+    put32(p, kCkptVersion);
+    const int32_t f[11] = {h.domain, h.basis, h.order, h.n_tilings, h.tiles_per_dim, h.weight_mode, h.F, h.A, h.algo, h.weight_dtype, h.aux_kind};
+    for (int32_t v : f) put32(p, (uint32_t)v);
+    put64(p, (uint64_t)h.n_learners); put64(p, h.step_count);
+}
+bool ckpt_decode(const uint8_t (&buf)[kCkptHeaderBytes], Ckpt* h, uint32_t* version) {
+    const uint8_t* p = buf;
+    if (memcmp(p, "RSRLHIPW", 8) != 0) return false;
+    p += 8;
+    *version = get32(p);
+    int32_t* f[11] = {&h->domain, &h->basis, &h->order, &h->n_tilings, &h->tiles_per_dim, &h->weight_mode, &h->F, &h->A, &h->algo, &h->weight_dtype, &h->aux_kind};
+    for (int32_t* v : f) *v = (int32_t)get32(p);
+    h->n_learners = (int64_t)get64(p); h->step_count = get64(p);
+    return true;
+}
+}  // namespace
+static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in);
 int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
     CHECK_CTX(c);
     if (!path) return fail(RSRL_HIP_EINVAL, "null path");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(RSRL_HIP_EINVAL, "cannot open %s for writing", path);
-    CkptHeader h; ckpt_fill(c, &h);
+    const Ckpt h = ckpt_of(c);
+    uint8_t hdr[kCkptHeaderBytes]; ckpt_encode(h, hdr);
     int rc = RSRL_HIP_OK;
-    if (fwrite(&h, sizeof(h), 1, f) != 1) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+    if (fwrite(hdr, 1, sizeof(hdr), f) != sizeof(hdr)) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
     std::vector<float> w((size_t)c->F * c->Aw);
-    for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
-        rc = rsrl_hip_get_weights(c, i, w.data());
-        if (rc == RSRL_HIP_OK && fwrite(w.data(), sizeof(float), w.size(), f) != w.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
-    }
-    fclose(f);
+    for (int pass = 0; pass < (h.aux_kind ? 2 : 1); ++pass)            // every learner's weights, then every learner's auxiliary matrix
+        for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
+            rc = pass == 0 ? rsrl_hip_get_weights(c, i, w.data()) : traces_rw(c, i, w.data(), nullptr);
+            if (rc == RSRL_HIP_OK && fwrite(w.data(), sizeof(float), w.size(), f) != w.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+        }
+    if (fclose(f) != 0 && rc == RSRL_HIP_OK) rc = fail(RSRL_HIP_EINVAL, "closing %s failed", path);
     return rc;
 }
 int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     CHECK_CTX(c);
     if (!path) return fail(RSRL_HIP_EINVAL, "null path");
+    HIP_TRY(hipSetDevice(c->cfg.device));
     FILE* f = fopen(path, "rb");
     if (!f) return fail(RSRL_HIP_EINVAL, "cannot open %s", path);
-    CkptHeader h, want; ckpt_fill(c, &want);
+    const Ckpt want = ckpt_of(c);
+    Ckpt h{}; uint32_t version = 0; uint8_t hdr[kCkptHeaderBytes];
     int rc = RSRL_HIP_OK;
-    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RSRLHIPW", 8) != 0 || h.version != 1) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
+    if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || !ckpt_decode(hdr, &h, &version)) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
+    else if (version != kCkptVersion) rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads version %u", path, version, kCkptVersion);
     else if (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
              h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
-             h.n_learners != want.n_learners)
+             h.algo != want.algo || h.weight_dtype != want.weight_dtype || h.aux_kind != want.aux_kind || h.n_learners != want.n_learners)
         rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration", path);
-    std::vector<float> w((size_t)c->F * c->Aw);
-    for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
-        if (fread(w.data(), sizeof(float), w.size(), f) != w.size()) { rc = fail(RSRL_HIP_EINVAL, "%s is truncated", path); break; }
-        rc = rsrl_hip_set_weights(c, i, w.data());
+    const size_t per = (size_t)c->F * c->Aw;
+    if (rc == RSRL_HIP_OK) {                                             // a truncated file is refused before anything is touched
+        const long long expect = (long long)kCkptHeaderBytes + (long long)(h.aux_kind ? 2 : 1) * h.n_learners * (long long)per * 4;
+        if (fseek(f, 0, SEEK_END) != 0 || ftell(f) != expect || fseek(f, (long)kCkptHeaderBytes, SEEK_SET) != 0)
+            rc = fail(RSRL_HIP_EINVAL, "%s is truncated or has trailing bytes (expected %lld bytes)", path, expect);
     }
+    if (rc != RSRL_HIP_OK) { fclose(f); return rc; }
+    // staged: the file goes into shadow copies of W (and of the auxiliary matrix); the ctx switches to them only when
+    // every learner has been read -- a failing load leaves the ctx exactly as it was
+    float* W_old = c->W; float* Z_old = c->Z; float* W_new = nullptr; float* Z_new = nullptr;
+    hipError_t e = hipMalloc((void**)&W_new, c->w_bytes);
+    if (e == hipSuccess && Z_old) e = hipMalloc((void**)&Z_new, c->w_bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(W_new, W_old, c->w_bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && Z_old) e = hipMemcpyAsync(Z_new, Z_old, c->w_bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e != hipSuccess) {
+        if (W_new) (void)hipFree(W_new);
+        if (Z_new) (void)hipFree(Z_new);
+        fclose(f);
+        return fail(e == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "staging buffers for %s: %s", path, hipGetErrorString(e));
+    }
+    c->W = W_new; c->Z = Z_new;
+    std::vector<float> w(per);
+    for (int pass = 0; pass < (h.aux_kind ? 2 : 1); ++pass)
+        for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
+            if (fread(w.data(), sizeof(float), per, f) != per) { rc = fail(RSRL_HIP_EINVAL, "%s: read error", path); break; }
+            rc = pass == 0 ? rsrl_hip_set_weights(c, i, w.data()) : traces_rw(c, i, nullptr, w.data());
+        }
     fclose(f);
-    if (rc == RSRL_HIP_OK) c->t = h.step_count;
+    (void)hipStreamSynchronize(c->stream);
+    if (rc == RSRL_HIP_OK) {
+        (void)hipFree(W_old); if (Z_old) (void)hipFree(Z_old);
+        c->t = h.step_count; c->q_valid = false;
+    } else {
+        std::string keep = g_last_error;
+        c->W = W_old; c->Z = Z_old;
+        (void)hipFree(W_new); if (Z_new) (void)hipFree(Z_new);
+        g_last_error = keep;
+    }
     return rc;
 }
 
@@ -926,20 +1120,6 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
                        c->F, c->Aw, d_w);
     KCHECK();
     if (!is_device_ptr(w)) HIP_TRY(hipStreamSynchronize(c->stream));
-    return RSRL_HIP_OK;
-}
-
-#define NCCL_TRY(expr)                                                                                   \
-    do {                                                                                                 \
-        ncclResult_t _r = (expr);                                                                        \
-        if (_r != ncclSuccess) return fail(RSRL_HIP_ERCCL, "%s failed: %s", #expr, ncclGetErrorString(_r)); \
-    } while (0)
-// The one exchange step of the path: sum the (F x A) f32 weight delta over the ranks so that every rank
-// applies the identical update and the replicas of W stay bit-identical.  In place, on the ctx's stream,
-// no host synchronisation.  At 432 B (MountainCar Fourier(5)) this is latency-bound, not link-bound.
-static int comm_allreduce_dw(rsrl_hip_ctx* c) {
-    if (!c->comm || c->world_size == 1) return RSRL_HIP_OK;
-    NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
     return RSRL_HIP_OK;
 }
 
@@ -991,7 +1171,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
-    const bool multi = c->comm && c->world_size > 1;
+    const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
     if (dense) {
         // single rank: the finalize kernel applies the summed delta itself (W += sum; one launch less)
         hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(1024), 0, c->stream, c->partials, (int)grid.x, n, c->dW,
@@ -1003,7 +1183,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         KCHECK();
     }
     if (multi || (!dense && !c->dW_rep)) {
-        TRY(comm_allreduce_dw(c));
+        TRY(exchange_dw(c, t, t_dev));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
@@ -1074,7 +1254,8 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && !has_aux(c->cfg.algo) && !is_pred(c->cfg.algo) &&
                            spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     // launch-bound loops go through a captured graph (RSRL_NO_GRAPH=1 keeps the plain launches, for A/B runs)
-    const bool graph_ok = (stream_k1 || shared) && c->own_stream && !stats_out && !(c->comm && c->world_size > 1) && !getenv("RSRL_NO_GRAPH");
+    // (multi-rank included: the RCCL all-reduce and the peer-exchange kernels are captured with the step like any other node)
+    const bool graph_ok = (stream_k1 || shared) && c->own_stream && !stats_out && !getenv("RSRL_NO_GRAPH");
     bool t_dev_set = false;
     int64_t done = 0;
     while (done < n_steps) {
@@ -1238,8 +1419,65 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
     HIP_TRY(hipSetDevice(c->cfg.device));
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
+    if (c->multi) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
+    if (c->cfg.exchange != RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
     NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
-    c->world_size = world_size; c->rank = rank;
+    c->world_size = world_size; c->rank = rank; c->multi = true;
+    return RSRL_HIP_OK;
+}
+
+// ---- RSRL_EXCHANGE_PEER set-up: export this rank's receive buffer, connect to everybody's -----------------------------
+struct PeerBlob { uint32_t magic; int32_t pid; uint64_t ptr; uint64_t bytes; int32_t world; int32_t pad; hipIpcMemHandle_t h; };
+static_assert(sizeof(PeerBlob) <= RSRL_HIP_PEER_HANDLE_BYTES, "peer handle blob must fit the ABI slot");
+int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
+    CHECK_CTX(c);
+    if (!handle_out || world_size < 1 || world_size > 64) return fail(RSRL_HIP_EINVAL, "bad peer arguments");
+    if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no exchange: shard by env_offset instead");
+    if (c->cfg.exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
+    if (c->multi || c->peer_recv) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->peer_recv_bytes = sizeof(uint2) * 2 * (size_t)world_size * c->dw_elems;
+    // fine-grained (uncached across agents) memory, as RCCL uses for its own flag/buffer exchange; RSRL_PEER_COARSE=1 falls
+    // back to a plain allocation (same-device peers only need the system-scope accesses the kernels already use)
+    hipError_t e = getenv("RSRL_PEER_COARSE") ? hipErrorNotSupported
+                                             : hipExtMallocWithFlags((void**)&c->peer_recv, c->peer_recv_bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc((void**)&c->peer_recv, c->peer_recv_bytes)); }
+    HIP_TRY(hipMemsetAsync(c->peer_recv, 0, c->peer_recv_bytes, c->stream));      // tag 0 never matches a batch-step (tags start at 1)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->peer_world = world_size;
+    PeerBlob b; memset(&b, 0, sizeof(b));
+    b.magic = 0x52504552u; b.pid = (int32_t)getpid(); b.ptr = (uint64_t)(uintptr_t)c->peer_recv; b.bytes = c->peer_recv_bytes; b.world = world_size;
+    HIP_TRY(hipIpcGetMemHandle(&b.h, c->peer_recv));
+    memset(handle_out, 0, RSRL_HIP_PEER_HANDLE_BYTES);
+    memcpy(handle_out, &b, sizeof(b));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_size, int rank) {
+    CHECK_CTX(c);
+    if (!handles || world_size < 1 || rank < 0 || rank >= world_size) return fail(RSRL_HIP_EINVAL, "bad peer arguments");
+    if (!c->peer_recv || c->peer_world != world_size) return fail(RSRL_HIP_ESTATE, "call rsrl_hip_peer_export(world_size) first");
+    if (c->multi) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->peer_ptrs.assign((size_t)world_size, nullptr); c->peer_opened.assign((size_t)world_size, 0);
+    for (int r = 0; r < world_size; ++r) {
+        PeerBlob b; memcpy(&b, handles + (size_t)r * RSRL_HIP_PEER_HANDLE_BYTES, sizeof(b));
+        if (b.magic != 0x52504552u || b.world != world_size || b.bytes != c->peer_recv_bytes)
+            return fail(RSRL_HIP_EINVAL, "peer handle %d does not describe a matching receive buffer", r);
+        if (r == rank) {
+            if ((uint64_t)(uintptr_t)c->peer_recv != b.ptr || b.pid != (int32_t)getpid()) return fail(RSRL_HIP_EINVAL, "handle %d is not this ctx's own export", r);
+            c->peer_ptrs[r] = c->peer_recv;
+        } else if (b.pid == (int32_t)getpid()) {
+            c->peer_ptrs[r] = (void*)(uintptr_t)b.ptr;          // a ctx of this very process (several ranks driven by one host process): its pointer is valid here
+        } else {
+            HIP_TRY(hipIpcOpenMemHandle(&c->peer_ptrs[r], b.h, hipIpcMemLazyEnablePeerAccess));
+            c->peer_opened[r] = 1;
+        }
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_peer_ptrs, sizeof(void*) * (size_t)world_size));
+    HIP_TRY(hipMemcpy(c->d_peer_ptrs, c->peer_ptrs.data(), sizeof(void*) * (size_t)world_size, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_peer_err, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->d_peer_err, 0, sizeof(uint32_t)));
+    c->world_size = world_size; c->rank = rank; c->multi = true;
     return RSRL_HIP_OK;
 }
 

@@ -61,6 +61,14 @@ class ControlPlane:
         self._dist.broadcast_object_list(box, src=src)
         return box[0]
 
+    def all_gather_bytes(self, payload):
+        """every rank's payload (bytes), in rank order, on every rank"""
+        if self._dist is None:
+            return [payload]
+        out = [None] * self.world
+        self._dist.all_gather_object(out, payload)
+        return out
+
     def max_over_ranks(self, value):
         if self._dist is None:
             return float(value)
@@ -84,11 +92,15 @@ class ControlPlane:
             self._dist = None
 
 
-def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=None, **cfg):
+def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=None, force_exchange=False, **cfg):
     """Create this rank's Context for its shard of `total_envs` environments.  In shared-weight mode with more
-    than one rank the RCCL communicator is set up: rank 0 draws the ncclUniqueId, the control plane broadcasts it."""
+    than one rank the exchange of the weight delta is set up (RCCL communicator, or the peer-write buffers when
+    cfg has exchange=EXCHANGE_PEER); force_exchange attaches it for a single rank too (a communicator of size 1 runs
+    the same finalize -> exchange -> apply sequence: how the multi-rank path is exercised on a one-GPU box)."""
     if context_cls is None:
         from .context import Context as context_cls
+    if total_envs < control.world:
+        raise ValueError(f"{total_envs} environments cannot be sharded over {control.world} ranks (every rank needs at least one)")
     offset, count = shard_range(total_envs, control.world, control.rank)
     cfg = dict(cfg)
     if "device" not in cfg:
@@ -96,8 +108,12 @@ def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=Non
         cfg["device"] = control.info.local_rank % max(1, device_count()) if context_cls.__name__ == "Context" else control.info.local_rank
     ctx = context_cls(n_envs=count, env_offset=cfg.pop("env_offset", 0) + offset, **cfg)
     shared = cfg.get("weight_mode", 0) == 1
-    if shared and control.world > 1:
-        fn = unique_id_fn or context_cls.comm_unique_id
-        uid = control.broadcast_bytes(fn() if control.rank == 0 else None, src=0)
-        ctx.comm_init(uid, control.world, control.rank)
+    if shared and (control.world > 1 or force_exchange):
+        if cfg.get("exchange", 0) == 1:        # one-hop peer-write: all-gather the receive-buffer handles
+            handles = control.all_gather_bytes(ctx.peer_export(control.world))
+            ctx.peer_connect(handles, control.rank)
+        else:                                  # RCCL: rank 0 draws the ncclUniqueId, the control plane broadcasts it
+            fn = unique_id_fn or context_cls.comm_unique_id
+            uid = control.broadcast_bytes(fn() if control.rank == 0 else None, src=0)
+            ctx.comm_init(uid, control.world, control.rank)
     return ctx

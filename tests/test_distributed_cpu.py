@@ -72,6 +72,19 @@ def test_shard_range_partitions_exactly():
         shard_range(10, 2, 2)
 
 
+def test_sharded_context_needs_one_env_per_rank():
+    # a rank with zero environments cannot create its ctx and would leave the others waiting in the communicator set-up
+    from rsrl_amd.distributed import ControlPlane, RankInfo, make_sharded_context
+
+    class Never:
+        def __init__(self, **kw):
+            raise AssertionError("must be refused before any ctx is created")
+    cp = ControlPlane(RankInfo(0, 0, 1))
+    cp.info.world = 4                       # pretend: 4 ranks, 3 environments
+    with pytest.raises(ValueError):
+        make_sharded_context(3, cp, context_cls=Never, weight_mode=1)
+
+
 def test_world2_gloo_sharding_and_control_plane(tmp_path, orc):
     import json
     port = _free_port()

@@ -1,0 +1,177 @@
+"""GPU parity, bitwise: the HIP path against the oracle's DEVICE-ORDER instantiation ("f32d": the f32 body with the
+device's sincos / exp polynomials restated, driven by orc_run_train_dev = carried phi / Q and the rank-1 post-update
+Q exactly as kernels_reg.hpp evaluates them).  Every learner, every step count: states, actions, episode counters and
+weights are compared bit for bit -- no "97 % of the trajectories" thresholds.  The chain that ties this to the
+reference: f32d == f32 == f64 up to rounding on the CPU (tests/test_oracle_device_order.py), f64 pinned to the
+reference's known-answer tests (tests/test_oracle_golden.py).
+Reference lines matched: q_learning.rs:51-71, sarsa.rs:53-75, expected_sarsa.rs:45-66, pal.rs:34-60,
+policies/mod.rs:45-61, greedy.rs:30-84, epsilon_greedy.rs:38-83, softmax.rs:15-37,74-82,131-143."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+def _bitwise(c, run, n_weights=None):
+    assert np.array_equal(c.states.T, run.state), "states differ"
+    assert np.array_equal(c.actions, run.action), "actions differ"
+    idx = range(c.N) if n_weights is None else np.linspace(0, c.N - 1, n_weights).astype(int)
+    for i in idx:
+        assert np.array_equal(c.get_weights(int(i)), run.weights[int(i)]), f"weights of learner {i} differ"
+
+
+@pytest.mark.parametrize("algo,policy", [(0, 1), (1, 1), (2, 1), (2, 2), (1, 2), (5, 1), (0, 0), (0, 2), (1, 3)])
+def test_c2_free_running_bitwise_all_agents(ra, orc, algo, policy):
+    # MountainCar + Fourier(5), every one-step agent x policy pairing, 2 000 batch-steps with episode restarts and step-cap
+    # truncations on the way, in launches of 256 / 1 / 7 steps: identical to the CPU run for ALL learners
+    N, K = 192, 2000
+    kw = dict(gamma=0.9, lr=0.001, alpha=0.7, epsilon=0.1, tau=0.8)
+    ag = orc.make_agent(algo=algo, policy=policy, seed=21, max_episode_steps=150, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    ost = run.train_dev(K)
+    for spl in (0, 1, 7):
+        with ra.Context(n_envs=N, algo=algo, policy=policy, seed=21, max_episode_steps=150, steps_per_launch=spl, **kw) as c:
+            c.reset()
+            st = c.train(K)
+            _bitwise(c, run, 24)
+            assert st["episodes"] == ost["episodes"] and st["episodes_truncated"] == ost["episodes_truncated"]
+            assert st["sum_episode_steps"] == ost["sum_episode_steps"] and st["sum_reward"] == ost["sum_reward"]
+            assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 1e-4 * ost["sum_abs_td_error"]   # fp32 partial sums per launch
+    assert ost["episodes"] > 0
+
+
+def test_c2_headline_20000_steps_bitwise(ra, orc):
+    # BASELINE.json configs[1] (QLearning + Fourier(5) + eps-greedy(0.1), gamma 0.9, SGD(0.001), cap 1000): 20 000 batch-steps,
+    # every learner still on the CPU run's trajectory, bit for bit; then the greedy rollout from those weights
+    N, K = 256, 20000
+    kw = dict(gamma=0.9, lr=0.001, epsilon=0.1)
+    ag = orc.make_agent(policy=orc.EGREEDY, seed=0, max_episode_steps=1000, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    ost = run.train_dev(K)
+    with ra.Context(n_envs=N, policy=ra.EPSILON_GREEDY, seed=0, max_episode_steps=1000, **kw) as c:
+        c.reset()
+        st = c.train(K)
+        _bitwise(c, run)
+        assert st["episodes"] == ost["episodes"] > 0
+        n_d, tot_d = c.rollout_greedy(500)
+    n_o, tot_o = run.rollout_greedy(500)
+    assert np.array_equal(n_d, n_o) and np.array_equal(tot_d, tot_o)     # lib.rs:448-479 with identical weights and arithmetic
+    assert len(np.unique(n_o)) > 1
+
+
+@pytest.mark.parametrize("domain,algo,policy", [(1, 0, 1), (1, 1, 2), (2, 2, 2), (2, 0, 1)])
+def test_cartpole_acrobot_register_family_bitwise(ra, orc, domain, algo, policy):
+    # the RK4 domains (sincos_cw inside the gradient, IEEE divisions) on the register family (Fourier order 1)
+    N, K = 128, 600
+    kw = dict(gamma=0.95, lr=0.01, alpha=0.5, epsilon=0.1, tau=1.0)
+    ag = orc.make_agent(domain=domain, order=1, algo=algo, policy=policy, seed=9, max_episode_steps=80, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    ost = run.train_dev(K)
+    with ra.Context(domain=domain, order=1, n_envs=N, algo=algo, policy=policy, seed=9, max_episode_steps=80, **kw) as c:
+        c.reset()
+        st = c.train(K)
+        _bitwise(c, run, 16)
+        assert st["episodes"] == ost["episodes"] > 0
+
+
+def test_split_calls_carry_q_bitwise(ra, orc):
+    # Q(s,.) is carried across launches / calls on both sides (qcache <-> orc_run qc): 3 calls == 1 call, and an outside
+    # write of the weights invalidates the carry on both sides
+    N = 64
+    ag = orc.make_agent(policy=orc.EGREEDY, seed=4, max_episode_steps=90)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    with ra.Context(n_envs=N, policy=1, seed=4, max_episode_steps=90) as c:
+        c.reset()
+        for k in (100, 33, 300):
+            run.train_dev(k); c.train(k)
+        _bitwise(c, run)
+        w = (run.weights[5] * 1.5).astype(np.float32)
+        run.weights[5] = w; run.invalidate_q()
+        c.set_weights(w, 5)
+        run.train_dev(200); c.train(200)
+        _bitwise(c, run)
+
+
+def test_offpolicy_expected_sarsa_is_qlearning(ra, orc):
+    # the agent owns its policy (expected_sarsa.rs:22-29): ExpectedSARSA with a Greedy target under an eps-greedy behaviour
+    # takes Q-learning's TD error on identical transitions (the expectation under Greedy is the max when it is unique)
+    M = 256
+    rng = np.random.default_rng(3)
+    lo, hi = orc.domain_bounds(0)
+    s = (lo[:, None] + (hi - lo)[:, None] * rng.random((2, M))).astype(np.float32)
+    a = rng.integers(0, 3, M).astype(np.int32)
+    kw = dict(gamma=0.95, lr=0.05, alpha=1.0, epsilon=0.3, seed=5, n_envs=M, policy=ra.EPSILON_GREEDY)
+    W = (rng.normal(size=(36, 3)) * 0.3).astype(np.float32)
+    with ra.Context(algo=ra.EXPECTED_SARSA, agent_policy=ra.GREEDY, **kw) as es, ra.Context(algo=ra.QLEARNING, **kw) as ql, \
+            ra.Context(algo=ra.EXPECTED_SARSA, **kw) as es_on:
+        for c in (es, ql, es_on):
+            c.set_weights_all(W)
+        es.states = s
+        frm, nxt, rew, term = es.domain_step(a)
+        term[::7] = 1
+        td_es, td_ql, td_on = (c.handle(frm, a, rew, nxt, term) for c in (es, ql, es_on))
+        assert np.array_equal(td_es, td_ql)
+        for i in (0, 1, 100, 255):
+            assert np.array_equal(es.get_weights(i), ql.get_weights(i))
+        assert np.max(np.abs(td_on - td_ql)) > 1e-3              # the on-policy expectation is a different target
+        # the oracle agrees (same agent_policy plumbing), f64 tolerance
+        ag = orc.make_agent(algo=orc.EXPECTED_SARSA, policy=orc.EGREEDY, agent_policy=orc.GREEDY, gamma=0.95, lr=0.05, alpha=1.0, epsilon=0.3)
+        for i in range(0, M, 17):
+            Wo = W.astype(np.float64)
+            d = orc.handle(ag, Wo, frm[:, i], a[i], rew[i], nxt[:, i], term[i], (0, 0, 0, 0), "f64")
+            assert abs(td_es[i] - d) <= 2e-5 * (1 + abs(d))
+    # free-running: SARSA whose own policy is Greedy (inner a' = argmax) under an eps-greedy behaviour, fused loop, bitwise
+    ag = orc.make_agent(algo=orc.SARSA, policy=orc.EGREEDY, agent_policy=orc.GREEDY, seed=8, max_episode_steps=70)
+    run = orc.Run(ag, 96, "f32d"); run.reset(); run.train_dev(500)
+    with ra.Context(n_envs=96, algo=ra.SARSA, policy=1, agent_policy=ra.GREEDY, seed=8, max_episode_steps=70) as c:
+        c.reset(); c.train(500)
+        _bitwise(c, run, 12)
+
+
+def test_diverged_learner_keeps_actions_in_range(ra):
+    # Q = NaN for every action (a diverged learner): argmaxima is empty, the reference panics ("No valid maxima",
+    # utils.rs:70-76); the device must keep the action -- a weight-column index -- inside [0, A) and leave the
+    # neighbours' weights alone
+    N = 130
+    with ra.Context(n_envs=N, policy=ra.GREEDY, seed=1, max_episode_steps=50) as c:
+        c.reset()
+        bad = np.full((36, 3), np.nan, dtype=np.float32)
+        c.set_weights(bad, 64)
+        c.train(40)
+        a = c.actions
+        assert a.min() >= 0 and a.max() <= 2
+        for i in (63, 65, 0, 129):
+            assert np.all(np.isfinite(c.get_weights(i)))
+        p = c.policy_probs(c.states)
+        assert np.all(np.isfinite(p[:, :64])) and np.all(np.isfinite(p[:, 65:]))
+    with ra.Context(n_envs=N, policy=ra.GREEDY, steps_per_launch=1, seed=1) as c:      # learner-major single-step kernel: colp = img + a*F
+        c.reset()
+        c.set_weights(np.full((36, 3), np.nan, dtype=np.float32), 3)
+        c.train(40)
+        assert c.actions.min() >= 0 and c.actions.max() <= 2
+        assert np.all(np.isfinite(c.get_weights(2))) and np.all(np.isfinite(c.get_weights(4)))
+
+
+def test_caller_actions_are_validated(ra):
+    N = 16
+    with ra.Context(n_envs=N) as c:
+        bad = np.zeros(N, dtype=np.int32); bad[5] = 3
+        with pytest.raises(ra.RsrlHipError) as ei:
+            c.actions = bad
+        assert ei.value.code == -1 and "action[5]" in str(ei.value)
+        with pytest.raises(ra.RsrlHipError):
+            c.domain_step(-bad)
+        s = c.states
+        with pytest.raises(ra.RsrlHipError):
+            c.handle(s, bad, np.zeros(N, np.float32), s, np.zeros(N, np.uint8))
+        assert np.all(c.get_weights(5) == 0.0)

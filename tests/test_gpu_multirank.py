@@ -1,0 +1,170 @@
+"""GPU tests of the multi-rank shared-W path on a ONE-GPU box:
+  * a communicator of size 1 (RCCL) and a peer group of size 1 run the same finalize -> exchange -> apply sequence as
+    world_size > 1 and must reproduce the exchange-free path bit for bit;
+  * G ranks as G ctxs with their own streams on one device, driven by G host threads, exchanging the weight delta through
+    the one-hop peer-write buffers (the "G streams on one device" simulation of SURVEY Appendix D);
+  * 2 ranks as 2 PROCESSES on the one device: the receive buffers are mapped with hipIpc exactly as they are across GPUs,
+    the control plane (gloo) all-gathers the handles -- the multi-process code path end to end.
+Every replica must hold bit-identical weights (each rank sums the slots in rank order) and agree with the unsharded run up
+to the fp32 summation order."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C4 = dict(domain=0, order=5, algo=0, policy=1, epsilon=0.1, gamma=0.9, weight_mode=1, seed=0, max_episode_steps=200)
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+def _run(c, steps=(40, 70)):
+    c.reset()
+    for k in steps:
+        c.train(k, want_stats=False)
+    c.sync()
+    return c.get_weights(), c.states, c.actions
+
+
+@pytest.mark.parametrize("kind", ["dense", "tile"])
+def test_size1_communicator_runs_the_multirank_sequence_bitwise(ra, kind):
+    # (a) no exchange, (b) RCCL communicator of size 1, (c) peer group of size 1: identical weights, states, actions.
+    # 110 batch-steps = plain launches + 3 graph replays (the all-reduce / peer kernels are captured with the step)
+    N = 8192
+    kw = dict(C4, n_envs=N, lr=0.001 / N) if kind == "dense" else \
+        dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=1, policy=1, epsilon=0.1, gamma=0.99, weight_mode=1, seed=0,
+             max_episode_steps=200, n_envs=N, lr=0.1 / 8 / N)
+    with ra.Context(**kw) as plain, ra.Context(**kw) as rccl, ra.Context(exchange=ra.EXCHANGE_PEER, **kw) as peer:
+        rccl.comm_init(ra.Context.comm_unique_id(), 1, 0)
+        peer.peer_connect([peer.peer_export(1)], 0)
+        ref = _run(plain)
+        assert np.abs(ref[0]).max() > 0
+        for other in (rccl, peer):
+            got = _run(other)
+            if kind == "dense":
+                assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+            else:       # tile coding: the device atomics of the delta table are order-dependent even without an exchange
+                assert np.allclose(ref[0], got[0], rtol=0, atol=1e-6 * np.abs(ref[0]).max() + 1e-9)
+        # rsrl_hip_handle all-reduces too: a teacher-forced mini-batch gives the same W with and without a communicator
+        s = plain.states
+        a = plain.actions
+        for c in (plain, rccl, peer):
+            c.states = s
+        frm, nxt, rew, term = plain.domain_step(a)
+        w = [c.handle(frm, a, rew, nxt, term) is not None and c.get_weights() for c in (plain, rccl, peer)]
+        if kind == "dense":
+            assert np.array_equal(w[0], w[1]) and np.array_equal(w[0], w[2])
+
+
+def test_g_ranks_as_g_streams_on_one_device(ra):
+    # 4 ctxs = 4 ranks on one device, one host thread each, peer-write exchange through same-process pointers
+    G, N = 4, 4096
+    kw = dict(C4, lr=0.001 / N, exchange=ra.EXCHANGE_PEER)
+    ctxs = [ra.Context(n_envs=N // G, env_offset=r * (N // G), **kw) for r in range(G)]
+    handles = [c.peer_export(G) for c in ctxs]
+    for r, c in enumerate(ctxs):
+        c.peer_connect(handles, r)
+    out, errs = [None] * G, []
+
+    def work(r):
+        try:
+            out[r] = _run(ctxs[r], steps=(30, 45))
+        except Exception as e:          # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(r,)) for r in range(G)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs and all(o is not None for o in out), errs
+    for r in range(1, G):
+        assert np.array_equal(out[0][0], out[r][0]), "replicas of W diverged"
+    with ra.Context(n_envs=N, **dict(kw, exchange=ra.EXCHANGE_RCCL)) as full:
+        ref = _run(full, steps=(30, 45))
+    # same mini-batch rule, another fp32 summation order (blocks within a rank, then ranks): close, and the trajectories agree
+    assert np.max(np.abs(ref[0] - out[0][0])) <= 2e-6 * max(1.0, np.abs(ref[0]).max())
+    states = np.concatenate([o[1] for o in out], axis=1)
+    same = np.all(np.abs(states - ref[1]) <= 1e-6, axis=0)
+    assert same.mean() >= 0.99
+    for c in ctxs:
+        c.close()
+
+
+def test_missing_peer_times_out_instead_of_hanging(ra):
+    # rank 1 never steps: rank 0's exchange gives up after its bounded spin and the next sync reports it
+    kw = dict(C4, lr=1e-6, exchange=ra.EXCHANGE_PEER)
+    a, b = ra.Context(n_envs=256, **kw), ra.Context(n_envs=256, env_offset=256, **kw)
+    h = [a.peer_export(2), b.peer_export(2)]
+    a.peer_connect(h, 0); b.peer_connect(h, 1)
+    a.reset()
+    a.train(1, want_stats=False)
+    with pytest.raises(ra.RsrlHipError) as ei:
+        a.sync()
+    assert ei.value.code == -4 and "timed out" in str(ei.value)
+    a.close(); b.close()
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["RSRL_ROOT"])
+import rsrl_amd
+from rsrl_amd.distributed import ControlPlane, make_sharded_context
+cp = ControlPlane()
+N = int(os.environ["RSRL_TOTAL"])
+kw = json.loads(os.environ["RSRL_KW"])
+ctx = make_sharded_context(N, cp, device=0, **kw)
+ctx.reset()
+cp.barrier()
+for k in (30, 45):
+    ctx.train(k, want_stats=False)
+ctx.sync()
+w = ctx.get_weights()
+td = ctx.handle(ctx.states, ctx.actions, np.zeros(ctx.N, np.float32), ctx.states, np.ones(ctx.N, np.uint8))
+w2 = ctx.get_weights()
+print("RESULT " + json.dumps({"rank": cp.rank, "w": w.tolist(), "w2": w2.tolist(), "states": ctx.states.tolist(), "chk": list(ctx.checksum())}))
+cp.barrier()
+ctx.close(); cp.close()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_two_processes_one_gpu_peer_exchange_over_hipipc(ra, tmp_path):
+    N = 4096
+    kw = dict(C4, lr=0.001 / N, exchange=1)
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RSRL_ROOT=ROOT, RSRL_TOTAL=str(N), RSRL_KW=json.dumps(kw), GLOO_SOCKET_IFNAME="lo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = {}
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, se[-3000:]
+        d = json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:])
+        res[d["rank"]] = d
+    w0, w1 = np.array(res[0]["w"], np.float32), np.array(res[1]["w"], np.float32)
+    assert np.array_equal(w0, w1) and np.abs(w0).max() > 0, "replicas of W diverged across processes"
+    assert np.array_equal(np.array(res[0]["w2"], np.float32), np.array(res[1]["w2"], np.float32))     # handle() exchanged too
+    assert res[0]["chk"][0] == res[1]["chk"][0]
+    with ra.Context(n_envs=N, **dict(kw, exchange=0)) as full:
+        ref = _run(full, steps=(30, 45))
+    assert np.max(np.abs(ref[0] - w0)) <= 2e-6 * max(1.0, np.abs(ref[0]).max())
+    states = np.concatenate([np.array(res[r]["states"], np.float32) for r in (0, 1)], axis=1)
+    assert np.all(np.abs(states - ref[1]) <= 1e-6, axis=0).mean() >= 0.99

@@ -227,7 +227,13 @@ def test_checkpoint_roundtrip_and_resume(ra, tmp_path):
         a.reset(); a.train(30)
         ref = (a.states.copy(), [a.get_weights(i) for i in (0, 150, 299)])
     raw = open(path, "rb").read()
-    assert raw[:8] == b"RSRLHIPW" and len(raw) == 64 + 300 * 36 * 3 * 4
+    assert raw[:8] == b"RSRLHIPW" and len(raw) == 72 + 300 * 36 * 3 * 4
+    import struct                                      # the documented byte layout (include/rsrl_hip.h), field by field
+    ver, *f11 = struct.unpack_from("<I11i", raw, 8)
+    n_learners, step_count = struct.unpack_from("<qQ", raw, 56)
+    assert ver == 2 and f11 == [0, 0, 5, 8, 8, 0, 36, 3, 0, 0, 0] and (n_learners, step_count) == (300, 50)
+    w0 = np.frombuffer(raw, dtype="<f4", count=108, offset=72).reshape(36, 3)
+    assert np.array_equal(w0, wa[0])
     with ra.Context(**kw) as b:
         b.load_weights(path)
         assert b.step_count == 50
@@ -240,6 +246,37 @@ def test_checkpoint_roundtrip_and_resume(ra, tmp_path):
     with ra.Context(n_envs=299, policy=1) as c:
         with pytest.raises(ra.RsrlHipError):
             c.load_weights(path)                      # different configuration
+    with ra.Context(algo=ra.SARSA, **kw) as c:
+        with pytest.raises(ra.RsrlHipError):
+            c.load_weights(path)                      # different agent (the header carries algo and weight dtype)
+    # a truncated file is refused before anything is touched: the ctx keeps its weights and its step counter
+    cut = tmp_path / "cut.rsrlw"
+    cut.write_bytes(raw[:72 + 150 * 432 + 100])
+    with ra.Context(**kw) as c:
+        c.reset(); c.train(20)
+        before = [c.get_weights(i) for i in (0, 149, 150, 299)]
+        with pytest.raises(ra.RsrlHipError) as ei:
+            c.load_weights(cut)
+        assert "truncated" in str(ei.value)
+        assert c.step_count == 20
+        for w, i in zip(before, (0, 149, 150, 299)):
+            assert np.array_equal(c.get_weights(i), w)
+        c.train(5)                                     # and still works
+    # GreedyGQ: the second approximator (fa_td) travels with the checkpoint -> the resumed run is bit-identical
+    gkw = dict(n_envs=64, algo=ra.GREEDY_GQ, policy=1, epsilon=0.1, seed=3, max_episode_steps=40, lr=0.05, lr_td=0.002)
+    gpath = tmp_path / "gq.rsrlw"
+    with ra.Context(**gkw) as a:
+        a.reset(); a.train(60)
+        a.save_weights(gpath)
+        v7 = a.get_td_weights(7)
+        a.reset(); a.train(25)
+        gref = (a.states.copy(), a.get_weights(7), a.get_td_weights(7))
+    assert len(open(gpath, "rb").read()) == 72 + 2 * 64 * 432 and np.abs(v7).max() > 0
+    with ra.Context(**gkw) as b:
+        b.load_weights(gpath)
+        assert np.array_equal(b.get_td_weights(7), v7)
+        b.reset(); b.train(25)
+        assert np.array_equal(b.states, gref[0]) and np.array_equal(b.get_weights(7), gref[1]) and np.array_equal(b.get_td_weights(7), gref[2])
     with ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=4, tiles_per_dim=4, weight_mode=ra.W_SHARED, n_envs=8) as t:
         t.set_weights(np.arange(4 * 256 * 2, dtype=np.float32).reshape(1024, 2))
         t.save_weights(tmp_path / "t.rsrlw")
