@@ -259,6 +259,16 @@ __device__ __forceinline__ float td_error_ap(const AlgoParams& alg, const Policy
     return td_error<A>(alg, pol, qsa, qn, r, term, xin, e);
 }
 
+// one dword of a wave-uniform row: descriptor built from the row pointer (SALU), lane offset in bytes
+__device__ __forceinline__ float row_load(const char* rowp, uint32_t voff) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void row_store(char* rowp, uint32_t voff, float v) {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rowp, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, (int)voff, 0, 0);
+}
+
 // q[a] by a compare/select chain.  Each compare sees its own opaque copy of the index: otherwise LLVM folds the
 // chain into a dynamic extractelement, which is legalised through a private array that promote-alloca moves to LDS
 // -- an exposed ds_write/ds_read round trip on the critical path of every step.
@@ -300,8 +310,7 @@ struct QCarry {
 //    used for s0 instead: terminal resets cost nothing extra and do not diverge; only a
 //    step-cap truncation (needs both Q(s') and Q(s0)) takes the divergent slow path;
 //  * the loop is unrolled by two with ping-pong phi buffers (no phi(s) <- phi(s') moves).
-// store_col: n_steps == 1 only -- write back just the updated column (the 608 B/step
-// streaming formulation); otherwise all A columns are written once at the end.
+// All A columns are written once at the end of the launch (one batch-step per launch is k_step_reg / k_step_reg_lm).
 // ---------------------------------------------------------------------------------------
 #ifndef RSRL_RANK1_QPOST
 #define RSRL_RANK1_QPOST 1
@@ -310,14 +319,25 @@ struct QCarry {
 #define RSRL_K1_STORE_ALL 1
 #endif
 
+// Registers: __launch_bounds__(kBlock, 2) = at most 256 per lane, so a launch of more than 1024 waves (> 65 536 learners) runs
+// TWO waves per SIMD: a lone wave issues one VALU instruction per ~3.4 cycles (packed fma 5.2, v_mad_u64 8, v_cndmask 8.4), two
+// co-resident waves one per 2.7 / 4.8 / 5.9 / 4.3 (profiles/r01_ubench_valu_issue.txt).  The loop itself needs ~225 registers;
+// what had pushed the first version to 460 (one wave per SIMD at EVERY size) was its prologue / epilogue: per-element 64-bit
+// addresses, CSE'd between the loads and the stores and kept alive across the loop.
 template <int DOMAIN, int ORDER, int ALGO, int POLICY>
-__global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int n_steps, int store_col,
-                                                      DevStats* __restrict__ stats) {
+__global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
     constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t N = c.n_envs;
+    // W rows through a per-row buffer descriptor (wave-uniform base in SGPRs) + a 32-bit lane offset: one buffer_load /
+    // buffer_store per element, no per-element 64-bit VALU address arithmetic and no address registers kept alive from the
+    // loads to the stores (the first version spent ~900 instructions of its entry block on addresses and, limited to 256
+    // registers, spilled all of them across the loop)
+    char* __restrict__ const wblk = reinterpret_cast<char*>(c.W + (int64_t)blockIdx.x * blockDim.x * c.w_ls);
+    const uint32_t wlane = threadIdx.x * (uint32_t)c.w_ls * 4u;          // byte offset of this lane inside a row, 32 bits
+    const int64_t wrow = c.w_stride * 4;                                 // bytes between (action, feature) rows
 
     unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
     double sum_abs = 0.0, sum_r = 0.0;
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
-            for (int f = 0; f < F; ++f) w.put(b, f, c.W[((int64_t)(b * F + f)) * c.w_stride + i * c.w_ls]);
+            for (int f = 0; f < F; ++f) w.put(b, f, row_load(wblk + (int64_t)(b * F + f) * wrow, wlane));
 
         static_assert(A <= 3, "QCarry holds up to 3 actions");
         Phi phi_a, phi_b;
@@ -354,7 +374,6 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
             }
             q_s.set<A>(q0);
         }
-        int a_taken = a;
         typename Dom::Pre pre_s = Dom::pre(s);
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
 
@@ -395,7 +414,6 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
                 for (int b = 0; b < A; ++b) sb[b] = (a == b) ? scale : 0.0f;
                 w.axpy(sb, phi_s);
             }
-            a_taken = a;
             // ---- policy.sample with the UPDATED weights (at s', or at s0 after a terminal transition)
 #if RSRL_RANK1_QPOST
             {   // W changed by a rank-1 term in column a only: Q_post[a] = Q_pre[a] + scale * <phi(s), phi(s')>
@@ -441,20 +459,10 @@ __global__ __launch_bounds__(kBlock) void k_train_reg(Common c, uint64_t t0, int
         c.qcache[i] = q_s.v0;
         if constexpr (A > 1) c.qcache[N + i] = q_s.v1;
         if constexpr (A > 2) c.qcache[2 * N + i] = q_s.v2;
-        if (store_col) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                float v = w.get(0, f);
+        for (int b = 0; b < A; ++b)
 #pragma unroll
-                for (int b = 1; b < A; ++b) v = (a_taken == b) ? w.get(b, f) : v;
-                c.W[((int64_t)(a_taken * F + f)) * c.w_stride + i * c.w_ls] = v;
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < A; ++b)
-#pragma unroll
-                for (int f = 0; f < F; ++f) c.W[((int64_t)(b * F + f)) * c.w_stride + i * c.w_ls] = w.get(b, f);
-        }
+            for (int f = 0; f < F; ++f) row_store(wblk + (int64_t)(b * F + f) * wrow, wlane, w.get(b, f));
     }
 
     // per-launch statistics: block-level reduction into this block's own slot (no atomics: a slot

@@ -7,11 +7,11 @@ namespace rsrl {
 
 // returns false when no instantiation exists for (order, algo, policy)
 bool launch_train_reg_d0(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
-                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats, const uint64_t* t_dev = nullptr);
+                         const Common& k, uint64_t t, int chunk, DevStats* stats, const uint64_t* t_dev = nullptr);
 bool launch_train_reg_d1(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
-                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats, const uint64_t* t_dev = nullptr);
+                         const Common& k, uint64_t t, int chunk, DevStats* stats, const uint64_t* t_dev = nullptr);
 bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
-                         const Common& k, uint64_t t, int chunk, int store_col, DevStats* stats, const uint64_t* t_dev = nullptr);
+                         const Common& k, uint64_t t, int chunk, DevStats* stats, const uint64_t* t_dev = nullptr);
 
 // chunk == -1 selects the single-step streaming kernel (k_step_reg), -2 its learner-major form (k_step_reg_lm)
 struct LambdaParams;
@@ -45,7 +45,7 @@ bool launch_reset_td(int domain, dim3 grid, dim3 block, hipStream_t st, const Co
         } else if (chunk == -1)                                                                             \
             hipLaunchKernelGGL((k_step_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats, t_dev);              \
         else                                                                                                \
-            hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, chunk, store_col, stats); \
+            hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, chunk, stats);            \
         return true;                                                                                        \
     }
 #define RSRL_TRAIN_POLICIES(DM, OR, AL) \

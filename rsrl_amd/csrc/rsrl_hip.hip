@@ -82,12 +82,13 @@ __global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int
     if (j >= n) return;
     const uint32_t want = (uint32_t)(t + 1);
     const uint64_t t_start = wall_clock64();
+    const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange timed out: fail fast, do not wait again
     float acc = 0.0f;
     for (int r = 0; r < world; ++r) {
         const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(t & 1) * world + r) * (size_t)n + j);
         uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((uint32_t)(g >> 32) != want) {
-            if (wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
+            if (broken || wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
             __builtin_amdgcn_s_sleep(8);
             g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -231,6 +232,7 @@ struct rsrl_hip_ctx {
     const char* kernel_name = "";
     // multi-rank shared-W (one process per GPU): the per-batch-step exchange of the weight delta
     ncclComm_t comm = nullptr;                 // RSRL_EXCHANGE_RCCL
+    int n_simd = 1024;                         // SIMDs of the device (4 per CU): launches of more waves than that co-schedule waves
     int world_size = 1, rank = 0;
     bool multi = false;                        // an exchange is attached (a communicator of size 1 included: same sequence)
     // RSRL_EXCHANGE_PEER: one-hop peer-write.  recv = this rank's receive buffer, granules {value bits, step tag}
@@ -569,6 +571,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(RSRL_HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
+    { int cus = 0; HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device)); if (cus > 0) c->n_simd = 4 * cus; }
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     const int64_t N = cfg->n_envs;
@@ -1203,9 +1206,9 @@ static int enqueue_k1_step(rsrl_hip_ctx* c, const Common& k, DevStats* d_stats, 
     bool ok;
     const int kind = c->w_ls != 1 ? -2 : -1;              // learner-major rows: k_step_reg_lm
     switch (c->cfg.domain) {
-    case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
-    case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
-    default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, 1, d_stats, t_dev); break;
+    case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, d_stats, t_dev); break;
+    case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, d_stats, t_dev); break;
+    default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, d_stats, t_dev); break;
     }
     if (!ok) return NO_MODEL(c);
     KCHECK();
@@ -1304,14 +1307,13 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
             c->kernel_name = c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg";
             c->q_valid = true; k.q_valid = 1;
         } else if (fourier && !is_generic_fourier(c->cfg)) {
-            const int store_col = (chunk == 1 && spl == 1) ? 1 : 0;
             const dim3 gr(grid_for(k.n_envs)), b(kBlock);
             const int kchunk = chunk;
             bool ok;
             switch (c->cfg.domain) {
-            case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
-            case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
-            default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, store_col, d_stats); break;
+            case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, d_stats); break;
+            case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, d_stats); break;
+            default: ok = launch_train_reg_d2(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, c->t, kchunk, d_stats); break;
             }
             if (!ok) return NO_MODEL(c);
             c->kernel_name = "k_train_reg";
