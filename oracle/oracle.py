@@ -145,6 +145,9 @@ def _declare(L):
         g("orc_run_train_dev").restype = C.c_int
         g("orc_run_train_dev").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_run_invalidate_q").argtypes = [C.c_void_p]
+        g("orc_run_train_wave").restype = C.c_int
+        g("orc_run_train_wave").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_int]
+        g("orc_run_reset_wave").argtypes = [C.c_void_p]
         g("orc_run_traces").restype = Rp
         g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
@@ -425,6 +428,19 @@ class Run:
         if self._f("orc_run_train_dev")(self._h, int(n_steps), C.byref(st)) != 0:
             raise ValueError("train_dev: one-step control agents on a Fourier basis with per-env weights only")
         return st.as_dict()
+
+    def train_wave(self, n_steps, bf16=False):
+        """The driver loop in the evaluation order of the device's wave family (Fourier order 7 on a 4-D domain: lane
+        partials + the DPP ladder; bf16: stochastic rounding of every updated weight) -- with prec="f32d" bit-identical to
+        k_train_wave."""
+        st = Stats()
+        if self._f("orc_run_train_wave")(self._h, int(n_steps), C.byref(st), int(bool(bf16))) != 0:
+            raise ValueError("train_wave: one-step control agents, Fourier order 7 on CartPole / Acrobot, per-env weights, f32 only")
+        return st.as_dict()
+
+    def reset_wave(self):
+        """reset() with the initial Q(s0,.) evaluated in the wave family's summation order"""
+        self._f("orc_run_reset_wave")(self._h)
 
     def invalidate_q(self):
         """Q(s,.) carried between train_dev calls is stale (weights / states were written from outside)"""

@@ -114,6 +114,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     int   orc_run_train_fast_##S(void* h, int64_t n_steps, orc_stats* st);                                        \
     int   orc_run_train_dev_##S(void* h, int64_t n_steps, orc_stats* st);                                         \
     void  orc_run_invalidate_q_##S(void* h);                                                                      \
+    int   orc_run_train_wave_##S(void* h, int64_t n_steps, orc_stats* st, int w_bf16);                            \
+    void  orc_run_reset_wave_##S(void* h);                                                                        \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \

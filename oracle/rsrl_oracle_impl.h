@@ -855,6 +855,35 @@ int FN(orc_run_train_fast)(void* h, int64_t n_steps, orc_stats* st) {
     return 0;
 }
 
+/* TD error of the one-step control agents from Q(s,.) and Q(s',.) (both with the PRE-update weights), as the device's
+ * td_dispatch evaluates it; *e_out = the error sent on to the approximator (alpha*delta for ExpectedSARSA and PAL).
+ *   q_learning.rs:51-71, sarsa.rs:53-75, expected_sarsa.rs:45-66, pal.rs:34-60 */
+static R FN(td_from_q)(const orc_agent* ag, const R* q_s, int a, const R* q_n, R r, int term, const uint32_t xin[4], R* e_out) {
+    int A = ag->n_actions, j; R delta;
+    if (term) {
+        delta = r - q_s[a];
+    } else if (ag->algo == ORC_QLEARNING) {
+        R m; FN(orc_find_max)(q_n, A, &m);
+        delta = r + (R)ag->gamma * m - q_s[a];
+    } else if (ag->algo == ORC_SARSA) {
+        int ia = FN(orc_policy_sample)(ag->apolicy, q_n, A, ag->aeps_thr, (R)ag->atau, xin);
+        delta = r + (R)ag->gamma * q_n[ia] - q_s[a];
+    } else if (ag->algo == ORC_PAL) {
+        int as = FN(orc_argmax_first)(q_s, A), nas = FN(orc_argmax_first)(q_n, A);
+        R td = r + (R)ag->gamma * q_n[as] - q_s[a];
+        R al = td - (R)ag->alpha * (q_s[as] - q_s[a]);
+        R alt = td - (R)ag->alpha * (q_n[nas] - q_n[a]);
+        delta = (al > alt) ? al : alt;
+    } else {
+        R p[ORC_MAX_ACTIONS], ev = 0;
+        FN(orc_policy_probs)(ag->apolicy, q_n, A, (R)ag->aepsilon, (R)ag->atau, p);
+        for (j = 0; j < A; j++) ev = ev + q_n[j] * p[j];
+        delta = r + (R)ag->gamma * ev - q_s[a];
+    }
+    *e_out = (ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL) ? (R)ag->alpha * delta : delta;
+    return delta;
+}
+
 /* The driver loop in the DEVICE's evaluation order (rsrl_amd/csrc/kernels_reg.hpp: k_train_reg / k_step_reg_lm), for bitwise
  * comparison with the HIP path (instantiation _f32d) and as a CPU cross-check of that order against orc_run_train
  * (_f32 / _f64: same trajectories up to rounding).  Differences from orc_run_train, all value-preserving up to rounding:
@@ -892,27 +921,7 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
             FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi_n);
             FN(dot_columns)(phi_n, W, A, F, q_n);                          /* PRE-update weights */
             if (ag->algo == ORC_SARSA) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
-            if (term) {
-                delta = r - q_s[a];
-            } else if (ag->algo == ORC_QLEARNING) {
-                R m; FN(orc_find_max)(q_n, A, &m);
-                delta = r + (R)ag->gamma * m - q_s[a];
-            } else if (ag->algo == ORC_SARSA) {
-                int ia = FN(orc_policy_sample)(ag->apolicy, q_n, A, ag->aeps_thr, (R)ag->atau, xin);
-                delta = r + (R)ag->gamma * q_n[ia] - q_s[a];
-            } else if (ag->algo == ORC_PAL) {
-                int as = FN(orc_argmax_first)(q_s, A), nas = FN(orc_argmax_first)(q_n, A);
-                R td = r + (R)ag->gamma * q_n[as] - q_s[a];
-                R al = td - (R)ag->alpha * (q_s[as] - q_s[a]);
-                R alt = td - (R)ag->alpha * (q_n[nas] - q_n[a]);
-                delta = (al > alt) ? al : alt;
-            } else {
-                R p[ORC_MAX_ACTIONS], ev = 0;
-                FN(orc_policy_probs)(ag->apolicy, q_n, A, (R)ag->aepsilon, (R)ag->atau, p);
-                for (j = 0; j < A; j++) ev = ev + q_n[j] * p[j];
-                delta = r + (R)ag->gamma * ev - q_s[a];
-            }
-            e = (ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL) ? (R)ag->alpha * delta : delta;
+            delta = FN(td_from_q)(ag, q_s, a, q_n, r, term, xin, &e);
             scale = (R)ag->lr * e;
             for (f = 0; f < F; f++) W[(size_t)f * A + a] = FN(fma_)(scale, phi_s[f], W[(size_t)f * A + a]);
             {   /* <phi(s), phi(s')> in the 4-way interleaved order of every dot product on this path */
@@ -946,6 +955,156 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
     free(phi_s); free(phi_n);
     if (st) *st = acc;
     return 0;
+}
+
+/* The driver loop in the evaluation order of the device's WAVE family (rsrl_amd/csrc/kernels_wave.hpp: one wavefront per
+ * learner, Fourier order 7 on a 4-D state space, F = 8^4 = 4096), for bitwise comparison with the HIP path (_f32d):
+ *   - internal feature index k = c0*512 + c1*64 + c2*8 + c3 over ALL coefficient vectors; k = 0 (cos 0 = 1, computed as the
+ *     product of the tables' ones) is the constant that with_bias() stacks last: reference feature f <-> k = (f + 1) mod F;
+ *   - lane l = c1*8 + c2 owns the 64 features (j = c0, v = c3); a dot product is the lane's 4 interleaved chains over
+ *     (j, v) in order, combined as (a0 + a1) + (a2 + a3), then the wave total by the DPP ladder row_shr 1, 2, 4, 8,
+ *     row_bcast 15 (rows 1, 3), row_bcast 31 (rows 2, 3), read from lane 63;
+ *   - Q(s',a) with the updated column is re-evaluated (no rank-1 shortcut in this family); Q(s,.) is carried;
+ *   - bf16 weight storage (w_bf16 != 0): every UPDATED weight is rounded to bf16 by stochastic rounding with the 16-bit
+ *     window (e >> 2) of word (e & 3) of the lane's Philox block (block id 16 + lane), e = j*8 + v.
+ * One-step control agents, per-env weights; returns -1 otherwise. */
+static R FN(wave_total)(const R* lane_part) {
+    R v[64], n[64]; int l, sh, row;
+    for (l = 0; l < 64; l++) v[l] = lane_part[l];
+    for (sh = 1; sh <= 8; sh <<= 1) {
+        for (l = 0; l < 64; l++) n[l] = v[l] + (((l & 15) >= sh) ? v[l - sh] : (R)0.0);
+        for (l = 0; l < 64; l++) v[l] = n[l];
+    }
+    for (l = 0; l < 64; l++) { row = l >> 4; n[l] = v[l] + ((row == 1 || row == 3) ? v[(row - 1) * 16 + 15] : (R)0.0); }
+    for (l = 0; l < 64; l++) v[l] = n[l];
+    for (l = 0; l < 64; l++) { row = l >> 4; n[l] = v[l] + ((row >= 2) ? v[31] : (R)0.0); }
+    return n[63];
+}
+static void FN(wave_project)(const orc_basis* b, const R* s, R* phi /* [64 lanes][8 j][8 v] */) {
+    R ct[4][8], st[4][8]; int d, n, l, j, v;
+    for (d = 0; d < 4; d++) {
+        const R lo = FN(basis_lo)(b)[d], hi = FN(basis_hi)(b)[d];
+        const R sc = (s[d] - lo) * ((R)1.0 / (hi - lo));
+        ct[d][0] = (R)1.0; st[d][0] = (R)0.0;
+#ifdef ORC_DEVTRIG
+        FN(sincospi01_dev)(sc, &st[d][1], &ct[d][1]);
+#else
+        ct[d][1] = (R)cos(M_PI * (double)sc); st[d][1] = (R)sin(M_PI * (double)sc);
+#endif
+        for (n = 2; n < 8; n++) {
+            ct[d][n] = FN(fma_)(-st[d][n - 1], st[d][1], ct[d][n - 1] * ct[d][1]);
+            st[d][n] = FN(fma_)(ct[d][n - 1], st[d][1], st[d][n - 1] * ct[d][1]);
+        }
+    }
+    for (l = 0; l < 64; l++) {
+        const int c1 = l >> 3, c2 = l & 7;
+        for (j = 0; j < 8; j++) {
+            R re = ct[0][j], im = st[0][j], nre, nim;
+            nre = FN(fma_)(-im, st[1][c1], re * ct[1][c1]); nim = FN(fma_)(re, st[1][c1], im * ct[1][c1]); re = nre; im = nim;
+            nre = FN(fma_)(-im, st[2][c2], re * ct[2][c2]); nim = FN(fma_)(re, st[2][c2], im * ct[2][c2]); re = nre; im = nim;
+            for (v = 0; v < 8; v++) phi[(l * 8 + j) * 8 + v] = FN(fma_)(-im, st[3][v], re * ct[3][v]);
+        }
+    }
+}
+/* reference row of the internal index k = j*512 + l*8 + v */
+static inline size_t FN(wave_row)(int l, int j, int v) { const int k = j * 512 + l * 8 + v; return (size_t)((k + 4095) & 4095); }
+static R FN(wave_dot)(const R* phi, const R* W, int A, int a) {
+    R part[64]; int l, j, v;
+    for (l = 0; l < 64; l++) {
+        R acc[4] = { 0, 0, 0, 0 };
+        for (j = 0; j < 8; j++)
+            for (v = 0; v < 8; v++) acc[v & 3] = FN(fma_)(phi[(l * 8 + j) * 8 + v], W[FN(wave_row)(l, j, v) * A + a], acc[v & 3]);
+        part[l] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    }
+    return FN(wave_total)(part);
+}
+int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), d, j, l, v;
+    int64_t N = run->n_envs, i, k;
+    R *phi_s, *phi_n, *tmp;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
+        !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
+    phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
+    for (i = 0; i < N; i++) {
+        R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
+        R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
+        int a = run->action[i]; uint32_t ep = run->ep_step[i];
+        FN(wave_project)(b, s, phi_s);
+        for (j = 0; j < A; j++) q_s[j] = FN(wave_dot)(phi_s, W, A, j);
+        for (k = 0; k < n_steps; k++) {
+            const uint64_t t = run->t + (uint64_t)k;
+            R r, delta, e, scale; int term, trunc, na; uint32_t x[4], xin[4] = { 0, 0, 0, 0 };
+            for (d = 0; d < D; d++) ns[d] = s[d];
+            term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+            ep += 1;
+            trunc = !term && ag->max_episode_steps > 0 && ep >= ag->max_episode_steps;
+            if (term) FN(orc_domain_reset)(ag->domain, ns);
+            FN(wave_project)(b, ns, phi_n);
+            for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+            if (ag->algo == ORC_SARSA) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+            delta = FN(td_from_q)(ag, q_s, a, q_n, r, term, xin, &e);
+            scale = (R)ag->lr * e;
+            for (l = 0; l < 64; l++) {
+                uint32_t rnd[4] = { 0, 0, 0, 0 };
+                if (w_bf16) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + (uint32_t)l, rnd);
+                for (j = 0; j < 8; j++)
+                    for (v = 0; v < 8; v++) {
+                        R* wp = &W[FN(wave_row)(l, j, v) * A + a];
+                        float xw = (float)FN(fma_)(scale, phi_s[(l * 8 + j) * 8 + v], *wp);
+                        if (w_bf16) {
+                            const int el = j * 8 + v; uint32_t bits;
+                            memcpy(&bits, &xw, 4);
+                            bits += (rnd[el & 3] >> (el >> 2)) & 0xffffu;
+                            bits &= 0xffff0000u;
+                            memcpy(&xw, &bits, 4);
+                        }
+                        *wp = (R)xw;
+                    }
+            }
+            q_n[a] = FN(wave_dot)(phi_n, W, A, a);                          /* Q(s',a) with the UPDATED column */
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, term ? ORC_BLK_RESET : ORC_BLK_STEP, x);
+            na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
+            acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
+            if (term) { acc.episodes += 1; acc.sum_episode_steps += ep; ep = 0; }
+            if (trunc) {
+                acc.episodes += 1; acc.episodes_truncated += 1; acc.sum_episode_steps += ep; ep = 0;
+                FN(orc_domain_reset)(ag->domain, ns);
+                FN(wave_project)(b, ns, phi_n);
+                for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+                orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_RESET, x);
+                na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
+            }
+            for (d = 0; d < D; d++) s[d] = ns[d];
+            for (j = 0; j < A; j++) q_s[j] = q_n[j];
+            tmp = phi_s; phi_s = phi_n; phi_n = tmp;
+            a = na;
+        }
+        run->action[i] = a; run->ep_step[i] = ep;
+    }
+    run->t += (uint64_t)n_steps;
+    free(phi_s); free(phi_n);
+    if (st) *st = acc;
+    return 0;
+}
+/* the wave family's initial policy.sample (k_wave_reset): Q(s0,.) in the wave order */
+void FN(orc_run_reset_wave)(void* h) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
+    int D = ag->basis.dim, A = ag->n_actions, j; int64_t i;
+    R* phi = (R*)malloc(sizeof(R) * 4096);
+    run->q_valid = 0;
+    for (i = 0; i < run->n_envs; i++) {
+        R q[ORC_MAX_ACTIONS]; uint32_t x[4];
+        R* s = run->state + (size_t)i * D;
+        FN(orc_domain_reset)(ag->domain, s);
+        FN(wave_project)(&ag->basis, s, phi);
+        for (j = 0; j < A; j++) q[j] = FN(wave_dot)(phi, FN(run_W)(run, i), A, j);
+        orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INIT, x);
+        run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+        run->ep_step[i] = 0;
+    }
+    free(phi);
 }
 
 /* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340

@@ -216,6 +216,7 @@ struct rsrl_hip_ctx {
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
     size_t n_stat_slots = 0;
     uint64_t t = 0;          // batch-steps executed (RNG counter)
+    int64_t pending = 0;     // batch-steps accepted by rsrl_hip_train but not launched yet (launch coalescing, see rsrl_hip_train)
     uint64_t api_calls = 0;  // RNG counter of rsrl_hip_policy_sample
     Scratch scratch[8];
     // timing of train launches
@@ -442,6 +443,9 @@ static int peer_check(rsrl_hip_ctx* c) {
     return RSRL_HIP_OK;
 }
 
+static int flush_pending(rsrl_hip_ctx* c);      // launch the batch-steps rsrl_hip_train has accepted but not launched yet
+#define FLUSH(c) TRY(flush_pending(c))
+
 // ------------------------------------------------------------------------------- API
 extern "C" {
 
@@ -647,7 +651,7 @@ int rsrl_hip_create(const rsrl_hip_config* cfg, rsrl_hip_ctx** out) {
 }
 
 int rsrl_hip_sync(rsrl_hip_ctx* c) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return peer_check(c);
@@ -658,7 +662,7 @@ int rsrl_hip_n_actions(const rsrl_hip_ctx* c) { return c ? c->A : RSRL_HIP_EINVA
 int rsrl_hip_n_outputs(const rsrl_hip_ctx* c) { return c ? c->Aw : RSRL_HIP_EINVAL; }
 int rsrl_hip_n_features(const rsrl_hip_ctx* c) { return c ? c->F : RSRL_HIP_EINVAL; }
 int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* c) { return c ? c->cfg.n_envs : RSRL_HIP_EINVAL; }
-uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* c) { return c ? c->t : 0; }
+uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* c) { return c ? c->t + (uint64_t)c->pending : 0; }
 
 int rsrl_hip_state_bounds(const rsrl_hip_ctx* c, double* lo, double* hi) {
     CHECK_CTX(c);
@@ -674,14 +678,14 @@ int rsrl_hip_state_bounds(const rsrl_hip_ctx* c, double* lo, double* hi) {
 }
 
 int rsrl_hip_set_epsilon(rsrl_hip_ctx* c, double eps) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!(eps >= 0.0 && eps <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon must be in [0,1]");   // gen_bool panics otherwise
     c->cfg.epsilon = eps;
     return RSRL_HIP_OK;
 }
 
 int rsrl_hip_reset(rsrl_hip_ctx* c) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const Common k = make_common(c);
@@ -702,14 +706,14 @@ int rsrl_hip_reset(rsrl_hip_ctx* c) {
 }
 
 int rsrl_hip_get_states(rsrl_hip_ctx* c, float* states) {
-    CHECK_CTX(c); if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c); FLUSH(c); if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(states, c->state, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false; if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
@@ -717,14 +721,14 @@ int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_get_actions(rsrl_hip_ctx* c, int32_t* actions) {
-    CHECK_CTX(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c); FLUSH(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(actions, c->action, sizeof(int32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
-    CHECK_CTX(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c); FLUSH(c); if (!actions) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(check_host_actions(actions, (size_t)c->cfg.n_envs, c->A));
     HIP_TRY(hipMemcpyAsync(c->action, actions, sizeof(int32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
@@ -736,7 +740,7 @@ int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
 
 int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_states, float* next_states,
                          float* rewards, uint8_t* terminal) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs; const size_t DN = (size_t)c->D * N;
@@ -763,7 +767,7 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
 }
 
 int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs;
@@ -783,7 +787,7 @@ int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
 
 static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* fout, size_t fcount, int32_t* iout,
                size_t icount = 0) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!states || M_ < 1 || M_ > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M_, (long long)c->cfg.n_envs);
     if (is_pred(c->cfg.algo) && op != QOP_EVALUATE && op != QOP_FEATURES)
         return fail(RSRL_HIP_ESTATE, "a prediction agent has a state-value function only (use rsrl_hip_q_evaluate for V(s))");
@@ -852,7 +856,7 @@ int rsrl_hip_tile_indices(rsrl_hip_ctx* c, const float* states, int64_t M, int32
 
 int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* actions, const float* rewards,
                     const float* to_states, const uint8_t* terminal, int64_t M, float* td_error_out) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!from_states || !actions || !rewards || !to_states || !terminal) return fail(RSRL_HIP_EINVAL, "null argument");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch size");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -903,7 +907,7 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
 }
 
 int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
-    CHECK_CTX(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    CHECK_CTX(c); FLUSH(c); if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -922,7 +926,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
@@ -942,7 +946,7 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     return RSRL_HIP_OK;
 }
 static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no auxiliary matrix (eligibility trace / fa_td weights)");
     if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1031,7 +1035,7 @@ bool ckpt_decode(const uint8_t (&buf)[kCkptHeaderBytes], Ckpt* h, uint32_t* vers
 }  // namespace
 static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in);
 int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!path) return fail(RSRL_HIP_EINVAL, "null path");
     FILE* f = fopen(path, "wb");
     if (!f) return fail(RSRL_HIP_EINVAL, "cannot open %s for writing", path);
@@ -1049,7 +1053,7 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
     return rc;
 }
 int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!path) return fail(RSRL_HIP_EINVAL, "null path");
     HIP_TRY(hipSetDevice(c->cfg.device));
     FILE* f = fopen(path, "rb");
@@ -1105,7 +1109,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
 }
 
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     if (c->cfg.weight_mode == RSRL_W_SHARED) return rsrl_hip_set_weights(c, 0, w);
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1242,9 +1246,7 @@ static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     return RSRL_HIP_OK;
 }
 
-int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
-    CHECK_CTX(c);
-    if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
+static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
@@ -1349,8 +1351,49 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     return RSRL_HIP_OK;
 }
 
-int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
+static int flush_pending(rsrl_hip_ctx* c) {
+    if (!c || c->pending == 0) return RSRL_HIP_OK;
+    const int64_t n = c->pending;
+    c->pending = 0;
+    return train_now(c, n, nullptr);
+}
+// fused register-family loop: any split of n batch-steps into launches gives bit-identical results (Q(s,.) is carried between
+// launches, the RNG is addressed by the batch-step) -- the property launch coalescing relies on (tests: fused == stepwise)
+static bool coalescable(const rsrl_hip_ctx* c) {
+    const auto& g = c->cfg;
+    return g.weight_mode == RSRL_W_PER_ENV && g.basis == RSRL_FOURIER && !is_wave(g) && !is_generic_fourier(g) && !has_aux(g.algo) &&
+           !is_pred(g.algo) && g.steps_per_launch != 1 && !getenv("RSRL_NO_COALESCE");
+}
+// rsrl_hip_train is asynchronous when no statistics are requested: it returns once the work is accepted.  A short call (the
+// 20 batch-steps of a driver loop) costs a full load + store of every learner's weights around ~20 us of arithmetic, so calls
+// that arrive while the stream is still busy are COALESCED: their steps are held back and launched fuse-depth (256) at a time,
+// or as soon as anything observes or changes the ctx (every other entry point flushes first, rsrl_hip_sync included), or
+// when a call finds the stream idle (then nothing is gained by waiting).  Invisible to the caller: same results bit for bit,
+// same ordering; 5 000 back-to-back train(20) calls run as ~400 launches instead of 5 000.  RSRL_NO_COALESCE=1 disables it.
+int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     CHECK_CTX(c);
+    if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
+    if (stats_out || !coalescable(c)) {
+        FLUSH(c);
+        return train_now(c, n_steps, stats_out);
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->pending += n_steps;
+    const int64_t depth = c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256;
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) return flush_pending(c);                       // idle stream: launch now
+    if (q != hipErrorNotReady) return fail(RSRL_HIP_EHIP, "hipStreamQuery: %s", hipGetErrorString(q));
+    (void)hipGetLastError();
+    if (c->pending >= depth) {
+        const int64_t n = c->pending - c->pending % depth;
+        c->pending -= n;
+        return train_now(c, n, nullptr);
+    }
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
+    CHECK_CTX(c); FLUSH(c);
     if (!n_states_out) return fail(RSRL_HIP_EINVAL, "null argument");
     if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1 (unbounded rollouts are not offered)");
     if (c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
@@ -1378,7 +1421,7 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_sta
 }
 
 int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!out) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(scratch_reserve(c, 7, 2 * sizeof(unsigned long long)));
@@ -1414,7 +1457,7 @@ int rsrl_hip_comm_unique_id(uint8_t* id_bytes) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size, int rank) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!id_bytes || world_size < 1 || rank < 0 || rank >= world_size) return fail(RSRL_HIP_EINVAL, "bad communicator arguments");
     if (c->comm) return fail(RSRL_HIP_ESTATE, "communicator already initialised");
     if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no collective: shard by env_offset instead");
@@ -1432,7 +1475,7 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
 struct PeerBlob { uint32_t magic; int32_t pid; uint64_t ptr; uint64_t bytes; int32_t world; int32_t pad; hipIpcMemHandle_t h; };
 static_assert(sizeof(PeerBlob) <= RSRL_HIP_PEER_HANDLE_BYTES, "peer handle blob must fit the ABI slot");
 int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!handle_out || world_size < 1 || world_size > 64) return fail(RSRL_HIP_EINVAL, "bad peer arguments");
     if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no exchange: shard by env_offset instead");
     if (c->cfg.exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
@@ -1455,7 +1498,7 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     return RSRL_HIP_OK;
 }
 int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_size, int rank) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     if (!handles || world_size < 1 || rank < 0 || rank >= world_size) return fail(RSRL_HIP_EINVAL, "bad peer arguments");
     if (!c->peer_recv || c->peer_world != world_size) return fail(RSRL_HIP_ESTATE, "call rsrl_hip_peer_export(world_size) first");
     if (c->multi) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
@@ -1484,13 +1527,13 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
 }
 
 int rsrl_hip_timing_enable(rsrl_hip_ctx* c, int enable) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     c->timing = enable != 0;
     c->events_used = 0;
     return RSRL_HIP_OK;
 }
 int rsrl_hip_timing_read(rsrl_hip_ctx* c, double* ms_total, uint64_t* launches, const char** kernel_name) {
-    CHECK_CTX(c);
+    CHECK_CTX(c); FLUSH(c);
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double tot = 0.0;

@@ -109,7 +109,7 @@ with ra.Context(n_envs=N, **dict(kw, exchange=ra.EXCHANGE_RCCL)) as full:
 err_w = float(np.max(np.abs(ref[0] - out[0][0])) / max(1.0, np.abs(ref[0]).max()))
 states = np.concatenate([o[1] for o in out], axis=1)
 same = float(np.all(np.abs(states - ref[1]) <= 1e-6, axis=0).mean())
-print("RESULT " + json.dumps({"err_w": err_w, "same": same, "absw": float(np.abs(ref[0]).max())}))
+print("RESULT " + json.dumps({"err_w": err_w, "same": same, "absw": float(np.abs(ref[0]).max())}), flush=True)
 os._exit(0)
 '''
 

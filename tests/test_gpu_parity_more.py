@@ -378,3 +378,28 @@ def test_long_run_population_statistics_other_configs(ra, orc, name, okw, dkw, K
         assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 0.03 * ost["sum_abs_td_error"]
         assert abs(np.abs(Wd).mean() - np.abs(run.weights).mean()) <= 0.03 * np.abs(run.weights).mean()
         assert abs(st["sum_reward"] - ost["sum_reward"]) <= 0.03 * abs(ost["sum_reward"]) + 3
+
+
+def test_launch_coalescing_is_invisible(ra, monkeypatch):
+    # rsrl_hip_train holds back short calls that arrive while the stream is busy and launches them fuse-depth at a time; every
+    # other entry point flushes first.  Same results bit for bit, same step counter, parameter changes land where they were made.
+    kw = dict(n_envs=5000, policy=1, epsilon=0.2, seed=3, max_episode_steps=50)
+
+    def drive(c):
+        c.reset()
+        for _ in range(200):
+            c.train(7, want_stats=False)
+        assert c.step_count == 1400                 # accepted steps count, launched or not
+        c.set_epsilon(0.05)                         # flushes the pending steps with the OLD epsilon first
+        for _ in range(50):
+            c.train(3, want_stats=False)
+        st = c.train(10)                            # statistics: immediate launch after a flush
+        return c.checksum(), c.states, c.actions, c.get_weights(4999), st, c.step_count
+
+    with ra.Context(**kw) as a:
+        got = drive(a)
+    monkeypatch.setenv("RSRL_NO_COALESCE", "1")
+    with ra.Context(**kw) as b:
+        ref = drive(b)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    assert got[4] == ref[4] and got[5] == ref[5] == 1560

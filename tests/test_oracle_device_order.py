@@ -94,3 +94,19 @@ def test_agent_policy_greedy_target_is_qlearning(orc):
         assert abs(d[0] - d[2]) <= 1e-12 and abs(d[1] - d[2]) <= 1e-12
         diff = max(diff, abs(d[3] - d[2]))
     assert diff > 1e-3
+
+
+@pytest.mark.parametrize("domain,algo,policy", [(2, 2, 2), (1, 0, 1)])
+def test_wave_order_loop_follows_the_reference_order_loop(orc, domain, algo, policy):
+    # the wave family's evaluation order (feature index k = (f+1) mod F, lane partials + DPP ladder) against orc_run_train
+    kw = dict(gamma=0.99, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0)
+    ag = orc.make_agent(domain=domain, order=7, algo=algo, policy=policy, seed=23, max_episode_steps=15, **kw)
+    N, K = 4, 24
+    ref = orc.Run(ag, N, "f32"); ref.reset(); ref.train(K)
+    wav = orc.Run(ag, N, "f32d"); wav.reset_wave(); wav.train_wave(K)
+    assert np.all(np.abs(ref.state - wav.state) <= 1e-3 * (1 + np.abs(ref.state))) and np.array_equal(ref.action, wav.action)
+    assert np.max(np.abs(ref.weights - wav.weights)) <= 1e-6
+    b16 = orc.Run(ag, N, "f32d"); b16.reset_wave(); b16.train_wave(K, bf16=True)
+    assert np.all((b16.weights.view(np.uint32) & 0xffff) == 0) and np.abs(b16.weights).max() > 0
+    with pytest.raises(ValueError):
+        orc.Run(orc.make_agent(order=5), 2, "f32d").train_wave(1)
