@@ -12,9 +12,12 @@ N > 1 without a launcher (WORLD_SIZE unset): bench.py starts the N ranks itself 
 GPU, rendezvous on 127.0.0.1).  Under a launcher it is one of the ranks.  Envs are sharded by global id with NO
 data-path collective (independent learners) => weak scaling.
 
-Timed region: a K-step call is short (K = 20 is ~40 us of GPU work), so the call is repeated R times back to back
-between ONE pair of barrier + synchronize (R is chosen so that the region lasts >= ~0.25 s and is reported in
+Timed region: a K-step call is short (K = 20 is ~20 us of arithmetic), so the call is repeated R times back to back
+between ONE pair of barrier + synchronize (R is chosen so that the region lasts >= ~0.3 s and is reported in
 config.repeats); ms_per_step = region / (K * R), value = all ranks' env-steps / max-over-ranks region time.
+rsrl_hip_train is asynchronous and coalesces calls that arrive while the stream is busy (same results bit for bit,
+include/rsrl_hip.h): the R x K batch-steps run as launches of up to 256 steps -- config.steps_per_launch and
+roofline.launches report what was actually launched; RSRL_NO_COALESCE=1 gives one launch per call.
 """
 import argparse
 import json
@@ -36,7 +39,7 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs, max clock
 # HBM bytes one launch of the fused kernel must move per learner, whatever its depth: W in + W out (2 x 432), state in/out
 # (2 x 8), action in/out (2 x 4), episode counter in/out (2 x 4), carried Q in/out (2 x 12)
 FUSED_BYTES_PER_LEARNER_LAUNCH = 2 * (432 + 8 + 4 + 4 + 12)
-TARGET_REGION_S = 0.25
+TARGET_REGION_S = 0.3
 
 
 def usable_cores():
@@ -284,11 +287,13 @@ def main():
     # R: how many K-step calls make a >= 0.25 s region (one untimed calibration call; the same R on every rank)
     repeats = args.repeats
     if repeats <= 0:
+        burst = 32                                   # back-to-back, as in the timed region (the library coalesces short calls)
         t0 = time.perf_counter()
-        ctx.train(args.steps, want_stats=False)
+        for _ in range(burst):
+            ctx.train(args.steps, want_stats=False)
         ctx.sync()
-        t_call = cp.max_over_ranks(time.perf_counter() - t0)
-        repeats = int(min(200000, max(3, -(-TARGET_REGION_S // max(t_call, 1e-7)))))
+        t_call = cp.max_over_ranks(time.perf_counter() - t0) / burst
+        repeats = int(min(400000, max(3, -(-TARGET_REGION_S // max(t_call, 1e-7)))))
     cp.barrier()
     ctx.sync()
     ctx.timing_enable(True)

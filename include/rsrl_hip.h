@@ -251,6 +251,11 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 /* The fused driver loop (examples/q_learning.rs:40-52) x n_envs x n_steps with auto-reset
  * on terminal / step cap.  stats_out is a HOST pointer (optional). */
 int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out);
+/*   Without stats_out the call is ASYNCHRONOUS: it returns once the work is accepted.  Short calls (a driver loop's 20
+ *   batch-steps) that arrive while the ctx's stream is still busy are coalesced -- held back and launched fuse-depth (256)
+ *   at a time, when anything observes or changes the ctx (every other entry point, rsrl_hip_sync included, flushes first),
+ *   or when a call finds the stream idle.  Results are bit-identical to one launch per call (the fused loop carries Q(s,.)
+ *   between launches and addresses the RNG by the batch-step); RSRL_NO_COALESCE=1 in the environment disables it. */
 /* batch-steps executed so far by rsrl_hip_train and rsrl_hip_handle (the RNG counter) */
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
 

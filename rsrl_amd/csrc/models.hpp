@@ -631,6 +631,151 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
+// ---------------------------------------------------------------------------------------
+// Shared weights, dense basis: ONE launch per batch-step (k_shared_step).
+// A dependent kernel costs ~4 us on this machine whatever it does, so the delta reduction no longer has a kernel of its
+// own: every block of batch-step t first folds the partial rows of batch-step t-1 into the weights itself,
+//     W_t = W_{t-1} + sum over rows (reduce_rows: one fixed order, identical in every block => identical W_t everywhere)
+// keeps W_t in LDS for both phases, and block 0 writes it out for the next launch (two W buffers and two row buffers in
+// ping-pong: a launch never writes what a block of the same launch may still read).  The kernel boundary is the only
+// synchronisation.  rows_in / n_rows_in = 0: nothing to fold (first step of a train call; multi-rank mode, where
+// finalize -> exchange -> apply run between the launches instead).
+//   mode bit 0: phase C of the previous batch-step (policy.sample with W_t, episode restarts)
+//   mode bit 1: phase A of this batch-step (transition, TD error against W_t, the learner's term into this block's row)
+// ---------------------------------------------------------------------------------------
+// out_j = sum over the rows of rows[r][j]: lane l of ONE wave adds rows l, l+64, l+128, ... in ascending order, then the
+// 64 lane sums go through the DPP ladder.  Must be called by all 64 lanes of a wave with the same j.
+__device__ __forceinline__ float reduce_rows(const float* __restrict__ rows, int n_rows, int n, int j, int lane) {
+    float acc = 0.0f;
+    int r = lane;
+    for (; r + 192 < n_rows; r += 256) {          // 4 independent loads in flight, added in ascending row order
+        const float v0 = rows[(int64_t)r * n + j], v1 = rows[(int64_t)(r + 64) * n + j];
+        const float v2 = rows[(int64_t)(r + 128) * n + j], v3 = rows[(int64_t)(r + 192) * n + j];
+        acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; r < n_rows; r += 64) acc += rows[(int64_t)r * n + j];
+    return wave_sum_all(acc);
+}
+template <class M, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,
+                                                        float* __restrict__ W_out, const float* __restrict__ rows_in, int n_rows_in,
+                                                        float* __restrict__ rows_out, uint8_t* __restrict__ flags,
+                                                        DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
+    static_assert(M::kDense, "dense bases only");
+    if (t_dev) t += *t_dev;
+    constexpr int D = M::D, A = M::A, F = M::F, AF = A * F;
+    const bool do_c = (mode & 1) != 0, do_a = (mode & 2) != 0;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    __shared__ __attribute__((aligned(16))) float sh_w[AF];
+    // ---- W_t = W_{t-1} + the previous batch-step's delta, in LDS (every block, same order => same bits)
+    if (n_rows_in > 0) {
+        for (int j = wave; j < AF; j += BLOCK / 64) {
+            const float tot = reduce_rows(rows_in, n_rows_in, AF, j, lane);
+            if (lane == 0) sh_w[j] = W_in[j] + tot;
+        }
+    } else {
+        for (int j = threadIdx.x; j < AF; j += BLOCK) sh_w[j] = W_in[j];
+    }
+    __syncthreads();
+    if (W_out && blockIdx.x == 0)
+        for (int j = threadIdx.x; j < AF; j += BLOCK) W_out[j] = sh_w[j];
+    typename M::Feat fs;
+    int a = 0;
+    float scale = 0.0f;
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D], ns[D], q_s[A];
+        uint32_t ep = c.ep_step[i];
+        bool done = false;
+        if (do_c) done = flags[i] != 0;
+        if (done) { M::Dom::reset(s); ep = 0; }
+        else load_state<M>(c.state, N, i, s);
+        M::features(s, g, fs);
+        M::q_all_lds(sh_w, fs, q_s);
+        if (do_c) {                                                     // ---- phase C of batch-step t-1
+            const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
+            a = policy_sample<A>(c.pol, q_s, x);
+        } else {
+            a = c.action[i];
+        }
+        if (do_a) {                                                     // ---- phase A of batch-step t
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = M::Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            typename M::Feat fn;
+            M::features(ns, g, fn);
+            float q_n[A];
+            M::q_all_lds(sh_w, fn, q_n);
+            U4 xin = U4{0, 0, 0, 0};
+            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+            scale = c.alg.lr * e;
+#pragma unroll
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+            c.action[i] = a;
+            c.ep_step[i] = ep;
+            flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+            sum_abs = (double)fabsf(delta); sum_r = (double)r;
+            if (term || trunc) { n_ep = 1; n_trunc = trunc ? 1 : 0; sum_len = ep; }
+        } else {                                                        // closing launch: phase C only
+            if (done) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+                c.ep_step[i] = 0;
+            }
+            c.action[i] = a;
+        }
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f) fs.phi[f] = 0.0f;
+    }
+    if (do_a) {
+        // block-level sum of the learners' terms through LDS, fixed order (reproducible): tile_t[f][i] = lr*e_i*phi_i[f]
+        // (feature-major rows, padded: conflict-free both ways), ind[b][i] = [a_i == b]; thread (h, b, f) sums the 128
+        // learners of part h in ascending order as ONE fma chain acc = ind*v + acc (ind in {0, 1}: exactly "acc += v" or
+        // "acc += 0"), 4 learners per 16-B LDS read; the H parts are then added in order.
+        constexpr int PER = 128, H = BLOCK / PER, LP = BLOCK + 4;
+        static_assert(BLOCK % PER == 0 && H * AF <= BLOCK, "dense shared-W reduction needs A*F*(BLOCK/128) <= BLOCK");
+        __shared__ __attribute__((aligned(16))) float tile_t[F][LP];
+        __shared__ __attribute__((aligned(16))) float ind[A][BLOCK];
+        __shared__ float part[H][AF];
+#pragma unroll
+        for (int f = 0; f < F; ++f) tile_t[f][threadIdx.x] = scale * fs.phi[f];
+#pragma unroll
+        for (int b = 0; b < A; ++b) ind[b][threadIdx.x] = (a == b) ? 1.0f : 0.0f;
+        __syncthreads();
+        if (threadIdx.x < H * AF) {
+            const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
+            const float4* __restrict__ vrow = reinterpret_cast<const float4*>(&tile_t[f][h * PER]);
+            const float4* __restrict__ drow = reinterpret_cast<const float4*>(&ind[b][h * PER]);
+            float acc = 0.0f;
+#pragma unroll 8
+            for (int q = 0; q < PER / 4; ++q) {
+                const float4 v = vrow[q], d = drow[q];
+                acc = fmaf(d.x, v.x, acc); acc = fmaf(d.y, v.y, acc); acc = fmaf(d.z, v.z, acc); acc = fmaf(d.w, v.w, acc);
+            }
+            part[h][j] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x < AF) {
+            float tot = part[0][threadIdx.x];
+#pragma unroll
+            for (int h = 1; h < H; ++h) tot += part[h][threadIdx.x];
+            rows_out[(int64_t)blockIdx.x * AF + threadIdx.x] = tot;
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
 // shared weights, stand-alone phase C (closes the last batch-step of a train call): policy.sample with the updated
 // weights; finished episodes restart from Domain::default() with a fresh sample.
 template <class M>

@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int
     }
     dW[j] = acc;
 }
+// multi-rank mode: the same sum as a kernel of its own (one wave per output), feeding the exchange
+__global__ __launch_bounds__(kBlock) void k_rows_finalize(const float* __restrict__ rows, int n_rows, int n, float* __restrict__ dW) {
+    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+    if (j >= n) return;
+    const float tot = reduce_rows(rows, n_rows, n, j, lane);
+    if (lane == 0) dW[j] = tot;
+}
+
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
 __global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
@@ -123,33 +131,6 @@ __global__ void k_weights_set_all(float* __restrict__ W, bool tile, int64_t N, i
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     for (int j = blockIdx.y; j < F * A; j += gridDim.y) W[w_index(tile, stride, i * ls, F, A, j / A, j % A)] = in[j];
-}
-// shared-W dense basis: dW[j] = sum over blocks of partials[blk][j] in a FIXED order (reproducible):
-// 8 interleaved partial sums (blocks b = p mod 8, ascending) per element, combined p = 0..7.
-__global__ __launch_bounds__(1024) void k_dw_finalize(const float* __restrict__ partials, int n_blocks, int n, float* __restrict__ dW,
-                                                      float* __restrict__ W_apply) {
-    __shared__ float part[8][128];
-    const int jl = threadIdx.x & 127, p = threadIdx.x >> 7;
-    const int j = blockIdx.x * 128 + jl;
-    float acc = 0.0f;
-    if (j < n) {
-        for (int b0 = p; b0 < n_blocks; b0 += 64) {            // 8 loads in flight, added in ascending block order
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int b = b0 + 8 * u; v[u] = b < n_blocks ? partials[(int64_t)b * n + j] : 0.0f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-    }
-    part[p][jl] = acc;
-    __syncthreads();
-    if (p == 0 && j < n) {
-        float tot = part[0][jl];
-#pragma unroll
-        for (int q = 1; q < 8; ++q) tot += part[q][jl];
-        if (W_apply) W_apply[j] += tot;                          // single rank: W_{t+1} = W_t + delta right here
-        else dW[j] = tot;                                        // multi rank: the delta goes through the all-reduce first
-    }
 }
 // the same sum for a learner-major W[N][AF], with every word weighted by the index it has in the feature-major layout
 // ((row)*N + learner): the checksum of the weights does not depend on the layout the ctx chose
@@ -205,7 +186,10 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
     float* dW_rep = nullptr; int n_rep = 1;      // shared tile coding: replicated delta tables (contention relief)
-    float* partials = nullptr;       // shared-W dense basis: one delta row per thread block
+    float* partials = nullptr;       // shared-W dense basis: one delta row per thread block, two buffers in ping-pong
+    float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
+    int sh_par = 0, sh_row = 0;      // which W buffer holds the current weights (0 = W); which row buffer was written last
+    unsigned sh_rows = 0;            // rows per buffer = blocks of k_shared_step
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
@@ -292,6 +276,7 @@ static TdParams make_td(const rsrl_hip_ctx* c) {
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+constexpr int kSharedBlock = 512;    // learners per block of k_shared_step: 256 blocks = one per CU for a 131 072-env shard
 
 // ---- (basis, domain, parameter) -> Model type ---------------------------------------------------
 // Fourier register family: F = (order+1)^D <= 36 features per learner held in VGPRs.
@@ -486,6 +471,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW) (void)hipFree(c->dW);
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->partials) (void)hipFree(c->partials);
+    if (c->W2) (void)hipFree(c->W2);
     if (c->step_graph_exec) (void)hipGraphExecDestroy(c->step_graph_exec);
     if (c->step_graph) (void)hipGraphDestroy(c->step_graph);
     if (c->d_t) (void)hipFree(c->d_t);
@@ -606,7 +592,11 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
-        if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->n_stat_slots));
+        if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) {
+            c->sh_rows = (unsigned)((N + kSharedBlock - 1) / kSharedBlock);
+            HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->sh_rows * 2));
+            HIP_TRY(hipMalloc((void**)&c->W2, c->w_bytes));
+        }
     }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
     HIP_TRY(hipMalloc((void**)&c->d_t, sizeof(uint64_t)));
@@ -1154,10 +1144,47 @@ static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
 // delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
 // train call is closed by a stand-alone phase C (enqueue_shared_c).
 // t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
+// dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's rows to
+// the weights first (single rank; in multi-rank mode finalize -> exchange -> apply run between the launches instead).
+static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, bool fold, uint64_t t,
+                              const uint64_t* t_dev) {
+    const size_t rowsz = (size_t)c->sh_rows * c->dw_elems;
+    const float* W_in = c->sh_par ? c->W2 : c->W;
+    float* W_out = fold ? (c->sh_par ? c->W : c->W2) : nullptr;
+    const float* rows_in = fold ? c->partials + (size_t)c->sh_row * rowsz : nullptr;
+    float* rows_out = c->partials + (size_t)(c->sh_row ^ 1) * rowsz;
+    bool ok = false;
+    for_model(c, [&](auto tag) {
+        using M = typename decltype(tag)::type;
+        if constexpr (M::kDense) {
+            hipLaunchKernelGGL((k_shared_step<M, kSharedBlock>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, t, mode, W_in, W_out, rows_in,
+                               fold ? (int)c->sh_rows : 0, rows_out, c->flags, d_stats, t_dev);
+            ok = true;
+        }
+    });
+    if (!ok) return NO_MODEL(c);
+    KCHECK();
+    if (fold) c->sh_par ^= 1;
+    if (mode & 2) c->sh_row ^= 1;
+    return RSRL_HIP_OK;
+}
 static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int do_c, uint64_t t,
                                const uint64_t* t_dev) {
     const dim3 grid(grid_for(k.n_envs)), block(kBlock);
     const bool dense = c->cfg.basis == RSRL_FOURIER;
+    if (dense) {
+        const int n = (int)c->dw_elems;
+        if (!c->multi) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
+        // multi-rank: the step (nothing to fold: W was updated by the apply below), then rows -> dW -> exchange -> W += dW
+        TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
+        const float* rows = c->partials + (size_t)c->sh_row * c->sh_rows * c->dw_elems;
+        hipLaunchKernelGGL(k_rows_finalize, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, rows, (int)c->sh_rows, n, c->dW);
+        KCHECK();
+        TRY(exchange_dw(c, t, t_dev));
+        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+        KCHECK();
+        return RSRL_HIP_OK;
+    }
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
@@ -1179,12 +1206,6 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-    if (dense) {
-        // single rank: the finalize kernel applies the summed delta itself (W += sum; one launch less)
-        hipLaunchKernelGGL(k_dw_finalize, dim3((n + 127) / 128), dim3(1024), 0, c->stream, c->partials, (int)grid.x, n, c->dW,
-                           multi ? (float*)nullptr : c->W);
-        KCHECK();
-    }
     if (!dense && c->dW_rep) {
         hipLaunchKernelGGL(k_apply_rep, dim3((n / 4 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n);
         KCHECK();
@@ -1197,6 +1218,15 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     return RSRL_HIP_OK;
 }
 static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
+    if (c->cfg.basis == RSRL_FOURIER) {
+        // closing launch: fold the last batch-step's rows (single rank), phase C; the result goes back to the canonical buffer
+        TRY(enqueue_dense_step(c, k, g, nullptr, 1, !c->multi, t_last + 1, nullptr));
+        if (c->sh_par) {
+            HIP_TRY(hipMemcpyAsync(c->W, c->W2, c->w_bytes, hipMemcpyDeviceToDevice, c->stream));
+            c->sh_par = 0;
+        }
+        return RSRL_HIP_OK;
+    }
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             hipLaunchKernelGGL((k_shared_c<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, t_last, c->flags);
@@ -1264,14 +1294,15 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     bool t_dev_set = false;
     int64_t done = 0;
     while (done < n_steps) {
-        if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? done > 0 : c->q_valid)) {
+        // (dense shared W: the W / row buffers alternate every batch-step, the graph is captured at the parity of an odd step count)
+        if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? (done > 0 && (!fourier || (done & 1))) : c->q_valid)) {
             Common kg = k; kg.q_valid = stream_k1 ? 1 : k.q_valid;
             TRY(ensure_step_graph(c, kg, g, stream_k1 ? 1 : 2));
             if (!t_dev_set) { hipLaunchKernelGGL(k_set_t, dim3(1), dim3(1), 0, c->stream, c->d_t, c->t); KCHECK(); t_dev_set = true; }
             TRY(timing_begin(c));
             HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
             TRY(timing_end(c, kStepsPerGraph));
-            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg") : "k_shared_ca";
+            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
             c->t += (uint64_t)kStepsPerGraph;
             done += kStepsPerGraph;
             continue;
@@ -1280,8 +1311,9 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
         TRY(timing_begin(c));
         if (shared) {
+            if (done == 0) c->sh_row = 0;
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
-            c->kernel_name = "k_shared_ca";
+            c->kernel_name = fourier ? "k_shared_step" : "k_shared_ca";
         } else if (is_pred(c->cfg.algo)) {
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_td(c), c->t, chunk, d_stats)) return NO_MODEL(c);
