@@ -643,19 +643,36 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
 //   mode bit 0: phase C of the previous batch-step (policy.sample with W_t, episode restarts)
 //   mode bit 1: phase A of this batch-step (transition, TD error against W_t, the learner's term into this block's row)
 // ---------------------------------------------------------------------------------------
-// out_j = sum over the rows of rows[r][j]: lane l of ONE wave adds rows l, l+64, l+128, ... in ascending order, then the
-// 64 lane sums go through the DPP ladder.  Must be called by all 64 lanes of a wave with the same j.
-__device__ __forceinline__ float reduce_rows(const float* __restrict__ rows, int n_rows, int n, int j, int lane) {
-    float acc = 0.0f;
-    int r = lane;
-    for (; r + 192 < n_rows; r += 256) {          // 4 independent loads in flight, added in ascending row order
-        const float v0 = rows[(int64_t)r * n + j], v1 = rows[(int64_t)(r + 64) * n + j];
-        const float v2 = rows[(int64_t)(r + 128) * n + j], v3 = rows[(int64_t)(r + 192) * n + j];
-        acc += v0; acc += v1; acc += v2; acc += v3;
+// Row sums.  The rows are stored TRANSPOSED, rowsT[j][r] (output-major): the 64 lanes of a wave read 64 consecutive rows of
+// one output j as one coalesced 256-B line.  out_k = sum over r of rowsT[j_k][r], j_k = j0 + k*jstride: lane l adds rows
+// l, l+64, l+128, ... in ascending order (a missing row adds +0), then the 64 lane sums go through the DPP ladder -- one fixed
+// order, whoever computes it.  All K outputs' loads of four 64-row chunks are in flight together (one round trip per 256
+// rows instead of one per output).  Must be called by all 64 lanes of a wave with the same arguments.
+template <int K>
+__device__ __forceinline__ void reduce_rows(const float* __restrict__ rowsT, int n_rows, int n, int j0, int jstride, int lane, float (&out)[K]) {
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+    for (int r0 = 0; r0 < n_rows; r0 += 256) {
+        float v[4][K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 64 * u + lane;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int j = j0 + k * jstride;
+                v[u][k] = (j < n && r < n_rows) ? rowsT[(int64_t)j * n_rows + r] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += v[u][k];
     }
-    for (; r < n_rows; r += 64) acc += rows[(int64_t)r * n + j];
-    return wave_sum_all(acc);
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = wave_sum_all(acc[k]);
 }
+
 template <class M, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,
                                                         float* __restrict__ W_out, const float* __restrict__ rows_in, int n_rows_in,
@@ -673,9 +690,12 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
     __shared__ __attribute__((aligned(16))) float sh_w[AF];
     // ---- W_t = W_{t-1} + the previous batch-step's delta, in LDS (every block, same order => same bits)
     if (n_rows_in > 0) {
-        for (int j = wave; j < AF; j += BLOCK / 64) {
-            const float tot = reduce_rows(rows_in, n_rows_in, AF, j, lane);
-            if (lane == 0) sh_w[j] = W_in[j] + tot;
+        constexpr int NW = BLOCK / 64, K = (AF + NW - 1) / NW;          // wave w owns the outputs j = w, w + NW, ...
+        float tot[K];
+        reduce_rows<K>(rows_in, n_rows_in, AF, wave, NW, lane, tot);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const int j = wave + k * NW; if (j < AF) sh_w[j] = W_in[j] + tot[k]; }
         }
     } else {
         for (int j = threadIdx.x; j < AF; j += BLOCK) sh_w[j] = W_in[j];
@@ -770,7 +790,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
             float tot = part[0][threadIdx.x];
 #pragma unroll
             for (int h = 1; h < H; ++h) tot += part[h][threadIdx.x];
-            rows_out[(int64_t)blockIdx.x * AF + threadIdx.x] = tot;
+            rows_out[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;        // transposed: rowsT[j][block]
         }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);

@@ -100,10 +100,45 @@ __global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int
 __global__ __launch_bounds__(kBlock) void k_rows_finalize(const float* __restrict__ rows, int n_rows, int n, float* __restrict__ dW) {
     const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
     if (j >= n) return;
-    const float tot = reduce_rows(rows, n_rows, n, j, lane);
-    if (lane == 0) dW[j] = tot;
+    float tot[1];
+    reduce_rows<1>(rows, n_rows, n, j, 1, lane, tot);
+    if (lane == 0) dW[j] = tot[0];
 }
 
+// dense peer path, two launches instead of four: the row sums go straight into every rank's receive slot ...
+__global__ __launch_bounds__(kBlock) void k_rows_finalize_push(const float* __restrict__ rows, int n_rows, int n, uint2* const* __restrict__ peers, int world,
+                                                               int rank, uint64_t t, const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;
+    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
+    if (j >= n) return;
+    float tot[1];
+    reduce_rows<1>(rows, n_rows, n, j, 1, lane, tot);
+    const uint64_t g = (uint64_t)__float_as_uint(tot[0]) | ((uint64_t)(uint32_t)(t + 1) << 32);
+    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
+    if (lane < world) __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[lane] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// ... and the sum over the ranks' slots is applied to W in the same launch (same order and bounded wait as k_peer_reduce)
+__global__ __launch_bounds__(256) void k_peer_reduce_apply(float* __restrict__ W, int n, const uint2* __restrict__ recv, int world, uint64_t t,
+                                                           const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
+    if (t_dev) t += *t_dev;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t want = (uint32_t)(t + 1);
+    const uint64_t t_start = wall_clock64();
+    const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    float acc = 0.0f;
+    for (int r = 0; r < world; ++r) {
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(t & 1) * world + r) * (size_t)n + j);
+        uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while ((uint32_t)(g >> 32) != want) {
+            if (broken || wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
+            __builtin_amdgcn_s_sleep(8);
+            g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        acc += __uint_as_float((uint32_t)g);
+    }
+    W[j] += acc;
+}
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
 __global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
@@ -1178,6 +1213,13 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         // multi-rank: the step (nothing to fold: W was updated by the apply below), then rows -> dW -> exchange -> W += dW
         TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
         const float* rows = c->partials + (size_t)c->sh_row * c->sh_rows * c->dw_elems;
+        if (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->world_size <= 64) {      // fused: rows -> every rank's slot; slots -> W
+            hipLaunchKernelGGL(k_rows_finalize_push, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, rows, (int)c->sh_rows, n,
+                               c->d_peer_ptrs, c->world_size, c->rank, t, t_dev);
+            hipLaunchKernelGGL(k_peer_reduce_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, n, c->peer_recv, c->world_size, t, t_dev, c->d_peer_err);
+            KCHECK();
+            return RSRL_HIP_OK;
+        }
         hipLaunchKernelGGL(k_rows_finalize, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, rows, (int)c->sh_rows, n, c->dW);
         KCHECK();
         TRY(exchange_dw(c, t, t_dev));
