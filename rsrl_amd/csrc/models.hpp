@@ -688,6 +688,15 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
     unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
     double sum_abs = 0.0, sum_r = 0.0;
     __shared__ __attribute__((aligned(16))) float sh_w[AF];
+    // the learner's own loads go out FIRST: they do not depend on the weights, and their latency then overlaps the row loads
+    // of the fold below instead of following them (two ~2 us round trips to memory the previous launch has just written)
+    const int64_t il = i < N ? i : N - 1;
+    float s_ld[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s_ld[d] = c.state[(int64_t)d * N + il];
+    const uint32_t ep_ld = c.ep_step[il];
+    const uint8_t flag_ld = do_c ? flags[il] : (uint8_t)0;
+    const int a_ld = c.action[il];
     // ---- W_t = W_{t-1} + the previous batch-step's delta, in LDS (every block, same order => same bits)
     if (n_rows_in > 0) {
         constexpr int NW = BLOCK / 64, K = (AF + NW - 1) / NW;          // wave w owns the outputs j = w, w + NW, ...
@@ -710,18 +719,20 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
         float s[D], ns[D], q_s[A];
-        uint32_t ep = c.ep_step[i];
-        bool done = false;
-        if (do_c) done = flags[i] != 0;
+        uint32_t ep = ep_ld;
+        const bool done = do_c && flag_ld != 0;
         if (done) { M::Dom::reset(s); ep = 0; }
-        else load_state<M>(c.state, N, i, s);
+        else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = s_ld[d];
+        }
         M::features(s, g, fs);
         M::q_all_lds(sh_w, fs, q_s);
         if (do_c) {                                                     // ---- phase C of batch-step t-1
             const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
         } else {
-            a = c.action[i];
+            a = a_ld;
         }
         if (do_a) {                                                     // ---- phase A of batch-step t
 #pragma unroll
