@@ -67,7 +67,12 @@ typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL
                RSRL_PAL = 5, RSRL_GREEDY_GQ = 6,
                /* prediction (state-value function on a ScalarLFA, ONE weight column; behaviour policy RSRL_RANDOM):
                 *   TD prediction/td/td.rs:25-59 (SGD(lr)), TDLambda prediction/td/td_lambda.rs:25-78 (step = the TD error) */
-               RSRL_TD = 7, RSRL_TD_LAMBDA = 8 } rsrl_algo;
+               RSRL_TD = 7, RSRL_TD_LAMBDA = 8,
+               /* QSigma, the n-step Q(sigma) agent (control/td/q_sigma.rs:80-202; config.sigma, config.n_steps, alpha, gamma, and the
+                * agent's own policy).  The reference panics at its first full backup -- Backup::propagate reads entries[n_steps]
+                * (q_sigma.rs:52-53 vs :113-114) -- so the library implements it with that one dead out-of-bounds read removed
+                * (rsrl_amd/csrc/kernels_qsigma.hpp).  Per-learner weights, register-family Fourier bases. */
+               RSRL_Q_SIGMA = 9 } rsrl_algo;
 /* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
 typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;
 /* rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}
@@ -132,6 +137,9 @@ typedef struct {
     int32_t  exchange;           /* rsrl_exchange: how ranks exchange the shared-W delta (rsrl_hip_comm_init)            */
     double   agent_epsilon;      /* EpsilonGreedy.epsilon of the agent's policy                                          */
     double   agent_tau;          /* Softmax.tau of the agent's policy                                                    */
+    double   sigma;              /* QSigma.sigma in [0, 1]: 1 = SARSA-like sampling, 0 = tree backup (q_sigma.rs:66-72)          */
+    int32_t  n_steps;            /* QSigma: Backup::new(n_steps), 1..32 (q_sigma.rs:94-104)                                      */
+    int32_t  reserved0;
 } rsrl_hip_config;
 /* size of the ABI 3 struct: the oldest layout rsrl_hip_create accepts */
 #define RSRL_HIP_CONFIG_SIZE_V3 ((uint32_t)offsetof(rsrl_hip_config, agent_policy))

@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA = 0, 1, 2, 3, 4, 5, 6, 7, 8
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA, Q_SIGMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EGREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 BLK_STEP, BLK_RESET, BLK_INNER, BLK_INIT, BLK_API = 0, 1, 2, 3, 4
@@ -38,7 +38,8 @@ class Agent(C.Structure):
                 ("epsilon", C.c_double), ("tau", C.c_double),
                 ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32),
                 ("lam", C.c_double), ("trace", C.c_int), ("lr_td", C.c_double),
-                ("apolicy", C.c_int), ("aepsilon", C.c_double), ("atau", C.c_double), ("aeps_thr", C.c_uint32)]
+                ("apolicy", C.c_int), ("aepsilon", C.c_double), ("atau", C.c_double), ("aeps_thr", C.c_uint32),
+                ("sigma", C.c_double), ("n_steps", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -148,6 +149,13 @@ def _declare(L):
         g("orc_run_train_wave").restype = C.c_int
         g("orc_run_train_wave").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_int]
         g("orc_run_reset_wave").argtypes = [C.c_void_p]
+        g("orc_qsigma_new").restype = C.c_void_p
+        g("orc_qsigma_new").argtypes = [C.c_int]
+        g("orc_qsigma_free").argtypes = [C.c_void_p]
+        g("orc_qsigma_len").restype = C.c_int
+        g("orc_qsigma_len").argtypes = [C.c_void_p]
+        g("orc_handle_qsigma").restype = R
+        g("orc_handle_qsigma").argtypes = [C.POINTER(Agent), Rp, C.c_void_p, Rp, C.c_int, R, Rp, C.c_int, u32p]
         g("orc_run_traces").restype = Rp
         g("orc_run_traces").argtypes = [C.c_void_p]
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
@@ -170,12 +178,13 @@ def _ptr(a, ct):
 def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
                gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000, lam=0.0,
-               trace=TRACE_ACCUMULATE, lr_td=0.0, agent_policy=None, agent_epsilon=0.1, agent_tau=1.0):
+               trace=TRACE_ACCUMULATE, lr_td=0.0, agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, sigma=0.0, n_steps=1):
     ag = Agent()
     lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
                          int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
                          max_episode_steps)
     ag.lam, ag.trace, ag.lr_td = lam, trace, lr_td
+    ag.sigma, ag.n_steps = sigma, n_steps
     if agent_policy is not None:      # the agent's own policy object (sarsa.rs:35-41, expected_sarsa.rs:22-29); default: the behaviour policy
         ag.apolicy, ag.aepsilon, ag.atau = agent_policy, agent_epsilon, agent_tau
         ag.aeps_thr = lib().orc_eps_threshold(agent_epsilon)
@@ -352,6 +361,31 @@ def handle_gq(ag, W, V, s, a, r, ns, term, prec="f64"):
     ns = np.array(ns, dtype=dt)
     return float(getattr(lib(), f"orc_handle_gq_{prec}")(C.byref(ag), _ptr(W, ct), _ptr(V, ct), _ptr(s, ct), int(a),
                                                          ct(r), _ptr(ns, ct), int(term)))
+
+
+class QSigmaBackup:
+    """One QSigma agent's n-step backup (q_sigma.rs:26-64) for single-transition tests: handle() updates W in place when the
+    backup is full and returns the residual it pushed."""
+
+    def __init__(self, n_steps, prec="f64"):
+        self.prec, self._L = prec, lib()
+        self._h = C.c_void_p(getattr(self._L, f"orc_qsigma_new_{prec}")(int(n_steps)))
+
+    def __len__(self):
+        return int(getattr(self._L, f"orc_qsigma_len_{self.prec}")(self._h))
+
+    def handle(self, ag, W, s, a, r, ns, term, x_inner=(0, 0, 0, 0)):
+        dt, ct = _np_dtype(self.prec), _ct(self.prec)
+        assert W.dtype == dt and W.flags.c_contiguous
+        s, ns = np.array(s, dtype=dt), np.array(ns, dtype=dt)
+        xx = (C.c_uint32 * 4)(*[int(v) for v in x_inner])
+        return float(getattr(self._L, f"orc_handle_qsigma_{self.prec}")(C.byref(ag), _ptr(W, ct), self._h, _ptr(s, ct), int(a), ct(r),
+                                                                         _ptr(ns, ct), int(term), xx))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            getattr(self._L, f"orc_qsigma_free_{self.prec}")(self._h)
+            self._h = None
 
 
 class Run:

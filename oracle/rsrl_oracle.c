@@ -156,6 +156,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     ag->max_episode_steps = max_episode_steps;
     ag->lambda = 0.0; ag->trace = ORC_TRACE_ACCUMULATE; ag->lr_td = 0.0;
     ag->apolicy = policy; ag->aepsilon = epsilon; ag->atau = tau; ag->aeps_thr = ag->eps_thr;
+    ag->sigma = 0.0; ag->n_steps = 1;
 }
 
 /* ------------------------------------------------------------------ */

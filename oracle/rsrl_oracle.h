@@ -14,7 +14,7 @@ extern "C" {
 enum { ORC_MOUNTAIN_CAR = 0, ORC_CART_POLE = 1, ORC_ACROBOT = 2 };
 enum { ORC_FOURIER = 0, ORC_TILE = 1 };
 enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBDA = 3, ORC_Q_LAMBDA = 4, ORC_PAL = 5,
-       ORC_GREEDY_GQ = 6, ORC_TD = 7, ORC_TD_LAMBDA = 8 };
+       ORC_GREEDY_GQ = 6, ORC_TD = 7, ORC_TD_LAMBDA = 8, ORC_Q_SIGMA = 9 };
 #define ORC_IS_LAMBDA(algo) ((algo) == ORC_SARSA_LAMBDA || (algo) == ORC_Q_LAMBDA)
 /* agents with a second per-learner matrix of W's shape: the trace Z (lambda agents) or fa_td's weights (GreedyGQ) */
 /* prediction agents: ONE weight column (ScalarLFA, the state-value function); the behaviour policy must be Random */
@@ -53,7 +53,11 @@ typedef struct {
     int apolicy;
     double aepsilon, atau;
     uint32_t aeps_thr;
+    /* QSigma{.., sigma, backup: Backup::new(n_steps)}  (q_sigma.rs:80-105) */
+    double sigma;
+    int n_steps;
 } orc_agent;
+#define ORC_MAX_NSTEPS 32
 
 typedef struct {
     uint64_t env_steps, episodes, episodes_truncated, sum_episode_steps;
@@ -116,6 +120,11 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     void  orc_run_invalidate_q_##S(void* h);                                                                      \
     int   orc_run_train_wave_##S(void* h, int64_t n_steps, orc_stats* st, int w_bf16);                            \
     void  orc_run_reset_wave_##S(void* h);                                                                        \
+    void* orc_qsigma_new_##S(int n_steps);                                                                        \
+    void  orc_qsigma_free_##S(void* backup);                                                                      \
+    int   orc_qsigma_len_##S(const void* backup);                                                                 \
+    R     orc_handle_qsigma_##S(const orc_agent* ag, R* W, void* backup, const R* s, int a, R r, const R* ns,     \
+                                int term, const uint32_t x_inner[4]);                                             \
     R*    orc_run_traces_##S(void* h);                                                                  \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \

@@ -657,6 +657,82 @@ R FN(orc_handle_td)(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* n
     return td;
 }
 
+/* QSigma: the n-step Q(sigma) agent (De Asis et al. 2017).
+ *   QSigma::handle         control/td/q_sigma.rs:138-201
+ *   QSigma::update_backup  control/td/q_sigma.rs:107-128
+ *   Backup::propagate      control/td/q_sigma.rs:46-63
+ * DEVIATION (the only one): propagate's loop `for k in 0..n_steps` reads entries[k + 1] (:52-53) although update_backup calls
+ * it with exactly n_steps entries (:113-114): the last iteration indexes out of bounds and the reference PANICS at the first
+ * full backup.  That iteration needs entries[k + 1] only to update z (:56), a value never used again; the restatement keeps
+ * every in-bounds operation (g += z*residual_k, the isr factor of all n entries) and drops that dead z update.
+ *   pi = 1/|maxima| if a' is a maximum of Q(s',.) else 0 (:162-166); exp_nqs is argmaxima's running maximum (:161)
+ *   mu = policy.evaluate((s', a')) (:167): greedy.rs:46-60 / epsilon_greedy.rs:49-63 probabilities, random.rs:28-32, and
+ *        for Softmax the raw action value (softmax.rs:84-92 -- its Function<(S, A)> is the Q-value, not a probability). */
+typedef struct { R s[8]; int a; R q, residual, pi, mu; } FN(qs_entry);
+typedef struct { int n_steps, head, len; FN(qs_entry) e[ORC_MAX_NSTEPS]; } FN(qs_backup);
+void* FN(orc_qsigma_new)(int n_steps) {
+    FN(qs_backup)* b = (FN(qs_backup)*)calloc(1, sizeof(*b));
+    b->n_steps = n_steps < 1 ? 1 : (n_steps > ORC_MAX_NSTEPS ? ORC_MAX_NSTEPS : n_steps);
+    return b;
+}
+void FN(orc_qsigma_free)(void* backup) { free(backup); }
+int FN(orc_qsigma_len)(const void* backup) { return ((const FN(qs_backup)*)backup)->len; }
+static R FN(policy_eval_sa)(int policy, const R* q, int A, R eps, int a) {
+    int ixs[ORC_MAX_ACTIONS], n, i, in = 0; R pg;
+    if (policy == ORC_SOFTMAX) return q[a];
+    if (policy == ORC_RANDOM) return (R)1.0 / (R)A;
+    n = FN(orc_argmaxima)(q, A, ixs, NULL);
+    for (i = 0; i < n; i++) if (ixs[i] == a) in = 1;
+    pg = in ? (R)1.0 / (R)(n < 1 ? 1 : n) : (R)0.0;
+    if (policy == ORC_GREEDY) return pg;
+    return eps / (R)A + ((R)1.0 - eps) * pg;
+}
+R FN(orc_handle_qsigma)(const orc_agent* ag, R* W, void* backup, const R* s, int a, R r, const R* ns, int term,
+                        const uint32_t x_inner[4]) {
+    FN(qs_backup)* bk = (FN(qs_backup)*)backup; const orc_basis* b = &ag->basis;
+    int A = ag->n_actions, D = b->dim, n = bk->n_steps, d, k;
+    const R sigma = (R)ag->sigma, gamma = (R)ag->gamma;
+    R qa = FN(orc_q_evaluate_index)(b, W, A, s, a);
+    R residual, pi, mu;
+    FN(qs_entry)* e;
+    if (term) {
+        residual = r - qa; pi = (R)0.0; mu = (R)1.0;
+    } else {
+        R nqs[ORC_MAX_ACTIONS], exp_nqs; int ixs[ORC_MAX_ACTIONS], nmax, na, in = 0, i;
+        FN(orc_q_evaluate)(b, W, A, ns, nqs);
+        na = FN(orc_policy_sample)(ag->apolicy, nqs, A, ag->aeps_thr, (R)ag->atau, x_inner);
+        nmax = FN(orc_argmaxima)(nqs, A, ixs, &exp_nqs);
+        for (i = 0; i < nmax; i++) if (ixs[i] == na) in = 1;
+        pi = in ? (R)1.0 / (R)nmax : (R)0.0;
+        mu = FN(policy_eval_sa)(ag->apolicy, nqs, A, (R)ag->aepsilon, na);
+        residual = r + gamma * (sigma * nqs[na] + ((R)1.0 - sigma) * exp_nqs) - qa;
+    }
+    e = &bk->e[(bk->head + bk->len) % n];
+    for (d = 0; d < D; d++) e->s[d] = s[d];
+    e->a = a; e->q = qa; e->residual = residual; e->pi = pi; e->mu = mu;
+    bk->len += 1;
+    if (bk->len >= n) {
+        R g = bk->e[bk->head].q, z = (R)1.0, isr = (R)1.0, qsa, err;
+        FN(qs_entry)* anchor;
+        for (k = 0; k < n; k++) {
+            const FN(qs_entry)* b1 = &bk->e[(bk->head + k) % n];
+            g += z * b1->residual;
+            if (k + 1 < n) {
+                const FN(qs_entry)* b2 = &bk->e[(bk->head + k + 1) % n];
+                z *= gamma * (((R)1.0 - sigma) * b2->pi + sigma);
+            }
+            isr *= (R)1.0 - sigma + sigma * b1->pi / b1->mu;
+        }
+        anchor = &bk->e[bk->head];
+        bk->head = (bk->head + 1) % n; bk->len -= 1;
+        qsa = FN(orc_q_evaluate_index)(b, W, A, anchor->s, anchor->a);
+        err = (R)ag->alpha * isr * (g - qsa);
+        FN(orc_q_update_index)(b, W, A, anchor->s, anchor->a, (R)ag->lr, err);
+    }
+    if (term) bk->len = 0;
+    return residual;
+}
+
 /* ------------------------------------------------------------------ */
 /* Vectorised driver loop (examples/q_learning.rs:34-55 x N envs)      */
 /* ------------------------------------------------------------------ */
@@ -670,6 +746,7 @@ typedef struct {
     R* W;            /* per-env: [N][F][A]; shared: [F][A] */
     R* Z;            /* per-env [N][F][A]: eligibility traces (lambda agents) or fa_td weights (GreedyGQ) */
     uint64_t t;      /* global batch-step counter */
+    FN(qs_backup)* qs; /* [N] QSigma backups */
     R* qc;           /* [N][A] Q(s,.) of the current state carried between orc_run_train_dev calls (the device's qcache) */
     int q_valid;     /* 0: qc is stale -> recompute from W at the next orc_run_train_dev call */
 } FN(orc_run);
@@ -697,11 +774,16 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->Z = ORC_HAS_AUX(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
     run->qc = (R*)calloc((size_t)n_envs * ORC_MAX_ACTIONS, sizeof(R)); run->q_valid = 0;
+    run->qs = NULL;
+    if (ag->algo == ORC_Q_SIGMA) {
+        int64_t i; run->qs = (FN(qs_backup)*)calloc((size_t)n_envs, sizeof(FN(qs_backup)));
+        for (i = 0; i < n_envs; i++) run->qs[i].n_steps = ag->n_steps < 1 ? 1 : (ag->n_steps > ORC_MAX_NSTEPS ? ORC_MAX_NSTEPS : ag->n_steps);
+    }
     return run;
 }
 void FN(orc_run_destroy)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h;
-    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run);
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run->qs); free(run);
 }
 R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
 int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
@@ -756,6 +838,8 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
                 delta = FN(orc_handle_td)(ag, FN(run_W)(run, i), run->Z ? run->Z + (size_t)i * F : NULL, s, r, ns, term);
             } else if (ORC_IS_LAMBDA(ag->algo)) {
                 delta = FN(orc_handle_lambda)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term, xi);
+            } else if (ag->algo == ORC_Q_SIGMA) {
+                delta = FN(orc_handle_qsigma)(ag, FN(run_W)(run, i), &run->qs[i], s, a, r, ns, term, xi);
             } else if (ag->algo == ORC_GREEDY_GQ) {
                 delta = FN(orc_handle_gq)(ag, FN(run_W)(run, i), run->Z + (size_t)i * F * A, s, a, r, ns, term);
             } else if (!ag->shared_w) {

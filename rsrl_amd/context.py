@@ -8,7 +8,7 @@ from . import _abi
 
 MOUNTAIN_CAR, CART_POLE, ACROBOT = 0, 1, 2
 FOURIER, TILE_CODING = 0, 1
-QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA = 0, 1, 2, 3, 4, 5, 6, 7, 8
+QLEARNING, SARSA, EXPECTED_SARSA, SARSA_LAMBDA, Q_LAMBDA, PAL, GREEDY_GQ, TD, TD_LAMBDA, Q_SIGMA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
@@ -53,6 +53,7 @@ class Context:
         agent  = QLearning{gamma} | SARSA | ExpectedSARSA{alpha} | PAL{alpha}      (algo, gamma, alpha)
                  | SARSALambda / QLambda {trace(gamma, lam), alpha}                (lam, trace)
                  | GreedyGQ {fa_td = LFA(SGD(lr_td))} | TD | TDLambda              (lr_td; TD/TDLambda need policy=RANDOM)
+                 | QSigma {alpha, gamma, sigma, n_steps}                            (sigma, n_steps)
                  SARSA / ExpectedSARSA / SARSALambda own a policy of their own       (agent_policy, agent_epsilon, agent_tau;
                                                                                      None = the behaviour policy object)
 
@@ -66,7 +67,7 @@ class Context:
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
                  max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0,
-                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL):
+                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -81,6 +82,7 @@ class Context:
         # the policy owned by the agent (SARSA's inner draw, ExpectedSARSA's expectation); None = the behaviour policy itself
         cfg.agent_policy = -1 if agent_policy is None else int(agent_policy)
         cfg.agent_epsilon, cfg.agent_tau, cfg.exchange = agent_epsilon, agent_tau, exchange
+        cfg.sigma, cfg.n_steps = sigma, n_steps                   # QSigma{sigma, Backup::new(n_steps)}
         self.cfg = cfg
         self._h = C.c_void_p()
         _abi.check(self._L.rsrl_hip_create(C.byref(cfg), C.byref(self._h)))

@@ -36,6 +36,13 @@ bool launch_handle_td(int domain, int order, bool lambda, dim3 grid, dim3 block,
 bool launch_v_evaluate(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const float* states, int64_t Mn, float* out);
 bool launch_reset_td(int domain, dim3 grid, dim3 block, hipStream_t st, const Common& k, uint64_t t);
 
+struct QsParams;
+struct BasisGeom;
+// from == nullptr: the QSigma driver loop (chunk batch-steps); otherwise Handler::handle on Mn caller-supplied transitions
+bool launch_qsigma(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const QsParams& qp, const BasisGeom& g, uint64_t t,
+                   int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                   int64_t Mn, float* td_out);
+
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
         if (chunk == -2) {                                                                                  \

@@ -21,6 +21,7 @@
 #include "kernels_lambda.hpp"
 #include "kernels_gq.hpp"
 #include "kernels_td.hpp"
+#include "kernels_qsigma.hpp"
 
 using namespace rsrl;
 
@@ -226,6 +227,7 @@ struct rsrl_hip_ctx {
     int sh_par = 0, sh_row = 0;      // which W buffer holds the current weights (0 = W); which row buffer was written last
     unsigned sh_rows = 0;            // rows per buffer = blocks of k_shared_step
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
+    float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
@@ -299,6 +301,13 @@ static GqParams make_gq(const rsrl_hip_ctx* c) {
     GqParams gp{};
     gp.V = c->Z; gp.lr_td = (float)c->cfg.lr_td;
     return gp;
+}
+
+static QsParams make_qs(const rsrl_hip_ctx* c) {
+    QsParams qp{};
+    qp.buf = c->qs_buf; qp.head = c->qs_head; qp.len = c->qs_len; qp.n_steps = c->cfg.n_steps;
+    qp.sigma = (float)c->cfg.sigma; qp.alpha = (float)c->cfg.alpha;
+    return qp;
 }
 
 static TdParams make_td(const rsrl_hip_ctx* c) {
@@ -490,6 +499,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
     cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0; cfg->lr_td = 0.0;
     cfg->agent_policy = -1; cfg->agent_epsilon = 0.1; cfg->agent_tau = 1.0; cfg->exchange = RSRL_EXCHANGE_RCCL;
+    cfg->sigma = 0.0; cfg->n_steps = 1;
     return RSRL_HIP_OK;
 }
 
@@ -507,6 +517,9 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->partials) (void)hipFree(c->partials);
     if (c->W2) (void)hipFree(c->W2);
+    if (c->qs_buf) (void)hipFree(c->qs_buf);
+    if (c->qs_head) (void)hipFree(c->qs_head);
+    if (c->qs_len) (void)hipFree(c->qs_len);
     if (c->step_graph_exec) (void)hipGraphExecDestroy(c->step_graph_exec);
     if (c->step_graph) (void)hipGraphDestroy(c->step_graph);
     if (c->d_t) (void)hipFree(c->d_t);
@@ -536,7 +549,13 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->n_envs < 1) return fail(RSRL_HIP_EINVAL, "n_envs must be >= 1");
     if (cfg->n_envs + cfg->env_offset > (int64_t)0xffffffffLL || cfg->env_offset < 0)
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
-    if (cfg->algo < 0 || cfg->algo > RSRL_TD_LAMBDA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo < 0 || cfg->algo > RSRL_Q_SIGMA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
+    if (cfg->algo == RSRL_Q_SIGMA) {
+        if (cfg->basis != RSRL_FOURIER || cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32 || (cfg->order == kWaveOrder && cfg->domain != RSRL_MOUNTAIN_CAR))
+            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights on a register-family Fourier basis (MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (!(cfg->sigma >= 0.0 && cfg->sigma <= 1.0)) return fail(RSRL_HIP_EINVAL, "sigma must be in [0, 1]");
+        if (cfg->n_steps < 1 || cfg->n_steps > 32) return fail(RSRL_HIP_EINVAL, "n_steps must be in [1, 32]");
+    }
     if (cfg->policy < 0 || cfg->policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", cfg->policy);
     // Softmax::new panics for |tau| < 1e-7 (policies/softmax.rs:63-66)
     if (cfg->policy == RSRL_SOFTMAX && std::fabs(cfg->tau) < 1e-7)
@@ -607,7 +626,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     // a ctx that steps one batch-step per launch streams W every step: learner-major rows (W[N][A][F]) let k_step_reg_lm
     // write back only the touched column (RSRL_K1_FEATURE_MAJOR=1 keeps the feature-major layout, for A/B runs)
     if (!shared && cfg->steps_per_launch == 1 && cfg->basis == RSRL_FOURIER && !is_wave(*cfg) && !is_generic_fourier(*cfg) &&
-        !has_aux(cfg->algo) && !is_pred(cfg->algo) && (c->A * c->F) % 4 == 0 && c->F % 4 == 0 &&
+        !has_aux(cfg->algo) && !is_pred(cfg->algo) && cfg->algo != RSRL_Q_SIGMA && (c->A * c->F) % 4 == 0 && c->F % 4 == 0 &&
         (uint64_t)c->w_elems * 4ull < (1ull << 32) && !getenv("RSRL_K1_FEATURE_MAJOR")) {
         c->w_stride = 1;
         c->w_ls = (int64_t)c->A * c->F;
@@ -621,6 +640,17 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
+    if (cfg->algo == RSRL_Q_SIGMA) {
+        if (is_wave(*cfg) || is_generic_fourier(*cfg))
+            return fail(RSRL_HIP_EINVAL, "QSigma needs a register-family Fourier basis (MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        const size_t nf = (size_t)(c->D + 5) * (size_t)cfg->n_steps * (size_t)N;
+        HIP_TRY(hipMalloc((void**)&c->qs_buf, sizeof(float) * nf));
+        HIP_TRY(hipMalloc((void**)&c->qs_head, sizeof(uint32_t) * (size_t)N));
+        HIP_TRY(hipMalloc((void**)&c->qs_len, sizeof(uint32_t) * (size_t)N));
+        HIP_TRY(hipMemsetAsync(c->qs_buf, 0, sizeof(float) * nf, c->stream));
+        HIP_TRY(hipMemsetAsync(c->qs_head, 0, sizeof(uint32_t) * (size_t)N, c->stream));
+        HIP_TRY(hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)N, c->stream));          // Backup::new: empty
+    }
     if (has_aux(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
         HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
@@ -898,6 +928,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     if (is_pred(c->cfg.algo)) {
         if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
                               d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+    } else if (c->cfg.algo == RSRL_Q_SIGMA) {
+        if (!launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, 0, nullptr,
+                           d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
     } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
         if (!launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
                               d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
@@ -1328,7 +1361,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : (c->cfg.steps_per_launch ? c->cfg.steps_per_launch : 256);
     // single-step streaming kernel: needs the whole W addressable through one 32-bit buffer descriptor
-    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && !has_aux(c->cfg.algo) && !is_pred(c->cfg.algo) &&
+    const bool stream_k1 = !shared && fourier && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && !has_aux(c->cfg.algo) && !is_pred(c->cfg.algo) && c->cfg.algo != RSRL_Q_SIGMA &&
                            spl == 1 && (uint64_t)c->w_elems * 4ull < (1ull << 32);
     // launch-bound loops go through a captured graph (RSRL_NO_GRAPH=1 keeps the plain launches, for A/B runs)
     // (multi-rank included: the RCCL all-reduce and the peer-exchange kernels are captured with the step like any other node)
@@ -1360,6 +1393,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_td(c), c->t, chunk, d_stats)) return NO_MODEL(c);
             c->kernel_name = "k_train_td";
+            KCHECK();
+        } else if (c->cfg.algo == RSRL_Q_SIGMA) {
+            if (!launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, chunk, d_stats,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr)) return NO_MODEL(c);
+            c->kernel_name = "k_train_qsigma";
             KCHECK();
         } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
             if (!launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
@@ -1436,7 +1474,7 @@ static int flush_pending(rsrl_hip_ctx* c) {
 static bool coalescable(const rsrl_hip_ctx* c) {
     const auto& g = c->cfg;
     return g.weight_mode == RSRL_W_PER_ENV && g.basis == RSRL_FOURIER && !is_wave(g) && !is_generic_fourier(g) && !has_aux(g.algo) &&
-           !is_pred(g.algo) && g.steps_per_launch != 1 && !getenv("RSRL_NO_COALESCE");
+           !is_pred(g.algo) && g.algo != RSRL_Q_SIGMA && g.steps_per_launch != 1 && !getenv("RSRL_NO_COALESCE");
 }
 // rsrl_hip_train is asynchronous when no statistics are requested: it returns once the work is accepted.  A short call (the
 // 20 batch-steps of a driver loop) costs a full load + store of every learner's weights around ~20 us of arithmetic, so calls
