@@ -51,7 +51,7 @@ def test_qsigma_handle_sequences(ra, orc, n_steps, sigma, policy):
         assert max(np.abs(Wd[i] - W0[i]).max() for i in range(M)) > 1e-3
 
 
-@pytest.mark.parametrize("domain,order,n_steps,sigma,policy", [(0, 5, 3, 0.5, 1), (0, 5, 1, 0.0, 1), (0, 3, 8, 1.0, 2), (2, 1, 4, 0.5, 1), (1, 1, 2, 0.0, 0)])
+@pytest.mark.parametrize("domain,order,n_steps,sigma,policy", [(0, 5, 3, 0.5, 1), (0, 5, 1, 0.0, 1), (0, 3, 8, 0.0, 2), (0, 3, 8, 1.0, 2), (2, 1, 4, 0.5, 1), (1, 1, 2, 0.0, 0)])
 def test_qsigma_free_running_bitwise(ra, orc, domain, order, n_steps, sigma, policy):
     N, K = 160, 700
     kw = dict(gamma=0.95, lr=0.01, alpha=0.8, epsilon=0.1, tau=1.0)
@@ -66,7 +66,11 @@ def test_qsigma_free_running_bitwise(ra, orc, domain, order, n_steps, sigma, pol
         st2 = c.train(K - 300)                      # the backup lives in device memory across launches
         assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
         for i in (0, 1, 80, 159):
-            assert np.array_equal(c.get_weights(i), run.weights[i]), i
+            # (Softmax with sigma > 0 divides by mu = the raw action value -- the reference's Function<(S, A)> of Softmax,
+            # softmax.rs:84-92 -- and diverges; the device reproduces even that, NaN for NaN)
+            assert np.array_equal(c.get_weights(i), run.weights[i], equal_nan=True), i
+        if not (policy == 2 and sigma > 0):
+            assert np.all(np.isfinite(run.weights)) and np.abs(run.weights).max() > 0
         assert st["episodes"] + st2["episodes"] == ost["episodes"] > 0
         n_d, _ = c.rollout_greedy(200)
     n_o, _ = run.rollout_greedy(200)
