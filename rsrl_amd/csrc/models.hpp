@@ -188,21 +188,41 @@ struct TileModel {
             if (pending) atomicAdd(&dW[key], scale);
         }
     }
-    // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A floats, 32 KiB at
-    // 8^4 x 2) is privatised in LDS -- ds_add_f32 from every learner of the block, a sweep of the slice, then ONE device
-    // atomic per touched entry instead of one per learner.  The sweep is paid per block and tiling whatever the number of
-    // learners, so the shared-W driver runs this with 1024-learner blocks (DESIGN.md 4.3b has the measured ladder).
-    // `slice` is dynamic LDS of cells*A floats, zero on entry and left zero on exit.  All threads of the block must call.
-    __device__ static __forceinline__ void block_accumulate(float* __restrict__ dW, float* __restrict__ slice, const BasisGeom& g,
-                                                            const Feat& ft, int a, float scale, bool valid) {
+    // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A entries) is privatised
+    // in LDS -- an LDS atomic from every learner of the block, a sweep of the slice, then ONE device atomic per touched entry
+    // instead of one per learner.  The sweep is paid per block and tiling whatever the number of learners, so the shared-W
+    // driver runs this with 1024-learner blocks (DESIGN.md 4.3b has the measured ladder).
+    // The LDS accumulators are 64-bit FIXED-POINT integers, not floats: ds_add_f32 retires ONE LANE PER ~3 CYCLES whatever the
+    // addresses are (193 cycles per wave-instruction even for 64 conflict-free addresses, profiles/r02_ubench_lds_atomic.txt),
+    // ds_add_u64 costs 6 cycles for distinct addresses and 2 per duplicate of the most crowded one.  A term lr*e is scaled by
+    // the power of two 1/lsb (exact) and rounded to an integer: the block's sum is then EXACT and order-independent, and
+    // converting it back rounds once.  lsb = 2^(floor(log2 lr) - 28): |e| up to 2^12 and 2^20 learners on one entry fit 63 bits;
+    // a term keeps its full 24-bit mantissa down to |e| = 2^-4 and an absolute resolution of lr * 2^-28 below that.
+    // `slice` is dynamic LDS of 2 x cells*A 64-bit words (two slices), zero on entry and left zero on exit.  All threads of the block must call.
+    __device__ static __forceinline__ void block_accumulate(float* __restrict__ dW, long long* __restrict__ slice, const BasisGeom& g,
+                                                            const Feat& ft, int a, float scale, bool valid, float inv_lsb, float lsb) {
         const int S = (g.F / T) * A;                                    // entries per tiling
+        auto to_fixed = [&](float v) {
+            const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
+            return (unsigned long long)(long long)rintf(sc);
+        };
+        const unsigned long long term = to_fixed(scale);
+        // two slices in ping-pong (slice + S): tiling t+1 accumulates into one while tiling t's is swept -- one barrier per
+        // tiling instead of two
+        auto add = [&](int t, long long* sl) {
+            // (no in-wave folding of equal keys: a wave's 64 learners sit in ~46 distinct entries of a tiling with at most ~5 on
+            // one of them -- measured with the oracle on this configuration -- so ds_add_u64 costs ~6 + 2*5 cycles per wave as is)
+            if (valid) atomicAdd(reinterpret_cast<unsigned long long*>(&sl[(ft.idx[t] - t * (g.F / T)) * A + a]), term);
+        };
+        add(0, slice);
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            if (valid) atomicAdd(&slice[(ft.idx[t] - t * (g.F / T)) * A + a], scale);
-            __syncthreads();
+            long long* cur = slice + (t & 1) * S;
+            if (t + 1 < T) add(t + 1, slice + ((t + 1) & 1) * S);
             for (int j = threadIdx.x; j < S; j += blockDim.x) {
-                const float v = slice[j];
-                if (v != 0.0f) { atomicAdd(&dW[(int64_t)t * S + j], v); slice[j] = 0.0f; }
+                const long long v = cur[j];
+                if (v != 0) { atomicAdd(&dW[(int64_t)t * S + j], (float)v * lsb); cur[j] = 0; }
             }
             __syncthreads();
         }
@@ -585,11 +605,15 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     }
     if constexpr (!M::kDense) {
         if constexpr (M::kSparse) {
-            extern __shared__ float tile_slice[];                       // cells*A floats when the host could afford it
+            extern __shared__ long long tile_slice[];                   // cells*A 64-bit fixed-point accumulators when the host could afford it
             if (lds_slice_floats > 0) {
-                for (int j = threadIdx.x; j < lds_slice_floats; j += blockDim.x) tile_slice[j] = 0.0f;
+                for (int j = threadIdx.x; j < 2 * lds_slice_floats; j += blockDim.x) tile_slice[j] = 0;      // two slices (ping-pong)
                 __syncthreads();
-                M::block_accumulate(dW, tile_slice, g, fs, a, scale, i < N);
+                // lsb = 2^(floor(log2 |lr|) - 28), an exact power of two (the exponent field of lr, shifted)
+                const uint32_t eb = (__float_as_uint(c.alg.lr) >> 23) & 0xffu;
+                const int ex = (int)(eb < 30u ? 30u : eb) - 28;
+                const float lsb = __uint_as_float((uint32_t)ex << 23), inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
+                M::block_accumulate(dW, tile_slice, g, fs, a, scale, i < N, inv_lsb, lsb);
             } else {
                 M::accumulate(dW, g, fs, a, scale, i < N);            // all lanes call (DPP sums inside)
             }
