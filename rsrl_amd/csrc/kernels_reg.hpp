@@ -16,7 +16,11 @@ struct DevStats {
     double sum_abs_td_error, sum_reward;
 };
 
+// the parameters a driver changes between calls (EpsilonGreedy.epsilon is a pub field the reference's drivers decay,
+// examples/sarsa_lambda.rs:68): graph nodes read them from device memory so that a change does not re-capture the graph
+struct DynParams { PolicyParams pol, apol; };
 struct Common {
+    const DynParams* dyn;  // non-null inside a captured graph: pol / apol below are taken from here at run time
     int64_t n_envs;        // learners in this ctx
     int64_t env_offset;    // global id of learner 0
     uint64_t seed;
@@ -483,6 +487,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
 template <int DOMAIN, int ORDER, int ALGO, int POLICY>
 __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
     if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
+    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
     constexpr int D = Dom::D, A = Dom::A, F = Bas::F;
@@ -622,6 +627,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
 template <int DOMAIN, int ORDER, int ALGO, int POLICY>
 __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
     if (t_dev) t += *t_dev;
+    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
     constexpr int D = Dom::D, A = Dom::A, F = Bas::F, AF = A * F;

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
                                                       DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride,
                                                       const uint64_t* __restrict__ t_dev) {
     if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
+    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     // tile coding: the delta table is replicated n_rep times and block b adds into copy b % n_rep -- device atomics on one
     // 128-B line serialise at ~11 ns each and the learners crowd into a few lines; k_apply_rep sums the copies
     float* __restrict__ dW = dW_base + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride;
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
                                                         DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
     static_assert(M::kDense, "dense bases only");
     if (t_dev) t += *t_dev;
+    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     constexpr int D = M::D, A = M::A, F = M::F, AF = A * F;
     const bool do_c = (mode & 1) != 0, do_a = (mode & 2) != 0;
     const int64_t N = c.n_envs;

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void k_peer_reduce_apply(float* __restrict__ W
     }
     W[j] += acc;
 }
+__global__ void k_set_dyn(DynParams* __restrict__ d, DynParams v) { *d = v; }
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
 __global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
 __global__ void k_apply_dw(float* __restrict__ W, float* __restrict__ dW, int n) {
@@ -247,6 +248,9 @@ struct rsrl_hip_ctx {
     size_t events_used = 0;
     // launch-bound inner loops (one batch-step per launch: the streaming kernel, the shared-W phases) replayed as a hipGraph
     uint64_t* d_t = nullptr;                   // device copy of the batch-step counter: graph nodes carry offsets to it
+    DynParams* d_dyn = nullptr;                // device copy of the policy parameters graph nodes read (epsilon can change between calls)
+    DynParams dyn_uploaded{};                  // what d_dyn holds
+    bool dyn_valid = false;
     hipGraph_t step_graph = nullptr;
     hipGraphExec_t step_graph_exec = nullptr;
     Common step_graph_key{};                   // kernel arguments the graph was captured with
@@ -523,6 +527,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->step_graph_exec) (void)hipGraphExecDestroy(c->step_graph_exec);
     if (c->step_graph) (void)hipGraphDestroy(c->step_graph);
     if (c->d_t) (void)hipFree(c->d_t);
+    if (c->d_dyn) (void)hipFree(c->d_dyn);
     if (c->qcache) (void)hipFree(c->qcache);
     if (c->Z) (void)hipFree(c->Z);
     if (c->flags) (void)hipFree(c->flags);
@@ -665,6 +670,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->d_stats, sizeof(DevStats) * c->n_stat_slots));
     HIP_TRY(hipMalloc((void**)&c->d_t, sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void**)&c->d_dyn, sizeof(DynParams)));
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
@@ -1371,7 +1377,15 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     while (done < n_steps) {
         // (dense shared W: the W / row buffers alternate every batch-step, the graph is captured at the parity of an odd step count)
         if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? (done > 0 && (!fourier || (done & 1))) : c->q_valid)) {
+            // the graph's nodes read the policy parameters from device memory: set_epsilon between calls (the reference's drivers
+            // decay epsilon every episode, examples/sarsa_lambda.rs:68) refreshes 48 bytes instead of re-instantiating 32+ nodes
             Common kg = k; kg.q_valid = stream_k1 ? 1 : k.q_valid;
+            kg.dyn = c->d_dyn; kg.pol = PolicyParams{}; kg.apol = PolicyParams{};
+            const DynParams want{k.pol, k.apol};
+            if (!c->dyn_valid || memcmp(&want, &c->dyn_uploaded, sizeof(want)) != 0) {
+                hipLaunchKernelGGL(k_set_dyn, dim3(1), dim3(1), 0, c->stream, c->d_dyn, want); KCHECK();
+                c->dyn_uploaded = want; c->dyn_valid = true;
+            }
             TRY(ensure_step_graph(c, kg, g, stream_k1 ? 1 : 2));
             if (!t_dev_set) { hipLaunchKernelGGL(k_set_t, dim3(1), dim3(1), 0, c->stream, c->d_t, c->t); KCHECK(); t_dev_set = true; }
             TRY(timing_begin(c));

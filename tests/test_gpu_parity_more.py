@@ -293,7 +293,7 @@ def test_checkpoint_roundtrip_and_resume(ra, tmp_path):
 def test_graph_replay_equals_plain_launches(ra, monkeypatch, name, kw, bitwise):
     # the launch-bound loops (one batch-step per launch) are replayed as a captured hipGraph of 32 steps whose nodes read
     # the step counter from the device; RSRL_NO_GRAPH=1 keeps plain launches.  Same results either way, including across
-    # a change of the kernel arguments (set_epsilon re-captures) and chunk sizes that are not multiples of 32.
+    # a change of epsilon between replays (the nodes read the policy parameters from device memory: no re-capture) and chunk sizes that are not multiples of 32.
     def run(no_graph):
         if no_graph:
             monkeypatch.setenv("RSRL_NO_GRAPH", "1")
