@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     auto fa_theta = make_shared(fa::linear::LFA::vector(basis, fa::linear::optim::SGD(1.0), 3));
     policies::EpsilonGreedy policy(policies::Greedy(fa_theta), policies::Random(3), 0.2);
     auto trace = traces::Trace::replacing(GAMMA, LAMBDA);
-    control::td::SARSALambda agent(fa_theta, trace, ALPHA, GAMMA);
+    control::td::SARSALambda agent(fa_theta, policy, trace, ALPHA, GAMMA);      // SARSALambda { fa_theta, policy, trace, alpha, gamma }
 
     Session sess(env, agent, policy, /*seed=*/0, /*max_episode_steps=*/1000);
     sess.reset();

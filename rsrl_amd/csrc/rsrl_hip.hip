@@ -1218,6 +1218,9 @@ static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
 // delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
 // train call is closed by a stand-alone phase C (enqueue_shared_c).
 // t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
+// Every block of k_shared_step folding all the rows itself is quadratic in the number of blocks (256 blocks x 110 KB at
+// 131 072 learners; 2 048 x 885 KB = 1.8 GB of L2 reads at 1 048 576): beyond 512 rows the sum gets its own launch again.
+static inline bool fold_in_step(const rsrl_hip_ctx* c) { return !c->multi && c->sh_rows <= 512; }
 // dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's rows to
 // the weights first (single rank; in multi-rank mode finalize -> exchange -> apply run between the launches instead).
 static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, bool fold, uint64_t t,
@@ -1248,8 +1251,9 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     const bool dense = c->cfg.basis == RSRL_FOURIER;
     if (dense) {
         const int n = (int)c->dw_elems;
-        if (!c->multi) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
-        // multi-rank: the step (nothing to fold: W was updated by the apply below), then rows -> dW -> exchange -> W += dW
+        if (fold_in_step(c)) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
+        // multi-rank (or too many rows to fold in every block): the step (nothing to fold: W was updated by the apply below),
+        // then rows -> dW -> exchange -> W += dW
         TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
         const float* rows = c->partials + (size_t)c->sh_row * c->sh_rows * c->dw_elems;
         if (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->world_size <= 64) {      // fused: rows -> every rank's slot; slots -> W
@@ -1301,7 +1305,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
 static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
     if (c->cfg.basis == RSRL_FOURIER) {
         // closing launch: fold the last batch-step's rows (single rank), phase C; the result goes back to the canonical buffer
-        TRY(enqueue_dense_step(c, k, g, nullptr, 1, !c->multi, t_last + 1, nullptr));
+        TRY(enqueue_dense_step(c, k, g, nullptr, 1, fold_in_step(c), t_last + 1, nullptr));
         if (c->sh_par) {
             HIP_TRY(hipMemcpyAsync(c->W, c->W2, c->w_bytes, hipMemcpyDeviceToDevice, c->stream));
             c->sh_par = 0;

@@ -5,7 +5,7 @@
 //   rsrl::domains::{MountainCar, CartPole, Acrobot}      rsrl_domains/src/{mountain_car/discrete,cart_pole,acrobot}.rs
 //   rsrl::fa::linear::{basis::Fourier, optim::SGD, LFA}  rsrl/src/fa/linear.rs (re-exports of crate lfa)
 //   rsrl::policies::{Greedy, EpsilonGreedy, Softmax, Random}   rsrl/src/policies/*.rs
-//   rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}       rsrl/src/control/td/*.rs
+//   rsrl::control::td::{QLearning, SARSA, ExpectedSARSA, PAL, SARSALambda, QLambda, GreedyGQ, QSigma}   rsrl/src/control/td/*.rs
 //   rsrl::make_shared / Shared<T>                              rsrl/src/core.rs:13-44
 //
 // Everything is BATCHED: a Domain is N environments, a state is a column of a [D][N] array.  The objects
@@ -103,11 +103,28 @@ struct Agent {
     int algo; Shared<fa::linear::LFA> q_func; double gamma; double alpha = 1.0;
     int trace = RSRL_TRACE_ACCUMULATE; double lambda = 0.0;      // SARSALambda / QLambda
     double lr_td = 0.0;                                          // GreedyGQ: SGD rate of fa_td
+    // the policy the AGENT owns (SARSA / ExpectedSARSA / SARSALambda / QSigma: pub field `policy`).  Unset: the behaviour
+    // policy object itself, as in the reference's examples, which share one policy through make_shared.
+    bool owns_policy = false; policies::Policy policy{RSRL_GREEDY};
+    double sigma = 0.0; int n_steps = 1;                         // QSigma
+    Agent& with_policy(const policies::Policy& p) { owns_policy = true; policy = p; return *this; }
 };
 struct QLearning : Agent { QLearning(Shared<fa::linear::LFA> q, double gamma) : Agent{RSRL_QLEARNING, std::move(q), gamma} {} };
-struct SARSA : Agent { SARSA(Shared<fa::linear::LFA> q, double gamma) : Agent{RSRL_SARSA, std::move(q), gamma} {} };
+// SARSA { q_func, policy, gamma }                                                  (control/td/sarsa.rs:35-41)
+struct SARSA : Agent {
+    SARSA(Shared<fa::linear::LFA> q, double gamma) : Agent{RSRL_SARSA, std::move(q), gamma} {}
+    SARSA(Shared<fa::linear::LFA> q, const policies::Policy& p, double gamma) : Agent{RSRL_SARSA, std::move(q), gamma} { with_policy(p); }
+};
+// ExpectedSARSA { q_func, policy, alpha, gamma }                                   (control/td/expected_sarsa.rs:22-29)
 struct ExpectedSARSA : Agent {
     ExpectedSARSA(Shared<fa::linear::LFA> q, double alpha_, double gamma) : Agent{RSRL_EXPECTED_SARSA, std::move(q), gamma, alpha_} {}
+    ExpectedSARSA(Shared<fa::linear::LFA> q, const policies::Policy& p, double alpha_, double gamma)
+        : Agent{RSRL_EXPECTED_SARSA, std::move(q), gamma, alpha_} { with_policy(p); }
+};
+// QSigma::new(q_func, policy, alpha, gamma, sigma, n_steps)                         (control/td/q_sigma.rs:94-105)
+struct QSigma : Agent {
+    QSigma(Shared<fa::linear::LFA> q, const policies::Policy& p, double alpha_, double gamma, double sigma_, int n_steps_)
+        : Agent{RSRL_Q_SIGMA, std::move(q), gamma, alpha_} { with_policy(p); sigma = sigma_; n_steps = n_steps_; }
 };
 // PAL { q_func, alpha, gamma }                                                    (control/td/pal.rs:18-24)
 struct PAL : Agent { PAL(Shared<fa::linear::LFA> q, double alpha_, double gamma) : Agent{RSRL_PAL, std::move(q), gamma, alpha_} {} };
@@ -128,6 +145,8 @@ namespace control { namespace td {
 struct SARSALambda : Agent {
     SARSALambda(Shared<fa::linear::LFA> q, const traces::Trace& tr, double alpha_, double gamma)
         : Agent{RSRL_SARSA_LAMBDA, std::move(q), gamma, alpha_, tr.rule, tr.lambda} {}
+    SARSALambda(Shared<fa::linear::LFA> q, const policies::Policy& p, const traces::Trace& tr, double alpha_, double gamma)
+        : Agent{RSRL_SARSA_LAMBDA, std::move(q), gamma, alpha_, tr.rule, tr.lambda} { with_policy(p); }
 };
 struct QLambda : Agent {
     QLambda(Shared<fa::linear::LFA> q, const traces::Trace& tr, double alpha_, double gamma)
@@ -166,6 +185,11 @@ public:
         cfg.algo = agent.algo; cfg.gamma = agent.gamma; cfg.alpha = agent.alpha;
         cfg.trace = agent.trace; cfg.lambda = agent.lambda; cfg.lr_td = agent.lr_td;
         cfg.policy = policy.kind; cfg.epsilon = policy.epsilon; cfg.tau = policy.tau;
+        // an agent-owned policy equal to the behaviour policy IS the shared object of the reference's examples
+        if (agent.owns_policy && (agent.policy.kind != policy.kind || agent.policy.epsilon != policy.epsilon || agent.policy.tau != policy.tau)) {
+            cfg.agent_policy = agent.policy.kind; cfg.agent_epsilon = agent.policy.epsilon; cfg.agent_tau = agent.policy.tau;
+        }
+        cfg.sigma = agent.sigma; cfg.n_steps = agent.n_steps;
         cfg.seed = seed; cfg.max_episode_steps = max_episode_steps;
         check(rsrl_hip_create(&cfg, &ctx_));
         D_ = rsrl_hip_state_dim(ctx_); A_ = rsrl_hip_n_actions(ctx_); F_ = rsrl_hip_n_features(ctx_); N_ = env.n_envs;

@@ -111,7 +111,49 @@ def main():
                        "counted inside FMA_F32) and cndmask are static counts of the executed path; mad_u64 = INT64 (Philox: 2 per round); fp_fma = FMA_F32 - pk; "
                        "fp_other = MUL_F32 + ADD_F32"}
         json.dump({"k_train_reg": mix}, open(os.path.join(out, "isa_mix.json"), "w"), indent=1)
-    print(json.dumps({"traffic": traffic.get("k_train_reg"), "raw_keys": {k: sorted(v)[:20] for k, v in raw.items()}}, indent=1)[:3000])
+    # ---- the streaming kernel's PMC passes (k1_*) refresh its traffic record
+    k1 = {}
+    for d in sorted(glob.glob(os.path.join(src, "k1_*"))):
+        if os.path.isdir(d):
+            m, us = counter_means(d, "k_step_reg_lm")
+            k1.update(m)
+            if us:
+                k1.setdefault("kernel_us_under_pmc", {})[os.path.basename(d)] = us
+    if "FETCH_SIZE" in k1 and "WRITE_SIZE" in k1:
+        raw["k_step_reg_lm@1"] = k1
+        json.dump(raw, open(os.path.join(out, f"{tag}_pmc_raw.json"), "w"), indent=1)
+        fetch, write = 2.0 * k1["FETCH_SIZE"] * 1024.0, k1["WRITE_SIZE"] * 1024.0
+        rec = {"envs": ENVS, "steps_per_launch": 1, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
+               "source": f"profiles/{tag}_pmc_raw.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction, KiB units)"}
+        if "SQ_INSTS_VALU" in k1 and k1.get("SQ_WAVES", 0) > 0:
+            rec["valu_instr_per_env_step"] = k1["SQ_INSTS_VALU"] / k1["SQ_WAVES"]
+            rec["wave_quad_cycles_per_env_step"] = k1.get("SQ_WAVE_CYCLES", 0.0) / k1["SQ_WAVES"]
+        traffic["k_step_reg_lm"] = rec
+        json.dump(traffic, open(tp, "w"), indent=1)
+    # ---- per-kernel averages of the other configurations (rocprofv3 --kernel-trace --stats of scripts/prof_shared.py / bench_configs.py)
+    other = [f"# rocprofv3 --kernel-trace --stats of the other configurations ({tag}, 1 x MI355X)", ""]
+    titles = {"prof_fourier_none": "C4 share: 131 072 MountainCar envs, shared W, single rank (`scripts/prof_shared.py fourier none`)",
+              "prof_fourier_rccl": "C4 share with an RCCL communicator of size 1: finalize -> ncclAllReduce -> apply (`... fourier rccl`); RCCL serves a 1-rank "
+                                   "all-reduce with a device copy (`__amd_rocclr_copyBuffer`), it launches no collective kernel",
+              "prof_fourier_peer": "C4 share with the peer-write exchange, group of size 1 (`... fourier peer`)",
+              "prof_tile_none": "C3: 262 144 CartPole envs, SARSA, tiles 8 x 8^4, shared W (`scripts/prof_shared.py tile none`)",
+              "prof_configs": "C5/2 (bf16) and C5' (f32) Acrobot Fourier(7) wave family, L1 SARSA(lambda), C3' per-learner tile tables (`scripts/bench_configs.py`)"}
+    for key, title in titles.items():
+        f = glob.glob(os.path.join(src, key, "*kernel_stats.csv"))
+        if not f:
+            continue
+        other += [f"## {title}", "", "| kernel | calls | avg us | total ms | % |", "|---|---|---|---|---|"]
+        for row in list(csv.DictReader(open(f[0])))[:9]:
+            full = row["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            nm = (full.split("(rsrl::")[0] if "<" in full else full.split("(")[0]).strip()
+            other.append(f"| `{nm}` | {row['Calls']} | {float(row['AverageNs']) / 1e3:.2f} | {float(row['TotalDurationNs']) / 1e6:.2f} | {row['Percentage']} |")
+        other.append("")
+    for name in ("shared_walls.txt", "bench_configs.jsonl", "scale_n.jsonl"):
+        fp = os.path.join(src, name)
+        if os.path.exists(fp):
+            other += [f"## {name} (wall clock, no profiler)", "", "```"] + [ln.rstrip()[:400] for ln in open(fp) if ln.strip() and not ln.startswith(("RCCL", "HIP ver", "ROCm", "Hostname", "Librccl"))] + ["```", ""]
+    open(os.path.join(out, f"{tag}_kernel_stats_other.md"), "w").write("\n".join(other) + "\n")
+    print(json.dumps({"traffic": traffic, "raw_keys": {k: sorted(v)[:20] for k, v in raw.items()}}, indent=1)[:2500])
 
 
 if __name__ == "__main__":

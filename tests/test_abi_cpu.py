@@ -85,7 +85,7 @@ def test_cpp_host_mirror_compiles_against_the_abi(abi, tmp_path):
     if not shutil.which("g++"):
         pytest.skip("no g++")
     lib_dir = os.path.join(ROOT, "rsrl_amd", "lib")
-    for name in ("q_learning", "sarsa_lambda", "greedy_gq", "pal"):       # the reference's examples of the same names
+    for name in ("q_learning", "sarsa_lambda", "greedy_gq", "pal", "q_sigma"):       # the reference's examples of the same names
         exe = tmp_path / name
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", os.path.join(ROOT, "examples", name + ".cpp"),
                                "-L" + lib_dir, "-lrsrl_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + lib_dir,

@@ -369,6 +369,7 @@ def test_cpp_example_runs_on_gpu(tmp_path):
     ("sarsa_lambda", ["128", "6", "400"], r"max \|trace\| of learner 0: ([0-9.eE+-]+)"),
     ("greedy_gq", ["128", "4", "500"], r"max \|fa_td weight\| of learner 0: ([0-9.eE+-]+)"),
     ("pal", ["128", "3", "500"], r"mean \|residual\| ([0-9.eE+-]+)"),
+    ("q_sigma", ["128", "3", "800"], r"mean \|residual\| ([0-9.eE+-]+)"),
 ])
 def test_cpp_examples_of_the_next_rows_run_on_gpu(tmp_path, name, args, pattern):
     # examples/sarsa_lambda.cpp / greedy_gq.cpp / pal.cpp: the reference's examples of the same names through the C++ mirror
