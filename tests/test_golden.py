@@ -87,3 +87,73 @@ def test_device_matches_golden():
     agree = n == np.array(gr["n_states"])
     assert agree.mean() >= 0.85
     assert np.all(tot[agree] == np.array(gr["total_reward"])[agree])
+
+
+# ---- round 2: device-order (bitwise) vectors and QSigma, tests/golden/vectors_r02.json (made by make_golden_r02.py) ----
+G2 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors_r02.json")))["oracle"]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _digest(a):
+    b = _bits(a).astype(np.uint64).ravel()
+    return int((b * (2 * np.arange(b.size, dtype=np.uint64) + 1)).sum(dtype=np.uint64))
+
+
+def test_oracle_reproduces_golden_r02(orc):
+    g = G2["c2_device_order"]
+    run = orc.Run(orc.make_agent(**g["config"]), g["n_envs"], "f32d")
+    run.reset()
+    st = run.train_dev(g["steps"])
+    assert _bits(run.state).tolist() == g["states"] and run.action.tolist() == g["actions"]
+    assert _bits(run.weights[0]).tolist() == g["w_learner0"] and _digest(run.weights) == g["w_digest_all"] and st["episodes"] == g["episodes"]
+    g = G2["c5_wave_order_bf16"]
+    run = orc.Run(orc.make_agent(**g["config"]), g["n_envs"], "f32d")
+    run.reset_wave()
+    run.train_wave(g["steps"], bf16=True)
+    assert _bits(run.state).tolist() == g["states"] and run.action.tolist() == g["actions"]
+    assert [_digest(run.weights[i]) for i in range(g["n_envs"])] == g["w_digest"]
+    g = G2["qsigma"]
+    ag = orc.make_agent(**g["config"])
+    W = np.array(g["W0"], dtype=np.float64)
+    bk = [orc.QSigmaBackup(g["config"]["n_steps"], "f64") for _ in range(2)]
+    for k, stp in enumerate(g["steps"]):
+        for i in range(2):
+            d = bk[i].handle(ag, W[i], np.array(stp["s"])[:, i], stp["a"][i], -1.0, np.array(stp["ns"])[:, i], stp["term"][i], orc.draw(4, i, k, orc.BLK_INNER))
+            assert abs(d - stp["residual_f64"][i]) <= 1e-13
+    assert np.max(np.abs(W - np.array(g["W_after_f64"]))) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_device_matches_golden_r02_bitwise():
+    # the HIP path against the committed device-order vectors, without the live oracle: bit for bit
+    import rsrl_amd as ra
+    g = G2["c2_device_order"]
+    with ra.Context(n_envs=g["n_envs"], **g["config"]) as c:
+        c.reset()
+        st = c.train(g["steps"])
+        assert _bits(c.states.T).tolist() == g["states"] and c.actions.tolist() == g["actions"]
+        assert _bits(c.get_weights(0)).tolist() == g["w_learner0"] and st["episodes"] == g["episodes"]
+        assert _digest(np.stack([c.get_weights(i) for i in range(g["n_envs"])])) == g["w_digest_all"]
+    g = G2["c5_wave_order_bf16"]
+    with ra.Context(n_envs=g["n_envs"], weight_dtype=ra.W_BF16, **g["config"]) as c:
+        c.reset()
+        c.train(g["steps"])
+        assert _bits(c.states.T).tolist() == g["states"] and c.actions.tolist() == g["actions"]
+        assert [_digest(c.get_weights(i)) for i in range(g["n_envs"])] == g["w_digest"]
+        assert _bits(c.get_weights(0)[:4]).tolist() == g["w0_first_rows"]
+    g = G2["qsigma"]
+    W0 = np.array(g["W0"], dtype=np.float32)
+    with ra.Context(n_envs=2, **g["config"]) as c:
+        for i in range(2):
+            c.set_weights(W0[i], i)
+        for stp in g["steps"]:
+            td = c.handle(np.array(stp["s"], dtype=np.float32), np.array(stp["a"], dtype=np.int32), -np.ones(2, np.float32),
+                          np.array(stp["ns"], dtype=np.float32), np.array(stp["term"], dtype=np.uint8))
+            assert _bits(td).tolist() == stp["residual_f32d_bits"]
+            assert np.max(np.abs(td - np.array(stp["residual_f64"]))) <= 5e-5 * (1 + np.max(np.abs(stp["residual_f64"])))
+        W = np.stack([c.get_weights(i) for i in range(2)])
+        assert _bits(W).tolist() == g["W_after_f32d_bits"]
+        assert np.max(np.abs(W - np.array(g["W_after_f64"]))) <= 2e-5 * (1 + np.abs(np.array(g["W_after_f64"])).max())
