@@ -98,3 +98,60 @@ def test_lambda_full_size_determinism(ra):
             c.train(128)
             sums.append(c.checksum())
     assert sums[0] == sums[1]
+
+
+def test_c2_full_size_sampled_learners_bitwise_vs_oracle(ra, orc):
+    # BASELINE.json configs[1] at its FULL size (65 536 learners), 2 000 batch-steps: the learners are independent and their RNG
+    # streams are keyed by the global env id, so the CPU oracle (device order, f32d) can replay any slice of the batch on its
+    # own -- three slices of 192 learners (first wave, an interior block boundary, the last learners) must match the full-size
+    # device run bit for bit: states, actions, every weight
+    import threading
+    N, K, M = 65536, 2000, 192
+    offs = (0, 32768 - 96, N - M)
+    runs, th = {}, []
+
+    def cpu(off):
+        r = orc.Run(orc.make_agent(policy=orc.EGREEDY, epsilon=0.1, gamma=0.9, lr=0.001, seed=0, max_episode_steps=1000, env_offset=off), M, "f32d")
+        r.reset()
+        r.train_dev(K)
+        runs[off] = r
+    for off in offs:
+        th.append(threading.Thread(target=cpu, args=(off,)))
+        th[-1].start()
+    with ra.Context(n_envs=N, **C2) as c:
+        c.reset()
+        c.train(K, want_stats=False)
+        S, A = c.states, c.actions
+        [t.join() for t in th]
+        for off in offs:
+            r = runs[off]
+            assert np.array_equal(S[:, off:off + M].T, r.state) and np.array_equal(A[off:off + M], r.action), off
+            for i in range(0, M, 7):
+                assert np.array_equal(c.get_weights(off + i), r.weights[i]), (off, i)
+        n_dev, _ = c.rollout_greedy(400)
+    for off in offs:
+        n_cpu, _ = runs[off].rollout_greedy(400)
+        assert np.array_equal(n_dev[off:off + M], n_cpu)
+
+
+def test_c5_full_size_sampled_learners_bitwise_vs_oracle(ra, orc):
+    # BASELINE.json configs[4]'s per-GPU share (32 768 Acrobot learners, ExpectedSARSA + Fourier(7) + Softmax, bf16 weights):
+    # 24 sampled learners x 60 batch-steps of the full-size device run against the oracle's wave-order loop, bit for bit
+    N, K, M = 32768, 60, 8
+    kw = dict(domain=2, order=7, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0, seed=5, max_episode_steps=1000)
+    offs = (0, 16384 - 4, N - M)
+    runs = {}
+    for off in offs:
+        r = orc.Run(orc.make_agent(env_offset=off, **kw), M, "f32d")
+        r.reset_wave()
+        r.train_wave(K, bf16=True)
+        runs[off] = r
+    with ra.Context(n_envs=N, weight_dtype=ra.W_BF16, **kw) as c:
+        c.reset()
+        c.train(K, want_stats=False)
+        S, A = c.states, c.actions
+        for off in offs:
+            r = runs[off]
+            assert np.array_equal(S[:, off:off + M].T, r.state) and np.array_equal(A[off:off + M], r.action), off
+            for i in (0, M - 1):
+                assert np.array_equal(c.get_weights(off + i), r.weights[i]), (off, i)
