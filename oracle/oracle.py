@@ -149,6 +149,8 @@ def _declare(L):
         g("orc_run_train_wave").restype = C.c_int
         g("orc_run_train_wave").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_int]
         g("orc_run_reset_wave").argtypes = [C.c_void_p]
+        g("orc_run_train_shared_dev").restype = C.c_int
+        g("orc_run_train_shared_dev").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_qsigma_new").restype = C.c_void_p
         g("orc_qsigma_new").argtypes = [C.c_int]
         g("orc_qsigma_free").argtypes = [C.c_void_p]
@@ -470,6 +472,15 @@ class Run:
         st = Stats()
         if self._f("orc_run_train_wave")(self._h, int(n_steps), C.byref(st), int(bool(bf16))) != 0:
             raise ValueError("train_wave: one-step control agents, Fourier order 7 on CartPole / Acrobot, per-env weights, f32 only")
+        return st.as_dict()
+
+    def train_shared_dev(self, n_steps):
+        """Shared-W training (dense basis) in the device's evaluation order: 512-learner block sums as four 128-long fma chains,
+        rows reduced by lane partials + the DPP ladder, phase C of step t-1 fused with phase A of step t -- with prec="f32d"
+        bit-identical to the HIP path's k_shared_step."""
+        st = Stats()
+        if self._f("orc_run_train_shared_dev")(self._h, int(n_steps), C.byref(st)) != 0:
+            raise ValueError("train_shared_dev: one-step control agents, Fourier basis, shared weights, n_steps >= 1")
         return st.as_dict()
 
     def reset_wave(self):

@@ -120,6 +120,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     void  orc_run_invalidate_q_##S(void* h);                                                                      \
     int   orc_run_train_wave_##S(void* h, int64_t n_steps, orc_stats* st, int w_bf16);                            \
     void  orc_run_reset_wave_##S(void* h);                                                                        \
+    int   orc_run_train_shared_dev_##S(void* h, int64_t n_steps, orc_stats* st);                                  \
     void* orc_qsigma_new_##S(int n_steps);                                                                        \
     void  orc_qsigma_free_##S(void* backup);                                                                      \
     int   orc_qsigma_len_##S(const void* backup);                                                                 \

@@ -1191,6 +1191,101 @@ void FN(orc_run_reset_wave)(void* h) {
     free(phi);
 }
 
+/* Shared weights, dense basis, in the DEVICE's evaluation order (rsrl_amd/csrc/models.hpp: k_shared_step with 512-learner
+ * blocks), for bitwise comparison with the HIP path (_f32d).  The rule is SURVEY A.7's (every learner's error against the
+ * same W_t, the summed delta applied once, every learner then samples with W_{t+1}); what is mirrored is the ORDER of the sum:
+ *   block (512 learners): for each (action b, feature f) four fma chains over 128 consecutive learners each,
+ *       acc = fma([a_i == b], lr*e_i*phi_i[f], acc), the four parts added in order               -> one row per block
+ *   rows: "lane" l adds rows l, l+64, l+128, ... in ascending order (in groups of four, a missing row adding +0), then the
+ *       64 lane sums go through the DPP ladder (wave_total)                                      -> W_t = W_{t-1} + total
+ * and the launch structure: phase C of batch-step t-1 (sample with W_t; finished episodes restart) and phase A of batch-step
+ * t run together, a train call opens with phase A alone and closes with the last fold + phase C alone.
+ * One-step control agents on a Fourier basis, shared W; returns -1 otherwise. */
+static R FN(rows_total)(const R* rowsT, int n_rows, int j) {          /* rowsT[j][r] */
+    R lane[64]; int l, r0, u;
+    for (l = 0; l < 64; l++) {
+        R acc = (R)0.0;
+        for (r0 = 0; r0 < n_rows; r0 += 256)
+            for (u = 0; u < 4; u++) { const int r = r0 + 64 * u + l; acc += (r < n_rows) ? rowsT[(size_t)j * n_rows + r] : (R)0.0; }
+        lane[l] = acc;
+    }
+    return FN(wave_total)(lane);
+}
+int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
+    enum { BLOCK = 512, PER = 128, H = BLOCK / PER };
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), AF, d, f, j, a, hh, n_rows;
+    int64_t N = run->n_envs, i, k, blk;
+    R *phi, *W, *rowsT, *terms, *phis; uint8_t* flags; int* acts;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (b->kind != ORC_FOURIER || !ag->shared_w || n_steps < 1 ||
+        !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
+    AF = A * F; n_rows = (int)((N + BLOCK - 1) / BLOCK); W = run->W;
+    phi = (R*)malloc(sizeof(R) * (size_t)F); rowsT = (R*)calloc((size_t)AF * n_rows, sizeof(R));
+    terms = (R*)malloc(sizeof(R) * BLOCK); phis = (R*)malloc(sizeof(R) * (size_t)BLOCK * F); acts = (int*)malloc(sizeof(int) * BLOCK);
+    flags = (uint8_t*)calloc((size_t)N, 1);
+    for (k = 0; k <= n_steps; k++) {
+        const uint64_t t = run->t + (uint64_t)k;
+        const int do_c = k > 0, do_a = k < n_steps;
+        if (do_c)                                                     /* fold the previous batch-step's rows: W_t = W_{t-1} + total */
+            for (a = 0; a < A; a++) for (f = 0; f < F; f++) { j = a * F + f; W[(size_t)f * A + a] = W[(size_t)f * A + a] + FN(rows_total)(rowsT, n_rows, j); }
+        for (blk = 0; blk < n_rows; blk++) {
+            for (i = blk * BLOCK; i < (blk + 1) * (int64_t)BLOCK; i++) {
+                const int li = (int)(i - blk * BLOCK);
+                R s[8], ns[8], q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], r, e, delta; uint32_t x[4], xin[4] = { 0, 0, 0, 0 }; uint32_t ep; int done, term, trunc;
+                if (i >= N) { terms[li] = (R)0.0; acts[li] = 0; for (f = 0; f < F; f++) phis[(size_t)li * F + f] = (R)0.0; continue; }
+                ep = run->ep_step[i];
+                done = do_c && flags[i] != 0;
+                if (done) { FN(orc_domain_reset)(ag->domain, s); ep = 0; }
+                else for (d = 0; d < D; d++) s[d] = run->state[(size_t)i * D + d];
+                FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+                FN(dot_columns)(phi, W, A, F, q_s);
+                if (do_c) {
+                    orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t - 1, done ? ORC_BLK_RESET : ORC_BLK_STEP, x);
+                    a = FN(orc_policy_sample)(ag->policy, q_s, A, ag->eps_thr, (R)ag->tau, x);
+                } else a = run->action[i];
+                if (do_a) {
+                    for (d = 0; d < D; d++) ns[d] = s[d];
+                    term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+                    ep += 1;
+                    trunc = !term && ag->max_episode_steps > 0 && ep >= ag->max_episode_steps;
+                    for (f = 0; f < F; f++) phis[(size_t)li * F + f] = phi[f];            /* phi(s): the gradient direction */
+                    FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), ns, phi);
+                    FN(dot_columns)(phi, W, A, F, q_n);
+                    if (ag->algo == ORC_SARSA) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+                    delta = FN(td_from_q)(ag, q_s, a, q_n, r, term, xin, &e);
+                    terms[li] = (R)ag->lr * e; acts[li] = a;
+                    for (d = 0; d < D; d++) run->state[(size_t)i * D + d] = ns[d];
+                    run->action[i] = a; run->ep_step[i] = ep;
+                    flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+                    acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
+                    if (term || trunc) { acc.episodes += 1; acc.episodes_truncated += trunc ? 1 : 0; acc.sum_episode_steps += ep; }
+                } else {                                              /* closing launch: phase C only */
+                    if (done) { for (d = 0; d < D; d++) run->state[(size_t)i * D + d] = s[d]; run->ep_step[i] = 0; }
+                    run->action[i] = a;
+                }
+            }
+            if (do_a)
+                for (a = 0; a < A; a++) for (f = 0; f < F; f++) {
+                    R tot = (R)0.0;
+                    for (hh = 0; hh < H; hh++) {
+                        R part = (R)0.0; int li;
+                        for (li = hh * PER; li < (hh + 1) * PER; li++) {
+                            const R v = terms[li] * phis[(size_t)li * F + f];
+                            part = FN(fma_)((acts[li] == a) ? (R)1.0 : (R)0.0, v, part);
+                        }
+                        tot = (hh == 0) ? part : tot + part;
+                    }
+                    rowsT[(size_t)(a * F + f) * n_rows + blk] = tot;
+                }
+        }
+    }
+    run->t += (uint64_t)n_steps;
+    free(phi); free(rowsT); free(terms); free(phis); free(acts); free(flags);
+    if (st) *st = acc;
+    return 0;
+}
+
 /* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340
  * One fresh default env per learner i, evaluated with learner i's weights. */
 int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward) {

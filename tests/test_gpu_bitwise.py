@@ -200,3 +200,26 @@ def test_c5_wave_family_bitwise(ra, orc, domain, algo, policy, bf16):
     assert np.abs(run.weights).max() > 0 and ost["episodes"] > 0
     if bf16:
         assert np.all((run.weights.view(np.uint32) & 0xffff) == 0)
+
+
+@pytest.mark.parametrize("algo,policy,N", [(0, 1, 3000), (1, 1, 3000), (2, 2, 1111), (5, 1, 700), (0, 1, 131072)])
+def test_c4_shared_weights_bitwise(ra, orc, algo, policy, N):
+    # BASELINE.json configs[3]'s rule (one shared approximator, synchronous mini-batch update) on the dense basis:
+    # the device's sums have one fixed order (512-learner blocks as four 128-long fma chains, rows by lane partials + the DPP
+    # ladder), restated in orc_run_train_shared_dev -- weights, states and actions bit for bit, through plain launches and
+    # graph replays, at a ragged size and at the full per-GPU share (131 072 learners, 256 blocks)
+    K1, K2 = (40, 70) if N < 100000 else (12, 38)
+    kw = dict(gamma=0.9, lr=0.001 / N, alpha=0.7, epsilon=0.1, tau=0.8)
+    ag = orc.make_agent(algo=algo, policy=policy, seed=2, max_episode_steps=60, shared_w=True, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    o1 = run.train_shared_dev(K1)
+    o2 = run.train_shared_dev(K2)
+    with ra.Context(n_envs=N, algo=algo, policy=policy, seed=2, max_episode_steps=60, weight_mode=ra.W_SHARED, **kw) as c:
+        c.reset()
+        s1 = c.train(K1)                       # statistics: plain launches
+        c.train(K2, want_stats=False)          # graph replay + plain remainder
+        assert np.array_equal(c.get_weights(), run.weights), np.abs(c.get_weights() - run.weights).max()
+        assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
+        assert s1["episodes"] == o1["episodes"] and s1["sum_reward"] == o1["sum_reward"]
+    assert np.abs(run.weights).max() > 0 and o1["episodes"] + o2["episodes"] > 0
