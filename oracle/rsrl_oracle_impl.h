@@ -824,9 +824,23 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
     R* ns_all = (R*)malloc(sizeof(R) * (size_t)N * D);
     uint8_t* term_all = (uint8_t*)malloc((size_t)N);
     R* dW = ag->shared_w ? (R*)malloc(sizeof(R) * (size_t)F * A) : NULL;
+    /* Shared tile coding in the device's arithmetic type (float instantiations): the mini-batch delta is accumulated in 64-bit
+     * FIXED POINT, as the device does (rsrl_amd/csrc/models.hpp TileModel::block_accumulate, k_apply_rep): a term lr*e is scaled
+     * by the exact power of two 1/lsb, lsb = 2^(floor(log2 lr) - 28), clamped to +-2^42 and rounded to an integer; the sum over
+     * the batch is exact and order-independent and converts back with one rounding -- so this loop and the HIP path agree bit
+     * for bit whatever order the device's atomics retire in.  (f64 keeps the plain sum: the reference rule.) */
+    const int fixed = ag->shared_w && ag->basis.kind == ORC_TILE && sizeof(R) == 4;
+    int64_t* qacc = fixed ? (int64_t*)malloc(sizeof(int64_t) * (size_t)F * A) : NULL;
+    float lsb_f = 1.0f, inv_lsb_f = 1.0f;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (fixed) {
+        const float lrf = (float)ag->lr; uint32_t u, eb, ex, v;
+        memcpy(&u, &lrf, 4); eb = (u >> 23) & 0xffu; ex = (eb < 30u ? 30u : eb) - 28u;
+        v = ex << 23; memcpy(&lsb_f, &v, 4); v = (254u - ex) << 23; memcpy(&inv_lsb_f, &v, 4);
+    }
     for (k = 0; k < n_steps; k++, run->t++) {
         if (dW) memset(dW, 0, sizeof(R) * (size_t)F * A);
+        if (qacc) memset(qacc, 0, sizeof(int64_t) * (size_t)F * A);
         for (i = 0; i < N; i++) {
             R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
             R r, delta; int a = run->action[i], term; uint32_t xi[4];
@@ -846,11 +860,19 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
                 delta = FN(orc_handle)(ag, FN(run_W)(run, i), s, a, r, ns, term, xi);
             } else {
                 R e = FN(orc_td_error)(ag, run->W, s, a, r, ns, term, xi, &delta);
+                if (fixed) {
+                    int idx[ORC_MAX_TILINGS], tt; float sf[8], sc = (float)((R)ag->lr * e) * inv_lsb_f;
+                    for (tt = 0; tt < D; tt++) sf[tt] = (float)s[tt];
+                    orc_tile_indices(&ag->basis, sf, idx);
+                    sc = sc < -4.398046511104e12f ? -4.398046511104e12f : (sc > 4.398046511104e12f ? 4.398046511104e12f : sc);
+                    for (tt = 0; tt < ag->basis.n_tilings; tt++) qacc[(size_t)idx[tt] * A + a] += (int64_t)rintf(sc);
+                } else
                 FN(orc_q_update_index)(&ag->basis, dW, A, s, a, (R)ag->lr, e);   /* dW += lr*e*phi(s) on column a */
             }
             acc.sum_abs_td_error += fabs((double)delta);
             acc.sum_reward += (double)r;
         }
+        if (fixed) { int j; for (j = 0; j < F * A; j++) dW[j] = (R)((float)qacc[j] * lsb_f); }
         if (dW && dw_hook) dw_hook(dW, F * A, user);
         if (dW) { int j; for (j = 0; j < F * A; j++) run->W[j] += dW[j]; }
         for (i = 0; i < N; i++) {
@@ -875,7 +897,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             run->action[i] = na;
         }
     }
-    free(ns_all); free(term_all); free(dW);
+    free(ns_all); free(term_all); free(dW); free(qacc);
     if (st) *st = acc;
 }
 

@@ -196,11 +196,14 @@ struct TileModel {
     // addresses are (193 cycles per wave-instruction even for 64 conflict-free addresses, profiles/r02_ubench_lds_atomic.txt),
     // ds_add_u64 costs 6 cycles for distinct addresses and 2 per duplicate of the most crowded one.  A term lr*e is scaled by
     // the power of two 1/lsb (exact) and rounded to an integer: the block's sum is then EXACT and order-independent, and
-    // converting it back rounds once.  lsb = 2^(floor(log2 lr) - 28): |e| up to 2^12 and 2^20 learners on one entry fit 63 bits;
+    // converting it back rounds once (in k_apply_rep).  lsb = 2^(floor(log2 lr) - 28): |e| up to 2^12 and 2^20 learners on one entry fit 63 bits;
     // a term keeps its full 24-bit mantissa down to |e| = 2^-4 and an absolute resolution of lr * 2^-28 below that.
     // `slice` is dynamic LDS of 2 x cells*A 64-bit words (two slices), zero on entry and left zero on exit.  All threads of the block must call.
-    __device__ static __forceinline__ void block_accumulate(float* __restrict__ dW, long long* __restrict__ slice, const BasisGeom& g,
-                                                            const Feat& ft, int a, float scale, bool valid, float inv_lsb, float lsb) {
+    // The device-wide delta table is fixed-point too (dW64: n_rep copies of cells*T*A 64-bit words): the sum over the
+    // whole batch is then EXACT whatever the order of the atomics -- the update W += fl(sum * lsb) is bitwise reproducible
+    // from run to run and restated exactly by the oracle (tests: bit-identical weights).
+    __device__ static __forceinline__ void block_accumulate(long long* __restrict__ dW64, long long* __restrict__ slice, const BasisGeom& g,
+                                                            const Feat& ft, int a, float scale, bool valid, float inv_lsb) {
         const int S = (g.F / T) * A;                                    // entries per tiling
         auto to_fixed = [&](float v) {
             const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
@@ -222,7 +225,7 @@ struct TileModel {
             if (t + 1 < T) add(t + 1, slice + ((t + 1) & 1) * S);
             for (int j = threadIdx.x; j < S; j += blockDim.x) {
                 const long long v = cur[j];
-                if (v != 0) { atomicAdd(&dW[(int64_t)t * S + j], (float)v * lsb); cur[j] = 0; }
+                if (v != 0) { atomicAdd(reinterpret_cast<unsigned long long*>(&dW64[(int64_t)t * S + j]), (unsigned long long)v); cur[j] = 0; }
             }
             __syncthreads();
         }
@@ -613,8 +616,9 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
                 // lsb = 2^(floor(log2 |lr|) - 28), an exact power of two (the exponent field of lr, shifted)
                 const uint32_t eb = (__float_as_uint(c.alg.lr) >> 23) & 0xffu;
                 const int ex = (int)(eb < 30u ? 30u : eb) - 28;
-                const float lsb = __uint_as_float((uint32_t)ex << 23), inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
-                M::block_accumulate(dW, tile_slice, g, fs, a, scale, i < N, inv_lsb, lsb);
+                const float inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
+                M::block_accumulate(reinterpret_cast<long long*>(dW_base) + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride, tile_slice, g, fs, a,
+                                    scale, i < N, inv_lsb);
             } else {
                 M::accumulate(dW, g, fs, a, scale, i < N);            // all lanes call (DPP sums inside)
             }

@@ -30,26 +30,20 @@ static inline bool is_pred(int algo) { return algo == RSRL_TD || algo == RSRL_TD
 static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ || algo == RSRL_TD_LAMBDA; }   // second matrix of W's shape
 
 namespace {
-// tile coding, shared W: sum the n_rep copies of the delta table (and clear them); single rank: W += sum, otherwise the sum
-// goes to dW for the all-reduce.  n is a multiple of 4 (A * cells * T with even cells).
-__global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float* __restrict__ dW, float* __restrict__ rep, int n_rep, int n) {
-    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+// tile coding, shared W: sum the n_rep copies of the FIXED-POINT delta table (and clear them) -- exact 64-bit integer sums,
+// converted once: single rank W += fl(sum * lsb), otherwise that float goes to dW for the exchange.  n is a multiple of 2.
+__global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float* __restrict__ dW, long long* __restrict__ rep, int n_rep, int n, float lsb) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (j >= n) return;
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    long long a0 = 0, a1 = 0;
     for (int r = 0; r < n_rep; ++r) {
-        float4* p = reinterpret_cast<float4*>(rep + (int64_t)r * n + j);
-        const float4 v = *p;
-        if (v.x != 0.0f || v.y != 0.0f || v.z != 0.0f || v.w != 0.0f) {
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            *p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+        longlong2* p = reinterpret_cast<longlong2*>(rep + (int64_t)r * n + j);
+        const longlong2 v = *p;
+        if (v.x != 0 || v.y != 0) { a0 += v.x; a1 += v.y; *p = make_longlong2(0, 0); }
     }
-    if (W) {
-        float4* w = reinterpret_cast<float4*>(W + j);
-        float4 x = *w; x.x += acc.x; x.y += acc.y; x.z += acc.z; x.w += acc.w; *w = x;
-    } else {
-        *reinterpret_cast<float4*>(dW + j) = acc;
-    }
+    const float d0 = (float)a0 * lsb, d1 = (float)a1 * lsb;
+    if (W) { W[j] += d0; W[j + 1] += d1; }
+    else { dW[j] = d0; dW[j + 1] = d1; }
 }
 // actions index weight columns: whatever a caller stored through a DEVICE pointer is brought into [0, A)
 __global__ void k_clamp_actions(int32_t* __restrict__ a, int64_t n, int A) {
@@ -222,7 +216,7 @@ struct rsrl_hip_ctx {
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
     int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
-    float* dW_rep = nullptr; int n_rep = 1;      // shared tile coding: replicated delta tables (contention relief)
+    long long* dW_rep = nullptr; int n_rep = 1;  // shared tile coding: n_rep copies of the fixed-point (64-bit) delta table; nullptr: the float path
     float* partials = nullptr;       // shared-W dense basis: one delta row per thread block, two buffers in ping-pong
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
     int sh_par = 0, sh_row = 0;      // which W buffer holds the current weights (0 = W); which row buffer was written last
@@ -324,6 +318,14 @@ static TdParams make_td(const rsrl_hip_ctx* c) {
 }
 
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+// resolution of the fixed-point delta tables of shared tile coding: 2^(floor(log2 |lr|) - 28), the same bits the kernel derives
+static inline float tile_lsb(float lr) {
+    uint32_t u; memcpy(&u, &lr, 4);
+    const uint32_t eb = (u >> 23) & 0xffu;
+    const uint32_t ex = (eb < 30u ? 30u : eb) - 28u;
+    const uint32_t v = ex << 23; float f; memcpy(&f, &v, 4);
+    return f;
+}
 constexpr int kSharedBlock = 512;    // learners per block of k_shared_step: 256 blocks = one per CU for a 131 072-env shard
 
 // ---- (basis, domain, parameter) -> Model type ---------------------------------------------------
@@ -674,14 +676,13 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
-    if (shared && cfg->basis == RSRL_TILE_CODING && c->dw_elems % 4 == 0) {
+    // (the fixed-point tables serve the LDS-privatised scatter: one tiling's slice, twice, as 64-bit words must fit 128 KiB of LDS)
+    if (shared && cfg->basis == RSRL_TILE_CODING && c->dw_elems % 2 == 0 && (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024) {
         const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob; with the fixed-point LDS accumulators the device atomics are what is left:
         int r = e ? atoi(e) : 4;                            // 4 copies measured best (2: 30.7, 4: 27.6, 8: 27.8, 16: 29.9 us per batch-step at 262 144 envs)
         c->n_rep = r < 1 ? 1 : (r > 64 ? 64 : r);
-        if (c->n_rep > 1) {
-            HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(float) * c->dw_elems * c->n_rep));
-            HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(float) * c->dw_elems * c->n_rep, c->stream));
-        }
+        HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
+        HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
     }
     HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
     HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
@@ -1274,8 +1275,8 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
             int slice = 0; size_t lds = 0;
-            if (!dense) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; if (f * 16 <= 128 * 1024) { slice = (int)f; lds = (size_t)f * 16; } }   // two slices of 64-bit fixed-point accumulators
-            float* dwp = c->dW_rep ? c->dW_rep : c->dW;
+            if (!dense && c->dW_rep) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; slice = (int)f; lds = (size_t)f * 16; }   // two slices of 64-bit fixed-point accumulators
+            float* dwp = c->dW_rep ? reinterpret_cast<float*>(c->dW_rep) : c->dW;
             const int nrep = c->dW_rep ? c->n_rep : 1;
             if constexpr (M::kSparse) {
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
@@ -1292,7 +1293,8 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
     if (!dense && c->dW_rep) {
-        hipLaunchKernelGGL(k_apply_rep, dim3((n / 4 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n);
+        hipLaunchKernelGGL(k_apply_rep, dim3((n / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
+                           tile_lsb((float)c->cfg.lr));
         KCHECK();
     }
     if (multi || (!dense && !c->dW_rep)) {
