@@ -679,7 +679,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     // (the fixed-point tables serve the LDS-privatised scatter: one tiling's slice, twice, as 64-bit words must fit 128 KiB of LDS)
     if (shared && cfg->basis == RSRL_TILE_CODING && c->dw_elems % 2 == 0 && (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024) {
         const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob; with the fixed-point LDS accumulators the device atomics are what is left:
-        int r = e ? atoi(e) : 4;                            // 4 copies measured best (2: 30.7, 4: 27.6, 8: 27.8, 16: 29.9 us per batch-step at 262 144 envs)
+        int r = e ? atoi(e) : 8;                            // one copy per XCD (block b runs on XCD b % 8): 2: 35.0, 4: 29.7, 8: 28.7, 16: 29.5 us per batch-step at 262 144 envs
         c->n_rep = r < 1 ? 1 : (r > 64 ? 64 : r);
         HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
