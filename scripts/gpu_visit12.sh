@@ -1,3 +1,3 @@
 #!/bin/bash
 python scripts/prof_shared.py tile none
-timeout 1200 python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/full.log 2>&1; echo "exit $?" >> gpurun_out/full.log; grep -E "passed|failed|exit" gpurun_out/full.log
+timeout 600 python -m pytest tests/test_gpu_bitwise.py tests/test_gpu_parity_more.py tests/test_gpu_fullsize.py -m gpu -q --timeout 600 -k "tile or c3 or C3 or shared" 2>&1 | tail -3
