@@ -77,6 +77,18 @@ constexpr double kPi = 3.14159265358979323846;
 // scheduler can interleave it with the Philox / FMA chains of a lone wave per SIMD).
 // Measured against f64: |err| <= 9e-8 (<= 1.7 ulp) on the stated ranges.
 // ---------------------------------------------------------------------------------------
+// (sin, cos) of r + q*pi/2 from (s, c) = (sin r, cos r), q in 0..3:  (s, c), (c, -s), (-s, -c), (-c, s).
+// Written as one swap (two selects) and two sign-bit xors: as a ternary chain the compiler turned it into exec-mask
+// branches with half of the sine polynomial sunk into them -- a lone wave per SIMD pays every taken branch in full.
+__device__ __forceinline__ void quadrant_select(int q, float s, float c, float& sn, float& cs) {
+    const bool swap = (q & 1) != 0;
+    const float a = swap ? c : s;
+    const float b = swap ? s : c;
+    const uint32_t sa = ((uint32_t)q & 2u) << 30;                       // sin negative in quadrants 2, 3
+    const uint32_t sb = (((uint32_t)q + 1u) & 2u) << 30;                // cos negative in quadrants 1, 2
+    sn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) ^ sa);
+    cs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b) ^ sb);
+}
 // sin(pi x), cos(pi x) for x in [0, 1] (scaled states s~): q = rint(2x), r = x - q/2 in [-1/4, 1/4]
 __device__ __forceinline__ void sincospi01(float x, float& sn, float& cs) {
     const float q = rintf(x * 2.0f);
@@ -93,9 +105,7 @@ __device__ __forceinline__ void sincospi01(float x, float& sn, float& cs) {
     pc = fmaf(pc, u, 4.058707237243652f);
     pc = fmaf(pc, u, -4.934802055358887f);
     const float c = fmaf(pc, u, 1.0f);                                  // cos(pi r)
-    const int qi = (int)q;                                              // 0, 1, 2
-    sn = (qi == 1) ? c : ((qi == 2) ? -s : s);
-    cs = (qi == 1) ? -s : ((qi == 2) ? -c : c);
+    quadrant_select((int)q, s, c, sn, cs);                              // q = 0, 1, 2
 }
 // sin(x), cos(x) for |x| <= 100: Cody-Waite reduction by pi/2 (two-term, fma), polynomials on [-pi/4, pi/4]
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
@@ -114,9 +124,7 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     pc = fmaf(pc, u, 0.04166661202907562f);
     pc = fmaf(pc, u, -0.5f);
     const float c = fmaf(pc, u, 1.0f);
-    const int q = ((int)n) & 3;
-    sn = (q == 0) ? s : ((q == 1) ? c : ((q == 2) ? -s : -c));
-    cs = (q == 0) ? c : ((q == 1) ? -s : ((q == 2) ? -c : s));
+    quadrant_select(((int)n) & 3, s, c, sn, cs);
 }
 __device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
 // exp(x) for the softmax policy: n = rint(x log2 e), two-term Cody-Waite reduction by ln 2, degree-5 polynomial on top of
@@ -296,10 +304,13 @@ template <int A>
 __device__ __forceinline__ uint32_t argmaxima_mask(const float (&q)[A]) {
     float mx = -FLT_MAX; uint32_t mask = 0;
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-        const float d = fabsf(q[i] - mx);
-        if (d < 1e-7f) mask |= (1u << i);
-        else if (q[i] > mx) { mx = q[i]; mask = (1u << i); }
+    for (int i = 0; i < A; ++i) {                                     // selects only: no exec-mask branches
+        const float qi = q[i];
+        const bool near = fabsf(qi - mx) < 1e-7f;
+        const bool up = (!near) & (qi > mx);
+        const uint32_t m_or = mask | (1u << i), m_up = up ? (1u << i) : mask;
+        mask = near ? m_or : m_up;
+        mx = up ? qi : mx;
     }
     return mask;
 }
@@ -311,21 +322,27 @@ __device__ __forceinline__ int argmax_first(const float (&v)[A]) {
     for (int j = 0; j < A; ++j) { if (v[j] - bx > 1e-7f) { bi = j; bx = v[j]; } }
     return bi;
 }
-__device__ __forceinline__ int kth_set_bit(uint32_t mask, int k) {
-    for (int j = 0; j < k; ++j) mask &= mask - 1;                     // drop the k lowest set bits
+template <int A>
+__device__ __forceinline__ int kth_set_bit(uint32_t mask, int k) {   // k < popc(mask) <= A
+#pragma unroll
+    for (int j = 0; j < A - 1; ++j) {                                 // drop the k lowest set bits
+        const uint32_t dropped = mask & (mask - 1);
+        mask = (j < k) ? dropped : mask;
+    }
     return __ffs((int)mask) - 1;
 }
 // Greedy::sample -> argmax_choose_rng: the single maximum, else a uniform pick among the
 // maxima with the caller's rng                                 greedy.rs:77-81, utils.rs:63-79
 template <int A>
 __device__ __forceinline__ int greedy_sample(const float (&q)[A], uint32_t x_tie) {
-    const uint32_t mask = argmaxima_mask<A>(q);
-    const int n = __popc(mask);
-    if (n == 1) return __ffs((int)mask) - 1;
+    const uint32_t m0 = argmaxima_mask<A>(q);
+    const int n0 = __popc(m0);
     // no maximum at all (every Q is NaN or -inf: a diverged learner; the reference panics with "No valid maxima",
-    // utils.rs:70-76): the action indexes a weight column, so it must stay in [0, A) -- a uniform pick
-    if (n == 0) return (int)mulhi_u32(x_tie, (uint32_t)A);
-    return kth_set_bit(mask, (int)mulhi_u32(x_tie, (uint32_t)n));
+    // utils.rs:70-76): the action indexes a weight column, so it must stay in [0, A) -- a uniform pick among all A
+    const bool none = n0 == 0;
+    const uint32_t mask = none ? ((1u << A) - 1u) : m0;
+    const int n = none ? A : n0;
+    return kth_set_bit<A>(mask, (int)mulhi_u32(x_tie, (uint32_t)n));       // a single maximum: k = 0
 }
 // caller-supplied actions index weight columns: keep them in [0, A) whatever the caller passed
 template <int A>
@@ -367,9 +384,11 @@ template <int A>
 __device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float (&q)[A], const U4& x) {
     switch (pp.kind) {
     case POL_GREEDY: return greedy_sample<A>(q, x.z);
-    case POL_EGREEDY:
-        if ((x.x >> 8) < pp.eps_thr) return (int)mulhi_u32(x.y, (uint32_t)A);
-        return greedy_sample<A>(q, x.z);
+    case POL_EGREEDY: {
+        const int g = greedy_sample<A>(q, x.z), u = (int)mulhi_u32(x.y, (uint32_t)A);
+        const bool explore = (x.x >> 8) < pp.eps_thr;
+        return explore ? u : g;
+    }
     case POL_SOFTMAX: { float p[A]; softmax_probs<A>(q, pp.tau, p); return sample_probs<A>(p, x.z); }
     default: return (int)mulhi_u32(x.y, (uint32_t)A);
     }
@@ -409,25 +428,24 @@ struct AlgoParams { int kind; float gamma, lr, alpha; };
 template <int A>
 __device__ __forceinline__ float td_error(const AlgoParams& ap, const PolicyParams& pp, float qsa, const float (&qn)[A],
                                           float r, bool term, const U4& x_inner, float& e) {
-    float delta;
-    if (term) {
-        delta = r - qsa;
-    } else if (ap.kind == ALG_QLEARNING) {
-        float m; find_max<A>(qn, m);
-        delta = r + ap.gamma * m - qsa;
+    // the bootstrap value is computed whether or not the transition is terminal and SELECTED afterwards (no state is
+    // consumed by it: the draws are counter-based), so that the step is one basic block
+    float boot;
+    if (ap.kind == ALG_QLEARNING) {
+        find_max<A>(qn, boot);
     } else if (ap.kind == ALG_SARSA) {
         const int na = policy_sample<A>(pp, qn, x_inner);             // agent's own draw (sarsa.rs:61)
-        float qna = qn[0];
+        boot = qn[0];
 #pragma unroll
-        for (int i = 1; i < A; ++i) qna = (na == i) ? qn[i] : qna;
-        delta = r + ap.gamma * qna - qsa;
+        for (int i = 1; i < A; ++i) boot = (na == i) ? qn[i] : boot;
     } else {
         float p[A]; policy_probs<A>(pp, qn, p);
-        float ev = 0.0f;
+        boot = 0.0f;
 #pragma unroll
-        for (int i = 0; i < A; ++i) ev = ev + qn[i] * p[i];           // fold(0.0, acc + q*p)
-        delta = r + ap.gamma * ev - qsa;
+        for (int i = 0; i < A; ++i) boot = boot + qn[i] * p[i];       // fold(0.0, acc + q*p)
     }
+    const float d_term = r - qsa, d_boot = r + ap.gamma * boot - qsa;
+    const float delta = term ? d_term : d_boot;
     e = (ap.kind == ALG_ESARSA) ? ap.alpha * delta : delta;
     return delta;
 }

@@ -295,7 +295,7 @@ struct QCarry {
     template <int A> __device__ __forceinline__ void set(const float (&q)[A]) {
         v0 = q[0]; v1 = A > 1 ? q[A > 1 ? 1 : 0] : 0.0f; v2 = A > 2 ? q[A > 2 ? 2 : 0] : 0.0f;
     }
-    __device__ __forceinline__ float at(int a) const { return (a == 1) ? v1 : ((a == 2) ? v2 : v0); }
+    __device__ __forceinline__ float at(int a) const { const float t = (a == 2) ? v2 : v0; return (a == 1) ? v1 : t; }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
     const uint32_t wlane = threadIdx.x * (uint32_t)c.w_ls * 4u;          // byte offset of this lane inside a row, 32 bits
     const int64_t wrow = c.w_stride * 4;                                 // bytes between (action, feature) rows
 
-    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    uint32_t n_ep = 0, n_trunc = 0, sum_len = 0;      // per launch and learner: <= n_steps (+ the carried episode length), 32 bits
     double sum_abs = 0.0, sum_r = 0.0;
 
     if (i < N) {
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta);
             facc_r += r;
-            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
-            if (trunc) {                           // step cap: Q(s') was needed above, now the new episode
+            n_ep += term ? 1u : 0u; sum_len += term ? ep : 0u; ep = term ? 0u : ep;
+            if (__builtin_expect(trunc, 0)) {      // step cap: Q(s') was needed above, now the new episode
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
                 pre_s = Dom::pre(ns);
