@@ -35,15 +35,25 @@ constexpr int ipow(int b, int e) { return e == 0 ? 1 : b * ipow(b, e - 1); }
 // ---------------------------------------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
 
+// a ^ b ^ c in one instruction on the device (v_bitop3_b32, truth table 0x96): the compiler emits two v_xor for it,
+// 20 extra instructions in the ten rounds below, on the dependent chain of every draw
+__host__ __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 __host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                      uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
@@ -106,6 +116,31 @@ __device__ __forceinline__ void sincospi01(float x, float& sn, float& cs) {
     pc = fmaf(pc, u, -4.934802055358887f);
     const float c = fmaf(pc, u, 1.0f);                                  // cos(pi r)
     quadrant_select((int)q, s, c, sn, cs);                              // q = 0, 1, 2
+}
+// the same for two arguments at once (two state dimensions side by side in a register pair): v_pk_mul_f32 / v_pk_fma_f32
+// round each half exactly like the scalar instructions, so the results are bit-identical to two sincospi01 calls
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float x) { return f2{x, x}; }
+__device__ __forceinline__ void sincospi01_x2(f2 x, f2& sn, f2& cs) {
+    const f2 x2 = x * splat2(2.0f);
+    const f2 q = f2{rintf(x2.x), rintf(x2.y)};
+    const f2 r = __builtin_elementwise_fma(q, splat2(-0.5f), x);
+    const f2 u = r * r;
+    f2 ps = splat2(0.08100174367427826f);
+    ps = __builtin_elementwise_fma(ps, u, splat2(-0.5992020964622498f));
+    ps = __builtin_elementwise_fma(ps, u, splat2(2.5501625537872314f));
+    ps = __builtin_elementwise_fma(ps, u, splat2(-5.167712688446045f));
+    ps = __builtin_elementwise_fma(ps, u, splat2(3.1415927410125732f));
+    const f2 s = ps * r;
+    f2 pc = splat2(0.23132924735546112f);
+    pc = __builtin_elementwise_fma(pc, u, splat2(-1.335044503211975f));
+    pc = __builtin_elementwise_fma(pc, u, splat2(4.058707237243652f));
+    pc = __builtin_elementwise_fma(pc, u, splat2(-4.934802055358887f));
+    const f2 c = __builtin_elementwise_fma(pc, u, splat2(1.0f));
+    float s0, c0, s1, c1;
+    quadrant_select((int)q.x, s.x, c.x, s0, c0);
+    quadrant_select((int)q.y, s.y, c.y, s1, c1);
+    sn = f2{s0, s1}; cs = f2{c0, c1};
 }
 // sin(x), cos(x) for |x| <= 100: Cody-Waite reduction by pi/2 (two-term, fma), polynomials on [-pi/4, pi/4]
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
@@ -515,34 +550,87 @@ struct FourierTables {
     }
 };
 
-// register-resident projection: every feature index is a compile-time constant
+// register-resident projection: every feature index is a compile-time constant.
+// Even D: the per-dimension tables are built for two dimensions at a time in register pairs (packed fp32 multiply / fma
+// take one issue slot for both), and for D = 2 the products are formed two features at a time as well.  Same operations in
+// the same order per element as FourierTables::build + the scalar product below: bit-identical features.
 template <int DOMAIN, int ORDER>
 struct FourierReg {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, N1 = ORDER + 1, F = ipow(N1, D);
-    __device__ static __forceinline__ void project(const float (&s)[D], float (&phi)[F]) {
-        FourierTables<DOMAIN, ORDER> tb;
-        tb.build(s);
-        static_for<1, F>([&](auto Kk) {
-            constexpr int k = Kk;
-            // digits of k, most significant = dimension 0
-            constexpr int c0 = (k / ipow(N1, D - 1)) % N1;
-            float re = tb.ct[0][c0], im = tb.st[0][c0];
-            static_for<1, D>([&](auto Dd) {
-                constexpr int d = Dd;
-                constexpr int cd = (k / ipow(N1, D - 1 - d)) % N1;
-                if constexpr (cd == 0) {
-                    // multiply by (1, 0): exact identity
-                } else if constexpr (d == 1 && c0 == 0) {
-                    re = tb.ct[d][cd]; im = tb.st[d][cd];             // (1,0) * z == z exactly
-                } else {
-                    const float nre = fmaf(-im, tb.st[d][cd], re * tb.ct[d][cd]);
-                    const float nim = fmaf(re, tb.st[d][cd], im * tb.ct[d][cd]);
-                    re = nre; im = nim;
-                }
+    static constexpr bool kPairs = (D % 2 == 0) && ORDER >= 1;
+    struct PairTables {
+        f2 ct[D / 2 > 0 ? D / 2 : 1][N1], st[D / 2 > 0 ? D / 2 : 1][N1];
+        __device__ __forceinline__ float c(int d, int n) const { return (d & 1) ? ct[d >> 1][n].y : ct[d >> 1][n].x; }
+        __device__ __forceinline__ float s(int d, int n) const { return (d & 1) ? st[d >> 1][n].y : st[d >> 1][n].x; }
+        __device__ __forceinline__ void build(const float (&sv)[D]) {
+            static_for<0, D / 2>([&](auto Pp) {
+                constexpr int p = Pp, d0 = 2 * p, d1 = 2 * p + 1;
+                constexpr float lo0 = (float)Dom::lo_d(d0), hi0 = (float)Dom::hi_d(d0), lo1 = (float)Dom::lo_d(d1), hi1 = (float)Dom::hi_d(d1);
+                constexpr float inv0 = 1.0f / (hi0 - lo0), inv1 = 1.0f / (hi1 - lo1);       // as FourierTables::build
+                const f2 sc = (f2{sv[d0], sv[d1]} - f2{lo0, lo1}) * f2{inv0, inv1};
+                ct[p][0] = splat2(1.0f); st[p][0] = splat2(0.0f);
+                sincospi01_x2(sc, st[p][1], ct[p][1]);
+                static_for<2, N1>([&](auto Nn) {
+                    constexpr int n = Nn;
+                    ct[p][n] = __builtin_elementwise_fma(-st[p][n - 1], st[p][1], ct[p][n - 1] * ct[p][1]);
+                    st[p][n] = __builtin_elementwise_fma(ct[p][n - 1], st[p][1], st[p][n - 1] * ct[p][1]);
+                });
             });
-            phi[k - 1] = re;
+        }
+    };
+    // one feature (k = 1 .. F-1) from per-dimension tables
+    template <int k, class T>
+    __device__ static __forceinline__ float feature(const T& tb) {
+        constexpr int c0 = (k / ipow(N1, D - 1)) % N1;                 // digits of k, most significant = dimension 0
+        float re = tb.c(0, c0), im = tb.s(0, c0);
+        static_for<1, D>([&](auto Dd) {
+            constexpr int d = Dd;
+            constexpr int cd = (k / ipow(N1, D - 1 - d)) % N1;
+            if constexpr (cd == 0) {
+                // multiply by (1, 0): exact identity
+            } else if constexpr (d == 1 && c0 == 0) {
+                re = tb.c(d, cd); im = tb.s(d, cd);                    // (1,0) * z == z exactly
+            } else {
+                const float nre = fmaf(-im, tb.s(d, cd), re * tb.c(d, cd));
+                const float nim = fmaf(re, tb.s(d, cd), im * tb.c(d, cd));
+                re = nre; im = nim;
+            }
         });
+        return re;
+    }
+    struct ScalarTables {
+        FourierTables<DOMAIN, ORDER> t;
+        __device__ __forceinline__ float c(int d, int n) const { return t.ct[d][n]; }
+        __device__ __forceinline__ float s(int d, int n) const { return t.st[d][n]; }
+    };
+    __device__ static __forceinline__ void project(const float (&s)[D], float (&phi)[F]) {
+        if constexpr (kPairs) {
+            PairTables tb;
+            tb.build(s);
+            if constexpr (D == 2) {
+                // features 2j, 2j+1 (k = 2j+1, 2j+2) with the same dimension-0 harmonic c0 >= 1 and both dimension-1 harmonics
+                // >= 1: one packed multiply + one packed fma, the dimension-0 factor broadcast to both halves
+                static_for<0, F / 2>([&](auto Jj) {
+                    constexpr int j = Jj, ka = 2 * j + 1, kb = 2 * j + 2;
+                    constexpr int a0 = ka / N1, a1 = ka % N1, b0 = kb / N1, b1 = kb % N1;
+                    if constexpr (kb < F && a0 == b0 && a0 >= 1 && a1 >= 1 && b1 >= 1) {
+                        const f2 c1 = f2{tb.c(1, a1), tb.c(1, b1)}, s1 = f2{tb.s(1, a1), tb.s(1, b1)};
+                        const f2 v = __builtin_elementwise_fma(splat2(-tb.s(0, a0)), s1, splat2(tb.c(0, a0)) * c1);
+                        phi[2 * j] = v.x; phi[2 * j + 1] = v.y;
+                    } else {
+                        phi[2 * j] = feature<ka>(tb);
+                        if constexpr (kb < F) phi[2 * j + 1] = feature<kb>(tb);
+                    }
+                });
+            } else {
+                static_for<1, F>([&](auto Kk) { constexpr int k = Kk; phi[k - 1] = feature<k>(tb); });
+            }
+        } else {
+            ScalarTables tb;
+            tb.t.build(s);
+            static_for<1, F>([&](auto Kk) { constexpr int k = Kk; phi[k - 1] = feature<k>(tb); });
+        }
         phi[F - 1] = 1.0f;
     }
 };

@@ -122,7 +122,6 @@ __device__ __forceinline__ void q_from_reg(const float (&w)[A][F], const float (
 // ---- packed-pair variants (v_pk_fma_f32): at one wave per SIMD a wave issues one VALU instruction per ~3.4 cycles whatever
 // its width, and a packed FMA (two IEEE fmas) costs ~5.2 -- 25 % fewer cycles for the dot products, the column update and
 // the rank-1 term.  Same chain assignment as the scalar code (acc[f % 4] takes feature f), so results are bit-identical.
-typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef RSRL_PK
 #define RSRL_PK 1
 #endif
@@ -295,7 +294,16 @@ struct QCarry {
     template <int A> __device__ __forceinline__ void set(const float (&q)[A]) {
         v0 = q[0]; v1 = A > 1 ? q[A > 1 ? 1 : 0] : 0.0f; v2 = A > 2 ? q[A > 2 ? 2 : 0] : 0.0f;
     }
-    __device__ __forceinline__ float at(int a) const { const float t = (a == 2) ? v2 : v0; return (a == 1) ? v1 : t; }
+    // two selects; each compare sees its own opaque copy of the index (see select_a: LLVM would otherwise turn the chain
+    // into a dynamic extractelement through LDS)
+    __device__ __forceinline__ float at(int a) const {
+        int a1 = a, a2 = a;
+        asm("" : "+v"(a1));
+        asm("" : "+v"(a2));
+        const float x0 = v0, x1 = v1, x2 = v2;     // by value: ?: on two member lvalues is a select of ADDRESSES plus a load
+        const float t = (a2 == 2) ? x2 : x0;
+        return (a1 == 1) ? x1 : t;
+    }
 };
 
 // ---------------------------------------------------------------------------------------
