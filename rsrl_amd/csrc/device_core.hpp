@@ -147,18 +147,14 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     const float n = rintf(x * 0.6366197466850281f);
     float r = fmaf(n, -1.5707963705062866f, x);
     r = fmaf(n, 4.371138828673793e-08f, r);
-    const float u = r * r;
-    float ps = 2.715809387154877e-06f;
-    ps = fmaf(ps, u, -0.00019839033484458923f);
-    ps = fmaf(ps, u, 0.008333328180015087f);
-    ps = fmaf(ps, u, -0.1666666716337204f);
-    ps = fmaf(ps, u, 1.0f);
-    const float s = ps * r;
-    float pc = 2.4362980184378102e-05f;
-    pc = fmaf(pc, u, -0.001388643286190927f);
-    pc = fmaf(pc, u, 0.04166661202907562f);
-    pc = fmaf(pc, u, -0.5f);
-    const float c = fmaf(pc, u, 1.0f);
+    const f2 u = splat2(r * r);
+    f2 p = f2{2.715809387154877e-06f, 2.4362980184378102e-05f};        // (sine, cosine) polynomials side by side: same Horner
+    p = __builtin_elementwise_fma(p, u, f2{-0.00019839033484458923f, -0.001388643286190927f});   // steps, one packed fma each
+    p = __builtin_elementwise_fma(p, u, f2{0.008333328180015087f, 0.04166661202907562f});
+    p = __builtin_elementwise_fma(p, u, f2{-0.1666666716337204f, -0.5f});
+    p = __builtin_elementwise_fma(p, u, splat2(1.0f));
+    const float s = p.x * r;
+    const float c = p.y;
     quadrant_select(((int)n) & 3, s, c, sn, cs);
 }
 __device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
@@ -337,9 +333,11 @@ __device__ __forceinline__ int find_max(const float (&q)[A], float& val) {
 // returns the set as a bitmask (A <= 8 on this path)
 template <int A>
 __device__ __forceinline__ uint32_t argmaxima_mask(const float (&q)[A]) {
-    float mx = -FLT_MAX; uint32_t mask = 0;
+    // i = 0 against mx = -FLT_MAX, folded: the tolerance test can only hit q[0] == -FLT_MAX itself, so q[0] joins the set
+    // iff q[0] >= -FLT_MAX (not NaN, not -inf) and the running max becomes max(q[0], -FLT_MAX) either way
+    float mx = fmaxf(q[0], -FLT_MAX); uint32_t mask = (q[0] >= -FLT_MAX) ? 1u : 0u;
 #pragma unroll
-    for (int i = 0; i < A; ++i) {                                     // selects only: no exec-mask branches
+    for (int i = 1; i < A; ++i) {                                     // selects only: no exec-mask branches
         const float qi = q[i];
         const bool near = fabsf(qi - mx) < 1e-7f;
         const bool up = (!near) & (qi > mx);
@@ -357,14 +355,31 @@ __device__ __forceinline__ int argmax_first(const float (&v)[A]) {
     for (int j = 0; j < A; ++j) { if (v[j] - bx > 1e-7f) { bi = j; bx = v[j]; } }
     return bi;
 }
+// position of the (k+1)-th set bit of mask, k < popc(mask).  A <= 3: one lookup in a 48-bit table (2 bits per (mask, k)).
 template <int A>
-__device__ __forceinline__ int kth_set_bit(uint32_t mask, int k) {   // k < popc(mask) <= A
+__device__ __forceinline__ int kth_set_bit(uint32_t mask, int k) {
+    if constexpr (A <= 3) {
+        constexpr uint64_t table = [] {
+            uint64_t t = 0;
+            for (uint32_t m = 0; m < 8; ++m)
+                for (int kk = 0; kk < 3; ++kk) {
+                    int seen = 0, pos = 0;
+                    for (int b = 0; b < 3; ++b)
+                        if ((m >> b) & 1u) { if (seen == kk) pos = b; ++seen; }
+                    t |= (uint64_t)pos << (2 * (m * 3 + kk));
+                }
+            return t;
+        }();
+        const uint32_t sh = 2u * (mask * 3u + (uint32_t)k);
+        return (int)((uint32_t)(table >> sh) & 3u);
+    } else {
 #pragma unroll
-    for (int j = 0; j < A - 1; ++j) {                                 // drop the k lowest set bits
-        const uint32_t dropped = mask & (mask - 1);
-        mask = (j < k) ? dropped : mask;
+        for (int j = 0; j < A - 1; ++j) {                             // drop the k lowest set bits
+            const uint32_t dropped = mask & (mask - 1);
+            mask = (j < k) ? dropped : mask;
+        }
+        return __ffs((int)mask) - 1;
     }
-    return __ffs((int)mask) - 1;
 }
 // Greedy::sample -> argmax_choose_rng: the single maximum, else a uniform pick among the
 // maxima with the caller's rng                                 greedy.rs:77-81, utils.rs:63-79

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
         int a = c.action[i];
         uint32_t ep = c.ep_step[i];
+        const uint32_t ep_start = ep;
         constexpr bool PK = (RSRL_PK != 0) && (F % 4 == 0);
         using Phi = PhiBuf<F, PK>;
         WBuf<A, F, PK> w;
@@ -440,9 +441,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta);
             facc_r += r;
-            n_ep += term ? 1u : 0u; sum_len += term ? ep : 0u; ep = term ? 0u : ep;
+            n_ep += term ? 1u : 0u; ep = term ? 0u : ep;
             if (__builtin_expect(trunc, 0)) {      // step cap: Q(s') was needed above, now the new episode
-                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                n_ep += 1; n_trunc += 1; ep = 0;
                 Dom::reset(ns);
                 pre_s = Dom::pre(ns);
                 { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
@@ -463,6 +464,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         }
         if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
         sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+        // lengths of the episodes that ended in this launch: every step taken, plus what the first episode had before the launch,
+        // minus what the open one has now
+        sum_len = (uint32_t)n_steps + ep_start - ep;
 
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
