@@ -137,6 +137,121 @@ struct WaveFourier {
 #pragma unroll
             for (int j = 0; j < 8; ++j) WaveIO<WT>::store8(Wi, (int64_t)b * F + j * 512 + lane * 8, w[b][j]);
     }
+    // ---- the fused loop's forms: packed pairs, features streamed through LDS ------------------------------------------
+    // The fused loop keeps ONLY the weights in registers (A x 32 register pairs).  Features are produced one 8-wide chunk at
+    // a time, folded into the A running dot products at once and parked in the wave's own LDS buffer [chunk][lane][8]
+    // (two buffers: phi(s) of the current step, phi(s') of the next); the column update and Q(s',a) read them back.  With both
+    // phi buffers in registers next to W (320 values) the compiler had to shuttle ~130 of them through AGPRs around every use.
+    // Element (j, v) goes through exactly the operations of project() / dot() / update_col(), pairs (v, v+1) per packed op.
+    using PairTab = typename FourierReg<DOMAIN, kWaveOrder>::PairTables;
+    struct Stream {
+        float c0[8], s0[8];              // dimension-0 harmonics (chunk index j)
+        float e1r, e1i, e2r, e2i;        // this lane's dimension-1 / dimension-2 harmonics
+        f2 c3[4], s3[4];                 // dimension-3 harmonics, pairs (v, v+1)
+    };
+    __device__ static __forceinline__ void stream_begin(const float (&s)[D], int lane, Stream& st) {
+        PairTab tb;
+        tb.build(s);
+        const int c1 = lane >> 3, c2 = lane & 7;
+        st.e1r = tb.c(1, 0); st.e1i = tb.s(1, 0); st.e2r = tb.c(2, 0); st.e2i = tb.s(2, 0);
+#pragma unroll
+        for (int c = 1; c < N1; ++c) {
+            const float a1r = tb.c(1, c), a1i = tb.s(1, c), a2r = tb.c(2, c), a2i = tb.s(2, c);
+            st.e1r = (c1 == c) ? a1r : st.e1r; st.e1i = (c1 == c) ? a1i : st.e1i;
+            st.e2r = (c2 == c) ? a2r : st.e2r; st.e2i = (c2 == c) ? a2i : st.e2i;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st.c0[j] = tb.c(0, j); st.s0[j] = tb.s(0, j); }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { st.c3[p] = f2{tb.c(3, 2 * p), tb.c(3, 2 * p + 1)}; st.s3[p] = f2{tb.s(3, 2 * p), tb.s(3, 2 * p + 1)}; }
+    }
+    __device__ static __forceinline__ void stream_chunk(const Stream& st, int j, f2 (&phi)[4]) {
+        float re = st.c0[j], im = st.s0[j];
+        float nre = fmaf(-im, st.e1i, re * st.e1r), nim = fmaf(re, st.e1i, im * st.e1r);
+        re = nre; im = nim;
+        nre = fmaf(-im, st.e2i, re * st.e2r); nim = fmaf(re, st.e2i, im * st.e2r);
+        re = nre; im = nim;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) phi[p] = __builtin_elementwise_fma(splat2(-im), st.s3[p], splat2(re) * st.c3[p]);
+    }
+    __device__ static __forceinline__ void lds_put(float* __restrict__ P, int j, const f2 (&phi)[4]) {
+        float4* q = reinterpret_cast<float4*>(P + j * 512);
+        q[0] = make_float4(phi[0].x, phi[0].y, phi[1].x, phi[1].y);
+        q[1] = make_float4(phi[2].x, phi[2].y, phi[3].x, phi[3].y);
+    }
+    __device__ static __forceinline__ void lds_get(const float* __restrict__ P, int j, f2 (&phi)[4]) {
+        const float4* q = reinterpret_cast<const float4*>(P + j * 512);
+        const float4 a = q[0], b = q[1];
+        phi[0] = f2{a.x, a.y}; phi[1] = f2{a.z, a.w}; phi[2] = f2{b.x, b.y}; phi[3] = f2{b.z, b.w};
+    }
+    // phi(s) -> LDS buffer P (this lane's slots), Q(s, b) for every action (wave-uniform)
+    __device__ static __forceinline__ void stream_project_q(const float (&s)[D], int lane, float* __restrict__ P, const f2 (&w)[A][8][4],
+                                                            float (&q)[A]) {
+        Stream st;
+        stream_begin(s, lane, st);
+        f2 acc[A][2];
+#pragma unroll
+        for (int b = 0; b < A; ++b) { acc[b][0] = splat2(0.0f); acc[b][1] = splat2(0.0f); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f2 phi[4];
+            stream_chunk(st, j, phi);
+            lds_put(P, j, phi);
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[b][p & 1] = __builtin_elementwise_fma(phi[p], w[b][j][p], acc[b][p & 1]);
+        }
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = wave_sum_uniform((acc[b][0].x + acc[b][0].y) + (acc[b][1].x + acc[b][1].y));
+    }
+    // W[:,a] += scale * phi(s) from the LDS buffer Ps, then Q(s',a) with the updated column against phi(s') in Pn
+    template <class WT>
+    __device__ static __forceinline__ float stream_update_q(f2 (&wa)[8][4], const float* __restrict__ Ps, const float* __restrict__ Pn, float scale,
+                                                            const U4& rnd) {
+        f2 acc[2] = {splat2(0.0f), splat2(0.0f)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f2 ps[4], pn[4];
+            lds_get(Ps, j, ps);
+            lds_get(Pn, j, pn);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f2 x = __builtin_elementwise_fma(splat2(scale), ps[p], wa[j][p]);
+                if constexpr (WaveIO<WT>::kBf16) {
+                    x.x = round_bf16_sr(x.x, sr_bits(rnd, j * 8 + 2 * p));
+                    x.y = round_bf16_sr(x.y, sr_bits(rnd, j * 8 + 2 * p + 1));
+                }
+                wa[j][p] = x;
+                acc[p & 1] = __builtin_elementwise_fma(pn[p], x, acc[p & 1]);
+            }
+        }
+        return wave_sum_uniform((acc[0].x + acc[0].y) + (acc[1].x + acc[1].y));
+    }
+    template <class WT>
+    __device__ static __forceinline__ void load_w2(const WT* __restrict__ Wi, int lane, f2 (&w)[A][8][4]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float w8[8];
+                WaveIO<WT>::load8(Wi, (int64_t)b * F + j * 512 + lane * 8, w8);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) w[b][j][p] = f2{w8[2 * p], w8[2 * p + 1]};
+            }
+    }
+    template <class WT>
+    __device__ static __forceinline__ void store_w2(WT* __restrict__ Wi, int lane, const f2 (&w)[A][8][4]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float w8[8];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { w8[2 * p] = w[b][j][p].x; w8[2 * p + 1] = w[b][j][p].y; }
+                WaveIO<WT>::store8(Wi, (int64_t)b * F + j * 512 + lane * 8, w8);
+            }
+    }
     // Q(s,.) with W streamed from memory (granular ops)
     template <class WT>
     __device__ static __forceinline__ void q_from_mem(const WT* __restrict__ Wi, int lane, const float (&phi)[8][8], float (&q)[A]) {
@@ -194,15 +309,17 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
         for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
         int a = __builtin_amdgcn_readfirstlane(c.action[i]);
         uint32_t ep = c.ep_step[i];
-        float w[A][8][8];
-        WF::template load_w<WT>(Wi, lane, w);
-        float phi_a[8][8], phi_b[8][8], q_s[A];
-        WF::project(s, lane, phi_a);
-#pragma unroll
-        for (int b = 0; b < A; ++b) q_s[b] = WF::dot(phi_a, w[b]);
+        f2 w[A][8][4];
+        WF::template load_w2<WT>(Wi, lane, w);
+        // this wave's two feature buffers in LDS, [chunk][lane][8]: only this wave touches them (no barriers)
+        __shared__ __attribute__((aligned(16))) float sh_phi[kBlock / 64][2][8 * 64 * 8];
+        float* const P0 = &sh_phi[threadIdx.x >> 6][0][lane * 8];
+        float* const P1 = &sh_phi[threadIdx.x >> 6][1][lane * 8];
+        float q_s[A];
+        WF::stream_project_q(s, lane, P0, w, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
 
-        auto one_step = [&](const float (&phi_s)[8][8], float (&phi_n)[8][8], uint64_t t) {
+        auto one_step = [&](const float* __restrict__ Ps, float* __restrict__ Pn, uint64_t t) {
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
@@ -211,16 +328,12 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             ep += 1;
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);
-            WF::project(ns, lane, phi_n);
             float q_n[A];
-#pragma unroll
-            for (int b = 0; b < A; ++b) q_n[b] = WF::dot(phi_n, w[b]);
-            const float qsa = select_a<A>(q_s, a);
+            WF::stream_project_q(ns, lane, Pn, w, q_n);
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
             const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
-            (void)qsa;
             const float scale = c.alg.lr * e;
             U4 rnd = U4{0, 0, 0, 0};
             if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
@@ -228,10 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             float qa = 0.0f;
             static_for<0, A>([&](auto Bb) {
                 constexpr int b = Bb;
-                if (a == b) {
-                    WF::template update_col<WT>(w[b], phi_s, scale, rnd);
-                    qa = WF::dot(phi_n, w[b]);                       // Q(s',a) with the UPDATED column
-                }
+                if (a == b) qa = WF::template stream_update_q<WT>(w[b], Ps, Pn, scale, rnd);     // Q(s',a) with the UPDATED column
             });
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
@@ -242,9 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             if (trunc) {
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
-                WF::project(ns, lane, phi_n);
-#pragma unroll
-                for (int b = 0; b < A; ++b) q_n[b] = WF::dot(phi_n, w[b]);
+                WF::stream_project_q(ns, lane, Pn, w, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
                 na = policy_sample<A>(c.pol, q_n, xr);
             }
@@ -256,12 +364,12 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
         };
         int k = 0;
         for (; k + 1 < n_steps; k += 2) {
-            one_step(phi_a, phi_b, t0 + (uint64_t)k);
-            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+            one_step(P0, P1, t0 + (uint64_t)k);
+            one_step(P1, P0, t0 + (uint64_t)k + 1);
         }
-        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        if (k < n_steps) one_step(P0, P1, t0 + (uint64_t)k);
 
-        WF::template store_w<WT>(Wi, lane, w);
+        WF::template store_w2<WT>(Wi, lane, w);
         if (lane == 0) {
 #pragma unroll
             for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
