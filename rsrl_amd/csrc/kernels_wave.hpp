@@ -160,10 +160,17 @@ struct WaveFourier {
             st.e1r = (c1 == c) ? a1r : st.e1r; st.e1i = (c1 == c) ? a1i : st.e1i;
             st.e2r = (c2 == c) ? a2r : st.e2r; st.e2i = (c2 == c) ? a2i : st.e2i;
         }
+        // the state is the wave's (one learner per wave), so the dimension-0 / dimension-3 harmonics are the same bits in every lane:
+        // held as wave-uniform scalars they cost no vector registers next to the 192 of W (32 values that otherwise push the loop
+        // past the 256 architectural VGPRs and into AGPR copies around every use)
+        auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { st.c0[j] = tb.c(0, j); st.s0[j] = tb.s(0, j); }
+        for (int j = 0; j < 8; ++j) { st.c0[j] = uni(tb.c(0, j)); st.s0[j] = uni(tb.s(0, j)); }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { st.c3[p] = f2{tb.c(3, 2 * p), tb.c(3, 2 * p + 1)}; st.s3[p] = f2{tb.s(3, 2 * p), tb.s(3, 2 * p + 1)}; }
+        for (int p = 0; p < 4; ++p) {
+            st.c3[p] = f2{uni(tb.c(3, 2 * p)), uni(tb.c(3, 2 * p + 1))};
+            st.s3[p] = f2{uni(tb.s(3, 2 * p)), uni(tb.s(3, 2 * p + 1))};
+        }
     }
     __device__ static __forceinline__ void stream_chunk(const Stream& st, int j, f2 (&phi)[4]) {
         float re = st.c0[j], im = st.s0[j];
