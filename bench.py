@@ -217,7 +217,8 @@ def valu_roofline(kname, per_gpu_steps_per_s):
         return None
     cost = {"pk": 4.47, "mad_u64": 4.96, "cndmask": 4.13, "other": 2.46}
     cyc = sum(mix[k] * cost[k] for k in cost)
-    flop = mix["pk"] * 4 + mix.get("fp_fma", 0) * 2 + mix.get("fp_other", 0)
+    pk_fma = mix.get("pk_fma", mix["pk"])
+    flop = pk_fma * 4 + (mix["pk"] - pk_fma) * 2 + mix.get("fp_fma", 0) * 2 + mix.get("fp_other", 0)
     peak = N_SIMD * 64 * CLOCK_HZ / cyc
     return {"bound": "valu", "achieved": per_gpu_steps_per_s, "peak": peak, "unit": "env-steps/s per GPU", "frac": per_gpu_steps_per_s / peak,
             "valu_instr_per_env_step": sum(mix[k] for k in cost), "saturated_issue_cycles_per_env_step": cyc,

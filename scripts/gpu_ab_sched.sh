@@ -6,7 +6,7 @@ summ() { python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('$1 value %.4g ms/launch %.5f rollout %.1f'%(d['value'],d['roofline']['avg_launch_ms'],d['greedy_rollout_mean_n_states']))
+        d=json.loads(l); print('$1 value %.4g ms/launch %.5f'%(d['value'],d['roofline']['avg_launch_ms']))
     elif 'rror' in l: print(l.strip())
 "; }
 VARIANTS=${VARIANTS:-base maxmem pk pkmem pkilp}
