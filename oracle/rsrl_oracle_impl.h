@@ -1218,39 +1218,34 @@ void FN(orc_run_reset_wave)(void* h) {
  * same W_t, the summed delta applied once, every learner then samples with W_{t+1}); what is mirrored is the ORDER of the sum:
  *   block (512 learners): for each (action b, feature f) four fma chains over 128 consecutive learners each,
  *       acc = fma([a_i == b], lr*e_i*phi_i[f], acc), the four parts added in order               -> one row per block
- *   rows: "lane" l adds rows l, l+64, l+128, ... in ascending order (in groups of four, a missing row adding +0), then the
- *       64 lane sums go through the DPP ladder (wave_total)                                      -> W_t = W_{t-1} + total
+ *   blocks: every block's sums are rounded to 64-bit fixed point (lsb = 2^(floor(log2 lr) - 28), clamped to +-2^42), the
+ *       integers are added over the blocks (exact, any order) and converted back with one rounding -> W_t = W_{t-1} + total
  * and the launch structure: phase C of batch-step t-1 (sample with W_t; finished episodes restart) and phase A of batch-step
  * t run together, a train call opens with phase A alone and closes with the last fold + phase C alone.
  * One-step control agents on a Fourier basis, shared W; returns -1 otherwise. */
-static R FN(rows_total)(const R* rowsT, int n_rows, int j) {          /* rowsT[j][r] */
-    R lane[64]; int l, r0, u;
-    for (l = 0; l < 64; l++) {
-        R acc = (R)0.0;
-        for (r0 = 0; r0 < n_rows; r0 += 256)
-            for (u = 0; u < 4; u++) { const int r = r0 + 64 * u + l; acc += (r < n_rows) ? rowsT[(size_t)j * n_rows + r] : (R)0.0; }
-        lane[l] = acc;
-    }
-    return FN(wave_total)(lane);
-}
 int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
     enum { BLOCK = 512, PER = 128, H = BLOCK / PER };
     int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), AF, d, f, j, a, hh, n_rows;
     int64_t N = run->n_envs, i, k, blk;
-    R *phi, *W, *rowsT, *terms, *phis; uint8_t* flags; int* acts;
+    R *phi, *W, *terms, *phis; uint8_t* flags; int* acts; int64_t* qsum;
+    float lsb_f, inv_lsb_f;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
     if (b->kind != ORC_FOURIER || !ag->shared_w || n_steps < 1 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
     AF = A * F; n_rows = (int)((N + BLOCK - 1) / BLOCK); W = run->W;
-    phi = (R*)malloc(sizeof(R) * (size_t)F); rowsT = (R*)calloc((size_t)AF * n_rows, sizeof(R));
+    phi = (R*)malloc(sizeof(R) * (size_t)F); qsum = (int64_t*)calloc((size_t)AF, sizeof(int64_t));
+    { const float lrf = (float)ag->lr; uint32_t u, eb, ex, v;
+      memcpy(&u, &lrf, 4); eb = (u >> 23) & 0xffu; ex = (eb < 30u ? 30u : eb) - 28u;
+      v = ex << 23; memcpy(&lsb_f, &v, 4); v = (254u - ex) << 23; memcpy(&inv_lsb_f, &v, 4); }
     terms = (R*)malloc(sizeof(R) * BLOCK); phis = (R*)malloc(sizeof(R) * (size_t)BLOCK * F); acts = (int*)malloc(sizeof(int) * BLOCK);
     flags = (uint8_t*)calloc((size_t)N, 1);
     for (k = 0; k <= n_steps; k++) {
         const uint64_t t = run->t + (uint64_t)k;
         const int do_c = k > 0, do_a = k < n_steps;
-        if (do_c)                                                     /* fold the previous batch-step's rows: W_t = W_{t-1} + total */
-            for (a = 0; a < A; a++) for (f = 0; f < F; f++) { j = a * F + f; W[(size_t)f * A + a] = W[(size_t)f * A + a] + FN(rows_total)(rowsT, n_rows, j); }
+        if (do_c)                                                     /* fold the previous batch-step's delta: W_t = W_{t-1} + total */
+            for (a = 0; a < A; a++) for (f = 0; f < F; f++) { j = a * F + f; W[(size_t)f * A + a] = W[(size_t)f * A + a] + (R)((float)qsum[j] * lsb_f); }
+        memset(qsum, 0, sizeof(int64_t) * (size_t)AF);
         for (blk = 0; blk < n_rows; blk++) {
             for (i = blk * BLOCK; i < (blk + 1) * (int64_t)BLOCK; i++) {
                 const int li = (int)(i - blk * BLOCK);
@@ -1298,12 +1293,14 @@ int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
                         }
                         tot = (hh == 0) ? part : tot + part;
                     }
-                    rowsT[(size_t)(a * F + f) * n_rows + blk] = tot;
+                    { float sc = (float)tot * inv_lsb_f;
+                      sc = sc < -4.398046511104e12f ? -4.398046511104e12f : (sc > 4.398046511104e12f ? 4.398046511104e12f : sc);
+                      qsum[a * F + f] += (int64_t)rintf(sc); }
                 }
         }
     }
     run->t += (uint64_t)n_steps;
-    free(phi); free(rowsT); free(terms); free(phis); free(acts); free(flags);
+    free(phi); free(qsum); free(terms); free(phis); free(acts); free(flags);
     if (st) *st = acc;
     return 0;
 }

@@ -663,15 +663,37 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
 // ---------------------------------------------------------------------------------------
 // Shared weights, dense basis: ONE launch per batch-step (k_shared_step).
 // A dependent kernel costs ~4 us on this machine whatever it does, so the delta reduction no longer has a kernel of its
-// own: every block of batch-step t first folds the partial rows of batch-step t-1 into the weights itself,
-//     W_t = W_{t-1} + sum over rows (reduce_rows: one fixed order, identical in every block => identical W_t everywhere)
-// keeps W_t in LDS for both phases, and block 0 writes it out for the next launch (two W buffers and two row buffers in
+// own: every block of batch-step t first folds the delta of batch-step t-1 into the weights itself (W_t = W_{t-1} + delta:
+// identical in every block), keeps W_t in LDS for both phases, and block 0 writes it out for the next launch (two W buffers in
 // ping-pong: a launch never writes what a block of the same launch may still read).  The kernel boundary is the only
-// synchronisation.  rows_in / n_rows_in = 0: nothing to fold (first step of a train call; multi-rank mode, where
+// synchronisation.  fold = 0: nothing to fold (first step of a train call; multi-rank mode, where
 // finalize -> exchange -> apply run between the launches instead).
 //   mode bit 0: phase C of the previous batch-step (policy.sample with W_t, episode restarts)
 //   mode bit 1: phase A of this batch-step (transition, TD error against W_t, the learner's term into this block's row)
 // ---------------------------------------------------------------------------------------
+// The mini-batch delta travels between launches as 64-BIT FIXED-POINT TABLES (as for shared tile coding): every block rounds
+// its 108-entry partial sum to integers of lsb = 2^(floor(log2 lr) - 28) and adds them with one device atomic each into one
+// of kTabRep copies of the table; the next launch's prologue adds the kTabRep copies (integers: exact, any order) and converts
+// back with one rounding.  Folding 256 float rows in every block instead read 110 KB per block from L2 (28 MB per batch-step,
+// 2.7 us of an 10.7 us step); the copies are 14 KB.  Three table sets rotate with the batch-step counter: step t accumulates
+// into set t mod 3, folds set (t-1) mod 3 and clears set (t+1) mod 3 -- a launch never clears what a block of the same launch
+// may still read or add to, and the kernel boundary is the only synchronisation.
+constexpr int kTabRep = 16;
+struct DeltaTab {
+    long long *out, *zero; const long long* in; float lsb, inv_lsb;
+    __device__ __forceinline__ DeltaTab(long long* tab, int n, float lr, uint64_t t) {
+        const size_t set = (size_t)kTabRep * n;
+        const unsigned r = (unsigned)(t % 3u);
+        out = tab + set * r; in = tab + set * ((r + 2u) % 3u); zero = tab + set * ((r + 1u) % 3u);
+        const uint32_t eb = (__float_as_uint(lr) >> 23) & 0xffu;
+        const int ex = (int)(eb < 30u ? 30u : eb) - 28;
+        lsb = __uint_as_float((uint32_t)ex << 23); inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
+    }
+    __device__ __forceinline__ unsigned long long quantise(float v) const {
+        const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
+        return (unsigned long long)(long long)rintf(sc);
+    }
+};
 // Row sums.  The rows are stored TRANSPOSED, rowsT[j][r] (output-major): the 64 lanes of a wave read 64 consecutive rows of
 // one output j as one coalesced 256-B line.  out_k = sum over r of rowsT[j_k][r], j_k = j0 + k*jstride: lane l adds rows
 // l, l+64, l+128, ... in ascending order (a missing row adds +0), then the 64 lane sums go through the DPP ladder -- one fixed
@@ -704,9 +726,9 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ rowsT, int
 
 template <class M, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,
-                                                        float* __restrict__ W_out, const float* __restrict__ rows_in, int n_rows_in,
-                                                        float* __restrict__ rows_out, uint8_t* __restrict__ flags,
-                                                        DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
+                                                        float* __restrict__ W_out, long long* __restrict__ tab, int fold,
+                                                        uint8_t* __restrict__ flags, DevStats* __restrict__ stats,
+                                                        const uint64_t* __restrict__ t_dev) {
     static_assert(M::kDense, "dense bases only");
     if (t_dev) t += *t_dev;
     if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
@@ -727,17 +749,19 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
     const uint32_t ep_ld = c.ep_step[il];
     const uint8_t flag_ld = do_c ? flags[il] : (uint8_t)0;
     const int a_ld = c.action[il];
-    // ---- W_t = W_{t-1} + the previous batch-step's delta, in LDS (every block, same order => same bits)
-    if (n_rows_in > 0) {
-        constexpr int NW = BLOCK / 64, K = (AF + NW - 1) / NW;          // wave w owns the outputs j = w, w + NW, ...
-        float tot[K];
-        reduce_rows<K>(rows_in, n_rows_in, AF, wave, NW, lane, tot);
-        if (lane == 0) {
+    // ---- W_t = W_{t-1} + the previous batch-step's delta, in LDS (every block: integer sums => same bits everywhere)
+    DeltaTab dt(tab, AF, c.alg.lr, t);
+    {
+        long long fsum = 0;
+        if (fold && threadIdx.x < AF) {
+            const long long* __restrict__ p = dt.in + threadIdx.x;
 #pragma unroll
-            for (int k = 0; k < K; ++k) { const int j = wave + k * NW; if (j < AF) sh_w[j] = W_in[j] + tot[k]; }
+            for (int r = 0; r < kTabRep; ++r) fsum += p[r * AF];                 // kTabRep independent loads, one round trip
         }
-    } else {
-        for (int j = threadIdx.x; j < AF; j += BLOCK) sh_w[j] = W_in[j];
+        if (threadIdx.x < AF) sh_w[threadIdx.x] = fold ? W_in[threadIdx.x] + (float)fsum * dt.lsb : W_in[threadIdx.x];
+        // the set the NEXT batch-step accumulates into (last read one launch ago) is cleared here, one copy per block
+        for (int r = blockIdx.x; r < kTabRep; r += gridDim.x)
+            if (threadIdx.x < AF) dt.zero[r * AF + threadIdx.x] = 0;
     }
     __syncthreads();
     if (W_out && blockIdx.x == 0)
@@ -831,7 +855,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
             float tot = part[0][threadIdx.x];
 #pragma unroll
             for (int h = 1; h < H; ++h) tot += part[h][threadIdx.x];
-            rows_out[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;        // transposed: rowsT[j][block]
+            atomicAdd(reinterpret_cast<unsigned long long*>(dt.out + (blockIdx.x % (unsigned)kTabRep) * AF + threadIdx.x), dt.quantise(tot));
         }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);

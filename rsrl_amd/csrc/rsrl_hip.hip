@@ -91,24 +91,30 @@ __global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int
     }
     dW[j] = acc;
 }
-// multi-rank mode: the same sum as a kernel of its own (one wave per output), feeding the exchange
-__global__ __launch_bounds__(kBlock) void k_rows_finalize(const float* __restrict__ rows, int n_rows, int n, float* __restrict__ dW) {
-    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
-    if (j >= n) return;
-    float tot[1];
-    reduce_rows<1>(rows, n_rows, n, j, 1, lane, tot);
-    if (lane == 0) dW[j] = tot[0];
+// multi-rank mode: the fold as a kernel of its own (the copies of batch-step t's fixed-point delta table -> one float per
+// output), feeding the exchange
+__device__ __forceinline__ float tab_total(const long long* __restrict__ tab, int n, int j, float lr, uint64_t t) {
+    DeltaTab dt(const_cast<long long*>(tab), n, lr, t);
+    long long s = 0;
+#pragma unroll
+    for (int r = 0; r < kTabRep; ++r) s += dt.out[r * n + j];
+    return (float)s * dt.lsb;
+}
+__global__ __launch_bounds__(kBlock) void k_tab_finalize(const long long* __restrict__ tab, int n, float lr, float* __restrict__ dW, uint64_t t,
+                                                         const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j < n) dW[j] = tab_total(tab, n, j, lr, t);
 }
 
-// dense peer path, two launches instead of four: the row sums go straight into every rank's receive slot ...
-__global__ __launch_bounds__(kBlock) void k_rows_finalize_push(const float* __restrict__ rows, int n_rows, int n, uint2* const* __restrict__ peers, int world,
-                                                               int rank, uint64_t t, const uint64_t* __restrict__ t_dev) {
+// dense peer path, two launches instead of four: the delta goes straight into every rank's receive slot ...
+__global__ __launch_bounds__(kBlock) void k_tab_finalize_push(const long long* __restrict__ tab, int n, float lr, uint2* const* __restrict__ peers, int world,
+                                                              int rank, uint64_t t, const uint64_t* __restrict__ t_dev) {
     if (t_dev) t += *t_dev;
     const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
     if (j >= n) return;
-    float tot[1];
-    reduce_rows<1>(rows, n_rows, n, j, 1, lane, tot);
-    const uint64_t g = (uint64_t)__float_as_uint(tot[0]) | ((uint64_t)(uint32_t)(t + 1) << 32);
+    const float tot = tab_total(tab, n, j, lr, t);
+    const uint64_t g = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(t + 1) << 32);
     const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
     if (lane < world) __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[lane] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -217,9 +223,11 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
     long long* dW_rep = nullptr; int n_rep = 1;  // shared tile coding: n_rep copies of the fixed-point (64-bit) delta table; nullptr: the float path
-    float* partials = nullptr;       // shared-W dense basis: one delta row per thread block, two buffers in ping-pong
+    float* partials = nullptr;       // shared-W generic kernels: one delta row per thread block
+    long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
+    uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
-    int sh_par = 0, sh_row = 0;      // which W buffer holds the current weights (0 = W); which row buffer was written last
+    int sh_par = 0;                  // which W buffer holds the current weights (0 = W)
     unsigned sh_rows = 0;            // rows per buffer = blocks of k_shared_step
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
     float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
@@ -522,6 +530,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW) (void)hipFree(c->dW);
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->partials) (void)hipFree(c->partials);
+    if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
     if (c->qs_head) (void)hipFree(c->qs_head);
@@ -666,7 +675,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
         if (cfg->basis == RSRL_FOURIER && !is_generic_fourier(*cfg)) {
             c->sh_rows = (unsigned)((N + kSharedBlock - 1) / kSharedBlock);
-            HIP_TRY(hipMalloc((void**)&c->partials, sizeof(float) * c->dw_elems * c->sh_rows * 2));
+            HIP_TRY(hipMalloc((void**)&c->sh_tab, sizeof(long long) * 3 * kTabRep * c->dw_elems));
+            HIP_TRY(hipMemset(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems));
             HIP_TRY(hipMalloc((void**)&c->W2, c->w_bytes));
         }
     }
@@ -1219,31 +1229,25 @@ static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
 // delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
 // train call is closed by a stand-alone phase C (enqueue_shared_c).
 // t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
-// Every block of k_shared_step folding all the rows itself is quadratic in the number of blocks (256 blocks x 110 KB at
-// 131 072 learners; 2 048 x 885 KB = 1.8 GB of L2 reads at 1 048 576): beyond 512 rows the sum gets its own launch again.
-static inline bool fold_in_step(const rsrl_hip_ctx* c) { return !c->multi && c->sh_rows <= 512; }
-// dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's rows to
+static inline bool fold_in_step(const rsrl_hip_ctx* c) { return !c->multi; }
+// dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's delta to
 // the weights first (single rank; in multi-rank mode finalize -> exchange -> apply run between the launches instead).
 static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, bool fold, uint64_t t,
                               const uint64_t* t_dev) {
-    const size_t rowsz = (size_t)c->sh_rows * c->dw_elems;
     const float* W_in = c->sh_par ? c->W2 : c->W;
     float* W_out = fold ? (c->sh_par ? c->W : c->W2) : nullptr;
-    const float* rows_in = fold ? c->partials + (size_t)c->sh_row * rowsz : nullptr;
-    float* rows_out = c->partials + (size_t)(c->sh_row ^ 1) * rowsz;
     bool ok = false;
     for_model(c, [&](auto tag) {
         using M = typename decltype(tag)::type;
         if constexpr (M::kDense) {
-            hipLaunchKernelGGL((k_shared_step<M, kSharedBlock>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, t, mode, W_in, W_out, rows_in,
-                               fold ? (int)c->sh_rows : 0, rows_out, c->flags, d_stats, t_dev);
+            hipLaunchKernelGGL((k_shared_step<M, kSharedBlock>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, t, mode, W_in, W_out, c->sh_tab,
+                               fold ? 1 : 0, c->flags, d_stats, t_dev);
             ok = true;
         }
     });
     if (!ok) return NO_MODEL(c);
     KCHECK();
     if (fold) c->sh_par ^= 1;
-    if (mode & 2) c->sh_row ^= 1;
     return RSRL_HIP_OK;
 }
 static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int do_c, uint64_t t,
@@ -1253,18 +1257,16 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     if (dense) {
         const int n = (int)c->dw_elems;
         if (fold_in_step(c)) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
-        // multi-rank (or too many rows to fold in every block): the step (nothing to fold: W was updated by the apply below),
-        // then rows -> dW -> exchange -> W += dW
+        // multi-rank: the step (nothing to fold: W was updated by the apply below), then delta table -> dW -> exchange -> W += dW
         TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
-        const float* rows = c->partials + (size_t)c->sh_row * c->sh_rows * c->dw_elems;
-        if (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->world_size <= 64) {      // fused: rows -> every rank's slot; slots -> W
-            hipLaunchKernelGGL(k_rows_finalize_push, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, rows, (int)c->sh_rows, n,
+        if (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->world_size <= 64) {      // fused: delta -> every rank's slot; slots -> W
+            hipLaunchKernelGGL(k_tab_finalize_push, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr,
                                c->d_peer_ptrs, c->world_size, c->rank, t, t_dev);
             hipLaunchKernelGGL(k_peer_reduce_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, n, c->peer_recv, c->world_size, t, t_dev, c->d_peer_err);
             KCHECK();
             return RSRL_HIP_OK;
         }
-        hipLaunchKernelGGL(k_rows_finalize, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, rows, (int)c->sh_rows, n, c->dW);
+        hipLaunchKernelGGL(k_tab_finalize, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr, c->dW, t, t_dev);
         KCHECK();
         TRY(exchange_dw(c, t, t_dev));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
@@ -1380,6 +1382,10 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     const bool graph_ok = (stream_k1 || shared) && c->own_stream && !stats_out && !getenv("RSRL_NO_GRAPH");
     bool t_dev_set = false;
     int64_t done = 0;
+    // the delta tables rotate with the batch-step counter: a counter that did not simply continue (reset, restored checkpoint)
+    // finds them in another phase -- start from clean tables then
+    if (shared && c->sh_tab && n_steps > 0 && c->t != c->sh_tab_t)
+        HIP_TRY(hipMemsetAsync(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems, c->stream));
     while (done < n_steps) {
         // (dense shared W: the W / row buffers alternate every batch-step, the graph is captured at the parity of an odd step count)
         if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? (done > 0 && (!fourier || (done & 1))) : c->q_valid)) {
@@ -1406,7 +1412,6 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         const int chunk = (int)((n_steps - done < spl) ? (n_steps - done) : spl);
         TRY(timing_begin(c));
         if (shared) {
-            if (done == 0) c->sh_row = 0;
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
             c->kernel_name = fourier ? "k_shared_step" : "k_shared_ca";
         } else if (is_pred(c->cfg.algo)) {
@@ -1466,7 +1471,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         c->t += (uint64_t)chunk;
         done += chunk;
     }
-    if (shared && n_steps > 0) TRY(enqueue_shared_c(c, k, g, c->t - 1));     // phase C of the last batch-step
+    if (shared && n_steps > 0) { TRY(enqueue_shared_c(c, k, g, c->t - 1)); c->sh_tab_t = c->t; }     // phase C of the last batch-step
     if (stats_out) {
         HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
