@@ -115,23 +115,20 @@ __global__ __launch_bounds__(kBlock) void k_tab_finalize(const long long* __rest
     if (j < n) dW[j] = tab_total(tab, n, j, lr, t);
 }
 
-// dense peer path, two launches instead of four: the delta goes straight into every rank's receive slot ...
-__global__ __launch_bounds__(kBlock) void k_tab_finalize_push(const long long* __restrict__ tab, int n, float lr, uint2* const* __restrict__ peers, int world,
-                                                              int rank, uint64_t t, const uint64_t* __restrict__ t_dev) {
-    if (t_dev) t += *t_dev;
-    const int j = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = (int)(threadIdx.x & 63);
-    if (j >= n) return;
-    const float tot = tab_total(tab, n, j, lr, t);
-    const uint64_t g = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(t + 1) << 32);
-    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
-    if (lane < world) __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[lane] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// ... and the sum over the ranks' slots is applied to W in the same launch (same order and bounded wait as k_peer_reduce)
-__global__ __launch_bounds__(256) void k_peer_reduce_apply(float* __restrict__ W, int n, const uint2* __restrict__ recv, int world, uint64_t t,
-                                                           const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
+// dense peer path, ONE launch instead of four: the delta of batch-step t goes from the fixed-point table straight into every
+// rank's receive slot, and the same thread then sums the ranks' slots (rank order, bounded wait as k_peer_reduce) into W.
+// Every rank pushes before it waits, so the ranks cannot wait for each other's pushes in a cycle.
+__global__ __launch_bounds__(256) void k_tab_exchange_apply(const long long* __restrict__ tab, int n, float lr, uint2* const* __restrict__ peers,
+                                                            const uint2* __restrict__ recv, float* __restrict__ W, int world, int rank, uint64_t t,
+                                                            const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
     if (t_dev) t += *t_dev;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
+    const float tot = tab_total(tab, n, j, lr, t);
+    const uint64_t mine = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(t + 1) << 32);
+    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
+    for (int r = 0; r < world; ++r)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const uint32_t want = (uint32_t)(t + 1);
     const uint64_t t_start = wall_clock64();
     const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -1267,10 +1264,9 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         if (fold_in_step(c)) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
         // multi-rank: the step (nothing to fold: W was updated by the apply below), then delta table -> dW -> exchange -> W += dW
         TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
-        if (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->world_size <= 64) {      // fused: delta -> every rank's slot; slots -> W
-            hipLaunchKernelGGL(k_tab_finalize_push, dim3((unsigned)((n * 64 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr,
-                               c->d_peer_ptrs, c->world_size, c->rank, t, t_dev);
-            hipLaunchKernelGGL(k_peer_reduce_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, n, c->peer_recv, c->world_size, t, t_dev, c->d_peer_err);
+        if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {                              // fused: delta -> every rank's slot; slots -> W
+            hipLaunchKernelGGL(k_tab_exchange_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sh_tab, n, k.alg.lr, c->d_peer_ptrs, c->peer_recv, c->W,
+                               c->world_size, c->rank, t, t_dev, c->d_peer_err);
             KCHECK();
             return RSRL_HIP_OK;
         }
