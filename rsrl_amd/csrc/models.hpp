@@ -666,8 +666,9 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
 // own: every block of batch-step t first folds the delta of batch-step t-1 into the weights itself (W_t = W_{t-1} + delta:
 // identical in every block), keeps W_t in LDS for both phases, and block 0 writes it out for the next launch (two W buffers in
 // ping-pong: a launch never writes what a block of the same launch may still read).  The kernel boundary is the only
-// synchronisation.  fold = 0: nothing to fold (first step of a train call; multi-rank mode, where
-// finalize -> exchange -> apply run between the launches instead).
+// synchronisation.  fold = 0: nothing to fold (first step of a train call; peer-exchange mode, where the exchange kernel between
+// the launches applies the sum itself); fold = 1: this rank's own table (single rank); fold = 2: the float delta dW_in that
+// finalize -> all-reduce left behind between the launches (RCCL mode).
 //   mode bit 0: phase C of the previous batch-step (policy.sample with W_t, episode restarts)
 //   mode bit 1: phase A of this batch-step (transition, TD error against W_t, the learner's term into this block's row)
 // ---------------------------------------------------------------------------------------
@@ -727,8 +728,8 @@ __device__ __forceinline__ void reduce_rows(const float* __restrict__ rowsT, int
 template <class M, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,
                                                         float* __restrict__ W_out, long long* __restrict__ tab, int fold,
-                                                        uint8_t* __restrict__ flags, DevStats* __restrict__ stats,
-                                                        const uint64_t* __restrict__ t_dev) {
+                                                        const float* __restrict__ dW_in, uint8_t* __restrict__ flags,
+                                                        DevStats* __restrict__ stats, const uint64_t* __restrict__ t_dev) {
     static_assert(M::kDense, "dense bases only");
     if (t_dev) t += *t_dev;
     if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
@@ -753,12 +754,16 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
     DeltaTab dt(tab, AF, c.alg.lr, t);
     {
         long long fsum = 0;
-        if (fold && threadIdx.x < AF) {
+        if (fold == 1 && threadIdx.x < AF) {
             const long long* __restrict__ p = dt.in + threadIdx.x;
 #pragma unroll
             for (int r = 0; r < kTabRep; ++r) fsum += p[r * AF];                 // kTabRep independent loads, one round trip
         }
-        if (threadIdx.x < AF) sh_w[threadIdx.x] = fold ? W_in[threadIdx.x] + (float)fsum * dt.lsb : W_in[threadIdx.x];
+        // fold = 1: this rank's own table (single rank); fold = 2: the delta as floats, already summed over the ranks by the exchange
+        if (threadIdx.x < AF) {
+            const float d = fold == 2 ? dW_in[threadIdx.x] : (float)fsum * dt.lsb;
+            sh_w[threadIdx.x] = fold ? W_in[threadIdx.x] + d : W_in[threadIdx.x];
+        }
         // the set the NEXT batch-step accumulates into (last read one launch ago) is cleared here, one copy per block
         for (int r = blockIdx.x; r < kTabRep; r += gridDim.x)
             if (threadIdx.x < AF) dt.zero[r * AF + threadIdx.x] = 0;

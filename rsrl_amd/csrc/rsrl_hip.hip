@@ -1234,10 +1234,12 @@ static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
 // delta finalize (+ apply when there is a single rank) -> [all-reduce over ranks -> apply]; the last step of a
 // train call is closed by a stand-alone phase C (enqueue_shared_c).
 // t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
-static inline bool fold_in_step(const rsrl_hip_ctx* c) { return !c->multi; }
+// what the step kernel's prologue folds into the weights: 1 = this rank's own delta table (single rank), 2 = the float delta the
+// all-reduce left in dW (RCCL), 0 = nothing (peer exchange: its kernel applies the sum itself)
+static inline int fold_in_step(const rsrl_hip_ctx* c) { return !c->multi ? 1 : (c->cfg.exchange == RSRL_EXCHANGE_PEER ? 0 : 2); }
 // dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's delta to
-// the weights first (single rank; in multi-rank mode finalize -> exchange -> apply run between the launches instead).
-static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, bool fold, uint64_t t,
+// the weights first.
+static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, int fold, uint64_t t,
                               const uint64_t* t_dev) {
     const float* W_in = c->sh_par ? c->W2 : c->W;
     float* W_out = fold ? (c->sh_par ? c->W : c->W2) : nullptr;
@@ -1246,7 +1248,7 @@ static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom&
         using M = typename decltype(tag)::type;
         if constexpr (M::kDense) {
             hipLaunchKernelGGL((k_shared_step<M, kSharedBlock>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, t, mode, W_in, W_out, c->sh_tab,
-                               fold ? 1 : 0, c->flags, d_stats, t_dev);
+                               fold, c->dW, c->flags, d_stats, t_dev);
             ok = true;
         }
     });
@@ -1261,9 +1263,11 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     const bool dense = c->cfg.basis == RSRL_FOURIER;
     if (dense) {
         const int n = (int)c->dw_elems;
-        if (fold_in_step(c)) return enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, do_c != 0, t, t_dev);
-        // multi-rank: the step (nothing to fold: W was updated by the apply below), then delta table -> dW -> exchange -> W += dW
-        TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, false, t, t_dev));
+        const int fold = do_c ? fold_in_step(c) : 0;
+        TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, fold, t, t_dev));
+        if (!c->multi) return RSRL_HIP_OK;
+        // multi-rank: the delta table of this batch-step -> exchange; the sum reaches the weights in the exchange kernel (peer) or
+        // in the next launch's prologue (RCCL: table -> dW -> all-reduce, folded as floats)
         if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {                              // fused: delta -> every rank's slot; slots -> W
             hipLaunchKernelGGL(k_tab_exchange_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sh_tab, n, k.alg.lr, c->d_peer_ptrs, c->peer_recv, c->W,
                                c->world_size, c->rank, t, t_dev, c->d_peer_err);
@@ -1273,8 +1277,6 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         hipLaunchKernelGGL(k_tab_finalize, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr, c->dW, t, t_dev);
         KCHECK();
         TRY(exchange_dw(c, t, t_dev));
-        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
-        KCHECK();
         return RSRL_HIP_OK;
     }
     if (!for_model(c, [&](auto tag) {
@@ -1312,8 +1314,10 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
 }
 static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
     if (c->cfg.basis == RSRL_FOURIER) {
-        // closing launch: fold the last batch-step's rows (single rank), phase C; the result goes back to the canonical buffer
-        TRY(enqueue_dense_step(c, k, g, nullptr, 1, fold_in_step(c), t_last + 1, nullptr));
+        // closing launch: fold the last batch-step's delta, phase C; the result goes back to the canonical buffer
+        const int fold = fold_in_step(c);
+        TRY(enqueue_dense_step(c, k, g, nullptr, 1, fold, t_last + 1, nullptr));
+        if (fold == 2) HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));      // consumed: dW is zero between operations
         if (c->sh_par) {
             HIP_TRY(hipMemcpyAsync(c->W, c->W2, c->w_bytes, hipMemcpyDeviceToDevice, c->stream));
             c->sh_par = 0;
