@@ -695,36 +695,6 @@ struct DeltaTab {
         return (unsigned long long)(long long)rintf(sc);
     }
 };
-// Row sums.  The rows are stored TRANSPOSED, rowsT[j][r] (output-major): the 64 lanes of a wave read 64 consecutive rows of
-// one output j as one coalesced 256-B line.  out_k = sum over r of rowsT[j_k][r], j_k = j0 + k*jstride: lane l adds rows
-// l, l+64, l+128, ... in ascending order (a missing row adds +0), then the 64 lane sums go through the DPP ladder -- one fixed
-// order, whoever computes it.  All K outputs' loads of four 64-row chunks are in flight together (one round trip per 256
-// rows instead of one per output).  Must be called by all 64 lanes of a wave with the same arguments.
-template <int K>
-__device__ __forceinline__ void reduce_rows(const float* __restrict__ rowsT, int n_rows, int n, int j0, int jstride, int lane, float (&out)[K]) {
-    float acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-    for (int r0 = 0; r0 < n_rows; r0 += 256) {
-        float v[4][K];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 64 * u + lane;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int j = j0 + k * jstride;
-                v[u][k] = (j < n && r < n_rows) ? rowsT[(int64_t)j * n_rows + r] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] += v[u][k];
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = wave_sum_all(acc[k]);
-}
-
 template <class M, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,
                                                         float* __restrict__ W_out, long long* __restrict__ tab, int fold,
