@@ -205,9 +205,10 @@ def test_c5_wave_family_bitwise(ra, orc, domain, algo, policy, bf16):
 @pytest.mark.parametrize("algo,policy,N", [(0, 1, 3000), (1, 1, 3000), (2, 2, 1111), (5, 1, 700), (0, 1, 131072)])
 def test_c4_shared_weights_bitwise(ra, orc, algo, policy, N):
     # BASELINE.json configs[3]'s rule (one shared approximator, synchronous mini-batch update) on the dense basis:
-    # the device's sums have one fixed order (512-learner blocks as four 128-long fma chains, rows by lane partials + the DPP
-    # ladder), restated in orc_run_train_shared_dev -- weights, states and actions bit for bit, through plain launches and
-    # graph replays, at a ragged size and at the full per-GPU share (131 072 learners, 256 blocks)
+    # the device's block sums have one fixed order (512-learner blocks as four 128-long fma chains) and travel between launches
+    # as 64-bit fixed-point tables (exact integer sums over the blocks), restated in orc_run_train_shared_dev -- weights, states
+    # and actions bit for bit, through plain launches and graph replays, at a ragged size and at the full per-GPU share
+    # (131 072 learners, 256 blocks)
     K1, K2 = (40, 70) if N < 100000 else (12, 38)
     kw = dict(gamma=0.9, lr=0.001 / N, alpha=0.7, epsilon=0.1, tau=0.8)
     ag = orc.make_agent(algo=algo, policy=policy, seed=2, max_episode_steps=60, shared_w=True, **kw)
@@ -223,6 +224,38 @@ def test_c4_shared_weights_bitwise(ra, orc, algo, policy, N):
         assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
         assert s1["episodes"] == o1["episodes"] and s1["sum_reward"] == o1["sum_reward"]
     assert np.abs(run.weights).max() > 0 and (N > 100000 or o1["episodes"] + o2["episodes"] > 0)
+
+
+def test_c4_delta_tables_follow_the_batch_step_counter(ra, orc, tmp_path):
+    # the three fixed-point delta-table sets rotate with the batch-step counter inside the kernel: one-step calls (every residue
+    # of the rotation, a closing launch after each) must reproduce the oracle, and a checkpoint restored into a fresh ctx (its
+    # counter jumps while its tables are in another phase) must continue exactly like the ctx that never stopped
+    N = 2000
+    kw = dict(gamma=0.9, lr=0.001 / N, epsilon=0.1)
+    ag = orc.make_agent(algo=0, policy=1, seed=5, max_episode_steps=40, shared_w=True, **kw)
+    ckw = dict(n_envs=N, algo=0, policy=1, seed=5, max_episode_steps=40, weight_mode=ra.W_SHARED, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    run.train_shared_dev(7)
+    path = tmp_path / "shared.rsrlw"
+    with ra.Context(**ckw) as a:
+        a.reset()
+        for _ in range(7):
+            a.train(1, want_stats=False)                       # 7 calls = 7 opening + 7 closing launches
+        assert np.array_equal(a.get_weights(), run.weights) and np.array_equal(a.states.T, run.state)
+        assert np.array_equal(a.actions, run.action)
+        a.train(5, want_stats=False)
+        a.save_weights(path)
+        a.reset()
+        a.train(45, want_stats=False)                          # graph replays included
+        ref = (a.get_weights().copy(), a.states.copy(), a.actions.copy())
+    with ra.Context(**ckw) as b:
+        b.load_weights(path)
+        assert b.step_count == 12
+        b.reset()
+        b.train(45, want_stats=False)
+        assert np.array_equal(b.get_weights(), ref[0]) and np.array_equal(b.states, ref[1]) and np.array_equal(b.actions, ref[2])
+    assert np.abs(ref[0]).max() > 0
 
 
 @pytest.mark.parametrize("algo,policy,N,T,B", [(1, 1, 3000, 8, 8), (0, 1, 2500, 4, 6), (2, 2, 1500, 8, 8), (1, 1, 65536, 8, 8)])
