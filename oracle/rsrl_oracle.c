@@ -127,12 +127,25 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-/* Draw block for (seed, global env id, batch-step t, block):
- *   key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block). */
+/* Draw for (seed, global env id, batch-step t, block):  key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block).
+ * The per-step draws (ORC_BLK_STEP with its alias ORC_BLK_RESET, ORC_BLK_INNER) use two words -- out[0] = explore?,
+ * out[1] = out[2] = the uniform pick -- and two consecutive batch-steps share one Philox block addressed by t >> 1 (even
+ * step: words 0, 1; odd step: words 2, 3), as on the device (rsrl_amd/csrc/device_core.hpp draw()).  Every other block index
+ * takes the whole 128-bit block at counter t. */
 void orc_draw(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t block, uint32_t out[4]) {
-    uint32_t ctr[4] = { (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)env_id, block };
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
-    orc_philox4x32_10(ctr, key, out);
+    if (block <= ORC_BLK_INNER) {
+        const uint64_t th = t >> 1;
+        uint32_t ctr[4] = { (uint32_t)th, (uint32_t)(th >> 32), (uint32_t)env_id, block == ORC_BLK_INNER ? ORC_BLK_INNER : ORC_BLK_STEP };
+        uint32_t p[4];
+        orc_philox4x32_10(ctr, key, p);
+        out[0] = (t & 1u) ? p[2] : p[0];
+        out[1] = out[2] = (t & 1u) ? p[3] : p[1];
+        out[3] = 0u;
+    } else {
+        uint32_t ctr[4] = { (uint32_t)t, (uint32_t)(t >> 32), (uint32_t)env_id, block };
+        orc_philox4x32_10(ctr, key, out);
+    }
 }
 uint32_t orc_mulhi(uint32_t x, uint32_t n) { return (uint32_t)(((uint64_t)x * n) >> 32); }
 uint32_t orc_eps_threshold(double eps) {

@@ -61,9 +61,24 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, u
     return U4{c0, c1, c2, c3};
 }
 enum : uint32_t { BLK_STEP = 0, BLK_RESET = 1, BLK_INNER = 2, BLK_INIT = 3, BLK_API = 4 };
-// key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block)
-__host__ __device__ __forceinline__ U4 draw(uint64_t seed, uint32_t env_id, uint64_t t, uint32_t block) {
+// key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block): the whole 128-bit block
+__host__ __device__ __forceinline__ U4 draw_block(uint64_t seed, uint32_t env_id, uint64_t t, uint32_t block) {
     return philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), env_id, block, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+// The per-step draws -- the behaviour policy's sample (BLK_STEP; the sample after an episode restart is that step's one and only
+// behaviour sample and uses the same draw: BLK_RESET is an alias) and the agent's own sample (BLK_INNER, sarsa.rs:61) -- need
+// TWO words: x = explore?, y = z = the uniform pick (a random action and a tie-break / softmax u exclude each other).  Two
+// consecutive batch-steps therefore share one Philox block, addressed by t >> 1: the even step takes words 0, 1, the odd step
+// words 2, 3 -- the fused loop generates one block per two steps.  Every other stream (initial sample BLK_INIT, API calls
+// BLK_API, stochastic-rounding blocks) takes a whole block per (t, block).
+__host__ __device__ __forceinline__ U4 half_block(const U4& p, bool odd) {
+    const uint32_t x = odd ? p.z : p.x, y = odd ? p.w : p.y;
+    return U4{x, y, y, 0u};
+}
+__host__ __device__ __forceinline__ U4 draw(uint64_t seed, uint32_t env_id, uint64_t t, uint32_t block) {
+    if (block <= BLK_INNER)
+        return half_block(draw_block(seed, env_id, t >> 1, block == BLK_INNER ? BLK_INNER : BLK_STEP), (t & 1u) != 0);
+    return draw_block(seed, env_id, t, block);
 }
 __host__ __device__ __forceinline__ uint32_t mulhi_u32(uint32_t x, uint32_t n) {
     return (uint32_t)(((uint64_t)x * n) >> 32);

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void k_train_gq(Common c, GqParams gp, uint
             v.axpy(sb3, phi_s);
             // ---- behaviour_policy.sample with the UPDATED fa_q (two columns may have moved: recompute)
             w.q(phi_n, q_n);
-            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_train_qsigma(Common c, QsParams qp, 
             typename M::Feat fn; float q_n[A];
             M::features(ns, g, fn);
             M::q_all(c, i, g, fn, q_n);
-            const U4 x = draw(c.seed, gid, t, (term || trunc) ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             a = policy_sample<A>(c.pol, q_n, x);
             facc_abs += fabsf(res); facc_r += r;
 #pragma unroll

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         typename Dom::Pre pre_s = Dom::pre(s);
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
 
-        auto one_step = [&](const Phi& phi_s, Phi& phi_n, uint64_t t) {
+        // x = this batch-step's behaviour-policy draw, xin = the agent's own (SARSA): halves of Philox blocks shared by two steps
+        auto one_step = [&](const Phi& phi_s, Phi& phi_n, const U4& x, const U4& xin) {
             // ---- Domain::transition
             float ns[D];
 #pragma unroll
@@ -407,8 +408,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             // ---- handle: delta with the PRE-update weights
             const float qsa = q_s.at(a);
             const float q_s_all[3] = {q_s.v0, q_s.v1, q_s.v2};
-            U4 xin = U4{0, 0, 0, 0};
-            if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
             float delta;
             if constexpr (ALGO == ALG_PAL) {
@@ -437,7 +436,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
 #else
             w.q(phi_n, q_n);
 #endif
-            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta);
             facc_r += r;
@@ -448,8 +446,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
                 pre_s = Dom::pre(ns);
                 { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
                 w.q(phi_n, q_n);
-                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(pol, q_n, xr);
+                na = policy_sample<A>(pol, q_n, x);          // the step's one behaviour sample: the same draw (BLK_RESET == BLK_STEP)
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
@@ -457,12 +454,24 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             a = na;
         };
 
+        constexpr bool INNER = ALGO == ALG_SARSA;                    // the only agent that draws for itself on this path
+        auto single = [&](uint64_t t) {                               // a step outside a pair: its half of the block
+            one_step(phi_a, phi_b, draw(c.seed, gid, t, BLK_STEP), INNER ? draw(c.seed, gid, t, BLK_INNER) : U4{0, 0, 0, 0});
+        };
         int k = 0;
-        for (; k + 1 < n_steps; k += 2) {
-            one_step(phi_a, phi_b, t0 + (uint64_t)k);
-            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+        if ((t0 & 1u) && n_steps > 0) {                               // pairs start at even batch-steps
+            single(t0);
+            const Phi tmp = phi_a; phi_a = phi_b; phi_b = tmp;        // phi(s) back into the first buffer (once per launch)
+            k = 1;
         }
-        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        for (; k + 1 < n_steps; k += 2) {
+            const uint64_t th = (t0 + (uint64_t)k) >> 1;              // ONE Philox block per stream for the two steps
+            const U4 p = draw_block(c.seed, gid, th, BLK_STEP);
+            const U4 pin = INNER ? draw_block(c.seed, gid, th, BLK_INNER) : U4{0, 0, 0, 0};
+            one_step(phi_a, phi_b, half_block(p, false), half_block(pin, false));
+            one_step(phi_b, phi_a, half_block(p, true), half_block(pin, true));
+        }
+        if (k < n_steps) single(t0 + (uint64_t)k);
         sum_abs = (double)facc_abs; sum_r = (double)facc_r;
         // lengths of the episodes that ended in this launch: every step taken, plus what the first episode had before the launch,
         // minus what the open one has now
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         Bas::project(ns, phi_n);
         U4 xin = U4{0, 0, 0, 0};
         if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
-        const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+        const U4 x = draw(c.seed, gid, t, BLK_STEP);
         // ---- Q(s,a): carried from the previous launch, or recomputed when the cache is stale
         constexpr int P = RSRL_DOT_SPLIT;
         float qs_arr[A];
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
     Bas::project(ns, phi_n);
     U4 xin = U4{0, 0, 0, 0};
     if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
-    const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+    const U4 x = draw(c.seed, gid, t, BLK_STEP);
 
     // transpose through LDS: linear 16-B writes, then each lane reads its own learner's A*F weights
 #pragma unroll

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_train_td(Common c, TdParams tp, uint
                 w.axpy(sb, phi_s);
             }
             w.q(phi_n, v_n);                              // V(s') with the UPDATED weights: the next step's prediction
-            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             int na = policy_sample<A>(pol, q0, x);
             facc_abs += fabsf(td); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }

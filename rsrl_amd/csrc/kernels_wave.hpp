@@ -352,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             });
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
-            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             int na = policy_sample<A>(c.pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
             const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
             M::update(c, i, g, fs, a, c.alg.lr * e);
             M::q_all(c, i, g, fn, q_n);                              // UPDATED weights
-            const U4 x = draw(c.seed, gid, t, term ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             int na = policy_sample<A>(c.pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         M::features(s, g, fs);
         if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s); else M::q_all(c, 0, g, fs, q_s);
         if (do_c) {                                                     // ---- phase C of batch-step t-1
-            const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
         } else {
             a = c.action[i];
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
         M::features(s, g, fs);
         M::q_all_lds(sh_w, fs, q_s);
         if (do_c) {                                                     // ---- phase C of batch-step t-1
-            const U4 x = draw(c.seed, gid, t - 1, done ? BLK_RESET : BLK_STEP);
+            const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
         } else {
             a = a_ld;
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_c(Common c, BasisGeom g, uint
     typename M::Feat ft; float q[A];
     M::features(s, g, ft);
     M::q_all(c, 0, g, ft, q);
-    const U4 x = draw(c.seed, gid, t, done ? BLK_RESET : BLK_STEP);
+    const U4 x = draw(c.seed, gid, t, BLK_STEP);
     c.action[i] = policy_sample<A>(c.pol, q, x);
 }
 
