@@ -1,0 +1,2 @@
+#!/bin/bash
+for i in 1 2 3; do timeout 300 python scripts/bench_configs.py "L1" 2>&1 | grep config | cut -c100-200; done
