@@ -104,7 +104,7 @@ def main():
         pk_fma = 157.0        # v_pk_fma_f32: Q(s',.) 54 + column update 54 + rank-1 dot 18 + projection (tables 16, sincos 10, products 5)
         pk_other = 23.0       # v_pk_mul_f32 21 (projection) + v_pk_add_f32 2
         pk = pk_fma + pk_other
-        cnd = 30.0            # v_cndmask_b32
+        cnd = 30.0            # v_cndmask_b32 (60 per unrolled pair of steps)
         mix = {"pk": pk, "pk_fma": pk_fma, "mad_u64": i64, "cndmask": cnd, "other": total - pk - i64 - cnd, "fp_fma": fma - pk_fma,
                "fp_other": (mul + add) - pk_other,
                "counters_per_env_step": {"SQ_INSTS_VALU": total, "FMA_F32": fma, "MUL_F32": mul, "ADD_F32": add, "INT64": i64, "INT32": i32, "CVT": cvt,
@@ -113,7 +113,7 @@ def main():
                "what": "VALU instructions per env-step of k_train_reg<MountainCar, Fourier 5, QLearning, EpsilonGreedy> (65 536 learners, 256 steps per launch): "
                        f"dynamic counts from the rocprofv3 class counters (profiles/{tag}_pmc_raw.json: SQ_INSTS_VALU_* / SQ_WAVES / steps); pk = packed fp32 "
                        "instructions (v_pk_fma_f32 = pk_fma, counted inside FMA_F32; v_pk_mul_f32 / v_pk_add_f32 inside MUL_F32 / ADD_F32) and cndmask are static "
-                       "counts of the executed path; mad_u64 = INT64 (Philox: 2 per round); fp_fma = FMA_F32 - pk_fma; fp_other = MUL_F32 + ADD_F32 - the packed ones"}
+                       "counts of the executed path; mad_u64 = INT64 (Philox: 2 per round, one block per TWO steps); fp_fma = FMA_F32 - pk_fma; fp_other = MUL_F32 + ADD_F32 - the packed ones"}
         json.dump({"k_train_reg": mix}, open(os.path.join(out, "isa_mix.json"), "w"), indent=1)
     # ---- the streaming kernel's PMC passes (k1_*) refresh its traffic record
     k1 = {}
