@@ -1216,8 +1216,9 @@ void FN(orc_run_reset_wave)(void* h) {
 /* Shared weights, dense basis, in the DEVICE's evaluation order (rsrl_amd/csrc/models.hpp: k_shared_step with 512-learner
  * blocks), for bitwise comparison with the HIP path (_f32d).  The rule is SURVEY A.7's (every learner's error against the
  * same W_t, the summed delta applied once, every learner then samples with W_{t+1}); what is mirrored is the ORDER of the sum:
- *   block (512 learners): for each (action b, feature f) four fma chains over 128 consecutive learners each,
- *       acc = fma([a_i == b], lr*e_i*phi_i[f], acc), the four parts added in order               -> one row per block
+ *   block (512 learners): for each (action b, feature f) eight chains over the 64 consecutive learners of a wave each
+ *       (the device runs them as rank-1 MFMA updates: same products, same roundings, same order),
+ *       acc = fma([a_i == b], lr*e_i*phi_i[f], acc), the eight parts added in order              -> one row per block
  *   blocks: every block's sums are rounded to 64-bit fixed point (lsb = 2^(floor(log2 lr) - 28), clamped to +-2^42), the
  *       integers are added over the blocks (exact, any order) and converted back with one rounding -> W_t = W_{t-1} + total
  * and the launch structure: phase C of batch-step t-1 (sample with W_t; finished episodes restart) and phase A of batch-step
@@ -1225,7 +1226,7 @@ void FN(orc_run_reset_wave)(void* h) {
  * One-step control agents on a Fourier basis, shared W; returns -1 otherwise. */
 int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
-    enum { BLOCK = 512, PER = 128, H = BLOCK / PER };
+    enum { BLOCK = 512, PER = 64, H = BLOCK / PER };
     int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), AF, d, f, j, a, hh, n_rows;
     int64_t N = run->n_envs, i, k, blk;
     R *phi, *W, *terms, *phis; uint8_t* flags; int* acts; int64_t* qsum;

@@ -799,31 +799,51 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
         for (int f = 0; f < F; ++f) fs.phi[f] = 0.0f;
     }
     if (do_a) {
-        // block-level sum of the learners' terms through LDS, fixed order (reproducible): tile_t[f][i] = lr*e_i*phi_i[f]
-        // (feature-major rows, padded: conflict-free both ways), ind[b][i] = [a_i == b]; thread (h, b, f) sums the 128
-        // learners of part h in ascending order as ONE fma chain acc = ind*v + acc (ind in {0, 1}: exactly "acc += v" or
-        // "acc += 0"), 4 learners per 16-B LDS read; the H parts are then added in order.
-        constexpr int PER = 128, H = BLOCK / PER, LP = BLOCK + 4;
-        static_assert(BLOCK % PER == 0 && H * AF <= BLOCK, "dense shared-W reduction needs A*F*(BLOCK/128) <= BLOCK");
-        __shared__ __attribute__((aligned(16))) float tile_t[F][LP];
-        __shared__ __attribute__((aligned(16))) float ind[A][BLOCK];
+        // block-level sum of the learners' terms, fixed order (reproducible).  Per wave: out[b][f] = sum over its 64 learners k
+        // (ascending) of [a_k == b] * lr*e_k*phi_k[f] is a chain of 64 rank-1 updates -- exactly what v_mfma_f32_4x4x1_16b_f32
+        // does: 16 independent 4x4 blocks, K = 1, D[blk][i][j] += A[blk][i] * B[blk][j].  With i = action, 4*blk + j = feature
+        // (= the lane) the A operand of learner k is the indicator [a_k == lane % 4] (a bit of a ballot mask: v_bfe + v_cvt) and
+        // the B operand is learner k's 36 terms ACROSS lanes -- the transpose of what the lanes hold, read back from the wave's own
+        // LDS tile (row = learner, padded to 37 words: conflict-free both ways).  K = 1 means one product and one rounding per
+        // accumulation, in program order: the fp32 chain acc = fma(ind, v, acc) over ascending learners, bit for bit (the probe
+        // scripts/ubench/mfma_4x4x1.hip checks layout and bits; the oracle restates the chain).  The 8 per-wave results are then
+        // added in wave order.  Against the LDS-only reduction (every (action, feature) a 128-long fma chain over float4 reads
+        // of the tile and of an indicator row: 442 KB of LDS reads per block) this reads each term once: 8.7 -> 8.3 us per
+        // batch-step; the chain of 64 dependent MFMAs is what it costs now (~0.6 us, measured with pieces compiled out).
+        constexpr int NWV = BLOCK / 64, H = NWV, TP = F + 1;
+        static_assert(F <= 64 && A <= 4, "dense shared-W reduction: features across the 64 lanes, actions across the 4 rows of a block");
+        __shared__ float tile[NWV][64][TP];
         __shared__ float part[H][AF];
+        {
+            float (*row)[TP] = tile[wave];
 #pragma unroll
-        for (int f = 0; f < F; ++f) tile_t[f][threadIdx.x] = scale * fs.phi[f];
+            for (int f = 0; f < F; ++f) row[lane][f] = scale * fs.phi[f];
+            const bool member = i < N;
+            unsigned long long m = 0;
 #pragma unroll
-        for (int b = 0; b < A; ++b) ind[b][threadIdx.x] = (a == b) ? 1.0f : 0.0f;
-        __syncthreads();
-        if (threadIdx.x < H * AF) {
-            const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
-            const float4* __restrict__ vrow = reinterpret_cast<const float4*>(&tile_t[f][h * PER]);
-            const float4* __restrict__ drow = reinterpret_cast<const float4*>(&ind[b][h * PER]);
-            float acc = 0.0f;
-#pragma unroll 8
-            for (int q = 0; q < PER / 4; ++q) {
-                const float4 v = vrow[q], d = drow[q];
-                acc = fmaf(d.x, v.x, acc); acc = fmaf(d.y, v.y, acc); acc = fmaf(d.z, v.z, acc); acc = fmaf(d.w, v.w, acc);
+            for (int b = 0; b < A; ++b) {
+                const unsigned long long mb = __ballot(member && a == b);
+                m = ((lane & 3) == b) ? mb : m;
             }
-            part[h][j] = acc;
+            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+            const int fl = lane < F ? lane : F - 1;                     // lanes past the features belong to unused blocks
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+            // all 64 LDS reads are issued before the chain starts (left to itself the compiler reads two terms, waits, and
+            // issues two MFMAs: 32 exposed LDS round trips)
+            float bv[64];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) bv[k] = row[k][fl];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                const float av = (float)(((k < 32 ? mlo : mhi) >> (k & 31)) & 1u);
+                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv[k], acc, 0, 0, 0);
+            }
+            if (lane < F) {
+#pragma unroll
+                for (int b = 0; b < A; ++b) part[wave][b * F + lane] = acc[b];
+            }
         }
         __syncthreads();
         if (threadIdx.x < AF) {
