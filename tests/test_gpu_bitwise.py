@@ -205,7 +205,8 @@ def test_c5_wave_family_bitwise(ra, orc, domain, algo, policy, bf16):
 @pytest.mark.parametrize("algo,policy,N", [(0, 1, 3000), (1, 1, 3000), (2, 2, 1111), (5, 1, 700), (0, 1, 131072)])
 def test_c4_shared_weights_bitwise(ra, orc, algo, policy, N):
     # BASELINE.json configs[3]'s rule (one shared approximator, synchronous mini-batch update) on the dense basis:
-    # the device's block sums have one fixed order (512-learner blocks as four 128-long fma chains) and travel between launches
+    # the device's block sums have one fixed order (512-learner blocks as eight 64-long chains, one per wave, run as rank-1 MFMA
+    # updates: the fp32 fma chain bit for bit) and travel between launches
     # as 64-bit fixed-point tables (exact integer sums over the blocks), restated in orc_run_train_shared_dev -- weights, states
     # and actions bit for bit, through plain launches and graph replays, at a ragged size and at the full per-GPU share
     # (131 072 learners, 256 blocks)
