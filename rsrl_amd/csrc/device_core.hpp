@@ -173,6 +173,16 @@ __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     quadrant_select(((int)n) & 3, s, c, sn, cs);
 }
 __device__ __forceinline__ float cos_cw(float x) { float s, c; sincos_cw(x, s, c); return c; }
+// ---- wave-uniform evaluation (one learner per wavefront: every lane holds the same scalars).  Independent evaluations of one
+// function are spread over lanes 0, 1, 2 and read back with v_readlane: one instruction stream instead of three.  Lane k runs
+// exactly the instructions every lane would have run on argument k, so the bits are unchanged.  All 64 lanes must be active.
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+__device__ __forceinline__ float lane_pick3(int lane, float x0, float x1, float x2) {
+    const float t = (lane == 2) ? x2 : x0;
+    return (lane == 1) ? x1 : t;
+}
 // exp(x) for the softmax policy: n = rint(x log2 e), two-term Cody-Waite reduction by ln 2, degree-5 polynomial on top of
 // 1 + r, scaled by 2^n (v_ldexp_f32).  Below -87 the result is 0 (no denormals), above 88.5 +inf.  Written out (instead
 // of expf -> v_exp_f32, whose bits are unspecified) so that the test oracle can restate it and compare the softmax paths
@@ -329,6 +339,42 @@ template <> struct Domain<2> {
         r = term ? 0.0f : -1.0f;                                       // REWARD_TERMINAL / REWARD_STEP (:31-32)
         return term;
     }
+    // the same transition for a WAVE-UNIFORM state (wave family): the three trigonometric evaluations of a gradient -- and the two
+    // of the terminal test -- run side by side in lanes 0..2 (one sincos instead of three per gradient: 14 -> 5 per step)
+    __device__ static __forceinline__ bool step_uniform(float (&s)[D], int a, float& r, int lane) {
+        constexpr float PI_ = (float)kPi;
+        const float torque = (float)(a - 1);
+        auto grad = [torque, lane](const float (&y)[4], float (&out)[4]) {
+            constexpr float M1 = 1.0f, M2 = 1.0f, L1 = 1.0f, LC1 = 0.5f, LC2 = 0.5f, I1 = 1.0f, I2 = 1.0f, G = 9.8f;
+            constexpr float PI_OVER_2 = (float)(kPi / 2.0);
+            const float theta1 = y[0], theta2 = y[1], dtheta1 = y[2], dtheta2 = y[3];
+            float sn, cs;
+            sincos_cw(lane_pick3(lane, theta2, theta1 + theta2 - PI_OVER_2, theta1 - PI_OVER_2), sn, cs);
+            const float sin_t2 = lane_bcast(sn, 0), cos_t2 = lane_bcast(cs, 0), cos_12 = lane_bcast(cs, 1), cos_1 = lane_bcast(cs, 2);
+            const float d1 = M1 * LC1 * LC1 + M2 * (L1 * L1 + LC2 * LC2 + 2.0f * L1 * LC2 * cos_t2) + I1 + I2;
+            const float d2 = M2 * (LC2 * LC2 + L1 * LC2 * cos_t2) + I2;
+            const float phi2 = M2 * LC2 * G * cos_12;
+            const float phi1 = -1.0f * L1 * LC2 * dtheta2 * dtheta2 * sin_t2
+                             - 2.0f * M2 * L1 * LC2 * dtheta2 * dtheta1 * sin_t2
+                             + (M1 * LC1 + M2 * L1) * G * cos_1
+                             + phi2;
+            const float dd1 = (torque + d2 / d1 * phi1 - M2 * L1 * LC2 * dtheta1 * dtheta1 * sin_t2 - phi2)
+                            / (M2 * LC2 * LC2 + I2 - d2 * d2 / d1);
+            out[0] = dtheta1; out[1] = dtheta2; out[2] = dd1;
+            out[3] = -(d2 * dd1 + phi1) / d1;
+        };
+        float ns[4] = {s[0], s[1], s[2], s[3]};
+        rk4(grad, ns, 0.2f);
+        s[0] = wrapf(-PI_, ns[0], PI_);
+        s[1] = wrapf(-PI_, ns[1], PI_);
+        s[2] = clipf(-4.0f * PI_, ns[2], 4.0f * PI_);
+        s[3] = clipf(-9.0f * PI_, ns[3], 9.0f * PI_);
+        float sn, cs;
+        sincos_cw(lane_pick3(lane, s[0], s[0] + s[1], s[0]), sn, cs);
+        const bool term = lane_bcast(cs, 0) + lane_bcast(cs, 1) < -1.0f;
+        r = term ? 0.0f : -1.0f;
+        return term;
+    }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -413,11 +459,25 @@ __device__ __forceinline__ int greedy_sample(const float (&q)[A], uint32_t x_tie
 template <int A>
 __device__ __forceinline__ int clamp_action(int a) { return a < 0 ? 0 : (a > A - 1 ? A - 1 : a); }
 // softmax_stable + softmax                                                   softmax.rs:15-37
+// ulane >= 0: q is wave-uniform and all 64 lanes are active -- element i is evaluated by lane i only (one exponential and one
+// division instead of A of each) and broadcast
 template <int A>
-__device__ __forceinline__ void softmax_probs(const float (&q)[A], float tau, float (&p)[A]) {
+__device__ __forceinline__ void softmax_probs(const float (&q)[A], float tau, float (&p)[A], int ulane = -1) {
     float m = q[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) m = (q[i] > m) ? q[i] : m;
+    if (ulane >= 0) {
+        static_assert(A <= 3, "lane_pick3");
+        const float ql = lane_pick3(ulane, q[0], q[A > 1 ? 1 : 0], q[A > 2 ? 2 : 0]);
+        const float el = exp_dev((ql - m) / tau);
+        float z = 0.0f;
+#pragma unroll
+        for (int i = 0; i < A; ++i) { p[i] = lane_bcast(el, i); z += p[i]; }
+        const float dl = fminf(el / z, FLT_MAX);
+#pragma unroll
+        for (int i = 0; i < A; ++i) p[i] = lane_bcast(dl, i);
+        return;
+    }
     float z = 0.0f;
 #pragma unroll
     for (int i = 0; i < A; ++i) { p[i] = exp_dev((q[i] - m) / tau); z += p[i]; }
@@ -446,7 +506,7 @@ struct PolicyParams { int kind; uint32_t eps_thr; float eps; float tau; };
 //   Random::sample         random.rs:43-45         (Uniform(0, A))
 //   Softmax::sample        softmax.rs:131-139
 template <int A>
-__device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float (&q)[A], const U4& x) {
+__device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float (&q)[A], const U4& x, int ulane = -1) {
     switch (pp.kind) {
     case POL_GREEDY: return greedy_sample<A>(q, x.z);
     case POL_EGREEDY: {
@@ -454,7 +514,7 @@ __device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float
         const bool explore = (x.x >> 8) < pp.eps_thr;
         return explore ? u : g;
     }
-    case POL_SOFTMAX: { float p[A]; softmax_probs<A>(q, pp.tau, p); return sample_probs<A>(p, x.z); }
+    case POL_SOFTMAX: { float p[A]; softmax_probs<A>(q, pp.tau, p, ulane); return sample_probs<A>(p, x.z); }
     default: return (int)mulhi_u32(x.y, (uint32_t)A);
     }
 }
@@ -467,8 +527,8 @@ __device__ __forceinline__ int policy_mode(const PolicyParams& pp, const float (
 // Function<(S,)> of the policy: action probabilities
 //   greedy.rs:30-44, epsilon_greedy.rs:38-45, softmax.rs:74-82, random.rs:22-26
 template <int A>
-__device__ __forceinline__ void policy_probs(const PolicyParams& pp, const float (&q)[A], float (&p)[A]) {
-    if (pp.kind == POL_SOFTMAX) { softmax_probs<A>(q, pp.tau, p); return; }
+__device__ __forceinline__ void policy_probs(const PolicyParams& pp, const float (&q)[A], float (&p)[A], int ulane = -1) {
+    if (pp.kind == POL_SOFTMAX) { softmax_probs<A>(q, pp.tau, p, ulane); return; }
     if (pp.kind == POL_RANDOM) {
 #pragma unroll
         for (int i = 0; i < A; ++i) p[i] = 1.0f / (float)A;
@@ -492,19 +552,19 @@ struct AlgoParams { int kind; float gamma, lr, alpha; };
 // returns delta; `e` is the error sent to the approximator (alpha*delta for ExpectedSARSA, :64)
 template <int A>
 __device__ __forceinline__ float td_error(const AlgoParams& ap, const PolicyParams& pp, float qsa, const float (&qn)[A],
-                                          float r, bool term, const U4& x_inner, float& e) {
+                                          float r, bool term, const U4& x_inner, float& e, int ulane = -1) {
     // the bootstrap value is computed whether or not the transition is terminal and SELECTED afterwards (no state is
     // consumed by it: the draws are counter-based), so that the step is one basic block
     float boot;
     if (ap.kind == ALG_QLEARNING) {
         find_max<A>(qn, boot);
     } else if (ap.kind == ALG_SARSA) {
-        const int na = policy_sample<A>(pp, qn, x_inner);             // agent's own draw (sarsa.rs:61)
+        const int na = policy_sample<A>(pp, qn, x_inner, ulane);      // agent's own draw (sarsa.rs:61)
         boot = qn[0];
 #pragma unroll
         for (int i = 1; i < A; ++i) boot = (na == i) ? qn[i] : boot;
     } else {
-        float p[A]; policy_probs<A>(pp, qn, p);
+        float p[A]; policy_probs<A>(pp, qn, p, ulane);
         boot = 0.0f;
 #pragma unroll
         for (int i = 0; i < A; ++i) boot = boot + qn[i] * p[i];       // fold(0.0, acc + q*p)
@@ -541,12 +601,12 @@ __device__ __forceinline__ float td_error_pal(const AlgoParams& ap, const float 
 // one entry point for all one-step agents: Q(s,.) in full, the action taken, Q(s',.) -> (delta, error sent on)
 template <int A>
 __device__ __forceinline__ float td_dispatch(const AlgoParams& ap, const PolicyParams& pp, const float (&qs)[A], int a,
-                                             const float (&qn)[A], float r, bool term, const U4& x_inner, float& e) {
+                                             const float (&qn)[A], float r, bool term, const U4& x_inner, float& e, int ulane = -1) {
     if (ap.kind == ALG_PAL) return td_error_pal<A>(ap, qs, qn, a, r, term, e);
     float qsa = qs[0];
 #pragma unroll
     for (int i = 1; i < A; ++i) qsa = (a == i) ? qs[i] : qsa;
-    return td_error<A>(ap, pp, qsa, qn, r, term, x_inner, e);
+    return td_error<A>(ap, pp, qsa, qn, r, term, x_inner, e, ulane);
 }
 
 // ---------------------------------------------------------------------------------------

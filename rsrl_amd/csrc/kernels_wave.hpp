@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
             float r;
-            const bool term = Dom::step(ns, a, r);
+            bool term;
+            if constexpr (DOMAIN == 2) term = Dom::step_uniform(ns, a, r, lane);      // wave-uniform state: trigonometry across lanes
+            else term = Dom::step(ns, a, r);
             ep += 1;
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e, lane);
             const float scale = c.alg.lr * e;
             U4 rnd = U4{0, 0, 0, 0};
             if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
             const U4 x = draw(c.seed, gid, t, BLK_STEP);
-            int na = policy_sample<A>(c.pol, q_n, x);
+            int na = policy_sample<A>(c.pol, q_n, x, lane);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
             if (trunc) {
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
                 Dom::reset(ns);
                 WF::stream_project_q(ns, lane, Pn, w, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr);
+                na = policy_sample<A>(c.pol, q_n, xr, lane);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
