@@ -532,13 +532,12 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
 // mini-batch delta.  phi(s) and Q(s,.) are computed once and serve both phases.  do_c = 0 on the first step of a
 // train call (the previous call already ran its phase C).  The env state becomes s'; flags[i] bit0 = terminal,
 // bit1 = truncated, consumed by the next phase C.
-//   dense basis : block-level reduction through LDS in a fixed order -> one row of `partials` per block (no atomics
-//                 => bitwise reproducible); k_dw_finalize sums the rows in block order.
 //   tile coding : per-tiling slice of the delta table privatised in LDS, one device atomic per touched entry into one of
 //                 n_rep copies of the table (k_apply_rep sums them).
+//   (the register-resident dense bases have a kernel of their own, k_shared_step below, and are not launched through this one)
 template <class M, int BLOCK = kBlock>
 __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW_base,
-                                                      float* __restrict__ partials, uint8_t* __restrict__ flags,
+                                                      uint8_t* __restrict__ flags,
                                                       DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride,
                                                       const uint64_t* __restrict__ t_dev) {
     if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
@@ -625,37 +624,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         } else {
             M::accumulate(dW, g, fs, a, scale, i < N);
         }
-    }
-    if constexpr (M::kDense) {
-        // block-level sum of the learners' terms through LDS, fixed order (reproducible):
-        //   tile_t[f][i] = lr*e_i*phi_i[f] (feature-major rows, padded: conflict-free both ways), ind[b][i] = [a_i == b];
-        //   thread (h, b, f) sums the learners of half h in ascending order as ONE fma chain acc = ind*v + acc (ind in
-        //   {0, 1}: exactly "acc += v" or "acc += 0"), reading 4 learners per 16-B LDS access.  The first version walked
-        //   tile[i][f] one learner per iteration with a compare/select: latency-bound, 5.9 of the kernel's 11.9 us.
-        constexpr int F = M::F, AF = A * F, H = 2, PER = kBlock / H, LP = kBlock + 4;
-        static_assert(H * AF <= kBlock && PER % 4 == 0, "dense shared-W reduction needs A*F*2 <= block size");
-        __shared__ __attribute__((aligned(16))) float tile_t[F][LP];
-        __shared__ __attribute__((aligned(16))) float ind[A][kBlock];
-        __shared__ float part[H][AF];
-#pragma unroll
-        for (int f = 0; f < F; ++f) tile_t[f][threadIdx.x] = scale * fs.phi[f];
-#pragma unroll
-        for (int b = 0; b < A; ++b) ind[b][threadIdx.x] = (a == b) ? 1.0f : 0.0f;
-        __syncthreads();
-        if (threadIdx.x < H * AF) {
-            const int h = threadIdx.x / AF, j = threadIdx.x % AF, b = j / F, f = j % F;
-            const float4* __restrict__ vrow = reinterpret_cast<const float4*>(&tile_t[f][h * PER]);
-            const float4* __restrict__ drow = reinterpret_cast<const float4*>(&ind[b][h * PER]);
-            float acc = 0.0f;
-#pragma unroll 8
-            for (int q = 0; q < PER / 4; ++q) {
-                const float4 v = vrow[q], d = drow[q];
-                acc = fmaf(d.x, v.x, acc); acc = fmaf(d.y, v.y, acc); acc = fmaf(d.z, v.z, acc); acc = fmaf(d.w, v.w, acc);
-            }
-            part[h][j] = acc;
-        }
-        __syncthreads();
-        if (threadIdx.x < AF) partials[(int64_t)blockIdx.x * AF + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x];
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }

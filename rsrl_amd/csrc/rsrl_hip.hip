@@ -228,7 +228,6 @@ struct rsrl_hip_ctx {
     float* W = nullptr; float* dW = nullptr;
     int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
     long long* dW_rep = nullptr; int n_rep = 1;  // shared tile coding: n_rep copies of the fixed-point (64-bit) delta table; nullptr: the float path
-    float* partials = nullptr;       // shared-W generic kernels: one delta row per thread block
     long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
@@ -534,7 +533,6 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->W) (void)hipFree(c->W);
     if (c->dW) (void)hipFree(c->dW);
     if (c->dW_rep) (void)hipFree(c->dW_rep);
-    if (c->partials) (void)hipFree(c->partials);
     if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
@@ -1290,11 +1288,11 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
                 if (slice > 0) {
                     hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, t, do_c, dwp,
-                                       c->partials, c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems, t_dev);
+                                       c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems, t_dev);
                     return;
                 }
             }
-            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, t, do_c, dwp, c->partials, c->flags, d_stats, slice, nrep,
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, slice, nrep,
                                (int64_t)c->dw_elems, t_dev);
         })) return NO_MODEL(c);
     KCHECK();
