@@ -16,7 +16,7 @@ Timed region: a K-step call is short (K = 20 is ~20 us of arithmetic), so the ca
 between ONE pair of barrier + synchronize (R is chosen so that the region lasts >= ~0.3 s and is reported in
 config.repeats); ms_per_step = region / (K * R), value = all ranks' env-steps / max-over-ranks region time.
 rsrl_hip_train is asynchronous and coalesces calls that arrive while the stream is busy (same results bit for bit,
-include/rsrl_hip.h): the R x K batch-steps run as launches of up to 256 steps -- config.steps_per_launch and
+include/rsrl_hip.h): the R x K batch-steps run as launches of up to 1024 steps -- config.steps_per_launch and
 roofline.launches report what was actually launched; RSRL_NO_COALESCE=1 gives one launch per call.
 """
 import argparse
@@ -66,9 +66,14 @@ def pmc_traffic(kernel, envs, steps_per_launch):
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), or None when no pass was collected for this
     kernel / configuration.  bench.py cannot run rocprofv3 on itself."""
     rec = (_profiles_json("pmc_traffic.json") or {}).get(kernel)
-    for r in (rec if isinstance(rec, list) else [rec] if rec else []):
-        if r.get("envs") == envs and abs(r.get("steps_per_launch", -1) - steps_per_launch) < 1e-9:
+    recs = [r for r in (rec if isinstance(rec, list) else [rec] if rec else []) if r.get("envs") == envs]
+    for r in recs:
+        if abs(r.get("steps_per_launch", -1) - steps_per_launch) < 1e-9:
             return r["traffic_bytes_per_launch"]
+    # the fused loop moves the same bytes per launch whatever its depth (W in + out, state: measured equal at 256 and at 20
+    # steps per launch): a launch of another depth takes the deepest measured one
+    if kernel == "k_train_reg" and recs and steps_per_launch > 1:
+        return max(recs, key=lambda r: r.get("steps_per_launch", 0))["traffic_bytes_per_launch"]
     return None
 
 
@@ -328,7 +333,8 @@ def main():
         n_gpus = min(world, ndev)
         fused = kname == "k_train_reg"
         traffic = pmc_traffic(kname, args.envs, round(steps_per_launch))
-        traffic_src = "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json)"
+        traffic_src = ("rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json; the fused loop's bytes "
+                       "per launch do not depend on its depth: passes at 256 and at 20 steps per launch)")
         if traffic is None and fused:
             traffic = float(FUSED_BYTES_PER_LEARNER_LAUNCH * args.envs)
             traffic_src = ("analytic: 920 B per learner per launch (W in + out, state, action, episode counter, carried Q), independent of the "

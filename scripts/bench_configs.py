@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rsrl_amd as ra  # noqa: E402
 
 CONFIGS = {
-    "C2 65536 MountainCar QL Fourier(5) eps-greedy per-env W (fused 256)": (dict(n_envs=65536, policy=1, epsilon=0.1, max_episode_steps=1000), 5120, 512, 608),
+    "C2 65536 MountainCar QL Fourier(5) eps-greedy per-env W (fused)": (dict(n_envs=65536, policy=1, epsilon=0.1, max_episode_steps=1000), 5120, 512, 608),
     "C2 same, 1 step per launch": (dict(n_envs=65536, policy=1, epsilon=0.1, max_episode_steps=1000, steps_per_launch=1), 3000, 300, 608),
     "L1 65536 MountainCar SARSA(lambda) Fourier(5) replacing traces (examples/sarsa_lambda.rs)": (dict(n_envs=65536, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.2, gamma=0.99, alpha=0.01,
                                                                                                      lam=0.7, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 2560, 256, 1040),

@@ -12,7 +12,7 @@ timeout 300 python scripts/scale_n.py > $O/scale_n.jsonl 2>&1; cat $O/scale_n.js
 for e in none rccl peer; do python scripts/prof_shared.py fourier $e; done > $O/shared_walls.txt 2>&1
 python scripts/prof_shared.py tile none >> $O/shared_walls.txt 2>&1; grep us/step $O/shared_walls.txt
 cd /tmp
-FU="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-shared-leg --no-streaming-leg --steps 2560 --warmup 256 --repeats 4"
+FU="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-shared-leg --no-streaming-leg --steps 2560 --warmup 256 --repeats 4 --steps-per-launch 256"   # the PMC passes are normalised per 256-step launch
 K20="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-shared-leg --no-streaming-leg --steps 20 --warmup 5 --repeats 200"
 K1="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-shared-leg --no-streaming-leg --steps-per-launch 1 --steps 400 --warmup 100 --repeats 2"
 i=0
