@@ -119,8 +119,8 @@ typedef struct {
     double   alpha;              /* ExpectedSARSA.alpha (expected_sarsa.rs:26,64)             */
     double   epsilon;            /* EpsilonGreedy.epsilon (pub field, epsilon_greedy.rs:19)  */
     double   tau;                /* Softmax.tau (softmax.rs:52); |tau| < 1e-7 is rejected (:63-66) */
-    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default: 1024 for the register-resident one-step agents,
-                                    256 for the other fused loops). 1 = one batch-step per launch:
+    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default: 1024 for the register-resident loops,
+                                    256 for the memory-resident and wave-family ones). 1 = one batch-step per launch:
                                     the ctx then keeps W learner-major and streams it once per step (the 608 B/env-step
                                     formulation), replayed as a hipGraph; results are bit-identical for every depth */
     int32_t  trace;              /* rsrl_trace (lambda agents)                                */

@@ -1374,15 +1374,19 @@ static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
 // batch-steps per launch of the fused loops.  Every launch of the register-family loop loads and stores every learner's weights
 // (60.7 MB at 65 536 MountainCar learners: ~11 us) and pays a launch-to-launch gap around its arithmetic (0.77 us per
 // batch-step): 1 024 steps per launch instead of 256 is worth +7 % (8.3e10 -> 8.9e10 env-steps/s, 2 048: 9.0e10) and a
-// launch still lasts under a millisecond.  The other fused loops keep 256 (their steps are 3-150x longer).
+// launch still lasts under a millisecond (2.4 ms for the trace agents).  The memory-resident and wave-family loops keep 256
+// (their steps are 15-150x longer).
 static bool register_family_fused(const rsrl_hip_ctx* c) {
     const auto& g = c->cfg;
     return g.weight_mode == RSRL_W_PER_ENV && g.basis == RSRL_FOURIER && !is_wave(g) && !is_generic_fourier(g) && !has_aux(g.algo) &&
            !is_pred(g.algo) && g.algo != RSRL_Q_SIGMA;
 }
 static inline int64_t fuse_depth(const rsrl_hip_ctx* c) {
-    if (c->cfg.steps_per_launch) return c->cfg.steps_per_launch;
-    return register_family_fused(c) ? 1024 : 256;
+    const auto& g = c->cfg;
+    if (g.steps_per_launch) return g.steps_per_launch;
+    // every register-resident loop (also the trace / GreedyGQ / TD ones, which load and store two matrices per launch)
+    const bool reg = g.weight_mode == RSRL_W_PER_ENV && g.basis == RSRL_FOURIER && !is_wave(g) && !is_generic_fourier(g) && g.algo != RSRL_Q_SIGMA;
+    return reg ? 1024 : 256;
 }
 
 static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
