@@ -35,6 +35,24 @@ __device__ __forceinline__ float wave_sum_all(float v) {
 // geometry of the basis that is not a template parameter
 struct BasisGeom { int F; int tiles_per_dim; };
 
+// 64-bit fixed point for every cross-learner sum of the shared-W modes: a term is scaled by the exact power of two 1/lsb,
+// lsb = 2^(floor(log2 |lr|) - 28), clamped to +-2^42 and rounded to an integer; integer sums are exact whatever order the
+// atomics retire in, and convert back with one rounding -- reproducible run to run and restated exactly by the oracle.
+struct FxScale {
+    float lsb, inv_lsb;
+    __host__ __device__ __forceinline__ explicit FxScale(float lr) {
+        uint32_t u = __builtin_bit_cast(uint32_t, lr);
+        const uint32_t eb = (u >> 23) & 0xffu;
+        const uint32_t ex = (eb < 30u ? 30u : eb) - 28u;
+        lsb = __builtin_bit_cast(float, ex << 23); inv_lsb = __builtin_bit_cast(float, (254u - ex) << 23);
+    }
+};
+__device__ __forceinline__ unsigned long long fx_quantise(float v, float inv_lsb) {
+    const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
+    return (unsigned long long)(long long)rintf(sc);
+}
+__device__ __forceinline__ void fx_add(long long* p, unsigned long long q) { atomicAdd(reinterpret_cast<unsigned long long*>(p), q); }
+
 template <int DOMAIN, int ORDER>
 struct FourierModel {
     using Dom = Domain<DOMAIN>;
@@ -86,11 +104,11 @@ struct FourierModel {
     }
     // dW has the shared layout [A][F]
     // must be called by ALL lanes of the wave (uniform control flow); lanes without work pass valid = false
-    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
-                                                      bool valid) {
+    __device__ static __forceinline__ void accumulate(long long* __restrict__ fx, const BasisGeom&, const Feat& ft, int a, float scale,
+                                                      bool valid, float inv_lsb) {
         if (valid) {
 #pragma unroll
-            for (int f = 0; f < F; ++f) atomicAdd(&dW[a * F + f], scale * ft.phi[f]);
+            for (int f = 0; f < F; ++f) fx_add(&fx[a * F + f], fx_quantise(scale * ft.phi[f], inv_lsb));
         }
     }
 };
@@ -163,30 +181,14 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) iout[(int64_t)t * Mn + i] = ft.idx[t];
     }
-    // dW has the shared layout [F][A].  Many learners sit in the same few tiles (all start at Domain::default()),
-    // so before the f32 atomics the wave folds its heavy hitters: up to kRounds times the first pending lane's
-    // key is broadcast, all lanes holding it are summed (DPP) and ONE atomic is issued for them.
-    // Must be called by ALL lanes of the wave (the DPP sum needs full exec); lanes without work pass valid = false.
-    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom&, const Feat& ft, int a, float scale,
-                                                      bool valid) {
-        constexpr int kRounds = 3;         // more rounds cost more than the atomics they save: a wave holds tens of distinct keys
+    // Device-wide form (rsrl_hip_handle on a shared table; the driver loop when a tiling's slice does not fit LDS): the learner's
+    // term as ONE integer, added to its T entries with device atomics -- the same integers block_accumulate adds through LDS.
+    __device__ static __forceinline__ void accumulate(long long* __restrict__ fx, const BasisGeom&, const Feat& ft, int a, float scale,
+                                                      bool valid, float inv_lsb) {
+        if (!valid) return;
+        const unsigned long long term = fx_quantise(scale, inv_lsb);     // the same integer goes to all T entries
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int key = valid ? ft.idx[t] * A + a : -1;
-            bool pending = valid;
-#pragma unroll
-            for (int r = 0; r < kRounds; ++r) {
-                const unsigned long long todo = __ballot(pending);
-                if (todo == 0ull) break;
-                const int leader = __ffsll((long long)todo) - 1;
-                const int lkey = __shfl(key, leader, 64);
-                const bool mine = pending && key == lkey;
-                const float tot = wave_sum_all(mine ? scale : 0.0f);
-                if (mine && (int)(threadIdx.x & 63) == leader) atomicAdd(&dW[lkey], tot);
-                pending = pending && !mine;
-            }
-            if (pending) atomicAdd(&dW[key], scale);
-        }
+        for (int t = 0; t < T; ++t) fx_add(&fx[ft.idx[t] * A + a], term);
     }
     // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A entries) is privatised
     // in LDS -- an LDS atomic from every learner of the block, a sweep of the slice, then ONE device atomic per touched entry
@@ -320,11 +322,11 @@ struct FourierGenericModel {
                                                           float* __restrict__ fout, int32_t* __restrict__) {
         for (int f = 0; f < g.F; ++f) fout[(int64_t)f * Mn + i] = phi_at(g, ft, f);
     }
-    // dW has the shared layout [A][F]; plain atomics (used by rsrl_hip_handle in shared mode only)
-    __device__ static __forceinline__ void accumulate(float* __restrict__ dW, const BasisGeom& g, const Feat& ft, int a, float scale,
-                                                      bool valid) {
+    // the shared layout [A][F] in fixed point (used by rsrl_hip_handle in shared mode only)
+    __device__ static __forceinline__ void accumulate(long long* __restrict__ fx, const BasisGeom& g, const Feat& ft, int a, float scale,
+                                                      bool valid, float inv_lsb) {
         if (valid)
-            for (int f = 0; f < g.F; ++f) atomicAdd(&dW[a * g.F + f], scale * phi_at(g, ft, f));
+            for (int f = 0; f < g.F; ++f) fx_add(&fx[a * g.F + f], fx_quantise(scale * phi_at(g, ft, f), inv_lsb));
     }
 };
 
@@ -391,13 +393,14 @@ __global__ __launch_bounds__(kBlock) void k_qop(Common c, BasisGeom g, int op, c
 
 // Handler<&Transition>::handle on caller-supplied transitions (teacher forcing / drop-in use).
 // per-env weights: learner m's column is updated in place.
-// shared weights : lr*e*phi(s) is accumulated into dW; k_apply_dw then applies it -- all M errors are
-//                  computed against the same W_t (synchronous mini-batch rule).
+// shared weights : lr*e*phi(s) is accumulated into the fixed-point delta table (exact, order-independent); k_fx_finalize turns
+//                  it into dW and k_apply_dw applies it -- all M errors are computed against the same W_t (synchronous
+//                  mini-batch rule).
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const float* __restrict__ from, const int32_t* __restrict__ act,
                                                    const float* __restrict__ rew, const float* __restrict__ to,
                                                    const uint8_t* __restrict__ termf, int64_t Mn, uint64_t t,
-                                                   float* __restrict__ td_out, float* __restrict__ dW) {
+                                                   float* __restrict__ td_out, long long* __restrict__ fx) {
     constexpr int D = M::D, A = M::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < Mn;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
         if (!shared) M::update(c, wi, g, fs, a, scale);
         if (td_out) td_out[i] = delta;
     }
-    if (shared) M::accumulate(dW, g, fs, a, scale, valid);      // wave-uniform call (shared is a kernel argument)
+    if (shared) M::accumulate(fx, g, fs, a, scale, valid, FxScale(c.alg.lr).inv_lsb);
 }
 
 // Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states, weights read from memory      lib.rs:448-479, :340
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     // tile coding: the delta table is replicated n_rep times and block b adds into copy b % n_rep -- device atomics on one
     // 128-B line serialise at ~11 ns each and the learners crowd into a few lines; k_apply_rep sums the copies
-    float* __restrict__ dW = dW_base + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride;
+    long long* __restrict__ fx = reinterpret_cast<long long*>(dW_base) + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride;
     constexpr int D = M::D, A = M::A;
     const int64_t N = c.n_envs;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -616,13 +619,12 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
                 const uint32_t eb = (__float_as_uint(c.alg.lr) >> 23) & 0xffu;
                 const int ex = (int)(eb < 30u ? 30u : eb) - 28;
                 const float inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
-                M::block_accumulate(reinterpret_cast<long long*>(dW_base) + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride, tile_slice, g, fs, a,
-                                    scale, i < N, inv_lsb);
+                M::block_accumulate(fx, tile_slice, g, fs, a, scale, i < N, inv_lsb);
             } else {
-                M::accumulate(dW, g, fs, a, scale, i < N);            // all lanes call (DPP sums inside)
+                M::accumulate(fx, g, fs, a, scale, i < N, FxScale(c.alg.lr).inv_lsb);
             }
         } else {
-            M::accumulate(dW, g, fs, a, scale, i < N);
+            M::accumulate(fx, g, fs, a, scale, i < N, FxScale(c.alg.lr).inv_lsb);
         }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);

@@ -35,6 +35,15 @@ namespace {
 __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float* __restrict__ dW, long long* __restrict__ rep, int n_rep, int n, float lsb) {
     const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (j >= n) return;
+    if (j + 1 >= n || (n & 1)) {                      // odd table sizes (copies not 16-byte aligned): one entry at a time
+        for (int e = j; e < n && e < j + 2; ++e) {
+            long long a = 0;
+            for (int r = 0; r < n_rep; ++r) { long long* p = rep + (int64_t)r * n + e; const long long v = *p; if (v != 0) { a += v; *p = 0; } }
+            const float d = (float)a * lsb;
+            if (W) W[e] += d; else dW[e] = d;
+        }
+        return;
+    }
     // all copies' loads go out together (one memory round trip instead of n_rep dependent ones), then the touched ones are cleared
     constexpr int kMaxRep = 16;
     longlong2 v[kMaxRep];
@@ -52,6 +61,14 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
     const float d0 = (float)a0 * lsb, d1 = (float)a1 * lsb;
     if (W) { W[j] += d0; W[j + 1] += d1; }
     else { dW[j] = d0; dW[j + 1] = d1; }
+}
+// rsrl_hip_handle on shared weights: the mini-batch's fixed-point delta table -> float delta, table cleared
+__global__ __launch_bounds__(256) void k_fx_finalize(long long* __restrict__ fx, float* __restrict__ dW, int n, float lsb) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const long long v = fx[j];
+    dW[j] = (float)v * lsb;
+    if (v != 0) fx[j] = 0;
 }
 // actions index weight columns: whatever a caller stored through a DEVICE pointer is brought into [0, A)
 __global__ void k_clamp_actions(int32_t* __restrict__ a, int64_t n, int A) {
@@ -227,8 +244,10 @@ struct rsrl_hip_ctx {
     float* state = nullptr; int32_t* action = nullptr; uint32_t* ep_step = nullptr;
     float* W = nullptr; float* dW = nullptr;
     int Aw = 0;                      // columns of the weight matrix: A (control) or 1 (prediction: ScalarLFA)
-    long long* dW_rep = nullptr; int n_rep = 1;  // shared tile coding: n_rep copies of the fixed-point (64-bit) delta table; nullptr: the float path
+    long long* dW_rep = nullptr; int n_rep = 1;  // shared tile coding: n_rep copies of the fixed-point (64-bit) delta table
     long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
+    long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
+    bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
     int sh_par = 0;                  // which W buffer holds the current weights (0 = W)
@@ -534,6 +553,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW) (void)hipFree(c->dW);
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->sh_tab) (void)hipFree(c->sh_tab);
+    if (c->h_fx) (void)hipFree(c->h_fx);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
     if (c->qs_head) (void)hipFree(c->qs_head);
@@ -689,13 +709,20 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipHostMalloc((void**)&c->h_stats, sizeof(DevStats) * c->n_stat_slots, hipHostMallocDefault));
     HIP_TRY(hipMemsetAsync(c->W, 0, c->w_bytes, c->stream));                      // LFA::vector zero-initialises
     HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));
-    // (the fixed-point tables serve the LDS-privatised scatter: one tiling's slice, twice, as 64-bit words must fit 128 KiB of LDS)
-    if (shared && cfg->basis == RSRL_TILE_CODING && c->dw_elems % 2 == 0 && (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024) {
+    // shared tile coding: the mini-batch delta is accumulated in 64-bit fixed point, always.  When one tiling's slice, twice, as
+    // 64-bit words fits 128 KiB of LDS the scatter is privatised there and flushed into n_rep copies of the table; otherwise
+    // every learner adds its term to ONE copy with device atomics (same integers, same sum).
+    if (shared && cfg->basis == RSRL_TILE_CODING) {
+        c->tile_slice = (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024;
         const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob; with the fixed-point LDS accumulators the device atomics are what is left:
         int r = e ? atoi(e) : 8;                            // one copy per XCD (block b runs on XCD b % 8): 2: 35.0, 4: 29.7, 8: 28.7, 16: 29.5 us per batch-step at 262 144 envs
-        c->n_rep = r < 1 ? 1 : (r > 16 ? 16 : r);                    // k_apply_rep sums up to 16 copies
+        c->n_rep = !c->tile_slice ? 1 : (r < 1 ? 1 : (r > 16 ? 16 : r));                    // k_apply_rep sums up to 16 copies
         HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
+    }
+    if (shared) {
+        HIP_TRY(hipMalloc((void**)&c->h_fx, sizeof(long long) * c->dw_elems));
+        HIP_TRY(hipMemsetAsync(c->h_fx, 0, sizeof(long long) * c->dw_elems, c->stream));
     }
     HIP_TRY(hipMemsetAsync(c->action, 0, sizeof(int32_t) * (size_t)N, c->stream));
     HIP_TRY(hipMemsetAsync(c->ep_step, 0, sizeof(uint32_t) * (size_t)N, c->stream));
@@ -964,14 +991,16 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         });
     } else if (!for_model(c, [&](auto tag) {
             using Mo = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->dW);
+            hipLaunchKernelGGL((k_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev, c->h_fx);
         })) return NO_MODEL(c);
     KCHECK();
     if (c->cfg.weight_mode == RSRL_W_SHARED) {
-        // the mini-batch delta of ALL ranks is applied by every rank (replicas of W stay bit-identical): same exchange step
-        // as inside rsrl_hip_train
-        TRY(exchange_dw(c, c->t));
+        // the mini-batch delta (accumulated in fixed point: exact, reproducible) of ALL ranks is applied by every rank (replicas
+        // of W stay bit-identical): same exchange step as inside rsrl_hip_train
         const int n = (int)c->dw_elems;
+        hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.lr));
+        KCHECK();
+        TRY(exchange_dw(c, c->t));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
@@ -1281,9 +1310,9 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
             int slice = 0; size_t lds = 0;
-            if (!dense && c->dW_rep) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; slice = (int)f; lds = (size_t)f * 16; }   // two slices of 64-bit fixed-point accumulators
-            float* dwp = c->dW_rep ? reinterpret_cast<float*>(c->dW_rep) : c->dW;
-            const int nrep = c->dW_rep ? c->n_rep : 1;
+            if (c->tile_slice) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; slice = (int)f; lds = (size_t)f * 16; }   // two slices of 64-bit fixed-point accumulators
+            float* dwp = reinterpret_cast<float*>(c->dW_rep);
+            const int nrep = c->n_rep;
             if constexpr (M::kSparse) {
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
                 if (slice > 0) {
@@ -1298,12 +1327,12 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-    if (!dense && c->dW_rep) {
-        hipLaunchKernelGGL(k_apply_rep, dim3((n / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
+    {
+        hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
                            tile_lsb((float)c->cfg.lr));
         KCHECK();
     }
-    if (multi || (!dense && !c->dW_rep)) {
+    if (multi) {
         TRY(exchange_dw(c, t, t_dev));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();

@@ -281,3 +281,68 @@ def test_c3_shared_tile_coding_bitwise(ra, orc, algo, policy, N, T, B):
         assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
         assert s1["episodes"] == o1["episodes"]
     assert np.count_nonzero(run.weights) > 0
+
+
+def test_c3_table_too_large_for_lds_bitwise(ra, orc):
+    # Acrobot has three actions: a tiling's slice (8^4 cells x 3, twice, as 64-bit words) does not fit LDS, so every learner adds its
+    # fixed-point term to the device-wide table directly -- the same integers, the same exact sum: still bit-identical to the oracle
+    N, T, B = 3000, 8, 8
+    kw = dict(domain=2, basis=1, n_tilings=T, tiles_per_dim=B, gamma=0.99, lr=0.1 / T / N, epsilon=0.1)
+    ag = orc.make_agent(algo=1, policy=1, seed=4, max_episode_steps=60, shared_w=True, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    run.train(25)
+    run.train(40)
+    with ra.Context(n_envs=N, algo=1, policy=1, seed=4, max_episode_steps=60, weight_mode=ra.W_SHARED, **kw) as c:
+        c.reset()
+        c.train(25)
+        c.train(40, want_stats=False)
+        assert np.array_equal(c.get_weights(), run.weights)
+        assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
+    assert np.count_nonzero(run.weights) > 0
+
+
+@pytest.mark.parametrize("kind", ["dense", "tile"])
+def test_shared_handle_is_exact_and_reproducible(ra, orc, kind):
+    # rsrl_hip_handle on a shared approximator: the mini-batch delta is a sum of 64-bit fixed-point terms (lsb = 2^(floor(log2 lr)
+    # - 28), each term rounded once), so the update is the same bits on every call and equals the restatement below:
+    #   dense: term(i, f) = rint(lr*e_i*phi_i[f] / lsb) into column a_i;  tile: term(i) = rint(lr*e_i / lsb) into the T active entries
+    N = 2048
+    if kind == "dense":
+        kw = dict(gamma=0.9, lr=0.001 / N, epsilon=0.1)
+        akw = dict(policy=orc.EGREEDY, seed=9, shared_w=True, **kw)
+        ckw = dict(n_envs=N, policy=1, seed=9, weight_mode=ra.W_SHARED, **kw)
+    else:
+        kw = dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, gamma=0.99, lr=0.1 / 8 / N, epsilon=0.1)
+        akw = dict(algo=1, policy=orc.EGREEDY, seed=9, shared_w=True, **kw)
+        ckw = dict(n_envs=N, algo=1, policy=1, seed=9, weight_mode=ra.W_SHARED, **kw)
+    ag = orc.make_agent(**akw)
+    out = []
+    for _ in range(2):
+        with ra.Context(**ckw) as c:
+            c.reset()
+            c.train(30, want_stats=False)
+            w0, s, a = c.get_weights(), c.states, c.actions
+            frm, nxt, rew, term = c.domain_step(a)
+            td = c.handle(frm, a, rew, nxt, term)
+            out.append((w0, c.get_weights(), td, frm, nxt, rew, term, a))
+    assert all(np.array_equal(x, y) for x, y in zip(out[0], out[1]))                  # run to run
+    w0, w1, td, frm, nxt, rew, term, a = out[0]
+    lr32 = np.float32(kw["lr"])
+    ex = max(int(lr32.view(np.uint32) >> 23) & 0xff, 30) - 28
+    lsb = np.uint32(ex << 23).view(np.float32); inv = np.uint32((254 - ex) << 23).view(np.float32)
+    acc = np.zeros(w0.shape, np.int64)
+    for i in range(N):
+        sc = np.float32(lr32 * np.float32(td[i]))              # QLearning / SARSA: the error sent on is the TD error itself
+        if kind == "dense":
+            phi = orc.fourier_project(0, 5, frm[:, i], prec="f32d")
+            v = (np.float32(sc) * phi.astype(np.float32)).astype(np.float32) * inv
+            acc[:, a[i]] += np.rint(np.clip(v, -4.398046511104e12, 4.398046511104e12)).astype(np.int64)
+        else:
+            q = np.int64(np.rint(np.clip(np.float32(sc * inv), -4.398046511104e12, 4.398046511104e12)))
+            for k in orc.tile_indices(ag, frm[:, i].astype(np.float32)):
+                acc[k, a[i]] += q
+    want = (w0 + (acc.astype(np.float32) * lsb)).astype(np.float32)
+    assert np.array_equal(w1, want), np.abs(w1 - want).max()
+    assert np.abs(w1 - w0).max() > 0
+
