@@ -60,6 +60,22 @@ def test_draws_are_pure_functions_of_their_address(orc, seed, env, t, blk):
     assert list(orc.draw(seed, env, t + 1, blk)) != list(a) and list(orc.draw(seed, env + 1, t, blk)) != list(a)
 
 
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 2 ** 64 - 1), env=st.integers(0, 2 ** 31 - 1), t=st.integers(0, 2 ** 40))
+def test_per_step_draws_are_halves_of_a_shared_philox_block(orc, seed, env, t):
+    # the stream contract: the per-step draws (STEP with its alias RESET, INNER) use two words, and the batch-steps
+    # 2k and 2k + 1 share the Philox4x32-10 block at counter (k, env, block): words 0-1 for the even step, 2-3 for the odd one;
+    # every other block index takes the whole block at counter t
+    k = t >> 1
+    key = [seed & 0xffffffff, seed >> 32]
+    for blk, base in ((orc.BLK_STEP, orc.BLK_STEP), (orc.BLK_RESET, orc.BLK_STEP), (orc.BLK_INNER, orc.BLK_INNER)):
+        p = list(orc.philox([k & 0xffffffff, k >> 32, env, base], key))
+        even, odd = list(orc.draw(seed, env, 2 * k, blk)), list(orc.draw(seed, env, 2 * k + 1, blk))
+        assert even == [p[0], p[1], p[1], 0] and odd == [p[2], p[3], p[3], 0]
+    for blk in (orc.BLK_INIT, orc.BLK_API, 16, 79):
+        assert list(orc.draw(seed, env, t, blk)) == list(orc.philox([t & 0xffffffff, t >> 32, env, blk], key))
+
+
 @settings(max_examples=25, deadline=None)
 @given(domain=st.integers(0, 2), a=st.integers(0, 1), u=st.lists(st.floats(0.05, 0.95, **fin), min_size=4, max_size=4))
 def test_domain_steps_stay_inside_the_state_space(orc, domain, a, u):
