@@ -62,6 +62,33 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
     if (W) { W[j] += d0; W[j + 1] += d1; }
     else { dW[j] = d0; dW[j + 1] = d1; }
 }
+// Shared tile coding, the scatter as a kernel of its own.  Block (chunk c, tiling t) takes the terms of `per_block` consecutive
+// learners for ONE tiling: LDS slice of that tiling (64-bit fixed point), one LDS atomic per learner, ONE sweep, one device atomic
+// per touched entry into copy c % n_rep of the table.  Against scattering inside the step kernel (1 024 learners x 8 tilings per
+// block: a sweep per tiling per 1 024 learners, ~300 touched entries each) a block here covers 8x the learners per sweep and
+// per flush: an eighth of the sweeps, a quarter of the device atomics.  The sums are integers: the same table whatever the
+// grouping -- bit-identical to the fused scatter and to the oracle.
+__global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const long long* __restrict__ terms, int64_t N, int S,
+                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride) {
+    extern __shared__ long long scatter_slice[];
+    const int t = blockIdx.y;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) scatter_slice[j] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)blockIdx.x * per_block;
+    const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
+    const uint16_t* __restrict__ kt = keys + (int64_t)t * N;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const long long q = terms[i];
+        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&scatter_slice[kt[i]]), (unsigned long long)q);
+    }
+    __syncthreads();
+    long long* __restrict__ dst = dW64 + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride + (int64_t)t * S;
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const long long v = scatter_slice[j];
+        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[j]), (unsigned long long)v);
+    }
+}
+
 // rsrl_hip_handle on shared weights: the mini-batch's fixed-point delta table -> float delta, table cleared
 __global__ __launch_bounds__(256) void k_fx_finalize(long long* __restrict__ fx, float* __restrict__ dW, int n, float lsb) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -248,6 +275,8 @@ struct rsrl_hip_ctx {
     long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
     long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
     bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
+    uint16_t* sc_keys = nullptr;     // shared tile coding, separate scatter kernel: slice-relative entries [T][N]
+    long long* sc_terms = nullptr;   //   and fixed-point terms [N] handed from the step kernel to k_tile_scatter
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
     int sh_par = 0;                  // which W buffer holds the current weights (0 = W)
@@ -554,6 +583,8 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->dW_rep) (void)hipFree(c->dW_rep);
     if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->h_fx) (void)hipFree(c->h_fx);
+    if (c->sc_keys) (void)hipFree(c->sc_keys);
+    if (c->sc_terms) (void)hipFree(c->sc_terms);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
     if (c->qs_head) (void)hipFree(c->qs_head);
@@ -714,11 +745,16 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     // every learner adds its term to ONE copy with device atomics (same integers, same sum).
     if (shared && cfg->basis == RSRL_TILE_CODING) {
         c->tile_slice = (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024;
-        const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob; with the fixed-point LDS accumulators the device atomics are what is left:
-        int r = e ? atoi(e) : 8;                            // one copy per XCD (block b runs on XCD b % 8): 2: 35.0, 4: 29.7, 8: 28.7, 16: 29.5 us per batch-step at 262 144 envs
+        const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob.  Scatter fused into the step kernel (RSRL_TILE_FUSED_SCATTER=1), us per batch-step at
+        const bool fused_scatter = getenv("RSRL_TILE_FUSED_SCATTER") != nullptr;       // 262 144 envs: 2: 35.0, 4: 29.7, 8: 28.7, 16: 29.5; separate scatter kernel (the default,
+        int r = e ? atoi(e) : (fused_scatter ? 8 : 4);      // a quarter of the flushes): 1: 25.7, 2: 24.7, 4: 24.1, 8: 24.8, 16: 26.4
         c->n_rep = !c->tile_slice ? 1 : (r < 1 ? 1 : (r > 16 ? 16 : r));                    // k_apply_rep sums up to 16 copies
         HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
+        if (c->tile_slice && !fused_scatter) {                           // the scatter as a kernel of its own (A/B knob: the fused one)
+            HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
+            HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(long long) * (size_t)N));
+        }
     }
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->h_fx, sizeof(long long) * c->dw_elems));
@@ -1314,6 +1350,18 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             float* dwp = reinterpret_cast<float*>(c->dW_rep);
             const int nrep = c->n_rep;
             if constexpr (M::kSparse) {
+                if (c->sc_keys) {
+                    // step kernel (terms + entries per learner) -> scatter kernel: block (chunk, tiling), 8 192 learners per chunk
+                    hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, 0, nrep,
+                                       (int64_t)c->dw_elems, t_dev, c->sc_keys, c->sc_terms);
+                    static const int chunks_env = getenv("RSRL_SCATTER_CHUNKS") ? atoi(getenv("RSRL_SCATTER_CHUNKS")) : 32;
+                    int64_t per = (k.n_envs + chunks_env - 1) / chunks_env;
+                    per = ((per + 1023) / 1024) * 1024;
+                    const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
+                    hipLaunchKernelGGL(k_tile_scatter, dim3(chunks, (unsigned)c->cfg.n_tilings), dim3(1024), (size_t)slice * 8, c->stream, c->sc_keys, c->sc_terms,
+                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems);
+                    return;
+                }
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
                 if (slice > 0) {
                     hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, t, do_c, dwp,
