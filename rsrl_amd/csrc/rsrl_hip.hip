@@ -77,9 +77,17 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restric
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = keys + (int64_t)t * N;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const long long q = terms[i];
-        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&scatter_slice[kt[i]]), (unsigned long long)q);
+    for (int64_t ib = i0; ib < i1; ib += 8 * (int64_t)blockDim.x) {      // eight learners per thread, their loads in flight together
+        long long q[8]; uint16_t kk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t i = ib + e * (int64_t)blockDim.x + threadIdx.x;
+            q[e] = i < i1 ? terms[i] : 0;
+            kk[e] = i < i1 ? kt[i] : (uint16_t)0;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (q[e] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&scatter_slice[kk[e]]), (unsigned long long)q[e]);
     }
     __syncthreads();
     long long* __restrict__ dst = dW64 + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride + (int64_t)t * S;
