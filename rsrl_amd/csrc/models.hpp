@@ -543,7 +543,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
                                                       uint8_t* __restrict__ flags,
                                                       DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride,
                                                       const uint64_t* __restrict__ t_dev, uint16_t* __restrict__ keys = nullptr,
-                                                      long long* __restrict__ terms = nullptr) {
+                                                      float* __restrict__ terms = nullptr) {
     if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
     if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
     // tile coding: the delta table is replicated n_rep times and block b adds into copy b % n_rep -- device atomics on one
@@ -614,14 +614,14 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         if constexpr (M::kSparse) {
             extern __shared__ long long tile_slice[];                   // cells*A 64-bit fixed-point accumulators when the host could afford it
             if (keys) {
-                // the scatter has a kernel of its own (k_tile_scatter): this one hands over, per learner, its fixed-point term
-                // and the T slice-relative entries it goes to (16 bits each: a slice has at most 8 192 entries)
+                // the scatter has a kernel of its own (k_tile_scatter): this one hands over, per learner, its term lr*e (rounded to
+                // fixed point there) and the T slice-relative entries it goes to (16 bits each: a slice has at most 8 192 entries)
                 if (i < N) {
                     constexpr int T = (int)(sizeof(fs.idx) / sizeof(fs.idx[0]));
                     const int cells = g.F / T;
 #pragma unroll
                     for (int tt = 0; tt < T; ++tt) keys[(int64_t)tt * N + i] = (uint16_t)((fs.idx[tt] - tt * cells) * A + a);
-                    terms[i] = (long long)fx_quantise(scale, FxScale(c.alg.lr).inv_lsb);
+                    terms[i] = scale;
                 }
             } else if (lds_slice_floats > 0) {
                 for (int j = threadIdx.x; j < 2 * lds_slice_floats; j += blockDim.x) tile_slice[j] = 0;      // two slices (ping-pong)

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
 // block: a sweep per tiling per 1 024 learners, ~300 touched entries each) a block here covers 8x the learners per sweep and
 // per flush: an eighth of the sweeps, a quarter of the device atomics.  The sums are integers: the same table whatever the
 // grouping -- bit-identical to the fused scatter and to the oracle.
-__global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const long long* __restrict__ terms, int64_t N, int S,
-                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride) {
+__global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const float* __restrict__ terms, int64_t N, int S,
+                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb) {
     extern __shared__ long long scatter_slice[];
     const int t = blockIdx.y;
     for (int j = threadIdx.x; j < S; j += blockDim.x) scatter_slice[j] = 0;
@@ -78,16 +78,18 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restric
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = keys + (int64_t)t * N;
     for (int64_t ib = i0; ib < i1; ib += 8 * (int64_t)blockDim.x) {      // eight learners per thread, their loads in flight together
-        long long q[8]; uint16_t kk[8];
+        float sc[8]; uint16_t kk[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t i = ib + e * (int64_t)blockDim.x + threadIdx.x;
-            q[e] = i < i1 ? terms[i] : 0;
+            sc[e] = i < i1 ? terms[i] : 0.0f;
             kk[e] = i < i1 ? kt[i] : (uint16_t)0;
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (q[e] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&scatter_slice[kk[e]]), (unsigned long long)q[e]);
+        for (int e = 0; e < 8; ++e) {
+            const unsigned long long q = fx_quantise(sc[e], inv_lsb);      // the learner's term as ONE integer, the same for all its tilings
+            if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&scatter_slice[kk[e]]), q);
+        }
     }
     __syncthreads();
     long long* __restrict__ dst = dW64 + (int64_t)(blockIdx.x % (unsigned)n_rep) * rep_stride + (int64_t)t * S;
@@ -284,7 +286,7 @@ struct rsrl_hip_ctx {
     long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
     bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
     uint16_t* sc_keys = nullptr;     // shared tile coding, separate scatter kernel: slice-relative entries [T][N]
-    long long* sc_terms = nullptr;   //   and fixed-point terms [N] handed from the step kernel to k_tile_scatter
+    float* sc_terms = nullptr;       //   and terms lr*e [N] handed from the step kernel to k_tile_scatter
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
     float* W2 = nullptr;             // shared-W dense basis: second weight buffer (k_shared_step reads one, block 0 writes the other)
     int sh_par = 0;                  // which W buffer holds the current weights (0 = W)
@@ -761,7 +763,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
         if (c->tile_slice && !fused_scatter) {                           // the scatter as a kernel of its own (A/B knob: the fused one)
             HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
-            HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(long long) * (size_t)N));
+            HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(float) * (size_t)N));
         }
     }
     if (shared) {
@@ -1367,7 +1369,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
                     per = ((per + 1023) / 1024) * 1024;
                     const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
                     hipLaunchKernelGGL(k_tile_scatter, dim3(chunks, (unsigned)c->cfg.n_tilings), dim3(1024), (size_t)slice * 8, c->stream, c->sc_keys, c->sc_terms,
-                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems);
+                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb);
                     return;
                 }
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
