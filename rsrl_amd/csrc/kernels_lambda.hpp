@@ -63,14 +63,28 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
                 w.put(b, f, c.W[((int64_t)(b * F + f)) * N + i]);
                 z.put(b, f, lp.Z[((int64_t)(b * F + f)) * N + i]);
             }
-        Phi phi_a, phi_b;
+        Phi phi_a;
         float q_s[A];
         { float ph[F]; Bas::project(s, ph); phi_a.set(ph); }
         w.q(phi_a, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
         bool cut = false;          // trace.reset() of a terminal transition, applied as a zero decay rate at the next update
 
-        auto one_step = [&](const Phi& phi_s, Phi& phi_n, uint64_t t) {
+        // ONE feature buffer: the trace update is the only consumer of phi(s) and needs nothing of this step but the action, so it
+        // runs FIRST and phi(s') then overwrites the buffer (W and Z are 216 of the 256 architectural registers: a second
+        // 36-value buffer was paid for in AGPR copies)
+        auto one_step = [&](Phi& phi, uint64_t t) {
+            const float qsa = select_a<A>(q_s, a);
+            // ---- trace: (Q(lambda): cut unless the action was the greedy one) then z = rule(rate*z + grad)
+            float rate_eff = cut ? 0.0f : lp.rate;
+            if constexpr (ALGO == ALG_Q_LAMBDA) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : rate_eff;
+            {
+                float ind[A];
+#pragma unroll
+                for (int b = 0; b < A; ++b) ind[b] = (a == b) ? 1.0f : 0.0f;
+                z.decay_add(rate_eff, ind, phi);
+                if (lp.trace == TRACE_SATURATE) z.clip(-1.0f, 1.0f);
+            }
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
@@ -80,19 +94,9 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
             const bool trunc = !term && cap > 0 && ep >= cap;
             if (term) Dom::reset(ns);
             float q_n[A];
+            Phi& phi_n = phi;
             { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
             w.q(phi_n, q_n);
-            const float qsa = select_a<A>(q_s, a);
-            // ---- trace: (Q(lambda): cut unless the action was the greedy one) then z = rule(rate*z + grad)
-            float rate_eff = cut ? 0.0f : lp.rate;
-            if constexpr (ALGO == ALG_Q_LAMBDA) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : rate_eff;
-            {
-                float ind[A];
-#pragma unroll
-                for (int b = 0; b < A; ++b) ind[b] = (a == b) ? 1.0f : 0.0f;
-                z.decay_add(rate_eff, ind, phi_s);
-                if (lp.trace == TRACE_SATURATE) z.clip(-1.0f, 1.0f);
-            }
             // ---- residual with the PRE-update weights
             U4 xin = U4{0, 0, 0, 0};
             if constexpr (ALGO == ALG_SARSA_LAMBDA) xin = draw(c.seed, gid, t, BLK_INNER);
@@ -125,10 +129,10 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
         };
         int k = 0;
         for (; k + 1 < n_steps; k += 2) {
-            one_step(phi_a, phi_b, t0 + (uint64_t)k);
-            one_step(phi_b, phi_a, t0 + (uint64_t)k + 1);
+            one_step(phi_a, t0 + (uint64_t)k);
+            one_step(phi_a, t0 + (uint64_t)k + 1);
         }
-        if (k < n_steps) one_step(phi_a, phi_b, t0 + (uint64_t)k);
+        if (k < n_steps) one_step(phi_a, t0 + (uint64_t)k);
         sum_abs = (double)facc_abs; sum_r = (double)facc_r;
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
