@@ -1216,9 +1216,10 @@ void FN(orc_run_reset_wave)(void* h) {
 /* Shared weights, dense basis, in the DEVICE's evaluation order (rsrl_amd/csrc/models.hpp: k_shared_step with 512-learner
  * blocks), for bitwise comparison with the HIP path (_f32d).  The rule is SURVEY A.7's (every learner's error against the
  * same W_t, the summed delta applied once, every learner then samples with W_{t+1}); what is mirrored is the ORDER of the sum:
- *   block (512 learners): for each (action b, feature f) eight chains over the 64 consecutive learners of a wave each
- *       (the device runs them as rank-1 MFMA updates: same products, same roundings, same order),
- *       acc = fma([a_i == b], lr*e_i*phi_i[f], acc), the eight parts added in order              -> one row per block
+ *   block (512 learners): for each (action b, feature f), per wave of 64 consecutive learners FOUR chains
+ *       acc_c = fma([a_i == b], lr*e_i*phi_i[f], acc_c) over the learners i = c mod 4 in ascending order (the device runs them
+ *       as rank-1 MFMA updates on four accumulators: same products, same roundings, same order), the wave's part =
+ *       (acc_0 + acc_1) + (acc_2 + acc_3), the eight parts added in wave order                    -> one row per block
  *   blocks: every block's sums are rounded to 64-bit fixed point (lsb = 2^(floor(log2 lr) - 28), clamped to +-2^42), the
  *       integers are added over the blocks (exact, any order) and converted back with one rounding -> W_t = W_{t-1} + total
  * and the launch structure: phase C of batch-step t-1 (sample with W_t; finished episodes restart) and phase A of batch-step
@@ -1286,12 +1287,13 @@ int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
             if (do_a)
                 for (a = 0; a < A; a++) for (f = 0; f < F; f++) {
                     R tot = (R)0.0;
-                    for (hh = 0; hh < H; hh++) {
-                        R part = (R)0.0; int li;
+                    for (hh = 0; hh < H; hh++) {                    /* per wave: four chains (learner k -> chain k mod 4), (c0 + c1) + (c2 + c3) */
+                        R ch[4] = { (R)0.0, (R)0.0, (R)0.0, (R)0.0 }, part; int li;
                         for (li = hh * PER; li < (hh + 1) * PER; li++) {
                             const R v = terms[li] * phis[(size_t)li * F + f];
-                            part = FN(fma_)((acts[li] == a) ? (R)1.0 : (R)0.0, v, part);
+                            ch[li & 3] = FN(fma_)((acts[li] == a) ? (R)1.0 : (R)0.0, v, ch[li & 3]);
                         }
+                        part = (ch[0] + ch[1]) + (ch[2] + ch[3]);
                         tot = (hh == 0) ? part : tot + part;
                     }
                     { float sc = (float)tot * inv_lsb_f;

@@ -38,6 +38,9 @@ struct Common {
     int shared;            // one approximator for all learners (weight_mode == RSRL_W_SHARED)
     float* qcache;         // [A][N] Q(s,.) of the CURRENT state with the current weights, carried between launches
     int q_valid;           // 0: qcache is stale (weights/states were changed from outside) -> recompute from W
+    int64_t xdelta;        // multi-rank peer exchange: (exchanges this ctx has performed on its receive buffer) - (batch-step counter).
+                           // Slot parity and granule tags follow t + xdelta, a sequence number that only ever grows, whatever happens
+                           // to the batch-step counter (a restored checkpoint sets it back; other exchange paths advance it alone)
 };
 
 constexpr int kBlock = 256;

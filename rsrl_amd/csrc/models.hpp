@@ -660,6 +660,54 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
 // 2.7 us of an 10.7 us step); the copies are 14 KB.  Three table sets rotate with the batch-step counter: step t accumulates
 // into set t mod 3, folds set (t-1) mod 3 and clears set (t+1) mod 3 -- a launch never clears what a block of the same launch
 // may still read or add to, and the kernel boundary is the only synchronisation.
+
+// Block-level sum of the learners' terms of a shared dense approximator, the per-wave part: out[b][f] = sum over the wave's 64
+// learners k of [a_k == b] * (scale_k * phi_k[f]).  One learner's term is a rank-1 update -- exactly v_mfma_f32_4x4x1_16b_f32: 16
+// independent 4x4 blocks, K = 1, D[blk][i][j] += A[blk][i] * B[blk][j].  With i = action and 4*blk + j = feature (= the lane),
+// learner k's A operand is the indicator [a_k == lane % 4] (a bit of a ballot mask: v_bfe + v_cvt) and its B operand is its F terms
+// ACROSS lanes -- the transpose of what the lanes hold, read back from the wave's own LDS tile (row = learner, padded to F + 1
+// words: conflict-free both ways; all 64 reads issued before the first MFMA).  K = 1 means one exact product (the indicator is 0
+// or 1) and one rounding per accumulation, in program order: the fp32 chain acc = fma(ind, v, acc), bit for bit (probe:
+// scripts/ubench/mfma_4x4x1.hip).
+// FOUR chains per wave (round 3): chain c takes the learners k = c mod 4 in ascending order, the wave's sum is
+// (c0 + c1) + (c2 + c3) -- the convention of every dot product on this path.  One 64-long chain of DEPENDENT MFMAs cost 1.4 us
+// per batch-step (two waves per SIMD, measured with the chain compiled out, scripts/gpu_exp_persist.sh): each MFMA waited for
+// the one before it; four independent accumulators issue back to back.  The oracle restates the four chains
+// (orc_run_train_shared_dev).
+template <int A, int F>
+__device__ __forceinline__ void wave_rank1_sum(float (*row)[F + 1], int lane, float scale, const float (&phi)[F], bool member, int a,
+                                               float* __restrict__ out /* [A*F] in LDS */) {
+    static_assert(F <= 64 && A <= 4, "features across the 64 lanes, actions across the 4 rows of an MFMA block");
+#pragma unroll
+    for (int f = 0; f < F; ++f) row[lane][f] = scale * phi[f];
+    unsigned long long m = 0;
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        const unsigned long long mb = __ballot(member && a == b);
+        m = ((lane & 3) == b) ? mb : m;
+    }
+    const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+    const int fl = lane < F ? lane : F - 1;                     // lanes past the features belong to unused blocks
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) acc[ch] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+    float bv[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) bv[k] = row[k][fl];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const float av = (float)(((k < 32 ? mlo : mhi) >> (k & 31)) & 1u);
+        acc[k & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv[k], acc[k & 3], 0, 0, 0);
+    }
+    const f4v tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (lane < F) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) out[b * F + lane] = tot[b];
+    }
+}
+
 constexpr int kTabRep = 16;
 struct DeltaTab {
     long long *out, *zero; const long long* in; float lsb, inv_lsb;
@@ -780,52 +828,13 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
         for (int f = 0; f < F; ++f) fs.phi[f] = 0.0f;
     }
     if (do_a) {
-        // block-level sum of the learners' terms, fixed order (reproducible).  Per wave: out[b][f] = sum over its 64 learners k
-        // (ascending) of [a_k == b] * lr*e_k*phi_k[f] is a chain of 64 rank-1 updates -- exactly what v_mfma_f32_4x4x1_16b_f32
-        // does: 16 independent 4x4 blocks, K = 1, D[blk][i][j] += A[blk][i] * B[blk][j].  With i = action, 4*blk + j = feature
-        // (= the lane) the A operand of learner k is the indicator [a_k == lane % 4] (a bit of a ballot mask: v_bfe + v_cvt) and
-        // the B operand is learner k's 36 terms ACROSS lanes -- the transpose of what the lanes hold, read back from the wave's own
-        // LDS tile (row = learner, padded to 37 words: conflict-free both ways).  K = 1 means one product and one rounding per
-        // accumulation, in program order: the fp32 chain acc = fma(ind, v, acc) over ascending learners, bit for bit (the probe
-        // scripts/ubench/mfma_4x4x1.hip checks layout and bits; the oracle restates the chain).  The 8 per-wave results are then
-        // added in wave order.  Against the LDS-only reduction (every (action, feature) a 128-long fma chain over float4 reads
-        // of the tile and of an indicator row: 442 KB of LDS reads per block) this reads each term once: 8.7 -> 8.3 us per
-        // batch-step; the chain of 64 dependent MFMAs is what it costs now (~0.6 us, measured with pieces compiled out).
+        // block-level sum of the learners' terms, fixed order (reproducible): per wave the MFMA rank-1 chains of wave_rank1_sum,
+        // then the 8 per-wave results added in wave order
         constexpr int NWV = BLOCK / 64, H = NWV, TP = F + 1;
         static_assert(F <= 64 && A <= 4, "dense shared-W reduction: features across the 64 lanes, actions across the 4 rows of a block");
         __shared__ float tile[NWV][64][TP];
         __shared__ float part[H][AF];
-        {
-            float (*row)[TP] = tile[wave];
-#pragma unroll
-            for (int f = 0; f < F; ++f) row[lane][f] = scale * fs.phi[f];
-            const bool member = i < N;
-            unsigned long long m = 0;
-#pragma unroll
-            for (int b = 0; b < A; ++b) {
-                const unsigned long long mb = __ballot(member && a == b);
-                m = ((lane & 3) == b) ? mb : m;
-            }
-            const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-            const int fl = lane < F ? lane : F - 1;                     // lanes past the features belong to unused blocks
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            f4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
-            // all 64 LDS reads are issued before the chain starts (left to itself the compiler reads two terms, waits, and
-            // issues two MFMAs: 32 exposed LDS round trips)
-            float bv[64];
-#pragma unroll
-            for (int k = 0; k < 64; ++k) bv[k] = row[k][fl];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                const float av = (float)(((k < 32 ? mlo : mhi) >> (k & 31)) & 1u);
-                acc = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv[k], acc, 0, 0, 0);
-            }
-            if (lane < F) {
-#pragma unroll
-                for (int b = 0; b < A; ++b) part[wave][b * F + lane] = acc[b];
-            }
-        }
+        wave_rank1_sum<A, F>(tile[wave], lane, scale, fs.phi, i < N, a, part[wave]);
         __syncthreads();
         if (threadIdx.x < AF) {
             float tot = part[0][threadIdx.x];

@@ -22,6 +22,7 @@
 #include "kernels_gq.hpp"
 #include "kernels_td.hpp"
 #include "kernels_qsigma.hpp"
+#include "kernels_persist.hpp"
 
 using namespace rsrl;
 
@@ -121,37 +122,42 @@ __global__ void k_clamp_actions(int32_t* __restrict__ a, int64_t n, int A) {
 // order.  Two parities: a rank can be at most one exchange ahead of the slowest one (it cannot pass exchange t+1 before
 // every peer has pushed t+1, i.e. finished reading t).
 __global__ __launch_bounds__(256) void k_peer_push(const float* __restrict__ dW, int n, uint2* const* __restrict__ peers, int world, int rank,
-                                                   uint64_t t, const uint64_t* __restrict__ t_dev) {
+                                                   uint64_t t, const uint64_t* __restrict__ t_dev, int64_t xdelta) {
     if (t_dev) t += *t_dev;
+    const uint64_t xs = t + (uint64_t)xdelta;          // exchange sequence number: parity and tag (see Common::xdelta)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    const uint64_t g = (uint64_t)__float_as_uint(dW[j]) | ((uint64_t)(uint32_t)(t + 1) << 32);
-    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
+    const uint64_t g = (uint64_t)__float_as_uint(dW[j]) | ((uint64_t)(uint32_t)(xs + 1) << 32);
+    const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
     for (int r = 0; r < world; ++r)
         __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// dW[j] = sum over ranks (ascending) of slot [parity][r][j], each polled until its tag says "batch-step t".  The spin is
-// bounded (~4 s of the 100 MHz wall clock): a missing peer sets *err instead of hanging the GPU.
-__global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int n, const uint2* __restrict__ recv, int world, uint64_t t,
-                                                     const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
-    if (t_dev) t += *t_dev;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t want = (uint32_t)(t + 1);
+// sum over ranks (ascending) of slot [parity][r][j], each polled until its tag says "exchange xs".  The spin is bounded by the
+// wall clock (100 MHz; `timeout` ticks): a missing peer sets *err instead of hanging the GPU, and the sum is POISONED (NaN) --
+// a partial sum is never applied silently.
+__device__ __forceinline__ float peer_sum(const uint2* __restrict__ recv, int n, int world, int j, uint64_t xs, uint32_t* __restrict__ err, uint64_t timeout) {
+    const uint32_t want = (uint32_t)(xs + 1);
     const uint64_t t_start = wall_clock64();
-    const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange timed out: fail fast, do not wait again
+    bool failed = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // an earlier exchange timed out: fail fast, do not wait again
     float acc = 0.0f;
     for (int r = 0; r < world; ++r) {
-        const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(t & 1) * world + r) * (size_t)n + j);
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(xs & 1) * world + r) * (size_t)n + j);
         uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((uint32_t)(g >> 32) != want) {
-            if (broken || wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
+            if (failed || wall_clock64() - t_start > timeout) { atomicOr(err, 1u); failed = true; break; }
             __builtin_amdgcn_s_sleep(8);
             g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         acc += __uint_as_float((uint32_t)g);
     }
-    dW[j] = acc;
+    return failed ? __builtin_nanf("") : acc;
+}
+__global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int n, const uint2* __restrict__ recv, int world, uint64_t t,
+                                                     const uint64_t* __restrict__ t_dev, int64_t xdelta, uint32_t* __restrict__ err, uint64_t timeout) {
+    if (t_dev) t += *t_dev;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    dW[j] = peer_sum(recv, n, world, j, t + (uint64_t)xdelta, err, timeout);
 }
 // multi-rank mode: the fold as a kernel of its own (the copies of batch-step t's fixed-point delta table -> one float per
 // output), feeding the exchange
@@ -174,30 +180,17 @@ __global__ __launch_bounds__(kBlock) void k_tab_finalize(const long long* __rest
 // Every rank pushes before it waits, so the ranks cannot wait for each other's pushes in a cycle.
 __global__ __launch_bounds__(256) void k_tab_exchange_apply(const long long* __restrict__ tab, int n, float lr, uint2* const* __restrict__ peers,
                                                             const uint2* __restrict__ recv, float* __restrict__ W, int world, int rank, uint64_t t,
-                                                            const uint64_t* __restrict__ t_dev, uint32_t* __restrict__ err) {
+                                                            const uint64_t* __restrict__ t_dev, int64_t xdelta, uint32_t* __restrict__ err, uint64_t timeout) {
     if (t_dev) t += *t_dev;
+    const uint64_t xs = t + (uint64_t)xdelta;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const float tot = tab_total(tab, n, j, lr, t);
-    const uint64_t mine = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(t + 1) << 32);
-    const size_t slot = ((size_t)(t & 1) * world + rank) * (size_t)n + j;
+    const uint64_t mine = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(xs + 1) << 32);
+    const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
     for (int r = 0; r < world; ++r)
         __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint32_t want = (uint32_t)(t + 1);
-    const uint64_t t_start = wall_clock64();
-    const bool broken = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    float acc = 0.0f;
-    for (int r = 0; r < world; ++r) {
-        const uint64_t* p = reinterpret_cast<const uint64_t*>(recv + ((size_t)(t & 1) * world + r) * (size_t)n + j);
-        uint64_t g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        while ((uint32_t)(g >> 32) != want) {
-            if (broken || wall_clock64() - t_start > 400000000ull) { atomicOr(err, 1u); break; }
-            __builtin_amdgcn_s_sleep(8);
-            g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        acc += __uint_as_float((uint32_t)g);
-    }
-    W[j] += acc;
+    W[j] += peer_sum(recv, n, world, j, xs, err, timeout);
 }
 __global__ void k_set_dyn(DynParams* __restrict__ d, DynParams v) { *d = v; }
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
@@ -330,7 +323,15 @@ struct rsrl_hip_ctx {
     uint2* peer_recv = nullptr; size_t peer_recv_bytes = 0; int peer_world = 0;
     std::vector<void*> peer_ptrs; std::vector<char> peer_opened;
     uint2** d_peer_ptrs = nullptr;             // device copy of peer_ptrs
-    uint32_t* d_peer_err = nullptr;            // set by a rank that waited too long for a peer
+    uint32_t* d_peer_err = nullptr;            // set by a block / rank that waited too long for a peer (sticky; shared-W ctxs only)
+    uint64_t peer_seq = 0;                     // exchanges performed on peer_recv so far: parity and tags follow it (Common::xdelta)
+    uint64_t peer_timeout = 400000000ull;      // bound of every in-kernel wait, ticks of the 100 MHz wall clock (RSRL_PEER_TIMEOUT_MS, default 4000)
+    size_t peer_old_bytes = 0;                 // peer_recv = [granules of the per-step exchange kernels | hop-2 buffer of the persistent kernel]
+    // persistent shared-W kernel (kernels_persist.hpp): hop-1 buffer A, hop-2 buffer B (own; inside peer_recv in peer mode)
+    unsigned long long* px_A = nullptr; unsigned long long* px_B = nullptr; bool px_B_owned = false;
+    unsigned long long** d_px_Bptrs = nullptr; // device array [world] of every rank's hop-2 buffer
+    uint64_t px_seq = 0;                       // batch-steps exchanged through px_A / px_B so far (tags and parity)
+    int n_cu = 256;
 };
 
 static Common make_common(const rsrl_hip_ctx* c) {
@@ -353,6 +354,7 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.max_episode_steps = c->cfg.max_episode_steps;
     k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.w_ls = c->w_ls; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
     k.qcache = c->qcache; k.q_valid = c->q_valid ? 1 : 0;
+    k.xdelta = (int64_t)c->peer_seq - (int64_t)c->t;
     return k;
 }
 
@@ -526,12 +528,13 @@ static int check_host_actions(const int32_t* a, size_t n, int A) {
 // synchronisation, capturable into the step graph.  A communicator of size 1 runs the same sequence (that is how the
 // multi-rank path is exercised on a one-GPU box).  At 432 B (MountainCar Fourier(5)) this is latency-bound, not link-bound.
 //   t / t_dev: the batch-step this exchange belongs to (PEER: slot parity and granule tag); t_dev != nullptr inside a graph.
-static int exchange_dw(rsrl_hip_ctx* c, uint64_t t, const uint64_t* t_dev = nullptr) {
+static int exchange_dw(rsrl_hip_ctx* c, uint64_t t, const uint64_t* t_dev, int64_t xdelta) {
     if (!c->multi) return RSRL_HIP_OK;
     const int n = (int)c->dw_elems;
     if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {
-        hipLaunchKernelGGL(k_peer_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->d_peer_ptrs, c->world_size, c->rank, t, t_dev);
-        hipLaunchKernelGGL(k_peer_reduce, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->peer_recv, c->world_size, t, t_dev, c->d_peer_err);
+        hipLaunchKernelGGL(k_peer_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->d_peer_ptrs, c->world_size, c->rank, t, t_dev, xdelta);
+        hipLaunchKernelGGL(k_peer_reduce, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->peer_recv, c->world_size, t, t_dev, xdelta, c->d_peer_err,
+                           c->peer_timeout);
         KCHECK();
         return RSRL_HIP_OK;
     }
@@ -544,7 +547,8 @@ static int peer_check(rsrl_hip_ctx* c) {
     uint32_t e = 0;
     HIP_TRY(hipMemcpyAsync(&e, c->d_peer_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (e) return fail(RSRL_HIP_ERCCL, "peer exchange timed out: a rank did not deliver its weight delta (rank %d of %d)", c->rank, c->world_size);
+    if (e) return fail(RSRL_HIP_ERCCL, "shared-W exchange timed out: a block or rank did not deliver its weight delta (rank %d of %d); the update was not applied "
+                                       "(per-step exchange: the weights are poisoned with NaN)", c->rank, c->world_size);
     return RSRL_HIP_OK;
 }
 
@@ -613,6 +617,9 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->peer_recv) (void)hipFree(c->peer_recv);
     if (c->d_peer_ptrs) (void)hipFree(c->d_peer_ptrs);
     if (c->d_peer_err) (void)hipFree(c->d_peer_err);
+    if (c->px_A) (void)hipFree(c->px_A);
+    if (c->px_B && c->px_B_owned) (void)hipFree(c->px_B);
+    if (c->d_px_Bptrs) (void)hipFree(c->d_px_Bptrs);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RSRL_HIP_OK;
@@ -695,7 +702,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(RSRL_HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
-    { int cus = 0; HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device)); if (cus > 0) c->n_simd = 4 * cus; }
+    { int cus = 0; HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device)); if (cus > 0) { c->n_simd = 4 * cus; c->n_cu = cus; } }
+    if (const char* e = getenv("RSRL_PEER_TIMEOUT_MS")) { const long ms = atol(e); if (ms > 0) c->peer_timeout = (uint64_t)ms * 100000ull; }
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     const int64_t N = cfg->n_envs;
@@ -767,6 +775,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         }
     }
     if (shared) {
+        HIP_TRY(hipMalloc((void**)&c->d_peer_err, sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_peer_err, 0, sizeof(uint32_t), c->stream));
         HIP_TRY(hipMalloc((void**)&c->h_fx, sizeof(long long) * c->dw_elems));
         HIP_TRY(hipMemsetAsync(c->h_fx, 0, sizeof(long long) * c->dw_elems, c->stream));
     }
@@ -1046,7 +1056,8 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         const int n = (int)c->dw_elems;
         hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.lr));
         KCHECK();
-        TRY(exchange_dw(c, c->t));
+        TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
+        if (c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
@@ -1343,13 +1354,13 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         // in the next launch's prologue (RCCL: table -> dW -> all-reduce, folded as floats)
         if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {                              // fused: delta -> every rank's slot; slots -> W
             hipLaunchKernelGGL(k_tab_exchange_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sh_tab, n, k.alg.lr, c->d_peer_ptrs, c->peer_recv, c->W,
-                               c->world_size, c->rank, t, t_dev, c->d_peer_err);
+                               c->world_size, c->rank, t, t_dev, k.xdelta, c->d_peer_err, c->peer_timeout);
             KCHECK();
             return RSRL_HIP_OK;
         }
         hipLaunchKernelGGL(k_tab_finalize, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr, c->dW, t, t_dev);
         KCHECK();
-        TRY(exchange_dw(c, t, t_dev));
+        TRY(exchange_dw(c, t, t_dev, k.xdelta));
         return RSRL_HIP_OK;
     }
     if (!for_model(c, [&](auto tag) {
@@ -1391,7 +1402,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         KCHECK();
     }
     if (multi) {
-        TRY(exchange_dw(c, t, t_dev));
+        TRY(exchange_dw(c, t, t_dev, k.xdelta));
         hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
         KCHECK();
     }
@@ -1476,6 +1487,56 @@ static inline int64_t fuse_depth(const rsrl_hip_ctx* c) {
     return reg ? 1024 : 256;
 }
 
+// shared weights, dense basis: the whole train call as ONE persistent launch (kernels_persist.hpp) when every 512-learner block
+// can be resident at once (one per CU) -- single rank, or ranks exchanging through the one-hop peer buffers.  RSRL_NO_PERSIST=1
+// keeps one launch per batch-step (k_shared_step), which is also what larger shards and RCCL-attached ctxs run.
+static bool persist_ok(const rsrl_hip_ctx* c) {
+    if (c->cfg.weight_mode != RSRL_W_SHARED || !c->sh_tab) return false;
+    if (c->multi && c->cfg.exchange != RSRL_EXCHANGE_PEER) return false;
+    if (getenv("RSRL_NO_PERSIST")) return false;
+    return c->sh_rows <= (unsigned)c->n_cu;
+}
+static int ensure_persist_buffers(rsrl_hip_ctx* c) {
+    const size_t pairs = (c->dw_elems + 1) / 2;
+    if (!c->px_A) {
+        const size_t bytes = sizeof(unsigned long long) * pairs * c->sh_rows * 2;
+        HIP_TRY(hipMalloc((void**)&c->px_A, bytes));
+        HIP_TRY(hipMemsetAsync(c->px_A, 0, bytes, c->stream));          // tag 0 never matches
+    }
+    if (!c->px_B) {                                                     // single rank: a private hop-2 buffer
+        const size_t bytes = sizeof(unsigned long long) * 2 * pairs * 2;
+        HIP_TRY(hipMalloc((void**)&c->px_B, bytes));
+        c->px_B_owned = true;
+        HIP_TRY(hipMemsetAsync(c->px_B, 0, bytes, c->stream));
+        HIP_TRY(hipMalloc((void**)&c->d_px_Bptrs, sizeof(void*)));
+        HIP_TRY(hipMemcpyAsync(c->d_px_Bptrs, &c->px_B, sizeof(void*), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));                       // &c->px_B is read by the copy
+    }
+    return RSRL_HIP_OK;
+}
+static int enqueue_persist(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
+    TRY(ensure_persist_buffers(c));
+    PersistExch x{};
+    x.A = c->px_A; x.B = c->d_px_Bptrs; x.B_self = c->px_B; x.err = c->d_peer_err;
+    x.world = c->multi ? c->world_size : 1; x.rank = c->multi ? c->rank : 0; x.timeout_ticks = c->peer_timeout;
+    bool ok = false;
+    for_model(c, [&](auto tag) {
+        using M = typename decltype(tag)::type;
+        if constexpr (M::kDense) {
+            if (c->multi)
+                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, true>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, c->t, c->px_seq, (int)n_steps,
+                                   c->W, x, d_stats);
+            else
+                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, false>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, c->t, c->px_seq, (int)n_steps,
+                                   c->W, x, d_stats);
+            ok = true;
+        }
+    });
+    if (!ok) return NO_MODEL(c);
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+
 static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
@@ -1495,7 +1556,21 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     int64_t done = 0;
     // the delta tables rotate with the batch-step counter: a counter that did not simply continue (reset, restored checkpoint)
     // finds them in another phase -- start from clean tables then
-    if (shared && c->sh_tab && n_steps > 0 && c->t != c->sh_tab_t)
+    const bool persist = shared && n_steps > 0 && persist_ok(c);
+    const bool peer_steps = shared && c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER && !persist;   // per-step exchanges on peer_recv
+    if (persist) {
+        for (int64_t left = n_steps; left > 0;) {                       // (the kernel's step count is an int)
+            const int64_t chunk = left < (int64_t)1 << 30 ? left : (int64_t)1 << 30;
+            TRY(timing_begin(c));
+            TRY(enqueue_persist(c, k, g, chunk, d_stats));
+            TRY(timing_end(c, (uint32_t)chunk));
+            c->t += (uint64_t)chunk; c->px_seq += (uint64_t)chunk; left -= chunk;
+            k = make_common(c);
+        }
+        c->kernel_name = "k_shared_persist";
+        done = n_steps;
+    }
+    if (shared && !persist && c->sh_tab && n_steps > 0 && c->t != c->sh_tab_t)
         HIP_TRY(hipMemsetAsync(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems, c->stream));
     while (done < n_steps) {
         // (dense shared W: the W / row buffers alternate every batch-step, the graph is captured at the parity of an odd step count)
@@ -1516,6 +1591,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             TRY(timing_end(c, kStepsPerGraph));
             c->kernel_name = stream_k1 ? (c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
             c->t += (uint64_t)kStepsPerGraph;
+            if (peer_steps) c->peer_seq += (uint64_t)kStepsPerGraph;
             done += kStepsPerGraph;
             continue;
         }
@@ -1580,9 +1656,10 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         }
         TRY(timing_end(c));
         c->t += (uint64_t)chunk;
+        if (peer_steps) c->peer_seq += (uint64_t)chunk;
         done += chunk;
     }
-    if (shared && n_steps > 0) { TRY(enqueue_shared_c(c, k, g, c->t - 1)); c->sh_tab_t = c->t; }     // phase C of the last batch-step
+    if (shared && n_steps > 0 && !persist) { TRY(enqueue_shared_c(c, k, g, c->t - 1)); c->sh_tab_t = c->t; }     // phase C of the last batch-step
     if (stats_out) {
         HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1727,7 +1804,9 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     if (c->cfg.exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
     if (c->multi || c->peer_recv) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    c->peer_recv_bytes = sizeof(uint2) * 2 * (size_t)world_size * c->dw_elems;
+    c->peer_old_bytes = sizeof(uint2) * 2 * (size_t)world_size * c->dw_elems;
+    // second region: the hop-2 buffer of the persistent kernel, [2 (parity)][world][A*F rounded up to even] granules
+    c->peer_recv_bytes = c->peer_old_bytes + sizeof(unsigned long long) * 2 * (size_t)world_size * (((size_t)c->dw_elems + 1) / 2 * 2);
     // fine-grained (uncached across agents) memory, as RCCL uses for its own flag/buffer exchange; RSRL_PEER_COARSE=1 falls
     // back to a plain allocation (same-device peers only need the system-scope accesses the kernels already use)
     hipError_t e = getenv("RSRL_PEER_COARSE") ? hipErrorNotSupported
@@ -1758,7 +1837,20 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
             if ((uint64_t)(uintptr_t)c->peer_recv != b.ptr || b.pid != (int32_t)getpid()) return fail(RSRL_HIP_EINVAL, "handle %d is not this ctx's own export", r);
             c->peer_ptrs[r] = c->peer_recv;
         } else if (b.pid == (int32_t)getpid()) {
-            c->peer_ptrs[r] = (void*)(uintptr_t)b.ptr;          // a ctx of this very process (several ranks driven by one host process): its pointer is valid here
+            // a ctx of this very process (several ranks driven by one host process): its pointer is valid here -- once this
+            // ctx's device may access the memory of the device it lives on
+            c->peer_ptrs[r] = (void*)(uintptr_t)b.ptr;
+            hipPointerAttribute_t attr;
+            HIP_TRY(hipPointerGetAttributes(&attr, c->peer_ptrs[r]));
+            if (attr.device != c->cfg.device) {
+                int can = 0;
+                HIP_TRY(hipDeviceCanAccessPeer(&can, c->cfg.device, attr.device));
+                if (!can) return fail(RSRL_HIP_EINVAL, "device %d cannot access the memory of device %d (peer rank %d): use the RCCL exchange", c->cfg.device, attr.device, r);
+                const hipError_t pe = hipDeviceEnablePeerAccess(attr.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(RSRL_HIP_EHIP, "hipDeviceEnablePeerAccess(%d) from device %d: %s", attr.device, c->cfg.device, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
         } else {
             HIP_TRY(hipIpcOpenMemHandle(&c->peer_ptrs[r], b.h, hipIpcMemLazyEnablePeerAccess));
             c->peer_opened[r] = 1;
@@ -1766,8 +1858,17 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
     }
     HIP_TRY(hipMalloc((void**)&c->d_peer_ptrs, sizeof(void*) * (size_t)world_size));
     HIP_TRY(hipMemcpy(c->d_peer_ptrs, c->peer_ptrs.data(), sizeof(void*) * (size_t)world_size, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&c->d_peer_err, sizeof(uint32_t)));
-    HIP_TRY(hipMemset(c->d_peer_err, 0, sizeof(uint32_t)));
+    {   // the persistent kernel's hop-2 buffers: the second region of every rank's receive buffer
+        std::vector<unsigned long long*> bp((size_t)world_size);
+        for (int r = 0; r < world_size; ++r) bp[(size_t)r] = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->peer_ptrs[(size_t)r]) + c->peer_old_bytes);
+        if (c->px_B && c->px_B_owned) { HIP_TRY(hipFree(c->px_B)); }
+        c->px_B = bp[(size_t)rank]; c->px_B_owned = false;
+        if (c->d_px_Bptrs) { HIP_TRY(hipFree(c->d_px_Bptrs)); c->d_px_Bptrs = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->d_px_Bptrs, sizeof(void*) * (size_t)world_size));
+        HIP_TRY(hipMemcpy(c->d_px_Bptrs, bp.data(), sizeof(void*) * (size_t)world_size, hipMemcpyHostToDevice));
+        c->px_seq = 0;                                      // a fresh (cleared) hop-2 buffer: the sequence restarts, on every rank alike
+        if (c->px_A) { HIP_TRY(hipFree(c->px_A)); c->px_A = nullptr; }
+    }
     c->world_size = world_size; c->rank = rank; c->multi = true;
     return RSRL_HIP_OK;
 }
