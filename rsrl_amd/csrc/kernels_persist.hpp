@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
                                                           DevStats* __restrict__ stats) {
     static_assert(M::kDense, "dense bases only");
     constexpr int D = M::D, A = M::A, F = M::F, AF = A * F, PAIRS = (AF + 1) / 2, AFP = 2 * PAIRS;
-    constexpr int NWV = BLOCK / 64, TP = F + 1;
+    constexpr int NWV = BLOCK / 64;
     static_assert(F <= 64 && A <= 4, "features across the 64 lanes, actions across the 4 rows of an MFMA block");
     const int64_t N = c.n_envs;
     const int nb = (int)gridDim.x, b = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
     const int lane = tid & 63, wave = tid >> 6;
     const bool member = i < N;
     __shared__ __attribute__((aligned(16))) float sh_w[AF];
-    __shared__ float tile[NWV][64][TP];
+    __shared__ __attribute__((aligned(16))) float tile[NWV][F][kRank1Stride];
     __shared__ float part[NWV][AF];
     __shared__ unsigned long long red[2];
     __shared__ int sh_ok;

@@ -674,12 +674,16 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
 // per batch-step (two waves per SIMD, measured with the chain compiled out, scripts/gpu_exp_persist.sh): each MFMA waited for
 // the one before it; four independent accumulators issue back to back.  The oracle restates the four chains
 // (orc_run_train_shared_dev).
+// The tile is FEATURE-major, tile[f][learner] with rows of 68 words: a lane writes its term of feature f next to its neighbours'
+// (ds_write_b32, conflict-free) and reads FOUR learners' terms of its own feature with one ds_read_b128 (row stride 68 = 4 mod 64
+// words: the lanes of a b128 service group land on disjoint banks) -- 16 wide reads per lane instead of 64 narrow ones.
+constexpr int kRank1Stride = 68;
 template <int A, int F>
-__device__ __forceinline__ void wave_rank1_sum(float (*row)[F + 1], int lane, float scale, const float (&phi)[F], bool member, int a,
-                                               float* __restrict__ out /* [A*F] in LDS */) {
+__device__ __forceinline__ void wave_rank1_sum(float (*tile)[kRank1Stride] /* [F][68] of this wave, 16-byte aligned */, int lane, float scale,
+                                               const float (&phi)[F], bool member, int a, float* __restrict__ out /* [A*F] in LDS */) {
     static_assert(F <= 64 && A <= 4, "features across the 64 lanes, actions across the 4 rows of an MFMA block");
 #pragma unroll
-    for (int f = 0; f < F; ++f) row[lane][f] = scale * phi[f];
+    for (int f = 0; f < F; ++f) tile[f][lane] = scale * phi[f];
     unsigned long long m = 0;
 #pragma unroll
     for (int b = 0; b < A; ++b) {
@@ -694,7 +698,10 @@ __device__ __forceinline__ void wave_rank1_sum(float (*row)[F + 1], int lane, fl
     for (int ch = 0; ch < 4; ++ch) acc[ch] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
     float bv[64];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) bv[k] = row[k][fl];
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const f4v v = *reinterpret_cast<const f4v*>(&tile[fl][4 * k4]);
+        bv[4 * k4] = v.x; bv[4 * k4 + 1] = v.y; bv[4 * k4 + 2] = v.z; bv[4 * k4 + 3] = v.w;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 64; ++k) {
@@ -830,9 +837,9 @@ __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, ui
     if (do_a) {
         // block-level sum of the learners' terms, fixed order (reproducible): per wave the MFMA rank-1 chains of wave_rank1_sum,
         // then the 8 per-wave results added in wave order
-        constexpr int NWV = BLOCK / 64, H = NWV, TP = F + 1;
+        constexpr int NWV = BLOCK / 64, H = NWV;
         static_assert(F <= 64 && A <= 4, "dense shared-W reduction: features across the 64 lanes, actions across the 4 rows of a block");
-        __shared__ float tile[NWV][64][TP];
+        __shared__ __attribute__((aligned(16))) float tile[NWV][F][kRank1Stride];
         __shared__ float part[H][AF];
         wave_rank1_sum<A, F>(tile[wave], lane, scale, fs.phi, i < N, a, part[wave]);
         __syncthreads();
