@@ -27,7 +27,10 @@
  *   - all kernels of a ctx run on ONE HIP stream (the caller's, if given in the
  *     config, else a ctx-owned one).  Calls taking host output pointers return
  *     after the data has landed; calls with device pointers are asynchronous on
- *     that stream (use rsrl_hip_sync).
+ *     that stream (use rsrl_hip_sync).  On a CALLER-supplied stream every call has
+ *     enqueued all of its work when it returns: hipStreamSynchronize / an event on
+ *     that stream orders the caller's own work after it (launch coalescing, below,
+ *     is for ctx-owned streams only).
  *   - there is no CPU fallback: without a usable HIP device rsrl_hip_create fails.
  */
 #ifndef RSRL_HIP_H
@@ -40,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 4
+#define RSRL_HIP_ABI_VERSION 5
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -204,6 +207,10 @@ int rsrl_hip_q_evaluate(rsrl_hip_ctx* ctx, const float* states /*[D][M]*/, int64
  *   find_max / policy_mode / policy_probs / policy_sample / rollout_greedy return RSRL_HIP_ESTATE for them (no Q function). */
 /* Enumerable::find_max (ties -> last index)                         rsrl/src/core.rs:96-105 */
 int rsrl_hip_q_find_max(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* idx_out, float* val_out);
+/* Enumerable::find_min (the minimum; ties -> last index)            rsrl/src/core.rs:86-94 */
+int rsrl_hip_q_find_min(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* idx_out, float* val_out);
+/* Enumerable::expected_value(args, ps) = fold(0.0, acc + Q(s,a)*p_a) rsrl/src/core.rs:107-116; probs f32[A][M], out f32[M] */
+int rsrl_hip_q_expected_value(rsrl_hip_ctx* ctx, const float* states, int64_t M, const float* probs, float* out);
 /* basis.project(s): dense features phi f32[F][M] (Fourier) -- lfa Basis::project */
 int rsrl_hip_project(rsrl_hip_ctx* ctx, const float* states, int64_t M, float* phi_out /*[F][M]*/);
 /* tile coding: active indices int32[T][M] */
@@ -224,6 +231,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* ctx, const float* from_states, const int32_t* 
 int rsrl_hip_policy_sample(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
 int rsrl_hip_policy_mode(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
 int rsrl_hip_policy_probs(rsrl_hip_ctx* ctx, const float* states, int64_t M, float* probs_out /*[A][M]*/);
+/* Function<(S, A)> of the policy: the probability of action a in state s for Greedy / EpsilonGreedy / Random
+ *   (greedy.rs:46-60, epsilon_greedy.rs:49-63, random.rs:28-32) and -- faithfully -- the raw action value Q(s, a) for Softmax
+ *   (softmax.rs:84-92 forwards to the approximator).  actions int32[M] in [0, A), prob_out f32[M]. */
+int rsrl_hip_policy_prob(rsrl_hip_ctx* ctx, const float* states, const int32_t* actions, int64_t M, float* prob_out);
 /* the pub field EpsilonGreedy.epsilon (decayed by drivers, examples/sarsa_lambda.rs:68) */
 int rsrl_hip_set_epsilon(rsrl_hip_ctx* ctx, double epsilon);
 
@@ -240,16 +251,21 @@ int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[
 int rsrl_hip_get_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* v /*[F][A]*/);
 int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v /*[F][A]*/);
 /* Checkpoint of the approximator(s) (the reference's only persistence story is the optional serde
- * derive on the agents, rsrl/Cargo.toml:26).  File format version 2, little-endian, serialised field by field (no padding):
+ * derive on the agents, rsrl/Cargo.toml:26).  File format version 2 (3 for files that carry QSigma's backups), little-endian,
+ * serialised field by field (no padding):
  *   offset  0  char magic[8] = "RSRLHIPW"
- *           8  u32  version = 2
+ *           8  u32  version = 2 (3 iff aux_kind = 3)
  *          12  i32  domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A (weight columns),
- *                   algo, weight_dtype, aux_kind (0 none, 1 eligibility traces, 2 GreedyGQ's fa_td weights)     [11 x i32]
+ *                   algo, weight_dtype, aux_kind (0 none, 1 eligibility traces, 2 GreedyGQ's fa_td weights,
+ *                   3 QSigma's n-step backups)                                                                  [11 x i32]
  *          56  i64  n_learners (1 in shared mode)
  *          64  u64  step_count
  *          72  n_learners x f32[F][A] weights in the reference's row-major (F, A) order (Parameterised::weights,
  *              params/mod.rs:118), independent of the device layout and storage dtype;
- *              then, if aux_kind != 0, n_learners x f32[F][A] of the auxiliary matrix (traces / fa_td).
+ *              then, if aux_kind is 1 or 2, n_learners x f32[F][A] of the auxiliary matrix (traces / fa_td);
+ *              if aux_kind is 3 (file version 3): u32 head[N], u32 len[N], f32 entries[D + 5][n_steps][N] -- every learner's
+ *              Backup ring {s, a, q, residual, pi, mu} (q_sigma.rs:30-63), so that a QSigma run with n_steps > 1 resumes
+ *              bit-identically too.  Files of version 2 (no aux_kind 3) are still read.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header
  * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run resumes bit-identically. */
 int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
@@ -260,19 +276,33 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 /* The fused driver loop (examples/q_learning.rs:40-52) x n_envs x n_steps with auto-reset
  * on terminal / step cap.  stats_out is a HOST pointer (optional). */
 int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out);
-/*   Without stats_out the call is ASYNCHRONOUS: it returns once the work is accepted.  Short calls (a driver loop's 20
- *   batch-steps) that arrive while the ctx's stream is still busy are coalesced -- held back and launched fuse-depth (256)
- *   at a time, when anything observes or changes the ctx (every other entry point, rsrl_hip_sync included, flushes first),
- *   or when a call finds the stream idle.  Results are bit-identical to one launch per call (the fused loop carries Q(s,.)
- *   between launches and addresses the RNG by the batch-step); RSRL_NO_COALESCE=1 in the environment disables it. */
+/*   Without stats_out the call is ASYNCHRONOUS: it returns once the work is enqueued.  On a CTX-OWNED stream (config.stream
+ *   NULL) short calls (a driver loop's 20 batch-steps) that arrive while the stream is still busy are coalesced -- held back and
+ *   launched fuse-depth (1024 batch-steps) at a time, when anything observes or changes the ctx (every other entry point,
+ *   rsrl_hip_sync included, flushes first), or when a call finds the stream idle.  Results are bit-identical to one launch per
+ *   call (the fused loop carries Q(s,.) between launches and addresses the RNG by the batch-step); RSRL_NO_COALESCE=1 in the
+ *   environment disables it.  On a caller-supplied stream nothing is ever held back.
+ *   Shared dense weights (RSRL_W_SHARED on a register-family Fourier basis, at most one 512-learner block per CU): the whole
+ *   call is ONE persistent launch; the ranks of a peer group exchange inside it (RSRL_NO_PERSIST=1: one launch per batch-step). */
 /* batch-steps executed so far by rsrl_hip_train and rsrl_hip_handle (the RNG counter) */
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
+/* batch-steps rsrl_hip_train has accepted but not enqueued yet (launch coalescing); always 0 on a caller-supplied stream */
+int64_t rsrl_hip_pending_steps(const rsrl_hip_ctx* ctx);
 
 /* Domain::rollout with the closure s -> policy.mode(s) and Some(step_limit), + n_states
  *   rsrl_domains/src/lib.rs:448-479, :340; one fresh default env per learner, the ctx's
  *   training envs are untouched.  step_limit >= 1. */
 int rsrl_hip_rollout_greedy(rsrl_hip_ctx* ctx, int64_t step_limit,
                             uint32_t* n_states_out /*[N]*/, float* total_reward_out /*[N]*/);
+/* The same rollout for learners 0..M-1 with the Trajectory itself (rsrl_domains/src/lib.rs:334-409): every output but
+ * n_states_out is optional.
+ *   states_out   f32[step_limit][D][M]     row 0 = Trajectory.start, row k = the observation of steps[k-1]
+ *   actions_out  i32[step_limit-1][M]      steps[k].1        rewards_out f32[step_limit-1][M]   steps[k].2
+ *   terminal_out u8[M]                     the last observation is Observation::Terminal
+ * Rows past a learner's n_states are zero (host buffers) / untouched (device buffers).  Trajectory::total_reward (:391) =
+ * total_reward_out, n_states (:340) = n_states_out, n_transitions = n_states - 1. */
+int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* ctx, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out,
+                                float* states_out, int32_t* actions_out, float* rewards_out, uint8_t* terminal_out);
 
 /* Order-independent 64-bit checksums of the ctx's device state (sum of the 32-bit words, each multiplied by an odd
  * function of its index): out[0] weights (+traces), out[1] env states/actions/episode counters.  For determinism /
@@ -291,11 +321,26 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* ctx, const uint8_t* id_bytes, int world_siz
  * rsrl_hip_peer_export (allocates its receive buffer for world_size ranks and describes it in a 128-byte handle: an
  * hipIpcMemHandle plus the owner's pid), the caller's control plane all-gathers the handles, then every rank calls
  * rsrl_hip_peer_connect with all of them in rank order.  Ranks may live in different processes (one per GPU; the
- * buffers are mapped with hipIpcOpenMemHandle) or in one process (several ctxs, any devices).  A rank that waits more
- * than ~4 s for a peer's delta gives up: the next rsrl_hip_sync returns RSRL_HIP_ERCCL. */
+ * buffers are mapped with hipIpcOpenMemHandle) or in one process (several ctxs, any devices: peer access between the
+ * devices is enabled by the call, RSRL_HIP_EINVAL if the hardware cannot).  A rank that waits more than 4 s
+ * (RSRL_PEER_TIMEOUT_MS in the environment) for a peer's delta gives up: that update is NOT applied as a partial sum (the
+ * persistent kernel skips it and ends; the per-step exchange kernels poison the weights with NaN), and the next call that
+ * synchronises (rsrl_hip_sync, get_weights / get_states / checksum into host memory, save_weights) returns RSRL_HIP_ERCCL.
+ * Slot parity and granule tags follow the number of exchanges performed, not the batch-step counter: a restored checkpoint
+ * (rsrl_hip_load_weights sets the counter back) cannot make a stale slot look current. */
 #define RSRL_HIP_PEER_HANDLE_BYTES 128
 int rsrl_hip_peer_export(rsrl_hip_ctx* ctx, int world_size, uint8_t* handle_out /*[128]*/);
 int rsrl_hip_peer_connect(rsrl_hip_ctx* ctx, const uint8_t* handles /*[world_size][128]*/, int world_size, int rank);
+
+/* All ranks in ONE process (a single-threaded host, like the reference's Rc<RefCell> owner graph, rsrl/src/core.rs:13-15):
+ * attaches the exchange configured in the ctxs (all alike) to ctxs[0..n), rank = index.  PEER: export + connect of every
+ * ctx; RCCL: ncclCommInitAll over the ctxs' devices (one device per rank) plus a grouped warm-up all-reduce, so that no
+ * later call blocks on a rank the same thread has not driven yet.  Afterwards the host calls rsrl_hip_train(ctxs[i], ..)
+ * for each i in turn (the calls only enqueue) and rsrl_hip_sync(ctxs[i]) at the end. */
+int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n);
+/* what is attached: world size and rank as the exchange itself reports them (ncclCommCount / ncclCommUserRank for RCCL),
+ * exchange = -1 (none), RSRL_EXCHANGE_RCCL or RSRL_EXCHANGE_PEER.  Any output pointer may be NULL. */
+int rsrl_hip_comm_info(rsrl_hip_ctx* ctx, int* world_size, int* rank, int* exchange);
 
 /* ---- measurement hooks (bench.py) --------------------------------------------------------
  * HIP-event timing of the kernels launched by train since the last reset, on the ctx's

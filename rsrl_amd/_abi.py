@@ -55,6 +55,9 @@ SYMBOLS = {
     "rsrl_hip_domain_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_q_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_q_find_max": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rsrl_hip_q_find_min": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rsrl_hip_q_expected_value": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rsrl_hip_policy_prob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_tile_indices": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_handle": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64, C.c_void_p]),
@@ -73,12 +76,16 @@ SYMBOLS = {
     "rsrl_hip_set_td_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_train": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(Stats)]),
     "rsrl_hip_step_count": (C.c_uint64, [C.c_void_p]),
+    "rsrl_hip_pending_steps": (C.c_int64, [C.c_void_p]),
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rsrl_hip_rollout_trajectory": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
     "rsrl_hip_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rsrl_hip_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rsrl_hip_peer_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "rsrl_hip_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rsrl_hip_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rsrl_hip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rsrl_hip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_char_p)]),

@@ -176,6 +176,20 @@ class Context:
         _abi.check(self._L.rsrl_hip_q_find_max(self._h, _p(states), M, _p(idx), _p(val)))
         return idx, val
 
+    def q_find_min(self, states):
+        """Enumerable::find_min (core.rs:86-94): (index, value), ties -> last index"""
+        states, M = self._batch(states)
+        idx, val = np.empty(M, dtype=np.int32), np.empty(M, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_q_find_min(self._h, _p(states), M, _p(idx), _p(val)))
+        return idx, val
+
+    def q_expected_value(self, states, probs):
+        """Enumerable::expected_value (core.rs:107-116): sum_a Q(s, a) * probs[a]; probs (A, M)"""
+        states, M = self._batch(states)
+        out = np.empty(M, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_q_expected_value(self._h, _p(states), M, _p(_in(probs, np.float32, (self.A, M))), _p(out)))
+        return out
+
     def project(self, states):
         states, M = self._batch(states)
         out = np.empty((self.F, M), dtype=np.float32)
@@ -214,6 +228,13 @@ class Context:
         states, M = self._batch(states)
         out = np.empty((self.A, M), dtype=np.float32)
         _abi.check(self._L.rsrl_hip_policy_probs(self._h, _p(states), M, _p(out)))
+        return out
+
+    def policy_prob(self, states, actions):
+        """Function<(S, A)> of the policy: P(a | s) (Softmax: the raw Q(s, a), softmax.rs:84-92)"""
+        states, M = self._batch(states)
+        out = np.empty(M, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_policy_prob(self._h, _p(states), _p(_in(actions, np.int32, (M,))), M, _p(out)))
         return out
 
     def set_epsilon(self, eps):
@@ -264,11 +285,29 @@ class Context:
     def step_count(self):
         return int(self._L.rsrl_hip_step_count(self._h))
 
+    @property
+    def pending_steps(self):
+        """batch-steps accepted by train() but not enqueued yet (launch coalescing on a ctx-owned stream)"""
+        return int(self._L.rsrl_hip_pending_steps(self._h))
+
     def rollout_greedy(self, step_limit):
         n_states = np.empty(self.N, dtype=np.uint32)
         tot = np.empty(self.N, dtype=np.float32)
         _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit), _p(n_states), _p(tot)))
         return n_states, tot
+
+    def rollout_trajectory(self, step_limit, M=None):
+        """Domain::rollout with the Trajectory (lib.rs:334-409) of learners 0..M-1 -> dict(n_states, total_reward, states
+        (step_limit, D, M), actions / rewards (step_limit - 1, M), terminal (M,)); rows past n_states are zero"""
+        M = self.N if M is None else int(M)
+        L = int(step_limit)
+        out = dict(n_states=np.empty(M, dtype=np.uint32), total_reward=np.empty(M, dtype=np.float32),
+                   states=np.zeros((L, self.D, M), dtype=np.float32), actions=np.zeros((max(L - 1, 0), M), dtype=np.int32),
+                   rewards=np.zeros((max(L - 1, 0), M), dtype=np.float32), terminal=np.empty(M, dtype=np.uint8))
+        _abi.check(self._L.rsrl_hip_rollout_trajectory(self._h, L, M, _p(out["n_states"]), _p(out["total_reward"]), _p(out["states"]),
+                                                       _p(out["actions"]) if L > 1 else None, _p(out["rewards"]) if L > 1 else None,
+                                                       _p(out["terminal"])))
+        return out
 
     def checksum(self):
         """(weights(+traces), env state) 64-bit checksums computed on the device"""
@@ -300,6 +339,18 @@ class Context:
         blob = b"".join(handles)
         buf = (C.c_uint8 * len(blob))(*blob)
         _abi.check(self._L.rsrl_hip_peer_connect(self._h, buf, len(handles), int(rank)))
+
+    @staticmethod
+    def group_create(ctxs):
+        """all ranks in this process (rank = position in `ctxs`): attach the exchange the ctxs were configured with"""
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        _abi.check(_abi.lib().rsrl_hip_group_create(arr, len(ctxs)))
+
+    def comm_info(self):
+        """(world_size, rank, exchange) as the attached exchange reports them; exchange -1 = none"""
+        w, r, e = C.c_int(), C.c_int(), C.c_int()
+        _abi.check(self._L.rsrl_hip_comm_info(self._h, C.byref(w), C.byref(r), C.byref(e)))
+        return w.value, r.value, e.value
 
     # ---- measurement
     def timing_enable(self, on=True):

@@ -34,31 +34,6 @@ struct QsParams {
     float sigma, alpha;
 };
 
-// argmaxima with its running maximum (utils.rs:6-21: the tolerance test comes first, the maximum is not raised by near-ties)
-template <int A>
-__device__ __forceinline__ uint32_t argmaxima_mask_max(const float (&q)[A], float& mx_out) {
-    float mx = -FLT_MAX; uint32_t mask = 0;
-#pragma unroll
-    for (int i = 0; i < A; ++i) {
-        const float d = fabsf(q[i] - mx);
-        if (d < 1e-7f) mask |= (1u << i);
-        else if (q[i] > mx) { mx = q[i]; mask = (1u << i); }
-    }
-    mx_out = mx;
-    return mask;
-}
-// Function<(S, A)> of the four policies: greedy.rs:46-60, epsilon_greedy.rs:49-63, softmax.rs:84-92, random.rs:28-32
-template <int A>
-__device__ __forceinline__ float policy_eval_sa(const PolicyParams& pp, const float (&q)[A], int a) {
-    if (pp.kind == POL_SOFTMAX) return select_a<A>(q, a);
-    if (pp.kind == POL_RANDOM) return 1.0f / (float)A;
-    float mx;
-    const uint32_t mask = argmaxima_mask_max<A>(q, mx);
-    const float pg = ((mask >> a) & 1u) ? 1.0f / (float)max(1, __popc(mask)) : 0.0f;
-    if (pp.kind == POL_GREEDY) return pg;
-    return pp.eps / (float)A + (1.0f - pp.eps) * pg;
-}
-
 // QSigma::handle on one transition of learner i (W row stride = c.w_stride, learner offset wi).  Returns the one-step residual
 // pushed into the backup (the quantity the reference computes per transition); the weight update, when the backup is full,
 // happens at the ANCHOR.  Model M = FourierModel<DOMAIN, ORDER>.

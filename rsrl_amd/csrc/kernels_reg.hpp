@@ -309,6 +309,49 @@ struct QCarry {
     }
 };
 
+// argmaxima with its running maximum (utils.rs:6-21: the tolerance test comes first, the maximum is not raised by near-ties)
+template <int A>
+__device__ __forceinline__ uint32_t argmaxima_mask_max(const float (&q)[A], float& mx_out) {
+    float mx = -FLT_MAX; uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const float d = fabsf(q[i] - mx);
+        if (d < 1e-7f) mask |= (1u << i);
+        else if (q[i] > mx) { mx = q[i]; mask = (1u << i); }
+    }
+    mx_out = mx;
+    return mask;
+}
+// Function<(S, A)> of the four policies: greedy.rs:46-60, epsilon_greedy.rs:49-63, softmax.rs:84-92, random.rs:28-32
+template <int A>
+__device__ __forceinline__ float policy_eval_sa(const PolicyParams& pp, const float (&q)[A], int a) {
+    if (pp.kind == POL_SOFTMAX) return select_a<A>(q, a);
+    if (pp.kind == POL_RANDOM) return 1.0f / (float)A;
+    float mx;
+    const uint32_t mask = argmaxima_mask_max<A>(q, mx);
+    const float pg = ((mask >> a) & 1u) ? 1.0f / (float)max(1, __popc(mask)) : 0.0f;
+    if (pp.kind == POL_GREEDY) return pg;
+    return pp.eps / (float)A + (1.0f - pp.eps) * pg;
+}
+
+// Enumerable::find_min: fold `if acc.1 < x {acc} else {(i,x)}` => the minimum, ties go to the LAST index   core.rs:86-94
+template <int A>
+__device__ __forceinline__ int find_min(const float (&q)[A], float& val) {
+    int bi = 0; float bv = q[0];
+#pragma unroll
+    for (int i = 1; i < A; ++i) { if (!(bv < q[i])) { bi = i; bv = q[i]; } }
+    val = bv;
+    return bi;
+}
+// Enumerable::expected_value: zip(values, ps).fold(0.0, |acc, (x, p)| acc + x * p)                        core.rs:107-116
+template <int A>
+__device__ __forceinline__ float expected_value(const float (&q)[A], const float (&p)[A]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < A; ++i) acc = acc + q[i] * p[i];
+    return acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // The fused driver loop  (examples/q_learning.rs:40-52, order of operations SURVEY A.7)
 //   per step:  t = env.transition(a)            lib.rs:436-446

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(kBlock) void k_wave_reset(Common c, const WT* __res
 
 template <int DOMAIN, class WT>
 __global__ __launch_bounds__(kBlock) void k_wave_qop(Common c, const WT* __restrict__ Wbase, int op, const float* __restrict__ states,
-                                                     int64_t Mn, uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
+                                                     int64_t Mn, uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout,
+                                                     const float* __restrict__ fin, const int32_t* __restrict__ iin) {
     using WF = WaveFourier<DOMAIN>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
     const int lane = threadIdx.x & 63;
@@ -442,24 +443,13 @@ __global__ __launch_bounds__(kBlock) void k_wave_qop(Common c, const WT* __restr
     float q[A];
     WF::template q_from_mem<WT>(Wbase + i * (int64_t)(A * F), lane, phi, q);
     if (lane != 0 && op != QOP_SAMPLE) return;
-    if (op == QOP_EVALUATE) {
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
-    } else if (op == QOP_FIND_MAX) {
-        float v; const int bi = find_max<A>(q, v);
-        if (iout) iout[i] = bi;
-        if (fout) fout[i] = v;
-    } else if (op == QOP_SAMPLE) {
+    if (op == QOP_SAMPLE) {                 // (the softmax path may spread its exponentials over lanes: every lane evaluates)
         const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
         const int a = policy_sample<A>(c.pol, q, x);
         if (lane == 0) iout[i] = a;
-    } else if (op == QOP_MODE) {
-        iout[i] = policy_mode<A>(c.pol, q);
-    } else {
-        float p[A]; policy_probs<A>(c.pol, q, p);
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
+        return;
     }
+    qop_finish<A>(c, op, q, Mn, i, call, fout, iout, fin, iin);
 }
 
 template <int DOMAIN, class WT>
@@ -511,15 +501,19 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
 
 template <int DOMAIN, class WT>
 __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __restrict__ Wbase, int64_t step_limit,
-                                                         uint32_t* __restrict__ n_states, float* __restrict__ total_reward) {
+                                                         uint32_t* __restrict__ n_states, float* __restrict__ total_reward, int64_t Mn, TrajOut tr) {
     using WF = WaveFourier<DOMAIN>; using Dom = Domain<DOMAIN>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (i >= c.n_envs) return;
+    if (i >= Mn) return;
     float w[A][8][8];
     WF::template load_w<WT>(Wbase + i * (int64_t)(A * F), lane, w);
     float s[D]; Dom::reset(s);
+    if (tr.states && lane == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tr.states[(int64_t)d * tr.Mn + i] = s[d];
+    }
     float phi[8][8], q[A], r, tot = 0.0f;
     WF::project(s, lane, phi);
 #pragma unroll
@@ -528,6 +522,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __r
     bool term = Dom::step(s, a, r);
     int64_t steps = 0;
     while (steps < step_limit - 1) {
+        if (lane == 0) traj_record<D>(tr, i, steps, s, a, r);
         steps += 1; tot += r;
         if (term) break;
         if (steps >= step_limit - 1) break;
@@ -540,6 +535,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __r
     if (lane == 0) {
         n_states[i] = (uint32_t)(steps + 1);
         if (total_reward) total_reward[i] = tot;
+        if (tr.terminal) tr.terminal[i] = (steps > 0 && term) ? 1 : 0;
     }
 }
 

@@ -356,13 +356,48 @@ __global__ __launch_bounds__(kBlock) void k_reset(Common c, BasisGeom g, uint64_
     c.ep_step[i] = 0;
 }
 
-enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4, QOP_FEATURES = 5 };
+enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4, QOP_FEATURES = 5,
+              QOP_FIND_MIN = 6,      // Enumerable::find_min                                   core.rs:86-94
+              QOP_EXPECTED = 7,      // Enumerable::expected_value(ps), ps = fin f32[A][M]     core.rs:107-116
+              QOP_PROB_SA = 8 };     // Function<(S, A)> of the policy, a = iin i32[M]         greedy.rs:46-60, epsilon_greedy.rs:49-63,
+                                     //                                                        softmax.rs:84-92 (the raw action value), random.rs:28-32
+// the tail every family's qop kernel shares: q -> the requested output of learner i
+template <int A>
+__device__ __forceinline__ void qop_finish(const Common& c, int op, const float (&q)[A], int64_t Mn, int64_t i, uint64_t call,
+                                           float* __restrict__ fout, int32_t* __restrict__ iout, const float* __restrict__ fin,
+                                           const int32_t* __restrict__ iin) {
+    if (op == QOP_EVALUATE) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
+    } else if (op == QOP_FIND_MAX || op == QOP_FIND_MIN) {
+        float v; const int bi = op == QOP_FIND_MAX ? find_max<A>(q, v) : find_min<A>(q, v);
+        if (iout) iout[i] = bi;
+        if (fout) fout[i] = v;
+    } else if (op == QOP_SAMPLE) {
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+        iout[i] = policy_sample<A>(c.pol, q, x);
+    } else if (op == QOP_MODE) {
+        iout[i] = policy_mode<A>(c.pol, q);
+    } else if (op == QOP_EXPECTED) {
+        float p[A];
+#pragma unroll
+        for (int b = 0; b < A; ++b) p[b] = fin[(int64_t)b * Mn + i];
+        fout[i] = expected_value<A>(q, p);
+    } else if (op == QOP_PROB_SA) {
+        fout[i] = policy_eval_sa<A>(c.pol, q, clamp_action<A>(iin[i]));
+    } else {
+        float p[A]; policy_probs<A>(c.pol, q, p);
+#pragma unroll
+        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
+    }
+}
 
 // Function<(S,)>::evaluate / Enumerable::find_max / Policy::{sample,mode} / policy probabilities / basis.project
 //   fa/linear.rs:303-311, core.rs:96-105, policies/mod.rs:65-78
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_qop(Common c, BasisGeom g, int op, const float* __restrict__ states, int64_t Mn,
-                                                uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout) {
+                                                uint64_t call, float* __restrict__ fout, int32_t* __restrict__ iout,
+                                                const float* __restrict__ fin, const int32_t* __restrict__ iin) {
     constexpr int D = M::D, A = M::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Mn) return;
@@ -372,23 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_qop(Common c, BasisGeom g, int op, c
     if (op == QOP_FEATURES) { M::write_features(g, ft, Mn, i, fout, iout); return; }
     float q[A];
     M::q_all(c, c.shared ? 0 : i, g, ft, q);
-    if (op == QOP_EVALUATE) {
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
-    } else if (op == QOP_FIND_MAX) {
-        float v; const int bi = find_max<A>(q, v);
-        if (iout) iout[i] = bi;
-        if (fout) fout[i] = v;
-    } else if (op == QOP_SAMPLE) {
-        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
-        iout[i] = policy_sample<A>(c.pol, q, x);
-    } else if (op == QOP_MODE) {
-        iout[i] = policy_mode<A>(c.pol, q);
-    } else {
-        float p[A]; policy_probs<A>(c.pol, q, p);
-#pragma unroll
-        for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
-    }
+    qop_finish<A>(c, op, q, Mn, i, call, fout, iout, fin, iin);
 }
 
 // Handler<&Transition>::handle on caller-supplied transitions (teacher forcing / drop-in use).
@@ -434,20 +453,39 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
 }
 
 // Domain::rollout(|s| policy.mode(s), Some(limit)) + n_states, weights read from memory      lib.rs:448-479, :340
+// The Trajectory itself (lib.rs:334-409) when the caller asks for it: tr.states f32[step_limit][D][Mn] -- row 0 = `start`, row k =
+// the observation of steps[k-1] --, tr.actions i32[step_limit-1][Mn] and tr.rewards f32[step_limit-1][Mn] = steps[k].1 / .2,
+// tr.terminal u8[Mn] = the last observation is Observation::Terminal.  Rows past n_states are left untouched.
+struct TrajOut { float* states; int32_t* actions; float* rewards; uint8_t* terminal; int64_t Mn; };
+template <int D>
+__device__ __forceinline__ void traj_record(const TrajOut& tr, int64_t i, int64_t k, const float (&s)[D], int a, float r) {
+    // transition k (0-based): the observation it arrived at is state row k+1
+    if (tr.states) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tr.states[((k + 1) * D + d) * tr.Mn + i] = s[d];
+    }
+    if (tr.actions) tr.actions[k * tr.Mn + i] = a;
+    if (tr.rewards) tr.rewards[k * tr.Mn + i] = r;
+}
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64_t step_limit, uint32_t* __restrict__ n_states,
-                                                    float* __restrict__ total_reward) {
+                                                    float* __restrict__ total_reward, int64_t Mn, TrajOut tr) {
     constexpr int D = M::D, A = M::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c.n_envs) return;
+    if (i >= Mn) return;
     const int64_t wi = c.shared ? 0 : i;
     float s[D]; M::Dom::reset(s);
+    if (tr.states) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) tr.states[(int64_t)d * tr.Mn + i] = s[d];
+    }
     typename M::Feat ft; float q[A], r, tot = 0.0f;
     M::features(s, g, ft); M::q_all(c, wi, g, ft, q);
     int a = policy_mode<A>(c.pol, q);
     bool term = M::Dom::step(s, a, r);               // the first step is taken eagerly (lib.rs:457-459)
     int64_t steps = 0;
     while (steps < step_limit - 1) {
+        traj_record<D>(tr, i, steps, s, a, r);
         steps += 1; tot += r;
         if (term) break;                             // successors() stops after a Terminal observation
         if (steps >= step_limit - 1) break;
@@ -457,6 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64
     }
     n_states[i] = (uint32_t)(steps + 1);
     if (total_reward) total_reward[i] = tot;
+    if (tr.terminal) tr.terminal[i] = (steps > 0 && term) ? 1 : 0;     // (step_limit = 1: no transition is kept)
 }
 
 // ---------------------------------------------------------------------------------------

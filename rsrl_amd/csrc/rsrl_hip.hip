@@ -821,6 +821,7 @@ int rsrl_hip_n_outputs(const rsrl_hip_ctx* c) { return c ? c->Aw : RSRL_HIP_EINV
 int rsrl_hip_n_features(const rsrl_hip_ctx* c) { return c ? c->F : RSRL_HIP_EINVAL; }
 int64_t rsrl_hip_n_envs(const rsrl_hip_ctx* c) { return c ? c->cfg.n_envs : RSRL_HIP_EINVAL; }
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* c) { return c ? c->t + (uint64_t)c->pending : 0; }
+int64_t rsrl_hip_pending_steps(const rsrl_hip_ctx* c) { return c ? c->pending : 0; }
 
 int rsrl_hip_state_bounds(const rsrl_hip_ctx* c, double* lo, double* hi) {
     CHECK_CTX(c);
@@ -846,6 +847,9 @@ int rsrl_hip_reset(rsrl_hip_ctx* c) {
     CHECK_CTX(c); FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    // QSigma: fresh episodes start from an empty n-step backup (as after a terminal transition, q_sigma.rs:154) -- entries of the
+    // abandoned trajectories must not be mixed into the first anchor updates of the new ones
+    if (c->qs_len) HIP_TRY(hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
     if (is_pred(c->cfg.algo)) {
@@ -868,7 +872,7 @@ int rsrl_hip_get_states(rsrl_hip_ctx* c, float* states) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(states, c->state, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return RSRL_HIP_OK;
+    return peer_check(c);
 }
 int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
     CHECK_CTX(c); FLUSH(c);
@@ -944,7 +948,7 @@ int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
 }
 
 static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* fout, size_t fcount, int32_t* iout,
-               size_t icount = 0) {
+               size_t icount = 0, const float* fin = nullptr, size_t fin_count = 0, const int32_t* iin = nullptr) {
     CHECK_CTX(c); FLUSH(c);
     if (!states || M_ < 1 || M_ > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M_, (long long)c->cfg.n_envs);
     if (is_pred(c->cfg.algo) && op != QOP_EVALUATE && op != QOP_FEATURES)
@@ -954,6 +958,10 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     TRY(stage_in(c, 0, states, (size_t)c->D * M_, &d_states));
     TRY(stage_out(c, 1, fout, fcount, &of));
     TRY(stage_out(c, 2, iout, icount ? icount : (size_t)M_, &oi));
+    const float* d_fin = nullptr; const int32_t* d_iin = nullptr;
+    if (iin) TRY(check_host_actions(iin, (size_t)M_, c->A));
+    TRY(stage_in(c, 3, fin, fin_count, &d_fin));
+    TRY(stage_in(c, 4, iin, (size_t)M_, &d_iin));
     const Common k = make_common(c);
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
@@ -963,19 +971,31 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     } else if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
-            hipLaunchKernelGGL((k_wave_qop<T::domain, WT>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, op, d_states, M_, call, of.dev, oi.dev);
+            hipLaunchKernelGGL((k_wave_qop<T::domain, WT>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, op, d_states, M_, call, of.dev, oi.dev,
+                               d_fin, d_iin);
         });
     } else if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_qop<M>), dim3(grid_for(M_)), dim3(kBlock), 0, c->stream, k, g, op, d_states, M_, call, of.dev, oi.dev);
+            hipLaunchKernelGGL((k_qop<M>), dim3(grid_for(M_)), dim3(kBlock), 0, c->stream, k, g, op, d_states, M_, call, of.dev, oi.dev, d_fin, d_iin);
         })) return NO_MODEL(c);
     KCHECK();
-    bool sync = !is_device_ptr(states);
+    bool sync = !is_device_ptr(states) || (fin && !is_device_ptr(fin)) || (iin && !is_device_ptr(iin));
     TRY(flush_out(c, &of, &sync)); TRY(flush_out(c, &oi, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 
+int rsrl_hip_q_find_min(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* idx_out, float* val_out) {
+    return qop(c, QOP_FIND_MIN, states, M, val_out, (size_t)M, idx_out);
+}
+int rsrl_hip_q_expected_value(rsrl_hip_ctx* c, const float* states, int64_t M, const float* probs, float* out) {
+    if (!probs || !out) return fail(RSRL_HIP_EINVAL, "null argument");
+    return qop(c, QOP_EXPECTED, states, M, out, (size_t)M, nullptr, 0, probs, c ? (size_t)c->A * M : 0);
+}
+int rsrl_hip_policy_prob(rsrl_hip_ctx* c, const float* states, const int32_t* actions, int64_t M, float* prob_out) {
+    if (!actions || !prob_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    return qop(c, QOP_PROB_SA, states, M, prob_out, (size_t)M, nullptr, 0, nullptr, 0, actions);
+}
 int rsrl_hip_q_evaluate(rsrl_hip_ctx* c, const float* states, int64_t M, float* q_out) {
     if (!q_out) return fail(RSRL_HIP_EINVAL, "null argument");
     return qop(c, QOP_EVALUATE, states, M, q_out, c ? (size_t)c->Aw * M : 0, nullptr);
@@ -1086,7 +1106,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, (shared ? 0 : env_index) * c->w_ls, c->F, c->Aw, ow.dev);
     KCHECK();
     bool sync = false; TRY(flush_out(c, &ow, &sync));
-    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sync) { HIP_TRY(hipStreamSynchronize(c->stream)); return peer_check(c); }      // a failed exchange must not pass for weights
     return RSRL_HIP_OK;
 }
 int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
@@ -1159,13 +1179,15 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) 
 // ---- checkpoint: header + every learner's weights in the reference (F, A) order -----------------------------------
 // The header is serialised FIELD BY FIELD (little-endian, no implicit padding); layout in include/rsrl_hip.h.
 namespace {
-constexpr uint32_t kCkptVersion = 2;
+constexpr uint32_t kCkptVersion = 3;          // files carrying aux_kind 3 (QSigma's n-step backups); every other file is still written as version 2
 constexpr size_t kCkptHeaderBytes = 72;
 struct Ckpt {
     int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A, algo, weight_dtype, aux_kind;
     int64_t n_learners; uint64_t step_count;
 };
-int aux_kind_of(const rsrl_hip_ctx* c) { return !c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1); }   // 1 = eligibility traces, 2 = fa_td weights
+// 1 = eligibility traces, 2 = fa_td weights (both: a second matrix of W's shape), 3 = QSigma's per-learner n-step backups
+int aux_kind_of(const rsrl_hip_ctx* c) { return c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1)); }
+size_t qs_floats(const rsrl_hip_ctx* c) { return (size_t)(c->D + 5) * (size_t)c->cfg.n_steps * (size_t)c->cfg.n_envs; }
 Ckpt ckpt_of(const rsrl_hip_ctx* c) {
     Ckpt h{};
     h.domain = c->cfg.domain; h.basis = c->cfg.basis; h.order = c->cfg.order; h.n_tilings = c->cfg.n_tilings;
@@ -1181,7 +1203,7 @@ uint64_t get64(const uint8_t*& p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) 
 void ckpt_encode(const Ckpt& h, uint8_t (&buf)[kCkptHeaderBytes]) {
     uint8_t* p = buf;
     memcpy(p, "RSRLHIPW", 8); p += 8;
-    put32(p, kCkptVersion);
+    put32(p, h.aux_kind == 3 ? kCkptVersion : 2u);
     const int32_t f[11] = {h.domain, h.basis, h.order, h.n_tilings, h.tiles_per_dim, h.weight_mode, h.F, h.A, h.algo, h.weight_dtype, h.aux_kind};
     for (int32_t v : f) put32(p, (uint32_t)v);
     put64(p, (uint64_t)h.n_learners); put64(p, h.step_count);
@@ -1208,11 +1230,21 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
     int rc = RSRL_HIP_OK;
     if (fwrite(hdr, 1, sizeof(hdr), f) != sizeof(hdr)) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
     std::vector<float> w((size_t)c->F * c->Aw);
-    for (int pass = 0; pass < (h.aux_kind ? 2 : 1); ++pass)            // every learner's weights, then every learner's auxiliary matrix
+    for (int pass = 0; pass < ((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1); ++pass)            // every learner's weights, then every learner's auxiliary matrix
         for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
             rc = pass == 0 ? rsrl_hip_get_weights(c, i, w.data()) : traces_rw(c, i, w.data(), nullptr);
             if (rc == RSRL_HIP_OK && fwrite(w.data(), sizeof(float), w.size(), f) != w.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
         }
+    if (rc == RSRL_HIP_OK && h.aux_kind == 3) {                        // QSigma: ring heads, lengths, entries (SoA [field][slot][learner])
+        const size_t N = (size_t)c->cfg.n_envs, nf = qs_floats(c);
+        std::vector<uint32_t> hl(2 * N); std::vector<float> buf(nf);
+        hipError_t e = hipMemcpyAsync(hl.data(), c->qs_head, 4 * N, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(hl.data() + N, c->qs_len, 4 * N, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(buf.data(), c->qs_buf, 4 * nf, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the QSigma backups: %s", hipGetErrorString(e));
+        else if (fwrite(hl.data(), 4, 2 * N, f) != 2 * N || fwrite(buf.data(), 4, nf, f) != nf) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+    }
     if (fclose(f) != 0 && rc == RSRL_HIP_OK) rc = fail(RSRL_HIP_EINVAL, "closing %s failed", path);
     return rc;
 }
@@ -1226,14 +1258,15 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     Ckpt h{}; uint32_t version = 0; uint8_t hdr[kCkptHeaderBytes];
     int rc = RSRL_HIP_OK;
     if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || !ckpt_decode(hdr, &h, &version)) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
-    else if (version != kCkptVersion) rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads version %u", path, version, kCkptVersion);
+    else if (version != kCkptVersion && version != 2u) rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2 and %u", path, version, kCkptVersion);
     else if (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
              h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
              h.algo != want.algo || h.weight_dtype != want.weight_dtype || h.aux_kind != want.aux_kind || h.n_learners != want.n_learners)
         rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration", path);
     const size_t per = (size_t)c->F * c->Aw;
     if (rc == RSRL_HIP_OK) {                                             // a truncated file is refused before anything is touched
-        const long long expect = (long long)kCkptHeaderBytes + (long long)(h.aux_kind ? 2 : 1) * h.n_learners * (long long)per * 4;
+        const long long expect = (long long)kCkptHeaderBytes + (long long)((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1) * h.n_learners * (long long)per * 4 +
+                                 (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0);
         if (fseek(f, 0, SEEK_END) != 0 || ftell(f) != expect || fseek(f, (long)kCkptHeaderBytes, SEEK_SET) != 0)
             rc = fail(RSRL_HIP_EINVAL, "%s is truncated or has trailing bytes (expected %lld bytes)", path, expect);
     }
@@ -1253,13 +1286,29 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     }
     c->W = W_new; c->Z = Z_new;
     std::vector<float> w(per);
-    for (int pass = 0; pass < (h.aux_kind ? 2 : 1); ++pass)
+    for (int pass = 0; pass < ((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1); ++pass)
         for (int64_t i = 0; rc == RSRL_HIP_OK && i < h.n_learners; ++i) {
             if (fread(w.data(), sizeof(float), per, f) != per) { rc = fail(RSRL_HIP_EINVAL, "%s: read error", path); break; }
             rc = pass == 0 ? rsrl_hip_set_weights(c, i, w.data()) : traces_rw(c, i, nullptr, w.data());
         }
+    std::vector<uint32_t> hl; std::vector<float> ring;
+    if (rc == RSRL_HIP_OK && h.aux_kind == 3) {                        // read first, install only when everything has been read
+        const size_t N = (size_t)c->cfg.n_envs, nf = qs_floats(c);
+        hl.resize(2 * N); ring.resize(nf);
+        if (fread(hl.data(), 4, 2 * N, f) != 2 * N || fread(ring.data(), 4, nf, f) != nf) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
+        for (size_t i = 0; rc == RSRL_HIP_OK && i < N; ++i)
+            if (hl[i] >= (uint32_t)c->cfg.n_steps || hl[N + i] > (uint32_t)c->cfg.n_steps) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt QSigma backup of learner %zu", path, i);
+    }
     fclose(f);
     (void)hipStreamSynchronize(c->stream);
+    if (rc == RSRL_HIP_OK && h.aux_kind == 3) {
+        const size_t N = (size_t)c->cfg.n_envs;
+        hipError_t e2 = hipMemcpyAsync(c->qs_head, hl.data(), 4 * N, hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(c->qs_len, hl.data() + N, 4 * N, hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(c->qs_buf, ring.data(), 4 * ring.size(), hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the QSigma backups: %s", hipGetErrorString(e2));
+    }
     if (rc == RSRL_HIP_OK) {
         (void)hipFree(W_old); if (Z_old) (void)hipFree(Z_old);
         c->t = h.step_count; c->q_valid = false;
@@ -1684,8 +1733,10 @@ static int flush_pending(rsrl_hip_ctx* c) {
 }
 // fused register-family loop: any split of n batch-steps into launches gives bit-identical results (Q(s,.) is carried between
 // launches, the RNG is addressed by the batch-step) -- the property launch coalescing relies on (tests: fused == stepwise)
+// Only on a ctx-OWNED stream: a caller who supplied config.stream orders its own work on it (hipStreamSynchronize, events, a
+// capture in progress -- which hipStreamQuery would invalidate); everything train() accepted must be on that stream when it returns.
 static bool coalescable(const rsrl_hip_ctx* c) {
-    return register_family_fused(c) && c->cfg.steps_per_launch != 1 && !getenv("RSRL_NO_COALESCE");
+    return c->own_stream && register_family_fused(c) && c->cfg.steps_per_launch != 1 && !getenv("RSRL_NO_COALESCE");
 }
 // rsrl_hip_train is asynchronous when no statistics are requested: it returns once the work is accepted.  A short call (the
 // 20 batch-steps of a driver loop) costs a full load + store of every learner's weights around ~20 us of arithmetic, so calls
@@ -1715,32 +1766,53 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
     return RSRL_HIP_OK;
 }
 
-int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
+static int rollout_impl(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out, float* states_out,
+                        int32_t* actions_out, float* rewards_out, uint8_t* terminal_out) {
     CHECK_CTX(c); FLUSH(c);
     if (!n_states_out) return fail(RSRL_HIP_EINVAL, "null argument");
     if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1 (unbounded rollouts are not offered)");
+    if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M, (long long)c->cfg.n_envs);
     if (c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    const int64_t N = c->cfg.n_envs;
-    OutBuf<uint32_t> on; OutBuf<float> ot;
-    TRY(stage_out(c, 0, n_states_out, (size_t)N, &on));
-    TRY(stage_out(c, 1, total_reward_out, (size_t)N, &ot));
+    if (step_limit == 1) { actions_out = nullptr; rewards_out = nullptr; }      // Trajectory.steps is empty
+    OutBuf<uint32_t> on; OutBuf<float> ot, os, orw; OutBuf<int32_t> oa; OutBuf<uint8_t> otm;
+    const size_t tr_rows = (size_t)(step_limit - 1) * (size_t)M;
+    TRY(stage_out(c, 0, n_states_out, (size_t)M, &on));
+    TRY(stage_out(c, 1, total_reward_out, (size_t)M, &ot));
+    TRY(stage_out(c, 2, states_out, (size_t)step_limit * c->D * (size_t)M, &os));
+    TRY(stage_out(c, 3, actions_out, tr_rows, &oa));
+    TRY(stage_out(c, 4, rewards_out, tr_rows, &orw));
+    TRY(stage_out(c, 5, terminal_out, (size_t)M, &otm));
+    // rows past a trajectory's end stay as the caller left them in device memory; staged host outputs start from zero
+    if (os.staged) HIP_TRY(hipMemsetAsync(os.dev, 0, sizeof(float) * os.count, c->stream));
+    if (oa.staged) HIP_TRY(hipMemsetAsync(oa.dev, 0, sizeof(int32_t) * oa.count, c->stream));
+    if (orw.staged) HIP_TRY(hipMemsetAsync(orw.dev, 0, sizeof(float) * orw.count, c->stream));
+    const TrajOut tr{os.dev, oa.dev, orw.dev, otm.dev, M};
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
-            hipLaunchKernelGGL((k_wave_rollout<T::domain, WT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, step_limit, on.dev, ot.dev);
+            hipLaunchKernelGGL((k_wave_rollout<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, step_limit, on.dev, ot.dev, M, tr);
         });
     } else if (!for_model(c, [&](auto tag) {
-            using M = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_rollout<M>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev);
+            using Mo = typename decltype(tag)::type;
+            hipLaunchKernelGGL((k_rollout<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev, M, tr);
         })) return NO_MODEL(c);
     KCHECK();
     bool sync = false;
-    TRY(flush_out(c, &on, &sync)); TRY(flush_out(c, &ot, &sync));
+    TRY(flush_out(c, &on, &sync)); TRY(flush_out(c, &ot, &sync)); TRY(flush_out(c, &os, &sync));
+    TRY(flush_out(c, &oa, &sync)); TRY(flush_out(c, &orw, &sync)); TRY(flush_out(c, &otm, &sync));
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
+}
+int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
+    CHECK_CTX(c);
+    return rollout_impl(c, step_limit, c->cfg.n_envs, n_states_out, total_reward_out, nullptr, nullptr, nullptr, nullptr);
+}
+int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out,
+                                float* states_out, int32_t* actions_out, float* rewards_out, uint8_t* terminal_out) {
+    return rollout_impl(c, step_limit, M, n_states_out, total_reward_out, states_out, actions_out, rewards_out, terminal_out);
 }
 
 int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
@@ -1768,7 +1840,7 @@ int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
     HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     out[0] = h[0]; out[1] = h[1];
-    return RSRL_HIP_OK;
+    return peer_check(c);
 }
 
 int rsrl_hip_comm_unique_id(uint8_t* id_bytes) {
@@ -1791,6 +1863,17 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
     if (c->cfg.exchange != RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
     NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
     c->world_size = world_size; c->rank = rank; c->multi = true;
+    return RSRL_HIP_OK;
+}
+
+int rsrl_hip_comm_info(rsrl_hip_ctx* c, int* world_size, int* rank, int* exchange) {
+    CHECK_CTX(c);
+    int w = 1, r = 0;
+    if (c->comm) { NCCL_TRY(ncclCommCount(c->comm, &w)); NCCL_TRY(ncclCommUserRank(c->comm, &r)); }       // what RCCL itself reports
+    else if (c->multi) { w = c->world_size; r = c->rank; }
+    if (world_size) *world_size = w;
+    if (rank) *rank = r;
+    if (exchange) *exchange = !c->multi ? -1 : c->cfg.exchange;
     return RSRL_HIP_OK;
 }
 
@@ -1870,6 +1953,52 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
         if (c->px_A) { HIP_TRY(hipFree(c->px_A)); c->px_A = nullptr; }
     }
     c->world_size = world_size; c->rank = rank; c->multi = true;
+    return RSRL_HIP_OK;
+}
+
+// ---- single-process group: every rank is a ctx of THIS process (SURVEY 8b last row; the reference's owner graph is single-threaded,
+// rsrl/src/core.rs:13-15, so a Rust host cannot run one blocking ncclCommInitRank per ctx).  One call attaches an exchange to all
+// of them, rank = index:
+//   RSRL_EXCHANGE_PEER  export + connect of every ctx (same-process pointers; peer access enabled between the devices)
+//   RSRL_EXCHANGE_RCCL  ncclCommInitAll over the ctxs' devices (distinct devices, RCCL's rule), then one grouped warm-up
+//                       all-reduce so that connection set-up, which needs every rank, does not happen inside the first train()
+// Afterwards a single host thread drives the ranks by calling rsrl_hip_train on each ctx in turn: the calls only enqueue.
+int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1 || n > 64) return fail(RSRL_HIP_EINVAL, "bad group arguments");
+    for (int i = 0; i < n; ++i) {
+        rsrl_hip_ctx* c = ctxs[i];
+        if (!c) return fail(RSRL_HIP_EINVAL, "null ctx in the group");
+        for (int j = 0; j < i; ++j) if (ctxs[j] == c) return fail(RSRL_HIP_EINVAL, "ctx %d appears twice in the group", i);
+        FLUSH(c);
+        if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no exchange: shard by env_offset instead");
+        if (c->multi || c->comm || c->peer_recv) return fail(RSRL_HIP_ESTATE, "ctx %d already has an exchange attached", i);
+        if (c->cfg.exchange != ctxs[0]->cfg.exchange || c->dw_elems != ctxs[0]->dw_elems || c->cfg.basis != ctxs[0]->cfg.basis)
+            return fail(RSRL_HIP_EINVAL, "the ctxs of a group must share the approximator's shape and the exchange kind");
+    }
+    if (ctxs[0]->cfg.exchange == RSRL_EXCHANGE_PEER) {
+        std::vector<uint8_t> handles((size_t)n * RSRL_HIP_PEER_HANDLE_BYTES);
+        for (int i = 0; i < n; ++i) TRY(rsrl_hip_peer_export(ctxs[i], n, handles.data() + (size_t)i * RSRL_HIP_PEER_HANDLE_BYTES));
+        for (int i = 0; i < n; ++i) TRY(rsrl_hip_peer_connect(ctxs[i], handles.data(), n, i));
+        return RSRL_HIP_OK;
+    }
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        devs[(size_t)i] = ctxs[i]->cfg.device;
+        for (int j = 0; j < i; ++j)
+            if (devs[(size_t)j] == devs[(size_t)i]) return fail(RSRL_HIP_EINVAL, "RCCL needs one device per rank: ctxs %d and %d share device %d (use RSRL_EXCHANGE_PEER)", j, i, devs[(size_t)i]);
+    }
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    NCCL_TRY(ncclCommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[(size_t)i]; ctxs[i]->world_size = n; ctxs[i]->rank = i; ctxs[i]->multi = true; }
+    // warm-up: dW is zero between operations, so the grouped all-reduce leaves it zero
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        rsrl_hip_ctx* c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->cfg.device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
     return RSRL_HIP_OK;
 }
 
