@@ -12,12 +12,18 @@ N > 1 without a launcher (WORLD_SIZE unset): bench.py starts the N ranks itself 
 GPU, rendezvous on 127.0.0.1).  Under a launcher it is one of the ranks.  Envs are sharded by global id with NO
 data-path collective (independent learners) => weak scaling.
 
-Timed region: a K-step call is short (K = 20 is ~20 us of arithmetic), so the call is repeated R times back to back
-between ONE pair of barrier + synchronize (R is chosen so that the region lasts >= ~0.3 s and is reported in
-config.repeats); ms_per_step = region / (K * R), value = all ranks' env-steps / max-over-ranks region time.
-rsrl_hip_train is asynchronous and coalesces calls that arrive while the stream is busy (same results bit for bit,
-include/rsrl_hip.h): the R x K batch-steps run as launches of up to 1024 steps -- config.steps_per_launch and
-roofline.launches report what was actually launched; RSRL_NO_COALESCE=1 gives one launch per call.
+Timed regions (warm-up, >= 2 000 batch-steps, median of 5): a K-step call is short (K = 20 is ~15 us of
+arithmetic), so the call is repeated R times back to back between ONE pair of barrier + synchronize (R is chosen so that a
+region lasts >= ~1 s; config.repeats); the region is measured FIVE times and `value` / `ms_per_step` are the MEDIAN region
+(all ranks' env-steps / max-over-ranks region time); `regions_s` and `spread` carry all five.  rsrl_hip_train is asynchronous
+and, on its own stream, coalesces calls that arrive while the stream is busy (same results bit for bit, include/rsrl_hip.h):
+the R x K batch-steps run as launches of up to 1024 steps -- config.steps_per_launch and roofline.launches report what was
+actually launched, and `value_no_coalesce` is the same K-step driver call with one launch per call (RSRL_NO_COALESCE=1).
+
+roofline.frac is a fraction of a PUBLISHED peak (MI355X_MICROARCH.md): the fused kernel keeps W in the register file, so its
+bound is the fp32 vector unit -- frac = flop per env-step (profiles/isa_mix.json, from rocprofv3 instruction-class counters) x
+measured kernel rate / 157.3 TFLOP/s; `issue_slots` prices the same instruction mix at the guide's issue rates (2 cycles per
+plain VALU, 4 per packed); the micro-benchmarked ceiling of round 2 survives as a clearly named secondary field.
 """
 import argparse
 import json
@@ -39,7 +45,9 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs, max clock
 # HBM bytes one launch of the fused kernel must move per learner, whatever its depth: W in + W out (2 x 432), state in/out
 # (2 x 8), action in/out (2 x 4), episode counter in/out (2 x 4), carried Q in/out (2 x 12)
 FUSED_BYTES_PER_LEARNER_LAUNCH = 2 * (432 + 8 + 4 + 4 + 12)
-TARGET_REGION_S = 0.3
+TARGET_REGION_S = 1.0               # per timed region; the region is measured N_REGIONS times, `value` is the median
+N_REGIONS = 5
+SPEC_CYCLES = {"pk": 4.0, "other": 2.0}   # MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32; a packed fp32 op = two of them
 
 
 def usable_cores():
@@ -191,14 +199,18 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
                                    algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.9,
                                    lr=0.001 / (envs_per_gpu * cp.world), weight_mode=rsrl_amd.W_SHARED, seed=0,
                                    max_episode_steps=1000, exchange=exchange)
+        comm_world, comm_rank, comm_kind = ctx.comm_info()      # what the attached exchange itself reports (ncclCommCount for RCCL)
         ctx.reset()
         ctx.train(warmup, want_stats=False)
         ctx.sync()
         cp.barrier()
+        ctx.timing_enable(True)
         t0 = time.perf_counter()
         ctx.train(steps, want_stats=False)
         ctx.sync()
-        dt = cp.max_over_ranks(time.perf_counter() - t0)
+        dt_own = time.perf_counter() - t0
+        dt = cp.max_over_ranks(dt_own)
+        ms, n_l, kn = ctx.timing_read()
         w = ctx.get_weights()
         import numpy as np
         chk = float(np.abs(w).sum())
@@ -207,30 +219,77 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
         return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step "
                             f"{'peer-write' if exchange else 'RCCL all-reduce'} exchange of the 432 B delta", "ranks": cp.world, "steps": steps,
                 "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
+                "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
+                "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
+                "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
+                "roofline": {"bound": "hbm", "achieved": 32 * envs_per_gpu * steps / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": 32 * envs_per_gpu * steps / dt / HBM_PEAK, "algorithmic_bytes_per_env_step": 32, "traffic": None,
+                             "what": "SURVEY 8(d): 32 B/env-step (state, action, episode counter; W stays on the chip) -- a lower bound that does "
+                                     "not bind: the batch-step is bound by the two fabric hops of the delta all-reduce (~3.2 us of it, "
+                                     "profiles/r03_ubench_granule_allreduce.txt) plus ~700 VALU instructions per learner at two waves per SIMD"},
                 "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
     except Exception as e:                       # never let the secondary leg take the headline down
         return {"error": repr(e)}
 
 
-def valu_roofline(kname, per_gpu_steps_per_s):
-    """The fused kernel is VALU-issue bound (profiles/r0*_pmc_summary.md: W sits in the register file, HBM is idle).  Ceiling =
-    every SIMD issuing this kernel's own instruction mix at the SATURATED per-instruction issue cost measured by
-    scripts/ubench/valu_issue.hip (profiles/r01_ubench_valu_issue.txt, 8 waves/SIMD).  Mix: profiles/isa_mix.json (static
-    count of the steady-state loop body by scripts/isa_stats.py, cross-checked against SQ_INSTS_VALU)."""
+def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
+    """The fused kernel keeps W in the register file (HBM idle, profiles/r0*_pmc*): its bound is the fp32 VECTOR unit.
+    frac = flop per env-step x env-steps/s / 157.3 TFLOP/s (MI355X_MICROARCH.md, peak FP32 vector = the f32 matrix peak); the
+    flop count is the kernel's own executed instruction mix (profiles/isa_mix.json: rocprofv3 SQ_INSTS_VALU_* class counters
+    per env-step -- FMA = 2 flop per lane, packed = two lanes' worth, multiplies by zero of the masked column update included:
+    they are issued).  Secondary: `issue_slots` = the mix priced at the guide's issue rates (2 cycles per VALU instruction on a
+    SIMD-32, 4 per packed fp32 instruction) against 1024 SIMDs x 2.4 GHz; `ubench_ceiling` = round 2's ceiling from this
+    machine's measured saturated issue costs (scripts/ubench/valu_issue.hip), which is NOT a published peak."""
     mix = (_profiles_json("isa_mix.json") or {}).get(kname)
     if not mix:
         return None
-    cost = {"pk": 4.47, "mad_u64": 4.96, "cndmask": 4.13, "other": 2.46}
-    cyc = sum(mix[k] * cost[k] for k in cost)
     pk_fma = mix.get("pk_fma", mix["pk"])
     flop = pk_fma * 4 + (mix["pk"] - pk_fma) * 2 + mix.get("fp_fma", 0) * 2 + mix.get("fp_other", 0)
-    peak = N_SIMD * 64 * CLOCK_HZ / cyc
-    return {"bound": "valu", "achieved": per_gpu_steps_per_s, "peak": peak, "unit": "env-steps/s per GPU", "frac": per_gpu_steps_per_s / peak,
-            "valu_instr_per_env_step": sum(mix[k] for k in cost), "saturated_issue_cycles_per_env_step": cyc,
-            "fp32": {"flop_per_env_step": flop, "achieved_tflops": flop * per_gpu_steps_per_s / 1e12, "peak_tflops": FP32_VECTOR_PEAK / 1e12,
-                     "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK},
-            "source": "profiles/isa_mix.json (instruction mix of the loop body), profiles/r01_ubench_valu_issue.txt (issue cycles per "
-                      "instruction class at 8 waves/SIMD); peak = 1024 SIMDs x 64 lanes x 2.4 GHz / cycles per env-step"}
+    n_valu = mix["pk"] + mix["mad_u64"] + mix["cndmask"] + mix["other"]
+    spec_cyc = mix["pk"] * SPEC_CYCLES["pk"] + (n_valu - mix["pk"]) * SPEC_CYCLES["other"]
+    spec_peak = N_SIMD * 64 * CLOCK_HZ / spec_cyc
+    ub = {"pk": 4.47, "mad_u64": 4.96, "cndmask": 4.13, "other": 2.46}
+    ub_cyc = sum(mix[k] * ub[k] for k in ub)
+    ub_peak = N_SIMD * 64 * CLOCK_HZ / ub_cyc
+    tf = flop * per_gpu_steps_per_s / 1e12
+    return {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK,
+            "flop_per_env_step": flop, "env_steps_per_s_per_gpu": per_gpu_steps_per_s,
+            "issue_slots": {"valu_instr_per_env_step": n_valu, "packed": mix["pk"], "cycles_per_env_step_at_spec_rates": spec_cyc,
+                            "peak_env_steps_per_s": spec_peak, "frac": per_gpu_steps_per_s / spec_peak,
+                            "what": "2 cycles per VALU instruction, 4 per packed fp32 instruction (MI355X_MICROARCH.md), 1024 SIMDs x 2.4 GHz"},
+            "ubench_ceiling": {"peak_env_steps_per_s": ub_peak, "frac": per_gpu_steps_per_s / ub_peak,
+                               "what": "NOT a published peak: the same mix at this machine's measured saturated issue costs (8 waves/SIMD: packed 4.47, "
+                                       "mad_u64 4.96, cndmask 4.13, other 2.46 cycles; profiles/r01_ubench_valu_issue.txt)"},
+            "source": "profiles/isa_mix.json (rocprofv3 SQ_INSTS_VALU_* class counters per env-step) x HIP-event kernel rate of this run"}
+
+
+def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extra=None):
+    """Secondary measurement of another BASELINE.json configuration's per-GPU share (a parity-test configuration, never part of
+    `value`): env-steps/s, the dominant kernel's HIP-event time per batch-step, and a roofline object on SURVEY 8(d)'s
+    algorithmic bytes per env-step against the 8 TB/s of MI355X_MICROARCH.md."""
+    try:
+        ctx = rsrl_amd.Context(**kw)
+        ctx.reset()
+        ctx.train(warmup, want_stats=False)
+        ctx.sync()
+        ctx.timing_enable(True)
+        t0 = time.perf_counter()
+        ctx.train(steps, want_stats=False)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ms, n, kn = ctx.timing_read()
+        ctx.close()
+        per_step = ms * 1e-3 / max(1, steps)              # seconds of kernel time per batch-step (all launches of the call / its steps)
+        ach = bytes_per_env_step * kw["n_envs"] / per_step if per_step > 0 else 0.0
+        rec = {"workload": name, "value": kw["n_envs"] * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
+               "roofline": {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                            "algorithmic_bytes_per_env_step": bytes_per_env_step, "kernel_us_per_batch_step": per_step * 1e6,
+                            "traffic": None, "what": what}}
+        if extra:
+            rec["roofline"].update(extra)
+        return rec
+    except Exception as e:
+        return {"workload": name, "error": repr(e)}
 
 
 def spawn_ranks(n):
@@ -250,7 +309,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2560)
     ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--repeats", type=int, default=0, help="back-to-back repetitions of the K-step call inside the timed region (0 = auto: >= 0.25 s)")
+    ap.add_argument("--repeats", type=int, default=0, help="back-to-back repetitions of the K-step call inside one timed region (0 = auto: >= --region-seconds)")
+    ap.add_argument("--regions", type=int, default=N_REGIONS, help="how many times the timed region is measured (value = the median)")
+    ap.add_argument("--region-seconds", type=float, default=TARGET_REGION_S)
+    ap.add_argument("--no-nocoalesce-leg", action="store_true", help="skip the one-launch-per-call measurement")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the secondary C3 / C5 measurements")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="fuse depth (0 = library default)")
     ap.add_argument("--envs", type=int, default=N_ENVS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -290,45 +353,90 @@ def main():
     if args.warmup > 0:
         ctx.train(args.warmup, want_stats=False)
     ctx.sync()
-    # R: how many K-step calls make a >= 0.25 s region (one untimed calibration call; the same R on every rank)
+    # R: how many K-step calls make a >= 1 s region (one untimed calibration burst; the same R on every rank)
     repeats = args.repeats
     if repeats <= 0:
-        burst = 32                                   # back-to-back, as in the timed region (the library coalesces short calls)
+        burst = 64                                   # back-to-back, as in the timed region (the library coalesces short calls)
         t0 = time.perf_counter()
         for _ in range(burst):
             ctx.train(args.steps, want_stats=False)
         ctx.sync()
         t_call = cp.max_over_ranks(time.perf_counter() - t0) / burst
-        repeats = int(min(400000, max(3, -(-TARGET_REGION_S // max(t_call, 1e-7)))))
-    cp.barrier()
-    ctx.sync()
+        repeats = int(min(4000000, max(3, -(-1.15 * args.region_seconds // max(t_call, 1e-7)))))    # (the burst is a little slower per call than the steady state)
+
+    def timed_region(n_calls):
+        """n_calls back-to-back K-step calls between one barrier + synchronize pair -> (max over ranks, this rank's own) seconds"""
+        cp.barrier()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(n_calls):
+            ctx.train(args.steps, want_stats=False)
+        ctx.sync()
+        own = time.perf_counter() - t0
+        worst = cp.max_over_ranks(own)
+        cp.barrier()
+        return worst, own
+
     ctx.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(repeats):
-        ctx.train(args.steps, want_stats=False)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    dt = cp.max_over_ranks(dt)
-    cp.barrier()
+    regions = [timed_region(repeats) for _ in range(args.regions)]
     kernel_ms, launches, kname = ctx.timing_read()
     ctx.timing_enable(False)
+    order = sorted(range(len(regions)), key=lambda j: regions[j][0])
+    dt = regions[order[len(order) // 2]][0]                    # the MEDIAN region
+    own_rates = cp.all_gather_bytes(args.envs * args.steps * repeats / regions[order[len(order) // 2]][1])
+    # the same K-step driver call WITHOUT launch coalescing (one launch per call): what a single train(K) costs
+    no_coalesce = None
+    if not args.no_nocoalesce_leg and args.steps_per_launch != 1:
+        os.environ["RSRL_NO_COALESCE"] = "1"
+        try:
+            t0 = time.perf_counter()
+            for _ in range(64):
+                ctx.train(args.steps, want_stats=False)
+            ctx.sync()
+            t_call = cp.max_over_ranks(time.perf_counter() - t0) / 64
+            n_nc = int(min(400000, max(3, -(-0.3 // max(t_call, 1e-7)))))
+            ctx.timing_enable(True)
+            dt_nc = timed_region(n_nc)[0]
+            ms_nc, l_nc, _ = ctx.timing_read()
+            ctx.timing_enable(False)
+            no_coalesce = {"value": args.envs * world * args.steps * n_nc / dt_nc, "unit": "env-steps/s", "calls": n_nc, "region_s": dt_nc,
+                           "launches": l_nc, "avg_launch_ms": ms_nc / max(1, l_nc),
+                           "what": f"the same {args.steps}-step driver call, one launch per call (RSRL_NO_COALESCE=1): every call loads and stores every "
+                                   "learner's weights around its steps; `value` is the coalesced figure"}
+        finally:
+            os.environ.pop("RSRL_NO_COALESCE", None)
     rollout = guarded(lambda: greedy_rollout_check(ctx), 120) if rank == 0 else None
     # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
     streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
+    c3 = c5 = None
+    if not args.no_config_legs and world <= ndev:
+        c3 = guarded(lambda: config_leg(
+            rsrl_amd, "BASELINE.json configs[2]: 262144 CartPole envs, SARSA + tile coding (8 tilings x 8^4), eps-greedy, ONE shared table, 1 GPU",
+            dict(domain=rsrl_amd.CART_POLE, basis=rsrl_amd.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=rsrl_amd.SARSA, n_envs=262144,
+                 policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99, lr=0.0125 / 262144, weight_mode=rsrl_amd.W_SHARED, max_episode_steps=1000,
+                 env_offset=rank * 262144, device=device), 960, 64, 208,
+            "SURVEY 8(d): 208 B/env-step, of which 48 B are the HBM stream (state, action, counter) and 160 B are gathers / atomic "
+            "read-modify-writes of the shared table served by L2; the batch-step is bound by the scatter (device atomics) and its dependent launches"), 120)
+        c5 = guarded(lambda: config_leg(
+            rsrl_amd, "BASELINE.json configs[4], one GPU's share: 32768 Acrobot envs, ExpectedSARSA + Fourier(7) + Softmax, bf16 weights, per-env W",
+            dict(domain=rsrl_amd.ACROBOT, order=7, algo=rsrl_amd.EXPECTED_SARSA, policy=rsrl_amd.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,
+                 n_envs=32768, weight_dtype=rsrl_amd.W_BF16, max_episode_steps=1000, env_offset=rank * 32768, device=device), 512, 64, 32816,
+            "SURVEY 8(d): 32 816 B/env-step if W (24 KiB bf16 per learner) were streamed every step; the wave-family kernel keeps W in registers for "
+            "the whole launch, so the figure is an equivalent, not moved bytes: the kernel is VALU-issue bound at one wave per SIMD"), 180)
     shared = shared_peer = None
     if not args.no_shared_leg:
         shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
         if not (isinstance(shared, dict) and shared.get("error") == "timeout"):
             shared_peer = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_PEER), 240)
-    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared, shared_peer))
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared, shared_peer, c3, c5))
 
     if rank == 0:
         total_steps = args.steps * repeats
         total_env_steps = total_steps * args.envs * world
         value = total_env_steps / dt
         avg_launch_s = kernel_ms * 1e-3 / max(1, launches)
-        steps_per_launch = total_steps / max(1, launches)
+        steps_per_launch = total_steps * len(regions) / max(1, launches)
         per_gpu_kernel_rate = args.envs * steps_per_launch / avg_launch_s if avg_launch_s > 0 else 0.0
         n_gpus = min(world, ndev)
         fused = kname == "k_train_reg"
@@ -344,12 +452,15 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / total_steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "timed_region_s": dt,
+            "timed_region_s": dt, "regions_s": [r[0] for r in regions],
+            "spread": (max(r[0] for r in regions) - min(r[0] for r in regions)) / dt,
+            "timing": f"median of {len(regions)} regions, each {repeats} back-to-back calls of {args.steps} batch-steps between one barrier + synchronize pair",
+            "ranks_seen": world, "per_rank_env_steps_per_s": [float(x) for x in own_rates],
             "config": {"workload": f"{args.envs} vectorised MountainCar envs per GPU, QLearning + Fourier(5), "
                                    "eps-greedy(0.1), gamma 0.9, SGD(0.001), per-env W, 1xMI355X per rank "
                                    "(BASELINE.json configs[1])",
                        "envs_per_gpu": args.envs, "steps_per_launch": steps_per_launch, "repeats": repeats,
-                       "timed": f"{repeats} back-to-back calls of {args.steps} batch-steps between one barrier+synchronize pair",
+                       "timed": f"{repeats} back-to-back calls of {args.steps} batch-steps per region, {len(regions)} regions",
                        "ranks": world,
                        "parallelism": f"env-sharded x{world}, no data-path collective"},
         }
@@ -377,8 +488,14 @@ def main():
                                     "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}, **common)
         if rollout is not None:
             out["greedy_rollout"] = rollout
+        if no_coalesce is not None:
+            out["value_no_coalesce"] = no_coalesce
         if streaming is not None:
             out["roofline_streaming"] = streaming
+        if c3 is not None:
+            out["c3_shared_tiles"] = c3
+        if c5 is not None:
+            out["c5_wave_bf16"] = c5
         if shared is not None:
             out["shared_w"] = shared
         if shared_peer is not None:
