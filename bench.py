@@ -148,6 +148,20 @@ def greedy_rollout_check(ctx, sample=256, limit=500):
                     "differ only where an argmax margin is below fp32 resolution"}
 
 
+def parity_sample(m=2048):
+    """Device vs the f64 CPU oracle (the reference's precision) on m random in-range states, single-step quantities of SURVEY 8(d):
+    worst |dphi|, |dQ| / (1 + |Q|), |ddelta| / (1 + |delta|), |dW| after one update, and the three transitions (checker only:
+    scripts/measure_parity.py; tests/test_gpu_parity_mc.py asserts the tolerances, the bitwise suites compare against the
+    device-order oracle)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("measure_parity", os.path.join(ROOT, "scripts", "measure_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.measure(m)
+    out["sample"] = f"{m} uniformly random in-range states per quantity, device (fp32) vs oracle f64"
+    return out
+
+
 def guarded(fn, timeout_s):
     """Run a secondary measurement in a daemon thread; {"error": "timeout"} if it does not come back in time."""
     box = {}
@@ -406,6 +420,7 @@ def main():
         finally:
             os.environ.pop("RSRL_NO_COALESCE", None)
     rollout = guarded(lambda: greedy_rollout_check(ctx), 120) if rank == 0 else None
+    parity = guarded(parity_sample, 120) if (rank == 0 and not args.no_cpu_baseline) else None
     # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
     streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
@@ -488,6 +503,8 @@ def main():
                                     "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP}, **common)
         if rollout is not None:
             out["greedy_rollout"] = rollout
+        if parity is not None:
+            out["parity"] = parity
         if no_coalesce is not None:
             out["value_no_coalesce"] = no_coalesce
         if streaming is not None:

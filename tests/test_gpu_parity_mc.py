@@ -1,10 +1,18 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle on the headline configuration
 MountainCar + Fourier(5) + {QLearning, SARSA, ExpectedSARSA} + {Greedy, EpsilonGreedy, Softmax, Random}.
 
-Tolerances (fp32 device vs f64 oracle unless noted), all from identical fp32-representable inputs:
-  phi       <= 3e-6   (input rounding of s~ alone allows pi*order*ulp ~ 1e-6; measured ~1.6e-6 worst)
-  Q, delta  <= 2e-5 * (1 + |Q|)
-  W after one update <= 1e-6 abs
+Tolerances (fp32 device vs f64 oracle unless noted), all from identical fp32-representable inputs; the measured worst cases are
+those of scripts/measure_parity.py on 8 192 uniformly random in-range states (round 3, MI355X) -- bench.py reports a live sample
+of the same quantities as `parity`:
+  phi       <= 3e-6            measured 2.2e-6.  SURVEY 8(d) states 5e-7; that is below what ANY fp32 evaluation can reach: the
+                               scaled state s~ carries up to ~9e-8 of fp32 rounding (the bound -1.2 and 1/(hi - lo) are not fp32
+                               numbers, the product rounds once more) and feature (5,5) turns it into pi * 10 * 9e-8 = 2.8e-6.
+                               The polynomial itself is <= 1.7 ulp, and the comparison with the fp32 oracle (same inputs) is <= 1e-6.
+  Q         <= 1e-5 * (1 + |Q|)   SURVEY 8(d)'s figure; measured 2.4e-6
+  delta     <= 1e-5 * (1 + |d|)   SURVEY 8(d)'s figure; measured 6.2e-6
+  W after one update <= 1e-6 * (1 + |d|)   SURVEY 8(d)'s figure; measured 3.2e-7
+  transition: MountainCar 3.1e-8, CartPole 7.2e-8 relative (asserted at 1e-5); Acrobot 1.9e-4 (dt = 0.2 with |theta'| up to 9 pi
+                               amplifies sincos ulps through the four RK4 stages; asserted at 4e-4 = 2x measured)
   teacher-forced 1000 steps: max|dW| <= 1e-3 * max(1, max|W|)
   integer / index outputs (actions given identical Q, n_states from identical W with margins): exact
 """
@@ -60,7 +68,7 @@ def test_domain_step_matches_oracle(ra, orc, domain, steps):
             for i in range(0, N, 5):
                 es, er, et = orc.domain_step(domain, cur[:, i], a[i], "f32")
                 # Acrobot: dt = 0.2 with |theta'| up to 9*pi amplifies sincos ulps through the 4 RK4 stages
-                t32, t64 = (2e-5, 2e-4) if domain == 2 else (2e-6, 1e-5)
+                t32, t64 = (2e-5, 4e-4) if domain == 2 else (2e-6, 1e-5)
                 assert np.allclose(nxt[:, i], es, rtol=t32, atol=t32), (k, i, nxt[:, i], es)
                 es64, er64, et64 = orc.domain_step(domain, cur[:, i], a[i], "f64")
                 assert np.allclose(nxt[:, i], es64, rtol=t64, atol=t64)
@@ -111,7 +119,7 @@ def test_q_evaluate_and_find_max(ra, orc):
         idx, val = c.q_find_max(s)
         for i in range(N):
             q64 = orc.q_evaluate(ag, Ws[i].astype(np.float64), s[:, i], "f64")
-            assert np.allclose(q[:, i], q64, rtol=0, atol=2e-5 * (1 + np.abs(q64).max()))
+            assert np.allclose(q[:, i], q64, rtol=0, atol=1e-5 * (1 + np.abs(q64).max()))
             q32 = orc.q_evaluate(ag, Ws[i], s[:, i], "f32")
             assert np.allclose(q[:, i], q32, rtol=0, atol=3e-6 * (1 + np.abs(q32).max()))
             ei, ev = orc.find_max(q[:, i], "f32")
@@ -185,7 +193,7 @@ def test_handle_single_update(ra, orc, algo, policy):
         for i in range(M):
             x_in = orc.draw(5, i, 0, orc.BLK_INNER)
             Wd = c.get_weights(i)
-            for prec, tol_d, tol_w in (("f64", 2e-5, 1e-6), ("f32", 4e-6, 3e-7), ("f32d", 0.0, 0.0)):
+            for prec, tol_d, tol_w in (("f64", 1e-5, 1e-6), ("f32", 4e-6, 3e-7), ("f32d", 0.0, 0.0)):
                 W = Ws[i].astype(np.float64 if prec == "f64" else np.float32).copy()
                 d = orc.handle(ag, W, frm[:, i], a[i], rew[i], nxt[:, i], term[i], x_in, prec)
                 # "f32d" restates the device's own sincos / exp polynomials: the TD error and the updated weights are
@@ -249,29 +257,6 @@ def test_train_sharding_invariance(ra):
         assert np.array_equal(full.states[:, :256], lo.states) and np.array_equal(full.states[:, 256:], hi.states)
         assert np.array_equal(full.actions[256:], hi.actions)
         assert np.array_equal(full.get_weights(300), hi.get_weights(44))
-
-
-@pytest.mark.parametrize("algo,policy", [(0, 1), (1, 1), (2, 1), (0, 0)])
-def test_train_free_running_vs_oracle_f32(ra, orc, algo, policy):
-    # (the libm-based f32 oracle; the bitwise comparison against the device-order oracle is tests/test_gpu_bitwise.py)
-    # same seeds, same RNG: the fp32 oracle and the device follow the same trajectories until a
-    # near-tie is resolved differently (cos/sincos ulps); short horizon from W = 0.
-    N, K = 256, 120
-    kw = dict(gamma=0.9, lr=0.001, alpha=0.7, epsilon=0.1)
-    ag = orc.make_agent(algo=algo, policy=policy, seed=21, max_episode_steps=50, **kw)
-    run = orc.Run(ag, N, "f32")
-    run.reset()
-    ost = run.train(K)
-    with ra.Context(n_envs=N, algo=algo, policy=policy, seed=21, max_episode_steps=50, **kw) as c:
-        c.reset()
-        st = c.train(K)
-        same = np.all(np.abs(c.states.T - run.state) <= 1e-5, axis=1) & (c.actions == run.action)
-        assert same.mean() >= 0.97, same.mean()
-        for i in np.flatnonzero(same)[:40]:
-            assert np.max(np.abs(c.get_weights(i) - run.weights[i])) <= 2e-6
-        assert st["episodes"] == ost["episodes"] or abs(st["episodes"] - ost["episodes"]) <= 2
-        assert abs(st["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 1e-3 * ost["sum_abs_td_error"]
-        assert abs(st["sum_reward"] - ost["sum_reward"]) <= 1e-3 * abs(ost["sum_reward"])
 
 
 def test_teacher_forced_1000_steps_vs_oracle_f64(ra, orc):
