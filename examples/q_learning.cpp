@@ -44,5 +44,22 @@ int main(int argc, char** argv) {
     auto n = sess.rollout_n_states(500);                             // rollout(|s| policy.mode(s), Some(500)).n_states()
     double mean = 0; for (auto v : n) mean += v;
     printf("OOS: %.1f states on average...\n", mean / n_envs);
-    return 0;
+
+    // the rest of the trait surface on the path: the Trajectory itself, Enumerable::find_min / expected_value,
+    // Function<(S, A)> of the policy (lib.rs:334-409, core.rs:86-116, greedy.rs:46-60)
+    auto tr = sess.rollout(500);
+    bool same = true;
+    for (int64_t i = 0; i < n_envs; ++i) same = same && tr.n_states[i] == n[i];
+    auto s0 = sess.emit();
+    auto mx = sess.find_max(s0); auto mn = sess.find_min(s0);
+    auto ev = sess.expected_value(s0, sess.policy_probs(s0));       // under Greedy: the maximum (unless there are ties)
+    auto pa = sess.policy_prob(s0, mx.first);
+    bool ordered = true, greedy_ev = true;
+    for (int64_t i = 0; i < n_envs; ++i) {
+        ordered = ordered && mn.second[i] <= mx.second[i];
+        greedy_ev = greedy_ev && (pa[i] < 1.0f || ev[i] == mx.second[i]);
+    }
+    printf("trajectory == rollout: %d, min <= max: %d, E_greedy[Q] == max Q: %d, first trajectory: %u states, total reward %.1f\n",
+           (int)same, (int)ordered, (int)greedy_ev, tr.n_states[0], tr.total_reward[0]);
+    return (same && ordered && greedy_ev) ? 0 : 1;
 }

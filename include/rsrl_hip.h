@@ -309,6 +309,12 @@ int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* ctx, int64_t step_limit, int64_t M
  * sharding / fusion-invariance checks at sizes where copying the weights out is not practical. */
 int rsrl_hip_checksum(rsrl_hip_ctx* ctx, uint64_t out[2]);
 
+/* Shared weights: every cross-learner sum is 64-bit fixed point (lsb = 2^(floor(log2 lr) - 28)); a term or block sum beyond
+ * +-2^42 lsb (|lr*e*phi| > 16384 * 2^floor(log2 lr): a diverged learner) is CLAMPED, and counted here -- terms clamped so far by
+ * the shared-W kernels on this ctx's device, all ctxs of the process included (0 in every healthy run: the update then is
+ * exactly W += fl(sum of the quantised terms)). */
+int rsrl_hip_fx_saturations(rsrl_hip_ctx* ctx, uint64_t* count_out);
+
 /* ---- multi-GPU (one process per GPU; no reference counterpart) -------------------------
  * Shared-W mode across ranks: every batch-step all-reduces the (F x A) f32 weight delta
  * over RCCL.  id_bytes is an ncclUniqueId (128 bytes) produced on rank 0 and distributed

@@ -80,6 +80,7 @@ SYMBOLS = {
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rsrl_hip_rollout_trajectory": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
     "rsrl_hip_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rsrl_hip_fx_saturations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rsrl_hip_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

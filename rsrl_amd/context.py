@@ -315,6 +315,12 @@ class Context:
         _abi.check(self._L.rsrl_hip_checksum(self._h, out))
         return int(out[0]), int(out[1])
 
+    def fx_saturations(self):
+        """terms the shared-W fixed-point sums had to clamp so far on this device (0 in a healthy run)"""
+        n = C.c_uint64()
+        _abi.check(self._L.rsrl_hip_fx_saturations(self._h, C.byref(n)))
+        return int(n.value)
+
     # ---- multi-GPU (shared weights): RCCL communicator, one process per GPU
     @staticmethod
     def comm_unique_id():

@@ -268,6 +268,9 @@ template <> struct Domain<1> {
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r, const Pre&) { return step(s, a, r); }
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         constexpr float TW = (float)(kPi / 15.0);
+#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 2)          // A/B builds only: no RK4
+        s[0] += 0.001f * (float)a; s[2] += 0.0001f; r = 0.0f; return s[0] > 2.4f;
+#endif
         const float force = (a == 0) ? -10.0f : 10.0f;                 // ALL_ACTIONS (:26)
         auto grad = [force](const float (&y)[4], float (&out)[4]) {    // CartPole::grad (:52-72)
             constexpr float G = 9.8f, FOUR_THIRDS = (float)(4.0 / 3.0);

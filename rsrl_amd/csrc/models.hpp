@@ -47,8 +47,13 @@ struct FxScale {
         lsb = __builtin_bit_cast(float, ex << 23); inv_lsb = __builtin_bit_cast(float, (254u - ex) << 23);
     }
 };
+// terms clamped so far on this device (translation-unit-local symbol: only rsrl_hip.hip's kernels quantise; read by
+// rsrl_hip_fx_saturations).  A clamped term means the shared-W update departed from W += lr*e*phi: never silently.
+static __device__ unsigned int g_fx_saturations;
 __device__ __forceinline__ unsigned long long fx_quantise(float v, float inv_lsb) {
-    const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
+    const float raw = v * inv_lsb;
+    const float sc = __builtin_amdgcn_fmed3f(raw, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
+    if (__builtin_expect(!(fabsf(raw) <= 4.398046511104e12f), 0)) atomicAdd(&g_fx_saturations, 1u);  // (NaN counts: it was clamped too)
     return (unsigned long long)(long long)rintf(sc);
 }
 __device__ __forceinline__ void fx_add(long long* p, unsigned long long q) { atomicAdd(reinterpret_cast<unsigned long long*>(p), q); }
@@ -161,6 +166,13 @@ struct TileModel {
     __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
 #pragma unroll
         for (int b = 0; b < A; ++b) q[b] = 0.0f;
+#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 1)          // A/B builds only: no gathers
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int b = 0; b < A; ++b) q[b] = q[b] + (float)(ft.idx[t] + b) * 1e-6f;
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -207,11 +219,7 @@ struct TileModel {
     __device__ static __forceinline__ void block_accumulate(long long* __restrict__ dW64, long long* __restrict__ slice, const BasisGeom& g,
                                                             const Feat& ft, int a, float scale, bool valid, float inv_lsb) {
         const int S = (g.F / T) * A;                                    // entries per tiling
-        auto to_fixed = [&](float v) {
-            const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
-            return (unsigned long long)(long long)rintf(sc);
-        };
-        const unsigned long long term = to_fixed(scale);
+        const unsigned long long term = valid ? fx_quantise(scale, inv_lsb) : 0ull;
         // two slices in ping-pong (slice + S): tiling t+1 accumulates into one while tiling t's is swept -- one barrier per
         // tiling instead of two
         auto add = [&](int t, long long* sl) {
@@ -765,10 +773,7 @@ struct DeltaTab {
         const int ex = (int)(eb < 30u ? 30u : eb) - 28;
         lsb = __uint_as_float((uint32_t)ex << 23); inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
     }
-    __device__ __forceinline__ unsigned long long quantise(float v) const {
-        const float sc = __builtin_amdgcn_fmed3f(v * inv_lsb, -4.398046511104e12f, 4.398046511104e12f);    // +-2^42: no wrap-around
-        return (unsigned long long)(long long)rintf(sc);
-    }
+    __device__ __forceinline__ unsigned long long quantise(float v) const { return fx_quantise(v, inv_lsb); }
 };
 template <class M, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_shared_step(Common c, BasisGeom g, uint64_t t, int mode, const float* __restrict__ W_in,

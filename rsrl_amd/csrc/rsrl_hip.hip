@@ -1843,6 +1843,17 @@ int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
     return peer_check(c);
 }
 
+int rsrl_hip_fx_saturations(rsrl_hip_ctx* c, uint64_t* count_out) {
+    CHECK_CTX(c); FLUSH(c);
+    if (!count_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned int n = 0;
+    HIP_TRY(hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fx_saturations), sizeof(n), 0, hipMemcpyDeviceToHost));
+    *count_out = n;
+    return RSRL_HIP_OK;
+}
+
 int rsrl_hip_comm_unique_id(uint8_t* id_bytes) {
     if (!id_bytes) return fail(RSRL_HIP_EINVAL, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes in the ABI");

@@ -45,6 +45,14 @@ struct Transition {                       // lib.rs:130-142, batched SoA
     std::vector<float> reward;            // [N]
     std::vector<uint8_t> terminal;        // [N]  (Observation::Terminal flag of `to`, lib.rs:170)
 };
+struct Trajectory {                       // lib.rs:334-409, batched: `start` = states row 0, steps[k] = (states row k+1, actions[k], rewards[k])
+    std::vector<uint32_t> n_states;       // [N]  Trajectory::n_states()  (:340); n_transitions = n_states - 1
+    std::vector<float> total_reward;      // [N]  Trajectory::total_reward()  (:391)
+    std::vector<float> states;            // [step_limit][D][N], rows past n_states are zero
+    std::vector<int32_t> actions;         // [step_limit - 1][N]
+    std::vector<float> rewards;           // [step_limit - 1][N]
+    std::vector<uint8_t> terminal;        // [N]  the last observation is Observation::Terminal
+};
 struct Domain { int kind; int64_t n_envs; };
 struct MountainCar : Domain { explicit MountainCar(int64_t n = 1) : Domain{RSRL_MOUNTAIN_CAR, n} {} };
 struct CartPole : Domain { explicit CartPole(int64_t n = 1) : Domain{RSRL_CART_POLE, n} {} };
@@ -233,6 +241,24 @@ public:
     std::vector<float> evaluate(const std::vector<float>& states) {
         std::vector<float> q((size_t)O_ * N_); check(rsrl_hip_q_evaluate(ctx_, states.data(), N_, q.data())); return q;
     }
+    // Enumerable::find_max / find_min -> (index, value), ties -> last index        (core.rs:86-105)
+    std::pair<std::vector<int32_t>, std::vector<float>> find_max(const std::vector<float>& states) {
+        std::vector<int32_t> i(N_); std::vector<float> v(N_); check(rsrl_hip_q_find_max(ctx_, states.data(), N_, i.data(), v.data())); return {i, v};
+    }
+    std::pair<std::vector<int32_t>, std::vector<float>> find_min(const std::vector<float>& states) {
+        std::vector<int32_t> i(N_); std::vector<float> v(N_); check(rsrl_hip_q_find_min(ctx_, states.data(), N_, i.data(), v.data())); return {i, v};
+    }
+    // Enumerable::expected_value(args, ps)                                        (core.rs:107-116); ps is [A][N]
+    std::vector<float> expected_value(const std::vector<float>& states, const std::vector<float>& ps) {
+        std::vector<float> e(N_); check(rsrl_hip_q_expected_value(ctx_, states.data(), N_, ps.data(), e.data())); return e;
+    }
+    // Function<(S,)> / Function<(S, A)> of the policy                              (greedy.rs:30-60, epsilon_greedy.rs:38-63)
+    std::vector<float> policy_probs(const std::vector<float>& states) {
+        std::vector<float> p((size_t)A_ * N_); check(rsrl_hip_policy_probs(ctx_, states.data(), N_, p.data())); return p;
+    }
+    std::vector<float> policy_prob(const std::vector<float>& states, const std::vector<int32_t>& actions) {
+        std::vector<float> p(N_); check(rsrl_hip_policy_prob(ctx_, states.data(), actions.data(), N_, p.data())); return p;
+    }
     void set_epsilon(double eps) { check(rsrl_hip_set_epsilon(ctx_, eps)); }      // pub field EpsilonGreedy.epsilon
     // Parameterised::weights()                                                    (params/mod.rs:118)
     std::vector<float> weights(int64_t env = 0) {
@@ -254,6 +280,16 @@ public:
     // Domain::rollout(|s| policy.mode(s), Some(limit)).n_states()                 (lib.rs:448-479, :340)
     std::vector<uint32_t> rollout_n_states(int64_t step_limit) {
         std::vector<uint32_t> n(N_); check(rsrl_hip_rollout_greedy(ctx_, step_limit, n.data(), nullptr)); return n;
+    }
+    // Domain::rollout(..) as the Trajectory it returns                             (lib.rs:334-409, 448-479)
+    domains::Trajectory rollout(int64_t step_limit) {
+        domains::Trajectory tr;
+        tr.n_states.resize(N_); tr.total_reward.resize(N_); tr.terminal.resize(N_);
+        tr.states.assign((size_t)step_limit * D_ * N_, 0.0f);
+        tr.actions.assign((size_t)(step_limit - 1) * N_, 0); tr.rewards.assign((size_t)(step_limit - 1) * N_, 0.0f);
+        check(rsrl_hip_rollout_trajectory(ctx_, step_limit, N_, tr.n_states.data(), tr.total_reward.data(), tr.states.data(),
+                                          step_limit > 1 ? tr.actions.data() : nullptr, step_limit > 1 ? tr.rewards.data() : nullptr, tr.terminal.data()));
+        return tr;
     }
     rsrl_hip_ctx* raw() { return ctx_; }
 

@@ -234,3 +234,17 @@ def test_qsigma_backups_travel_with_the_checkpoint(ra, tmp_path):
     with ra.Context(**dict(kw, n_steps=2)) as other:
         with pytest.raises(ra.RsrlHipError):
             other.load_weights(path)                                     # another ring geometry: the size check refuses it
+
+
+def test_fixed_point_saturation_is_counted(ra):
+    # a healthy shared-W run clamps nothing; a diverged one (huge step size: |lr*e*phi| beyond 2^14 * 2^floor(log2 lr)) is counted
+    kw = dict(C4, n_envs=1024)
+    with ra.Context(lr=1e-6, **kw) as ok:
+        base = ok.fx_saturations()
+        ok.reset(); ok.train(50, want_stats=False); ok.sync()
+        assert ok.fx_saturations() == base
+    with ra.Context(lr=1e-30, **kw) as bad:                        # lsb = 2^-98 (the floor): any |term| > 2^-56 clamps
+        bad.reset(); bad.train(5, want_stats=False); bad.sync()
+        bad.set_weights(np.full((bad.F, bad.A), 1e20, np.float32))
+        bad.train(5, want_stats=False); bad.sync()
+        assert bad.fx_saturations() > base
