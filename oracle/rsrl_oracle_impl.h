@@ -550,16 +550,24 @@ R FN(orc_handle)(const orc_agent* ag, R* W, const R* s, int a, R r, const R* ns,
  *                                            Dutch: z = gl*(1-alpha)*z + g      (g = phi(s) in column a)
  *   weight update         Handler<ScaledGradientUpdate>: W += (alpha*residual) * Z  -- bypasses the optimiser
  *                         (fa/linear.rs:184-196)
- * Dense (Fourier) bases only.  Returns the TD error. */
+ * Fourier bases: g = phi(s) in column a.  Tile coding (round 3; the reference's traces are generic over the gradient buffer,
+ * traces.rs:6-12): g = 1.0 at the T active entries of column a, 0 elsewhere -- a dense trace table of W's shape per learner.
+ * Returns the TD error. */
 R FN(orc_handle_lambda)(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r, const R* ns, int term,
                         const uint32_t x_inner[4]) {
     const orc_basis* b = &ag->basis; int A = ag->n_actions, F = orc_basis_nfeat(b), f, c;
     R qs[ORC_MAX_ACTIONS], qsa, residual, rate, scale;
-    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+    R* phi = (R*)calloc((size_t)F, sizeof(R));
     FN(orc_q_evaluate)(b, W, A, s, qs);
     qsa = qs[a];
     if (ag->algo == ORC_Q_LAMBDA && a != FN(orc_argmax_first)(qs, A)) memset(Z, 0, sizeof(R) * (size_t)F * A);
-    FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+    if (b->kind == ORC_FOURIER) FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+    else {                                                               /* unit activations at the T active indices */
+        int idx[ORC_MAX_TILINGS], t; float sf[8];
+        for (t = 0; t < b->dim; t++) sf[t] = (float)s[t];
+        orc_tile_indices(b, sf, idx);
+        for (t = 0; t < b->n_tilings; t++) phi[idx[t]] = (R)1.0;
+    }
     rate = (R)ag->gamma * (R)ag->lambda;
     if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
     for (f = 0; f < F; f++)

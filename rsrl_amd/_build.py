@@ -45,11 +45,27 @@ def deps():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc, os.path.abspath(__file__)]
 
 
+STAMP_PATH = LIB_PATH + ".sha256"
+
+
+def source_digest(extra_flags=()):
+    """sha256 over everything the library is built from: every file under csrc/, the ABI header, the flags (per source too)
+    and hipcc's version -- content, not mtimes: a snapshot copied to another box (gpurun) keeps its digest."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(os.path.dirname(HERE), "include", "rsrl_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags))).encode())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
+    """True unless librsrl_hip.so exists AND was built from exactly the sources in the tree (digest stamped next to it)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    m = os.path.getmtime(LIB_PATH)
-    return any(os.path.exists(d) and os.path.getmtime(d) > m for d in deps())
+    return open(STAMP_PATH).read().strip() != source_digest()
 
 
 def _compile_one(args):
@@ -85,6 +101,9 @@ def _build_to(lib_path, extra_flags, verbose):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if os.path.abspath(lib_path) == os.path.abspath(LIB_PATH):
+        with open(STAMP_PATH, "w") as f:
+            f.write(source_digest() + "\n")
     return lib_path
 
 

@@ -15,11 +15,17 @@ bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block,
 
 // chunk == -1 selects the single-step streaming kernel (k_step_reg), -2 its learner-major form (k_step_reg_lm)
 struct LambdaParams;
+struct BasisGeom;
 bool launch_train_lambda(int domain, int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
                          const Common& k, const LambdaParams& lp, uint64_t t, int chunk, DevStats* stats);
 bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStream_t st, const Common& k, const LambdaParams& lp,
                           const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                           int64_t Mn, uint64_t t, float* td_out);
+
+// lambda agents on tile coding, per-learner tables: n_blocks = learners (driver loop) or Mn (handle: from != nullptr)
+bool launch_lambda_tile(int domain, int n_tilings, int64_t n_blocks, hipStream_t st, const Common& k, const BasisGeom& g, const LambdaParams& lp,
+                        uint64_t t, int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to,
+                        const uint8_t* termf, int64_t Mn, float* td_out);
 
 struct GqParams;
 bool launch_train_gq(int domain, int order, int policy, dim3 grid, dim3 block, hipStream_t st, const Common& k,

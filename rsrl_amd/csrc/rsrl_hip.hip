@@ -691,9 +691,10 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (!(cfg->lr_td >= 0.0)) return fail(RSRL_HIP_EINVAL, "lr_td must be >= 0");
     }
     if (is_lambda(cfg->algo)) {
-        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+        const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;     // dense per-learner trace tables
+        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
             return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1) or on tile coding");
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
     }
@@ -721,6 +722,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
+    if (is_lambda(cfg->algo) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
@@ -1057,6 +1059,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
         if (!launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
                               d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+    } else if (is_lambda(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
+        if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, M, c->stream, k, g, make_lambda(c), c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
+                                M, otd.dev)) return NO_MODEL(c);
     } else if (is_lambda(c->cfg.algo)) {
         if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
                                   d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
@@ -1138,14 +1143,14 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
     if (out) {
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
-        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->Aw, oz.dev);
+        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
         if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
         const float* d_z;
         TRY(stage_in(c, 0, in, (size_t)n, &d_z));
-        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, false, c->w_stride, env_index, c->F, c->Aw, d_z);
+        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, d_z);
         KCHECK();
         if (!is_device_ptr(in)) HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -1664,6 +1669,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (!launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_gq(c), c->t, chunk, d_stats)) return NO_MODEL(c);
             c->kernel_name = "k_train_gq";
+            KCHECK();
+        } else if (is_lambda(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
+            if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, k.n_envs, c->stream, k, g, make_lambda(c), c->t, chunk, d_stats, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, 0, nullptr)) return NO_MODEL(c);
+            c->kernel_name = "k_lambda_tile";
             KCHECK();
         } else if (is_lambda(c->cfg.algo)) {
             if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),
