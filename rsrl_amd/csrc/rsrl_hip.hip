@@ -69,8 +69,16 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
 // block: a sweep per tiling per 1 024 learners, ~300 touched entries each) a block here covers 8x the learners per sweep and
 // per flush: an eighth of the sweeps, a quarter of the device atomics.  The sums are integers: the same table whatever the
 // grouping -- bit-identical to the fused scatter and to the oracle.
+// W_apply != nullptr (single rank, every block of the grid resident): the APPLY is folded into this kernel -- k_apply_rep was a
+// third dependent launch per batch-step (4.7 us for 2 MB of traffic: a kernel boundary plus a handful of dependent loads).  The
+// blocks of ONE tiling meet at that tiling's arrival counter once their flushes have been performed (device atomics execute at
+// the memory side: s_waitcnt vmcnt(0) + barrier, then one arrival per block; the counter only ever grows, a block's round is
+// its own ticket / blocks-per-tiling), then each of them converts and applies its share of the tiling's entries:
+// W += fl(sum of the copies * lsb), copies cleared -- the same integers and the same single rounding as k_apply_rep.
 __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const float* __restrict__ terms, int64_t N, int S,
-                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb) {
+                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb,
+                                                       float* __restrict__ W_apply, unsigned long long* __restrict__ arrive, float lsb,
+                                                       uint32_t* __restrict__ err, uint64_t timeout) {
     extern __shared__ long long scatter_slice[];
     const int t = blockIdx.y;
     for (int j = threadIdx.x; j < S; j += blockDim.x) scatter_slice[j] = 0;
@@ -97,6 +105,38 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restric
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
         const long long v = scatter_slice[j];
         if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[j]), (unsigned long long)v);
+    }
+    if (!W_apply) return;
+    // ---- the tiling's blocks meet, then apply
+    __shared__ int go;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's flush atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+        gu64_t* cnt = (gu64_t*)(arrive + (size_t)t * 16);          // one counter per tiling, 128 bytes apart
+        const unsigned long long mine = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (mine / gridDim.x + 1ull) * gridDim.x;
+        const uint64_t t_start = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t_start > timeout) { atomicOr(err, 1u); ok = 0; break; }
+        }
+        go = ok;
+    }
+    __syncthreads();
+    if (!go) return;                                               // a block went missing: nothing is applied, the next sync reports it
+    const int per_e = (S + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int j0 = (int)blockIdx.x * per_e, j1 = j0 + per_e < S ? j0 + per_e : S;
+    for (int j = j0 + (int)threadIdx.x; j < j1; j += (int)blockDim.x) {
+        typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+        long long a = 0;
+        for (int r = 0; r < n_rep; ++r) {
+            long long* p = dW64 + (int64_t)r * rep_stride + (int64_t)t * S + j;
+            const long long v = (long long)__hip_atomic_load((gu64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // L2-bypassing: the atomics' result
+            if (v != 0) { a += v; __hip_atomic_store((gu64_t*)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+        W_apply[(int64_t)t * S + j] += (float)a * lsb;
     }
 }
 
@@ -278,6 +318,7 @@ struct rsrl_hip_ctx {
     long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
     long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
     bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
+    unsigned long long* tile_arrive = nullptr;     // shared tile coding: one arrival counter per tiling (apply folded into the scatter kernel)
     uint16_t* sc_keys = nullptr;     // shared tile coding, separate scatter kernel: slice-relative entries [T][N]
     float* sc_terms = nullptr;       //   and terms lr*e [N] handed from the step kernel to k_tile_scatter
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
@@ -598,6 +639,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->h_fx) (void)hipFree(c->h_fx);
     if (c->sc_keys) (void)hipFree(c->sc_keys);
+    if (c->tile_arrive) (void)hipFree(c->tile_arrive);
     if (c->sc_terms) (void)hipFree(c->sc_terms);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
@@ -774,6 +816,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (c->tile_slice && !fused_scatter) {                           // the scatter as a kernel of its own (A/B knob: the fused one)
             HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
             HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(float) * (size_t)N));
+            HIP_TRY(hipMalloc((void**)&c->tile_arrive, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings));
+            HIP_TRY(hipMemsetAsync(c->tile_arrive, 0, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings, c->stream));
         }
     }
     if (shared) {
@@ -1417,6 +1461,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         TRY(exchange_dw(c, t, t_dev, k.xdelta));
         return RSRL_HIP_OK;
     }
+    bool fused_apply = false;
     if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
@@ -1433,8 +1478,13 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
                     int64_t per = (k.n_envs + chunks_env - 1) / chunks_env;
                     per = ((per + 1023) / 1024) * 1024;
                     const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
+                    // the apply rides in the scatter kernel when its blocks can meet: single rank, the whole grid resident
+                    // -- measured SLOWER than the third launch (24.4 against 23.7 us per batch-step at 262 144 learners: the wait for the flush
+                    // atomics, the returning arrival and the poll are three fabric round trips; round 2's ticket version: 34.6): A/B knob only
+                    fused_apply = !c->multi && getenv("RSRL_TILE_FUSED_APPLY") && chunks * (unsigned)c->cfg.n_tilings <= (unsigned)c->n_cu;
                     hipLaunchKernelGGL(k_tile_scatter, dim3(chunks, (unsigned)c->cfg.n_tilings), dim3(1024), (size_t)slice * 8, c->stream, c->sc_keys, c->sc_terms,
-                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb);
+                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb,
+                                       fused_apply ? c->W : (float*)nullptr, c->tile_arrive, tile_lsb((float)c->cfg.lr), c->d_peer_err, c->peer_timeout);
                     return;
                 }
                 // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
@@ -1450,7 +1500,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-    {
+    if (!fused_apply) {
         hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
                            tile_lsb((float)c->cfg.lr));
         KCHECK();
