@@ -105,10 +105,25 @@ constexpr double kPi = 3.14159265358979323846;
 // (sin, cos) of r + q*pi/2 from (s, c) = (sin r, cos r), q in 0..3:  (s, c), (c, -s), (-s, -c), (-c, s).
 // Written as one swap (two selects) and two sign-bit xors: as a ternary chain the compiler turned it into exec-mask
 // branches with half of the sine polynomial sunk into them -- a lone wave per SIMD pays every taken branch in full.
+// x < 0 ? all ones : 0 as ONE v_ashrrev_i32, written as the instruction: the optimiser canonicalises `x >> 31` into sext(x < 0)
+// and the backend emits v_cmp + v_cndmask for that -- an SGPR round trip with a wait state in front of the select (gfx950), which a
+// lone wave per SIMD pays in full.  Selects on small integers go through such masks and v_bfi_b32 instead (same values).
+__device__ __forceinline__ uint32_t sign_mask(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t m;
+    asm("v_ashrrev_i32_e32 %0, 31, %1" : "=v"(m) : "v"(x));
+    return m;
+#else
+    return (uint32_t)(x >> 31);
+#endif
+}
+__device__ __forceinline__ float bitsel(uint32_t m, float x, float y) {          // m ? x : y for an all-ones / all-zeros m
+    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, x) & m) | (__builtin_bit_cast(uint32_t, y) & ~m));
+}
 __device__ __forceinline__ void quadrant_select(int q, float s, float c, float& sn, float& cs) {
-    const bool swap = (q & 1) != 0;
-    const float a = swap ? c : s;
-    const float b = swap ? s : c;
+    const uint32_t swap = sign_mask(q << 31);                           // q odd
+    const float a = bitsel(swap, c, s);
+    const float b = bitsel(swap, s, c);
     const uint32_t sa = ((uint32_t)q & 2u) << 30;                       // sin negative in quadrants 2, 3
     const uint32_t sb = (((uint32_t)q + 1u) & 2u) << 30;                // cos negative in quadrants 1, 2
     sn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) ^ sa);

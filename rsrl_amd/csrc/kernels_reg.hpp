@@ -275,6 +275,24 @@ __device__ __forceinline__ void row_store(char* rowp, uint32_t voff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, (int)voff, 0, 0);
 }
 
+// ---- selects on the ACTION as bit operations (round 3).  A v_cmp writes an SGPR pair and the v_cndmask behind it has to wait for
+// it (gfx950: s_nop 1 between them; 8.4 cycles per select for a lone wave, profiles/r01_ubench_valu_issue.txt).  The action is a
+// small integer, so "a == b" is available as an all-ones / all-zeros VECTOR mask from two integer instructions, and a select is
+// one v_bfi_b32 / v_and_b32 on it: same values, bit for bit, no SGPR round trip.  The masks are made opaque to the optimiser, which
+// would otherwise recognise sext(icmp) and fold the bit operations back into compare + select.
+struct ActionMask {
+    uint32_t m0, m1, m2;
+    __device__ __forceinline__ explicit ActionMask(int a) {            // a in {0, 1, 2}
+        m0 = sign_mask(a - 1);                                          // a == 0
+        m2 = sign_mask(1 - a);                                          // a == 2
+        m1 = ~(m0 | m2);
+    }
+    __device__ __forceinline__ uint32_t of(int b) const { return b == 0 ? m0 : (b == 1 ? m1 : m2); }
+};
+__device__ __forceinline__ float and_mask(uint32_t m, float x) {                 // m ? x : +0.0
+    return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & m);
+}
+
 // q[a] by a compare/select chain.  Each compare sees its own opaque copy of the index: otherwise LLVM folds the
 // chain into a dynamic extractelement, which is legalised through a private array that promote-alloca moves to LDS
 // -- an exposed ds_write/ds_read round trip on the critical path of every step.
@@ -373,6 +391,9 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 #ifndef RSRL_RANK1_QPOST
 #define RSRL_RANK1_QPOST 1
 #endif
+#ifndef RSRL_ACTION_MASKS
+#define RSRL_ACTION_MASKS 1
+#endif
 #ifndef RSRL_K1_STORE_ALL
 #define RSRL_K1_STORE_ALL 1
 #endif
@@ -452,7 +473,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
             w.q(phi_n, q_n);
             // ---- handle: delta with the PRE-update weights
+#if RSRL_ACTION_MASKS
+            static_assert(A <= 3, "ActionMask covers three actions");
+            const ActionMask am(a);
+            const float qsa = A > 2 ? bitsel(am.m2, q_s.v2, bitsel(am.m1, q_s.v1, q_s.v0)) : bitsel(am.m1, q_s.v1, q_s.v0);
+#else
             const float qsa = q_s.at(a);
+#endif
             const float q_s_all[3] = {q_s.v0, q_s.v1, q_s.v2};
             float e;
             float delta;
@@ -468,16 +495,26 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             const float scale = alg.lr * e;
             {
                 float sb[A];
+#if RSRL_ACTION_MASKS
+#pragma unroll
+                for (int b = 0; b < A; ++b) sb[b] = and_mask(am.of(b), scale);
+#else
 #pragma unroll
                 for (int b = 0; b < A; ++b) sb[b] = (a == b) ? scale : 0.0f;
+#endif
                 w.axpy(sb, phi_s);
             }
             // ---- policy.sample with the UPDATED weights (at s', or at s0 after a terminal transition)
 #if RSRL_RANK1_QPOST
             {   // W changed by a rank-1 term in column a only: Q_post[a] = Q_pre[a] + scale * <phi(s), phi(s')>
                 const float dot = Phi::dot(phi_s, phi_n);
+#if RSRL_ACTION_MASKS
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = bitsel(am.of(b), fmaf(scale, dot, q_n[b]), q_n[b]);
+#else
 #pragma unroll
                 for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
+#endif
             }
 #else
             w.q(phi_n, q_n);
