@@ -17,7 +17,7 @@ arithmetic), so the call is repeated R times back to back between ONE pair of ba
 region lasts >= ~1 s; config.repeats); the region is measured FIVE times and `value` / `ms_per_step` are the MEDIAN region
 (all ranks' env-steps / max-over-ranks region time); `regions_s` and `spread` carry all five.  rsrl_hip_train is asynchronous
 and, on its own stream, coalesces calls that arrive while the stream is busy (same results bit for bit, include/rsrl_hip.h):
-the R x K batch-steps run as launches of up to 1024 steps -- config.steps_per_launch and roofline.launches report what was
+the R x K batch-steps run as launches of up to 4096 steps -- config.steps_per_launch and roofline.launches report what was
 actually launched, and `value_no_coalesce` is the same K-step driver call with one launch per call (RSRL_NO_COALESCE=1).
 
 roofline.frac is a fraction of a PUBLISHED peak (MI355X_MICROARCH.md): the fused kernel keeps W in the register file, so its

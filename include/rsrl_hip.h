@@ -123,7 +123,7 @@ typedef struct {
     double   alpha;              /* ExpectedSARSA.alpha (expected_sarsa.rs:26,64)             */
     double   epsilon;            /* EpsilonGreedy.epsilon (pub field, epsilon_greedy.rs:19)  */
     double   tau;                /* Softmax.tau (softmax.rs:52); |tau| < 1e-7 is rejected (:63-66) */
-    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default: 1024 for the register-resident loops,
+    uint32_t steps_per_launch;   /* fuse depth of rsrl_hip_train (0 = library default: 4096 for the register-resident loops,
                                     256 for the memory-resident and wave-family ones). 1 = one batch-step per launch:
                                     the ctx then keeps W learner-major and streams it once per step (the 608 B/env-step
                                     formulation), replayed as a hipGraph; results are bit-identical for every depth */
@@ -279,7 +279,7 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* ctx, const float* w /*[F][A]*/);
 int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out);
 /*   Without stats_out the call is ASYNCHRONOUS: it returns once the work is enqueued.  On a CTX-OWNED stream (config.stream
  *   NULL) short calls (a driver loop's 20 batch-steps) that arrive while the stream is still busy are coalesced -- held back and
- *   launched fuse-depth (1024 batch-steps) at a time, when anything observes or changes the ctx (every other entry point,
+ *   launched fuse-depth (4096 batch-steps) at a time, when anything observes or changes the ctx (every other entry point,
  *   rsrl_hip_sync included, flushes first), or when a call finds the stream idle.  Results are bit-identical to one launch per
  *   call (the fused loop carries Q(s,.) between launches and addresses the RNG by the batch-step); RSRL_NO_COALESCE=1 in the
  *   environment disables it.  On a caller-supplied stream nothing is ever held back.

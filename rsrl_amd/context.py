@@ -59,7 +59,7 @@ class Context:
 
     (rsrl/examples/q_learning.rs:19-32 and the other examples).  `seed` keys the per-env Philox streams by GLOBAL env id
     (`env_offset` + local index), so a sharded run reproduces the unsharded one bit for bit.  `steps_per_launch`: fuse
-    depth of `train` (0 = library default: 1024 for the register-resident loops, 256 otherwise; 1 = one batch-step per launch).  Arrays are SoA: states `(D, M)`, actions `(M,)`; weights
+    depth of `train` (0 = library default: 4096 for the register-resident loops, 256 otherwise; 1 = one batch-step per launch).  Arrays are SoA: states `(D, M)`, actions `(M,)`; weights
     `(F, n_out)` row-major like the reference's `Parameterised::weights()`.  Every method raises `RsrlHipError` with the
     ABI's message on failure; there is no CPU fallback."""
 

@@ -1588,7 +1588,10 @@ static inline int64_t fuse_depth(const rsrl_hip_ctx* c) {
     if (g.steps_per_launch) return g.steps_per_launch;
     // every register-resident loop (also the trace / GreedyGQ / TD ones, which load and store two matrices per launch)
     const bool reg = g.weight_mode == RSRL_W_PER_ENV && g.basis == RSRL_FOURIER && !is_wave(g) && !is_generic_fourier(g) && g.algo != RSRL_Q_SIGMA;
-    return reg ? 1024 : 256;
+    // round 3, under the driver's invocation (20-step calls, coalesced; scripts/gpu_r3_v6.sh): 1 024 -> 8.96e10, 2 048 -> 9.06e10,
+    // 4 096 -> 9.12e10, 8 192 -> 9.17e10 env-steps/s; 4 096 (a 2.9 ms launch at 65 536 learners) is the default, RSRL_FUSE_DEPTH the A/B knob
+    static const int64_t reg_depth = getenv("RSRL_FUSE_DEPTH") ? atoll(getenv("RSRL_FUSE_DEPTH")) : 4096;
+    return reg ? (reg_depth > 0 ? reg_depth : 4096) : 256;
 }
 
 // shared weights, dense basis: the whole train call as ONE persistent launch (kernels_persist.hpp) when every 512-learner block
@@ -1800,7 +1803,7 @@ static bool coalescable(const rsrl_hip_ctx* c) {
 }
 // rsrl_hip_train is asynchronous when no statistics are requested: it returns once the work is accepted.  A short call (the
 // 20 batch-steps of a driver loop) costs a full load + store of every learner's weights around ~20 us of arithmetic, so calls
-// that arrive while the stream is still busy are COALESCED: their steps are held back and launched fuse-depth (1 024) at a time,
+// that arrive while the stream is still busy are COALESCED: their steps are held back and launched fuse-depth (4 096) at a time,
 // or as soon as anything observes or changes the ctx (every other entry point flushes first, rsrl_hip_sync included), or
 // when a call finds the stream idle (then nothing is gained by waiting).  Invisible to the caller: same results bit for bit,
 // same ordering; 5 000 back-to-back train(20) calls run as ~400 launches instead of 5 000.  RSRL_NO_COALESCE=1 disables it.
