@@ -144,7 +144,9 @@ typedef struct {
     double   agent_tau;          /* Softmax.tau of the agent's policy                                                    */
     double   sigma;              /* QSigma.sigma in [0, 1]: 1 = SARSA-like sampling, 0 = tree backup (q_sigma.rs:66-72)          */
     int32_t  n_steps;            /* QSigma: Backup::new(n_steps), 1..32 (q_sigma.rs:94-104)                                      */
-    int32_t  reserved0;
+    int32_t  peer_timeout_ms;    /* ABI 5 (was reserved0): bound of every in-kernel wait for a peer / block of the shared-W exchange, in
+                                    milliseconds; 0 = RSRL_PEER_TIMEOUT_MS from the environment, else 4000.  Make it longer than the
+                                    longest time one rank may spend away from the others (a rollout, a checkpoint) */
 } rsrl_hip_config;
 /* size of the ABI 3 struct: the oldest layout rsrl_hip_create accepts */
 #define RSRL_HIP_CONFIG_SIZE_V3 ((uint32_t)offsetof(rsrl_hip_config, agent_policy))

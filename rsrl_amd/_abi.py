@@ -19,7 +19,7 @@ class Config(C.Structure):
         ("trace", C.c_int32), ("stream", C.c_void_p), ("lam", C.c_double),
         ("lr_td", C.c_double),
         ("agent_policy", C.c_int32), ("exchange", C.c_int32), ("agent_epsilon", C.c_double), ("agent_tau", C.c_double),
-        ("sigma", C.c_double), ("n_steps", C.c_int32), ("reserved0", C.c_int32),
+        ("sigma", C.c_double), ("n_steps", C.c_int32), ("peer_timeout_ms", C.c_int32),
     ]
 
 

@@ -67,7 +67,7 @@ class Context:
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
                  max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0,
-                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1):
+                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1, peer_timeout_ms=0):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -83,6 +83,7 @@ class Context:
         cfg.agent_policy = -1 if agent_policy is None else int(agent_policy)
         cfg.agent_epsilon, cfg.agent_tau, cfg.exchange = agent_epsilon, agent_tau, exchange
         cfg.sigma, cfg.n_steps = sigma, n_steps                   # QSigma{sigma, Backup::new(n_steps)}
+        cfg.peer_timeout_ms = int(peer_timeout_ms)                # bound of the in-kernel waits of the shared-W exchange (0 = default)
         self.cfg = cfg
         self._h = C.c_void_p()
         _abi.check(self._L.rsrl_hip_create(C.byref(cfg), C.byref(self._h)))

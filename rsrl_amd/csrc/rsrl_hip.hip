@@ -746,7 +746,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->device < 0 || cfg->device >= ndev) return fail(RSRL_HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
     HIP_TRY(hipSetDevice(cfg->device));
     { int cus = 0; HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device)); if (cus > 0) { c->n_simd = 4 * cus; c->n_cu = cus; } }
-    if (const char* e = getenv("RSRL_PEER_TIMEOUT_MS")) { const long ms = atol(e); if (ms > 0) c->peer_timeout = (uint64_t)ms * 100000ull; }
+    if (cfg->peer_timeout_ms < 0) return fail(RSRL_HIP_EINVAL, "peer_timeout_ms must be >= 0");
+    if (cfg->peer_timeout_ms > 0) c->peer_timeout = (uint64_t)cfg->peer_timeout_ms * 100000ull;
+    else if (const char* e = getenv("RSRL_PEER_TIMEOUT_MS")) { const long ms = atol(e); if (ms > 0) c->peer_timeout = (uint64_t)ms * 100000ull; }
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     const int64_t N = cfg->n_envs;
@@ -1937,6 +1939,11 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
     if (c->cfg.exchange != RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
     NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
     c->world_size = world_size; c->rank = rank; c->multi = true;
+    // warm-up: RCCL sets its connections up lazily, at the first collective -- which must not be the one inside the step graph's
+    // stream capture.  dW is zero between operations, so all-reducing it leaves it zero; every rank makes this call (comm_init is
+    // collective by nature).
+    NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 

@@ -248,3 +248,29 @@ def test_fixed_point_saturation_is_counted(ra):
         bad.set_weights(np.full((bad.F, bad.A), 1e20, np.float32))
         bad.train(5, want_stats=False); bad.sync()
         assert bad.fx_saturations() > base
+
+
+@pytest.mark.parametrize("cfg", [dict(domain=0, order=2), dict(domain=0, order=4), dict(domain=1, order=1), dict(domain=2, order=1, algo=1),
+                                 dict(domain=0, order=5, algo=2, policy=2, tau=0.8), dict(domain=0, order=3, algo=5, alpha=0.5)])
+@pytest.mark.parametrize("N", [700, 3000])
+def test_persistent_kernel_equals_one_launch_per_step_on_every_shape(ra, cfg, N):
+    # the persistent shared-W kernel against the one-launch-per-batch-step path (itself bitwise against the oracle): odd A*F
+    # (order 2: 27 entries -> a padding granule; order 4: 75), A = 2 (CartPole), a ragged last block, fewer blocks than
+    # granule pairs (owners loop), every one-step agent family; launches of 1 / 9 / 33 batch-steps
+    kw = dict(dict(algo=0, policy=1, epsilon=0.15, gamma=0.95, weight_mode=1, seed=5, max_episode_steps=30, n_envs=N, lr=0.02 / N), **cfg)
+
+    def run():
+        with ra.Context(**kw) as c:
+            c.reset()
+            st = [c.train(k) for k in (1, 9, 33)]
+            c.sync()
+            return c.get_weights(), c.states, c.actions, [s["episodes"] for s in st], [s["sum_episode_steps"] for s in st]
+    got = run()
+    os.environ["RSRL_NO_PERSIST"] = "1"
+    try:
+        ref = run()
+    finally:
+        os.environ.pop("RSRL_NO_PERSIST", None)
+    assert np.abs(ref[0]).max() > 0
+    assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3]))
+    assert ref[3] == got[3] and ref[4] == got[4]

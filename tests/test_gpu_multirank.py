@@ -129,16 +129,27 @@ def test_g_ranks_as_g_streams_on_one_device(ra, tmp_path):
 
 def test_missing_peer_times_out_instead_of_hanging(ra):
     # rank 1 never steps: rank 0's exchange gives up after its bounded spin and the next sync reports it
-    kw = dict(C4, lr=1e-6, exchange=ra.EXCHANGE_PEER)
+    # (config.peer_timeout_ms: 300 ms here instead of the default 4 s); the update of the failed step is NOT applied, and every
+    # synchronising read reports the failure, not only rsrl_hip_sync
+    import time
+    kw = dict(C4, lr=1e-6, exchange=ra.EXCHANGE_PEER, peer_timeout_ms=300)
     a, b = ra.Context(n_envs=256, **kw), ra.Context(n_envs=256, env_offset=256, **kw)
     h = [a.peer_export(2), b.peer_export(2)]
     a.peer_connect(h, 0); b.peer_connect(h, 1)
     a.reset()
-    a.train(1, want_stats=False)
+    t0 = time.perf_counter()
+    a.train(3, want_stats=False)
     with pytest.raises(ra.RsrlHipError) as ei:
         a.sync()
     assert ei.value.code == -4 and "timed out" in str(ei.value)
+    assert time.perf_counter() - t0 < 3.0                      # the configured bound, not the default
+    for read in (a.get_weights, lambda: a.states, a.checksum):
+        with pytest.raises(ra.RsrlHipError) as ei:
+            read()
+        assert ei.value.code == -4
     a.close(); b.close()
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(n_envs=4, peer_timeout_ms=-1)
 
 
 WORKER = r'''
