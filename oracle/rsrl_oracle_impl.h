@@ -629,10 +629,20 @@ R FN(orc_handle_gq)(const orc_agent* ag, R* W, R* V, const R* s, int a, R r, con
  *               w += td * trace  -- `ScaledGradientUpdate { alpha: td_error, jacobian: &trace }` (td_lambda.rs:59-62, :71-74):
  *               the step is the TD error itself, no learning rate (fa/linear.rs:184-196 bypasses the optimiser);
  *               a terminal transition then resets the trace (:64).
- * Dense (Fourier) bases only.  w, z: F values.  Returns the TD error. */
+ * Fourier bases: phi dense.  Tile coding (round 3): V(s) = the sum of the T active weights in tiling order, grad = 1.0 at the T
+ * active entries.  w, z: F values.  Returns the TD error. */
+static R FN(v_tile)(const orc_basis* b, const R* w, const R* s, int* idx) {
+    int t; float sf[8]; R acc = 0;
+    for (t = 0; t < b->dim; t++) sf[t] = (float)s[t];
+    orc_tile_indices(b, sf, idx);
+    for (t = 0; t < b->n_tilings; t++) acc = acc + w[idx[t]];
+    return acc;
+}
 R FN(orc_v_evaluate)(const orc_basis* b, const R* w, const R* s) {
     int F = orc_basis_nfeat(b); R v;
-    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
+    R* phi;
+    if (b->kind != ORC_FOURIER) { int idx[ORC_MAX_TILINGS]; return FN(v_tile)(b, w, s, idx); }
+    phi = (R*)malloc(sizeof(R) * (size_t)F);
     FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
     FN(dot_columns)(phi, w, 1, F, &v);
     free(phi);
@@ -641,9 +651,15 @@ R FN(orc_v_evaluate)(const orc_basis* b, const R* w, const R* s) {
 R FN(orc_handle_td)(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* ns, int term) {
     const orc_basis* b = &ag->basis; int F = orc_basis_nfeat(b), f;
     R pred, td, rate;
-    R* phi = (R*)malloc(sizeof(R) * (size_t)F);
-    FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
-    FN(dot_columns)(phi, w, 1, F, &pred);
+    R* phi = (R*)calloc((size_t)F, sizeof(R));
+    if (b->kind == ORC_FOURIER) {
+        FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
+        FN(dot_columns)(phi, w, 1, F, &pred);
+    } else {
+        int idx[ORC_MAX_TILINGS], t;
+        pred = FN(v_tile)(b, w, s, idx);
+        for (t = 0; t < b->n_tilings; t++) phi[idx[t]] = (R)1.0;
+    }
     if (ag->algo == ORC_TD_LAMBDA) {
         rate = (R)ag->gamma * (R)ag->lambda;
         if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);

@@ -27,6 +27,11 @@ bool launch_lambda_tile(int domain, int n_tilings, int64_t n_blocks, hipStream_t
                         uint64_t t, int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to,
                         const uint8_t* termf, int64_t Mn, float* td_out);
 
+struct TdParams;
+bool launch_td_tile(int domain, int n_tilings, bool lambda, int64_t n_blocks, hipStream_t st, const Common& k, const BasisGeom& g, const TdParams& tp,
+                    uint64_t t, int chunk, DevStats* stats, const float* from, const float* rew, const float* to, const uint8_t* termf, int64_t Mn,
+                    float* td_out, const float* eval_states);
+
 struct GqParams;
 bool launch_train_gq(int domain, int order, int policy, dim3 grid, dim3 block, hipStream_t st, const Common& k,
                      const GqParams& gp, uint64_t t, int chunk, DevStats* stats);

@@ -717,9 +717,10 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (!is_wave(*cfg) && !model_supported(*cfg))
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     if (is_pred(cfg->algo)) {
-        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+        const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;
+        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
             return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1) or on tile coding");
         if (cfg->policy != RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "prediction agents have no Q function: the behaviour policy must be RSRL_RANDOM");
         if (cfg->algo == RSRL_TD_LAMBDA) {
             if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
@@ -766,7 +767,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
-    if (is_lambda(cfg->algo) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
+    if ((is_lambda(cfg->algo) || is_pred(cfg->algo)) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
@@ -1014,7 +1015,10 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
-    if (is_pred(c->cfg.algo) && op == QOP_EVALUATE) {
+    if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && c->cfg.basis == RSRL_TILE_CODING) {
+        if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, false, 0, c->stream, k, g, make_td(c), 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M_,
+                            of.dev, d_states)) return NO_MODEL(c);
+    } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE) {
         if (!launch_v_evaluate(c->cfg.domain, c->cfg.order, dim3(grid_for(M_)), dim3(kBlock), c->stream, k, d_states, M_, of.dev)) return NO_MODEL(c);
     } else if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
@@ -1096,7 +1100,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_pred(c->cfg.algo)) {
+    if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
+        if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, M, c->stream, k, g, make_td(c), c->t, 1, nullptr, d_from, d_rew,
+                            d_to, d_term, M, otd.dev, nullptr)) return NO_MODEL(c);
+    } else if (is_pred(c->cfg.algo)) {
         if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
                               d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
     } else if (c->cfg.algo == RSRL_Q_SIGMA) {
@@ -1710,6 +1717,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         if (shared) {
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
             c->kernel_name = fourier ? "k_shared_step" : "k_shared_ca";
+        } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
+            if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, k.n_envs, c->stream, k, g, make_td(c), c->t, chunk, d_stats,
+                                nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return NO_MODEL(c);
+            c->kernel_name = "k_td_tile";
+            KCHECK();
         } else if (is_pred(c->cfg.algo)) {
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_td(c), c->t, chunk, d_stats)) return NO_MODEL(c);

@@ -107,7 +107,7 @@ def test_td_config_errors(ra):
     with pytest.raises(ra.RsrlHipError):
         ra.Context(n_envs=8, algo=7, policy=1)                       # no Q to be greedy on
     with pytest.raises(ra.RsrlHipError):
-        ra.Context(n_envs=8, algo=7, policy=3, basis=ra.TILE_CODING)
+        ra.Context(n_envs=8, algo=7, policy=3, basis=ra.TILE_CODING, weight_mode=ra.W_SHARED)   # per-learner tables only
     with ra.Context(n_envs=8, algo=7, policy=3) as c:
         with pytest.raises(ra.RsrlHipError):
             c.get_traces(0)
