@@ -1097,7 +1097,10 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
  *   - Q(s',a) with the updated column is re-evaluated (no rank-1 shortcut in this family); Q(s,.) is carried;
  *   - bf16 weight storage (w_bf16 != 0): every UPDATED weight is rounded to bf16 by stochastic rounding with the 16-bit
  *     window (e >> 2) of word (e & 3) of the lane's Philox block (block id 16 + lane), e = j*8 + v.
- * One-step control agents, per-env weights; returns -1 otherwise. */
+ *   - the eligibility-trace agents (round 3; rsrl_amd/csrc/kernels_wave_lambda.hpp, f32 weights only): orc_handle_lambda's
+ *     operations with the wave-order dot products -- Q(s,.) carried, Q(s',.) with the pre-update weights, z = rule(rate*z + g)
+ *     and w += alpha*residual*z on every entry, then Q(s',.) of ALL columns with the updated weights.
+ * One-step control agents and SARSALambda / QLambda, per-env weights; returns -1 otherwise. */
 static R FN(wave_total)(const R* lane_part) {
     R v[64], n[64]; int l, sh, row;
     for (l = 0; l < 64; l++) v[l] = lane_part[l];
@@ -1155,7 +1158,8 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
     R *phi_s, *phi_n, *tmp;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
-        !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
+        !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
+          (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z))) return -1;
     phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
     for (i = 0; i < N; i++) {
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
@@ -1173,6 +1177,34 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
             if (term) FN(orc_domain_reset)(ag->domain, ns);
             FN(wave_project)(b, ns, phi_n);
             for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+            if (ORC_IS_LAMBDA(ag->algo)) {
+                R* Z = run->Z + (size_t)i * F * A; R rate, m; int c, na_in;
+                const R qsa = q_s[a];
+                const int cut = ag->algo == ORC_Q_LAMBDA && a != FN(orc_argmax_first)(q_s, A);
+                rate = (R)ag->gamma * (R)ag->lambda;
+                if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+                if (cut) memset(Z, 0, sizeof(R) * (size_t)F * A);
+                if (term) delta = r - qsa;
+                else if (ag->algo == ORC_SARSA_LAMBDA) {
+                    orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+                    na_in = FN(orc_policy_sample)(ag->apolicy, q_n, A, ag->aeps_thr, (R)ag->atau, xin);
+                    delta = r + (R)ag->gamma * q_n[na_in] - qsa;
+                } else { FN(orc_find_max)(q_n, A, &m); delta = r + (R)ag->gamma * m - qsa; }
+                scale = (R)ag->alpha * delta;
+                for (l = 0; l < 64; l++)
+                    for (j = 0; j < 8; j++)
+                        for (v = 0; v < 8; v++)
+                            for (c = 0; c < A; c++) {
+                                const size_t at = FN(wave_row)(l, j, v) * A + c;
+                                const R g = (c == a) ? phi_s[(l * 8 + j) * 8 + v] : (R)0.0;
+                                R z = FN(fma_)(rate, Z[at], g);
+                                if (ag->trace == ORC_TRACE_SATURATE) { z = (z < (R)1.0) ? z : (R)1.0; z = (z > (R)-1.0) ? z : (R)-1.0; }
+                                W[at] = FN(fma_)(scale, z, W[at]);
+                                Z[at] = term ? (R)0.0 : z;
+                            }
+                for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);          /* every column moved */
+                goto sampled_target;
+            }
             if (ag->algo == ORC_SARSA) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
             delta = FN(td_from_q)(ag, q_s, a, q_n, r, term, xin, &e);
             scale = (R)ag->lr * e;
@@ -1194,6 +1226,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                     }
             }
             q_n[a] = FN(wave_dot)(phi_n, W, A, a);                          /* Q(s',a) with the UPDATED column */
+sampled_target:
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, term ? ORC_BLK_RESET : ORC_BLK_STEP, x);
             na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
             acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;

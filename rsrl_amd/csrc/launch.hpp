@@ -2,6 +2,7 @@
 // (order x algo x policy) instantiations compile in parallel.
 #pragma once
 #include "kernels_reg.hpp"
+#include "kernels_reg_q4.hpp"
 
 namespace rsrl {
 
@@ -13,7 +14,8 @@ bool launch_train_reg_d1(int order, int algo, int policy, dim3 grid, dim3 block,
 bool launch_train_reg_d2(int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
                          const Common& k, uint64_t t, int chunk, DevStats* stats, const uint64_t* t_dev = nullptr);
 
-// chunk == -1 selects the single-step streaming kernel (k_step_reg), -2 its learner-major form (k_step_reg_lm)
+// chunk == -1 selects the single-step streaming kernel (k_step_reg), -2 its learner-major form (k_step_reg_lm), -3 the learner-major
+// form with four lanes per learner (k_step_reg_q4: grid = learners / 64)
 struct LambdaParams;
 struct BasisGeom;
 bool launch_train_lambda(int domain, int order, int algo, int policy, dim3 grid, dim3 block, hipStream_t st,
@@ -56,7 +58,11 @@ bool launch_qsigma(int domain, int order, dim3 grid, dim3 block, hipStream_t st,
 
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
-        if (chunk == -2) {                                                                                  \
+        if (chunk == -3) {                                                                                  \
+            if constexpr (FourierReg<DM, OR>::F % 4 == 0 && Domain<DM>::A <= 3)                               \
+                hipLaunchKernelGGL((k_step_reg_q4<DM, OR, AL, PO>), dim3((unsigned)((k.n_envs + 63) / 64)), block, 0, st, k, t, stats, t_dev); \
+            else return false;                                                                              \
+        } else if (chunk == -2) {                                                                           \
             if constexpr ((Domain<DM>::A * FourierReg<DM, OR>::F) % 4 == 0 && FourierReg<DM, OR>::F % 4 == 0)     \
                 hipLaunchKernelGGL((k_step_reg_lm<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats, t_dev);       \
             else return false;                                                                              \

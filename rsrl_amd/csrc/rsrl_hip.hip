@@ -23,6 +23,7 @@
 #include "kernels_td.hpp"
 #include "kernels_qsigma.hpp"
 #include "kernels_persist.hpp"
+#include "kernels_wave_lambda.hpp"
 
 using namespace rsrl;
 
@@ -335,6 +336,7 @@ struct rsrl_hip_ctx {
     int64_t w_ls = 1;                // stride between learners (A*F in the learner-major single-step layout, else 1)
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
     size_t n_stat_slots = 0;
+    bool k1_quad = false;                      // single-step streaming kernel with four lanes per learner (k_step_reg_q4)
     uint64_t t = 0;          // batch-steps executed (RNG counter)
     int64_t pending = 0;     // batch-steps accepted by rsrl_hip_train but not launched yet (launch coalescing, see rsrl_hip_train)
     uint64_t api_calls = 0;  // RNG counter of rsrl_hip_policy_sample
@@ -735,9 +737,11 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     }
     if (is_lambda(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;     // dense per-learner trace tables
-        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
+        const bool wave_ok = cfg->basis == RSRL_FOURIER && is_wave(*cfg) && cfg->weight_mode == RSRL_W_PER_ENV && cfg->weight_dtype == RSRL_W_F32;
+        if (!tile_ok && !wave_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
             return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1) or on tile coding");
+                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1), on the order-7 wave family with f32 weights, "
+                                         "or on tile coding");
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
     }
@@ -764,9 +768,11 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         (uint64_t)c->w_elems * 4ull < (1ull << 32) && !getenv("RSRL_K1_FEATURE_MAJOR")) {
         c->w_stride = 1;
         c->w_ls = (int64_t)c->A * c->F;
+        const char* kq = getenv("RSRL_K1_QUAD");
+        c->k1_quad = c->A <= 3 && !(kq && kq[0] == '0');                 // four lanes per learner (RSRL_K1_QUAD=0: one lane, k_step_reg_lm)
     }
     c->dw_elems = (size_t)c->Aw * c->F;
-    c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : grid_for(N);     // one statistics slot per thread block
+    c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : (c->k1_quad ? (size_t)((N + 63) / 64) : grid_for(N));     // one statistics slot per thread block
     if ((is_lambda(cfg->algo) || is_pred(cfg->algo)) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
@@ -1115,6 +1121,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     } else if (is_lambda(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, M, c->stream, k, g, make_lambda(c), c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
                                 M, otd.dev)) return NO_MODEL(c);
+    } else if (is_lambda(c->cfg.algo) && is_wave(c->cfg)) {
+        if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+        else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
     } else if (is_lambda(c->cfg.algo)) {
         if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
                                   d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
@@ -1196,14 +1205,16 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
     if (out) {
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
-        hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, oz.dev);
+        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_get<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->Z + env_index * (int64_t)n, c->F, c->A, oz.dev);
+        else hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
         if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
         const float* d_z;
         TRY(stage_in(c, 0, in, (size_t)n, &d_z));
-        hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, d_z);
+        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_set<float>), dim3((unsigned)(((int64_t)c->A * (c->F / 8) + 255) / 256)), dim3(256), 0, c->stream, c->Z, env_index, (int64_t)1, c->F, c->A, d_z);
+        else hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, d_z);
         KCHECK();
         if (!is_device_ptr(in)) HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -1544,7 +1555,7 @@ static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g
 static int enqueue_k1_step(rsrl_hip_ctx* c, const Common& k, DevStats* d_stats, uint64_t t, const uint64_t* t_dev) {
     const dim3 gr(grid_for(k.n_envs)), b(kBlock);
     bool ok;
-    const int kind = c->w_ls != 1 ? -2 : -1;              // learner-major rows: k_step_reg_lm
+    const int kind = c->w_ls != 1 ? (c->k1_quad ? -3 : -2) : -1;              // learner-major rows: k_step_reg_q4 / k_step_reg_lm
     switch (c->cfg.domain) {
     case 0: ok = launch_train_reg_d0(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, d_stats, t_dev); break;
     case 1: ok = launch_train_reg_d1(c->cfg.order, c->cfg.algo, c->cfg.policy, gr, b, c->stream, k, t, kind, d_stats, t_dev); break;
@@ -1705,7 +1716,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             TRY(timing_begin(c));
             HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
             TRY(timing_end(c, kStepsPerGraph));
-            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
+            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? (c->k1_quad ? "k_step_reg_q4" : "k_step_reg_lm") : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
             c->t += (uint64_t)kStepsPerGraph;
             if (peer_steps) c->peer_seq += (uint64_t)kStepsPerGraph;
             done += kStepsPerGraph;
@@ -1742,6 +1753,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
                                     nullptr, nullptr, nullptr, 0, nullptr)) return NO_MODEL(c);
             c->kernel_name = "k_lambda_tile";
             KCHECK();
+        } else if (is_lambda(c->cfg.algo) && is_wave(c->cfg)) {
+            if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            c->kernel_name = "k_wave_lambda";
+            KCHECK();
         } else if (is_lambda(c->cfg.algo)) {
             if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),
                                      c->stream, k, make_lambda(c), c->t, chunk, d_stats)) return NO_MODEL(c);
@@ -1756,7 +1772,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             KCHECK();
         } else if (stream_k1) {
             TRY(enqueue_k1_step(c, k, d_stats, c->t, nullptr));
-            c->kernel_name = c->w_ls != 1 ? "k_step_reg_lm" : "k_step_reg";
+            c->kernel_name = c->w_ls != 1 ? (c->k1_quad ? "k_step_reg_q4" : "k_step_reg_lm") : "k_step_reg";
             c->q_valid = true; k.q_valid = 1;
         } else if (fourier && !is_generic_fourier(c->cfg)) {
             const dim3 gr(grid_for(k.n_envs)), b(kBlock);

@@ -95,8 +95,10 @@ def test_lambda_error_paths(ra):
         pass
     with pytest.raises(ra.RsrlHipError):                                    # ... with per-learner tables only
         ra.Context(algo=4, basis=ra.TILE_CODING, domain=1, n_envs=4, weight_mode=ra.W_SHARED)
-    with pytest.raises(ra.RsrlHipError):                                    # the order-7 wave family has no trace kernels
-        ra.Context(algo=3, domain=2, order=7, n_envs=4)
+    with ra.Context(algo=3, domain=2, order=7, n_envs=4):                   # the order-7 wave family: built in round 3 (tests/test_gpu_wave_lambda.py)
+        pass
+    with pytest.raises(ra.RsrlHipError):                                    # ... with f32 tables only
+        ra.Context(algo=3, domain=2, order=7, n_envs=4, weight_dtype=ra.W_BF16)
     with pytest.raises(ra.RsrlHipError):
         ra.Context(algo=3, lam=1.5, n_envs=4)
     with ra.Context(n_envs=4) as c:

@@ -232,18 +232,27 @@ def test_train_fused_equals_stepwise_bitwise(ra):
     dict(domain=1, order=1, algo=0, policy=1, epsilon=0.1),                 # CartPole, A*F = 32
     dict(domain=2, order=1, algo=1, policy=0),                              # Acrobot SARSA Greedy, A*F = 48
 ])
-def test_single_step_kernels_equal_the_fused_kernel_for_every_agent(ra, kw):
-    # both single-step kernels (learner-major k_step_reg_lm, feature-major k_step_reg), plain and graph-replayed, against
-    # the fused kernel: 70 batch-steps, bit for bit, with episode restarts and step-cap truncations on the way
+@pytest.mark.parametrize("quad", ["1", "0"])
+def test_single_step_kernels_equal_the_fused_kernel_for_every_agent(ra, kw, quad, monkeypatch):
+    # the single-step kernels (learner-major with four lanes per learner k_step_reg_q4 / one lane k_step_reg_lm, feature-major
+    # k_step_reg), plain and graph-replayed, against the fused kernel: 70 batch-steps, bit for bit, with episode restarts and
+    # step-cap truncations on the way
+    monkeypatch.setenv("RSRL_K1_QUAD", quad)
     base = dict(n_envs=333, seed=7, max_episode_steps=25, gamma=0.95, lr=0.01)
     with ra.Context(steps_per_launch=70, **base, **kw) as a, ra.Context(steps_per_launch=1, **base, **kw) as b:
         a.reset(); b.reset()
         sa, sb = a.train(70), b.train(35)
-        b.train(35, want_stats=False)                      # second half through the captured graph (32) + plain launches (3)
+        sb2 = b.train(35)
         assert np.array_equal(a.states, b.states) and np.array_equal(a.actions, b.actions)
-        for i in (0, 63, 64, 332):
+        for i in (0, 15, 16, 63, 64, 332):
             assert np.array_equal(a.get_weights(i), b.get_weights(i))
         assert a.checksum() == b.checksum() and sa["env_steps"] == 2 * sb["env_steps"]
+        for key in ("episodes", "episodes_truncated", "sum_episode_steps"):
+            assert sa[key] == sb[key] + sb2[key], key
+        assert abs(sa["sum_abs_td_error"] - sb["sum_abs_td_error"] - sb2["sum_abs_td_error"]) <= 1e-5 * sa["sum_abs_td_error"]      # the fused kernel sums its launch in fp32
+        b.train(40, want_stats=False)                      # through the captured graph (32) + plain launches (8)
+        a.train(40, want_stats=False)
+        assert np.array_equal(a.states, b.states) and a.checksum() == b.checksum()
 
 
 def test_train_sharding_invariance(ra):
