@@ -397,6 +397,9 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 #ifndef RSRL_K1_STORE_ALL
 #define RSRL_K1_STORE_ALL 1
 #endif
+#ifndef RSRL_K1_SECTOR_STORE
+#define RSRL_K1_SECTOR_STORE 0     // A/B: k_step_reg_lm writes the touched column back as whole 64-byte sectors (slower below 1 M learners)
+#endif
 
 // Registers: __launch_bounds__(kBlock, 2) = at most 256 per lane, so a launch of more than 1024 waves (> 65 536 learners) runs
 // TWO waves per SIMD: a lone wave issues one VALU instruction per ~3.4 cycles (packed fma 5.2, v_mad_u64 8, v_cndmask 8.4), two
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         // ---- W[:,a] += lr * e * phi(s): old column from the LDS image (lane-dependent address), new column to memory
         const float scale = alg.lr * e;
         float vcol[F];
-        const float* __restrict__ colp = img + lane * AF + a * F;
+        float* __restrict__ colp = img + lane * AF + a * F;
         const int col_off = (lane * AF + a * F) * 4;
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
@@ -832,7 +835,11 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             v.x = fmaf(scale, phi_s[4 * k], o.x); v.y = fmaf(scale, phi_s[4 * k + 1], o.y);
             v.z = fmaf(scale, phi_s[4 * k + 2], o.z); v.w = fmaf(scale, phi_s[4 * k + 3], o.w);
             vcol[4 * k] = v.x; vcol[4 * k + 1] = v.y; vcol[4 * k + 2] = v.z; vcol[4 * k + 3] = v.w;
+#if RSRL_K1_SECTOR_STORE
+            *reinterpret_cast<f4*>(colp + 4 * k) = v;                     // merged into the wave's image, written back below
+#else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, 0);
+#endif
         }
         // ---- Q(s',.) with the UPDATED weights: only column a changed
         {
@@ -878,6 +885,26 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
 #pragma unroll
         for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
     }
+#if RSRL_K1_SECTOR_STORE
+    // A/B (off): the touched column goes back as WHOLE 64-byte sectors -- F*4 = 144 bytes at a 16-byte-aligned offset dirty three.
+    // With one lane per learner every store instruction still scatters 64 separate 16-byte pieces, and the kernel got SLOWER
+    // (10.3 vs 9.05 us per launch at 65 536 learners, 42.7 vs 38.0 at 262 144; 158 vs 175 at 1 M); k_step_reg_q4, whose quads
+    // store whole sectors with one instruction, keeps it.  The bytes around the column come from the wave's image, where every
+    // lane's update has been merged: two lanes whose sectors overlap store the same bytes; no sector is shared between waves.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i < N) {
+        static_assert((64 * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
+        constexpr int NSEC = (48 + F * 4 + 63) / 64;                    // sectors a 16-byte-aligned column can touch
+        const int sec = ((lane * AF + a * F) * 4) & ~63;
+#pragma unroll
+        for (int p = 0; p < 4 * NSEC; ++p) {
+            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + sec + 16 * p);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, sec + 16 * p, 0, 0);
+        }
+    }
+#endif
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 

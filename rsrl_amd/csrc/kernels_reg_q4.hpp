@@ -2,10 +2,12 @@
 //
 // k_step_reg_lm (kernels_reg.hpp) gives every learner one lane: a wave owns 64 learners and a 27 KB LDS image (A*F = 108 weights
 // each), a block of four waves fills the CU's LDS budget, and every SIMD holds ONE wave whose three phases -- load the image,
-// compute, store the touched column -- cannot overlap with anything: 0.55 of 8 TB/s at 65 536 learners, 0.45 at 1-4 M.
-// Here a learner is a QUAD of lanes: lane b of the quad owns action column b (F weights), so a wave covers 16 learners, its image
-// is 6.9 KB, and sixteen waves per CU (four per SIMD) are in different phases at any time -- one wave's loads run under
-// another's arithmetic and a third's stores.
+// compute, store the touched column -- cannot overlap with anything.  Here a learner is a QUAD of lanes: lane b of the quad owns
+// action column b (F weights), so a wave covers 16 learners, its image is 6.9 KB, and up to sixteen waves per CU are resident.
+// Measured (us per launch, one-lane kernel -> this one): 65 536 learners 9.05 -> 9.5 (ONE round of waves either way, all in the
+// same phase at the same time, and the quad replicates the learner's scalar work in four lanes: the one-lane kernel stays the
+// default there), 131 072: 21.3 -> 19.3, 262 144: 38.0 -> 31.5 (0.52 -> 0.62 of 8 TB/s on the 608 B/env-step accounting),
+// 1 M: 160-175 -> 152 -- where the access pattern alone, with no arithmetic, takes 127-140 (scripts/ubench/stream_pattern.hip).
 //   load : the wave's 16 x A x F image as ceil(432 / 64) fully coalesced 16-B loads per lane (contiguous 6.9 KB), through LDS
 //          (linear 16-B writes, then lane (learner q, column b) reads its F weights: F/4 ds_read_b128)
 //   math : transition, phi(s), phi(s'), the draws -- per quad, replicated in its four lanes (same instructions, same bits);
@@ -20,13 +22,14 @@
 namespace rsrl {
 
 #ifndef RSRL_Q4_AUX_LD
-#define RSRL_Q4_AUX_LD 0          // cache-policy bits of the image loads / column stores (A/B: 2 = nt)
+#define RSRL_Q4_AUX_LD 0          // cache-policy bits of the image loads / column stores; A/B: 2 = nt is SLOWER at every size (loads nt
+                                  // 13.3 vs 9.8 us at 65 536 learners -- W lives in L2 / MALL between launches --, both nt 331 vs 168 at 1 M)
 #endif
 #ifndef RSRL_Q4_AUX_ST
 #define RSRL_Q4_AUX_ST 0
 #endif
-#ifndef RSRL_Q4_STORE_ALL
-#define RSRL_Q4_STORE_ALL 0       // A/B: every column goes back (full lines, 3x the bytes) instead of the touched one
+#ifndef RSRL_Q4_SECTOR_STORE
+#define RSRL_Q4_SECTOR_STORE 1
 #endif
 
 template <int J>
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int bc = b < A ? b : 0;                                        // lane 3 of a three-action quad reads column 0 and is ignored
-    const int col_off = (q * AF + bc * F) * 4;                           // bytes, inside the wave's image and inside its slice of W
+    [[maybe_unused]] const int col_off = (q * AF + bc * F) * 4;          // bytes, inside the wave's image and inside its slice of W
     float wcol[1][F];
 #pragma unroll
     for (int k = 0; k < F4; ++k) {
@@ -132,24 +135,43 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     // ---- W[:,a] += lr * e * phi(s): lane a of the quad
     const float scale = alg.lr * e;
     const bool mine = b == a;
-    if (mine || (RSRL_Q4_STORE_ALL && b < A)) {
-        const float sc = mine ? scale : 0.0f;
+    if (mine) {
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
             f4 v;
-            if (RSRL_Q4_STORE_ALL) {
-                v.x = mine ? fmaf(sc, phi_s[4 * k], wcol[0][4 * k]) : wcol[0][4 * k]; v.y = mine ? fmaf(sc, phi_s[4 * k + 1], wcol[0][4 * k + 1]) : wcol[0][4 * k + 1];
-                v.z = mine ? fmaf(sc, phi_s[4 * k + 2], wcol[0][4 * k + 2]) : wcol[0][4 * k + 2]; v.w = mine ? fmaf(sc, phi_s[4 * k + 3], wcol[0][4 * k + 3]) : wcol[0][4 * k + 3];
-                wcol[0][4 * k] = v.x; wcol[0][4 * k + 1] = v.y; wcol[0][4 * k + 2] = v.z; wcol[0][4 * k + 3] = v.w;
-                if (i < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, RSRL_Q4_AUX_ST);
-                continue;
-            }
             v.x = fmaf(scale, phi_s[4 * k], wcol[0][4 * k]); v.y = fmaf(scale, phi_s[4 * k + 1], wcol[0][4 * k + 1]);
             v.z = fmaf(scale, phi_s[4 * k + 2], wcol[0][4 * k + 2]); v.w = fmaf(scale, phi_s[4 * k + 3], wcol[0][4 * k + 3]);
             wcol[0][4 * k] = v.x; wcol[0][4 * k + 1] = v.y; wcol[0][4 * k + 2] = v.z; wcol[0][4 * k + 3] = v.w;
+#if RSRL_Q4_SECTOR_STORE
+            *reinterpret_cast<f4*>(img + q * AF + bc * F + 4 * k) = v;                   // merged into the wave's image, written back below
+#else
             if (i < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, RSRL_Q4_AUX_ST);
+#endif
         }
     }
+#if RSRL_Q4_SECTOR_STORE
+    // The touched column goes back as WHOLE 64-byte sectors, one store instruction per sector with the quad's four lanes writing
+    // its four 16-byte pieces: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and a partially written sector is a
+    // read-modify-write for the memory side (scripts/ubench/stream_pattern.hip: read 432 + write 144 per learner, no arithmetic,
+    // 6.2 us per launch at 65 536 learners and 140 us at 1 M; 4.7 and 127-135 us with the columns widened to whole sectors /
+    // lines).  The bytes around the column come from the wave's image in LDS, where the quads' updates have been merged: two quads
+    // whose sectors overlap store the same bytes.  The image is a multiple of 64 bytes long: no sector is shared between waves.
+    // Measured on the kernel: 9.9 -> 9.5 us at 65 536 learners, 32.7 -> 31.5 at 262 144, 159 -> 152 at 1 M.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i < N) {
+        static_assert((LPW * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
+        constexpr int NSEC = (48 + F * 4 + 63) / 64;
+        const int sec = ((q * AF + a * F) * 4) & ~63;
+#pragma unroll
+        for (int p = 0; p < NSEC; ++p) {
+            const int off = sec + 64 * p + 16 * b;
+            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + off);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, RSRL_Q4_AUX_ST);
+        }
+    }
+#endif
     // ---- Q(s',.) with the UPDATED weights: only column a changed (rank-1 term, as k_step_reg_lm)
     {
         float dacc[P];

@@ -769,7 +769,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         c->w_stride = 1;
         c->w_ls = (int64_t)c->A * c->F;
         const char* kq = getenv("RSRL_K1_QUAD");
-        c->k1_quad = c->A <= 3 && !(kq && kq[0] == '0');                 // four lanes per learner (RSRL_K1_QUAD=0: one lane, k_step_reg_lm)
+        // four lanes per learner (k_step_reg_q4) pays once there is more than one round of one-lane waves to overlap: measured
+        // 19.8 vs 21.3 us per launch at 131 072 learners, 32.7 vs 38.0 at 262 144, but 9.8 vs 9.0 at 65 536 (RSRL_K1_QUAD=1 / 0 forces)
+        c->k1_quad = c->A <= 3 && (kq ? kq[0] != '0' : N >= 131072);
     }
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : (c->k1_quad ? (size_t)((N + 63) / 64) : grid_for(N));     // one statistics slot per thread block

@@ -2,11 +2,13 @@
 # round 3: cache-policy / store-all variants of the four-lanes-per-learner streaming kernel (built by scripts/build_variants.py)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-for v in base q4_ldnt q4_stnt q4_nt q4_all lm; do
+for v in base lm nosec_q4 nosec_lm; do
   for n in 65536 131072 262144 1048576; do
     lib=rsrl_amd/lib/variants/$v.so; quad=1
     [ $v = base ] && lib=rsrl_amd/lib/librsrl_hip.so
     [ $v = lm ] && lib=rsrl_amd/lib/librsrl_hip.so && quad=0
+    [ $v = nosec_q4 ] && lib=rsrl_amd/lib/variants/nosec.so
+    [ $v = nosec_lm ] && lib=rsrl_amd/lib/variants/nosec.so && quad=0
     RSRL_HIP_LIB=$lib RSRL_K1_QUAD=$quad python - <<PY
 import json, time, rsrl_amd as ra
 n=$n
