@@ -398,7 +398,8 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 #define RSRL_K1_STORE_ALL 1
 #endif
 #ifndef RSRL_K1_SECTOR_STORE
-#define RSRL_K1_SECTOR_STORE 0     // A/B: k_step_reg_lm writes the touched column back as whole 64-byte sectors (slower below 1 M learners)
+#define RSRL_K1_SECTOR_STORE 2     // k_step_reg_lm writes the touched column back as whole 64-byte sectors: 2 = four consecutive lanes per
+                                   // sector (default), 1 = each lane its own three sectors (A/B: slower), 0 = the 144 bytes directly
 #endif
 
 // Registers: __launch_bounds__(kBlock, 2) = at most 256 per lane, so a launch of more than 1024 waves (> 65 536 learners) runs
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         const float scale = alg.lr * e;
         float vcol[F];
         float* __restrict__ colp = img + lane * AF + a * F;
-        const int col_off = (lane * AF + a * F) * 4;
+        [[maybe_unused]] const int col_off = (lane * AF + a * F) * 4;
 #pragma unroll
         for (int k = 0; k < F4; ++k) {
             const f4 o = *reinterpret_cast<const f4*>(colp + 4 * k);
@@ -886,23 +887,40 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
     }
 #if RSRL_K1_SECTOR_STORE
-    // A/B (off): the touched column goes back as WHOLE 64-byte sectors -- F*4 = 144 bytes at a 16-byte-aligned offset dirty three.
-    // With one lane per learner every store instruction still scatters 64 separate 16-byte pieces, and the kernel got SLOWER
-    // (10.3 vs 9.05 us per launch at 65 536 learners, 42.7 vs 38.0 at 262 144; 158 vs 175 at 1 M); k_step_reg_q4, whose quads
-    // store whole sectors with one instruction, keeps it.  The bytes around the column come from the wave's image, where every
-    // lane's update has been merged: two lanes whose sectors overlap store the same bytes; no sector is shared between waves.
+    // The touched column goes back as WHOLE 64-byte sectors: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and
+    // what the memory side is slow at is a store instruction that scatters 64 separate 16-byte pieces (scripts/ubench/
+    // stream_pattern.hip: read 432 + write 144 per learner, no arithmetic, 6.2 us per launch at 65 536 learners; 4.7 us with the
+    // same columns written as whole sectors, four lanes per sector).  So the lanes' updates are merged into the wave's LDS image,
+    // and the wave then writes its 64 x 3 dirty sectors with FOUR CONSECUTIVE LANES PER SECTOR (the sector offsets come from the
+    // owning lanes by ds_bpermute): every store instruction writes 16 whole sectors.  Measured, us per launch: 9.05 -> 7.94 at
+    // 65 536 learners (0.53 -> 0.60 of 8 TB/s on the 608 B/env-step accounting), 21.3 -> 19.6 at 131 072, 37.9 -> 36.0 at 262 144.
+    // Each lane writing its own three sectors (variant 1: still 64 scattered pieces per instruction) was SLOWER than the direct
+    // stores: 10.3 us.  Two learners whose sectors overlap store the same bytes (both read the merged image); the image is a
+    // multiple of 64 bytes long, so no sector is shared between waves; sectors of learners beyond N fall outside the descriptor.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (i < N) {
+    {
         static_assert((64 * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
         constexpr int NSEC = (48 + F * 4 + 63) / 64;                    // sectors a 16-byte-aligned column can touch
-        const int sec = ((lane * AF + a * F) * 4) & ~63;
+        const int sec = i < N ? (((lane * AF + a * F) * 4) & ~63) : 0x40000000;       // invalid learner: out of the descriptor's range
+#if RSRL_K1_SECTOR_STORE == 2
+        // four consecutive lanes store one sector: every store instruction writes 16 whole sectors
 #pragma unroll
         for (int p = 0; p < 4 * NSEC; ++p) {
-            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + sec + 16 * p);
+            const int g = p * 64 + lane, sidx = g >> 2, j = sidx / NSEC, t = sidx - j * NSEC;
+            const int sj = __builtin_amdgcn_ds_bpermute(j * 4, sec);
+            const int off = sj + 64 * t + 16 * (g & 3);
+            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + (off & 0xffff));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, 0);
+        }
+#else
+#pragma unroll
+        for (int p = 0; p < 4 * NSEC; ++p) {
+            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + ((sec + 16 * p) & 0xffff));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, sec + 16 * p, 0, 0);
         }
+#endif
     }
 #endif
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
