@@ -776,6 +776,20 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
 #pragma unroll
     for (int m = 0; m < AF4; ++m)
         ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * m) * 16, 0, 0));
+#if RSRL_K1_SECTOR_STORE == 2
+    // where this lane will store in the write-back of the touched columns (see below): piece (g & 3) of sector t of learner j's
+    // column -- known from the actions alone, so the lane exchange runs here, under the loads
+    constexpr int NSEC = (48 + F * 4 + 63) / 64;                        // sectors a 16-byte-aligned column can touch
+    int wb_off[4 * NSEC];
+    {
+        const int sec = i < N ? (((lane * AF + a * F) * 4) & ~63) : 0x40000000;       // learner beyond N: outside the descriptor's range
+#pragma unroll
+        for (int p = 0; p < 4 * NSEC; ++p) {
+            const int g = p * 64 + lane, sidx = g >> 2, j = sidx / NSEC, t = sidx - j * NSEC;
+            wb_off[p] = __builtin_amdgcn_ds_bpermute(j * 4, sec) + 64 * t + 16 * (g & 3);
+        }
+    }
+#endif
 
     // ... and everything that needs only the state runs underneath them: the transition, both projections, the draws
     PolicyParams pol = c.pol; pol.kind = POLICY;
@@ -809,7 +823,8 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         wv[(4 * k + 2) / F][(4 * k + 2) % F] = v.z; wv[(4 * k + 3) / F][(4 * k + 3) % F] = v.w;
     }
 
-    if (i < N) {
+    // every lane computes (a lane beyond N repeats learner N-1 and stores nothing): no divergence around the wave-level write-back
+    {
         constexpr int P = RSRL_DOT_SPLIT;
         float qs_arr[A];
         if (c.q_valid) {
@@ -842,6 +857,40 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, 0);
 #endif
         }
+#if RSRL_K1_SECTOR_STORE
+        // The touched column goes back as WHOLE 64-byte sectors: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and
+        // what the memory side is slow at is a store instruction that scatters 64 separate 16-byte pieces (scripts/ubench/
+        // stream_pattern.hip: read 432 + write 144 per learner, no arithmetic, 6.2 us per launch at 65 536 learners; 4.7 us with the
+        // same columns written as whole sectors, four lanes per sector).  So the lanes' updates are merged into the wave's LDS image,
+        // and the wave then writes its 64 x 3 dirty sectors with FOUR CONSECUTIVE LANES PER SECTOR (the sector offsets come from the
+        // owning lanes by ds_bpermute): every store instruction writes 16 whole sectors.  Measured, us per launch: 9.05 -> 7.94 at
+        // 65 536 learners (0.53 -> 0.60 of 8 TB/s on the 608 B/env-step accounting), 21.3 -> 19.6 at 131 072, 37.9 -> 36.0 at 262 144.
+        // Each lane writing its own three sectors (variant 1: still 64 scattered pieces per instruction) was SLOWER than the direct
+        // stores: 10.3 us.  Two learners whose sectors overlap store the same bytes (both read the merged image); the image is a
+        // multiple of 64 bytes long, so no sector is shared between waves; sectors of learners beyond N fall outside the descriptor.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            static_assert((64 * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
+#if RSRL_K1_SECTOR_STORE == 2
+            // four consecutive lanes store one sector: every store instruction writes 16 whole sectors
+#pragma unroll
+            for (int p = 0; p < 4 * NSEC; ++p) {
+                const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + (wb_off[p] & 0xffff));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, wb_off[p], 0, 0);
+            }
+#else
+            constexpr int NSEC = (48 + F * 4 + 63) / 64;                    // sectors a 16-byte-aligned column can touch
+            const int sec = i < N ? (((lane * AF + a * F) * 4) & ~63) : 0x40000000;       // invalid learner: out of the descriptor's range
+#pragma unroll
+            for (int p = 0; p < 4 * NSEC; ++p) {
+                const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + ((sec + 16 * p) & 0xffff));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, sec + 16 * p, 0, 0);
+            }
+#endif
+        }
+#endif
         // ---- Q(s',.) with the UPDATED weights: only column a changed
         {
 #if RSRL_RANK1_QPOST
@@ -879,50 +928,17 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             const U4 xr = draw(c.seed, gid, t, BLK_RESET);
             na = policy_sample<A>(pol, q_n, xr);
         }
+        if (i < N) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
-        c.action[i] = na;
-        c.ep_step[i] = ep;
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+            c.action[i] = na;
+            c.ep_step[i] = ep;
 #pragma unroll
-        for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
-    }
-#if RSRL_K1_SECTOR_STORE
-    // The touched column goes back as WHOLE 64-byte sectors: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and
-    // what the memory side is slow at is a store instruction that scatters 64 separate 16-byte pieces (scripts/ubench/
-    // stream_pattern.hip: read 432 + write 144 per learner, no arithmetic, 6.2 us per launch at 65 536 learners; 4.7 us with the
-    // same columns written as whole sectors, four lanes per sector).  So the lanes' updates are merged into the wave's LDS image,
-    // and the wave then writes its 64 x 3 dirty sectors with FOUR CONSECUTIVE LANES PER SECTOR (the sector offsets come from the
-    // owning lanes by ds_bpermute): every store instruction writes 16 whole sectors.  Measured, us per launch: 9.05 -> 7.94 at
-    // 65 536 learners (0.53 -> 0.60 of 8 TB/s on the 608 B/env-step accounting), 21.3 -> 19.6 at 131 072, 37.9 -> 36.0 at 262 144.
-    // Each lane writing its own three sectors (variant 1: still 64 scattered pieces per instruction) was SLOWER than the direct
-    // stores: 10.3 us.  Two learners whose sectors overlap store the same bytes (both read the merged image); the image is a
-    // multiple of 64 bytes long, so no sector is shared between waves; sectors of learners beyond N fall outside the descriptor.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-        static_assert((64 * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
-        constexpr int NSEC = (48 + F * 4 + 63) / 64;                    // sectors a 16-byte-aligned column can touch
-        const int sec = i < N ? (((lane * AF + a * F) * 4) & ~63) : 0x40000000;       // invalid learner: out of the descriptor's range
-#if RSRL_K1_SECTOR_STORE == 2
-        // four consecutive lanes store one sector: every store instruction writes 16 whole sectors
-#pragma unroll
-        for (int p = 0; p < 4 * NSEC; ++p) {
-            const int g = p * 64 + lane, sidx = g >> 2, j = sidx / NSEC, t = sidx - j * NSEC;
-            const int sj = __builtin_amdgcn_ds_bpermute(j * 4, sec);
-            const int off = sj + 64 * t + 16 * (g & 3);
-            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + (off & 0xffff));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, 0);
+            for (int b = 0; b < A; ++b) c.qcache[(int64_t)b * N + i] = q_n[b];
+        } else {
+            n_ep = 0; n_trunc = 0; sum_len = 0; sum_abs = 0.0; sum_r = 0.0;
         }
-#else
-#pragma unroll
-        for (int p = 0; p < 4 * NSEC; ++p) {
-            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + ((sec + 16 * p) & 0xffff));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, sec + 16 * p, 0, 0);
-        }
-#endif
     }
-#endif
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
