@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     constexpr int D = Dom::D, A = Dom::A, F = Bas::F, AF = A * F;
     static_assert(F % 4 == 0 && A <= 4 && A <= 3, "16-byte columns, one lane of the quad per action, carried Q for A <= 3");
     constexpr int LPW = 16, IMG = LPW * AF, IMG4 = IMG / 4, NLD = (IMG4 + 63) / 64, F4 = F / 4;
-    __shared__ __attribute__((aligned(16))) float lds[(kBlock / 64) * IMG];
+    constexpr int IMGP = NLD * 64 * 4;                                   // image stride in LDS: whole load instructions (the last one overhangs)
+    __shared__ __attribute__((aligned(16))) float lds[(kBlock / 64) * IMGP];
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef int i4 __attribute__((ext_vector_type(4)));
     const int64_t N = c.n_envs;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     const int q = lane >> 2, b = lane & 3;
     const int64_t wbase = ((int64_t)blockIdx.x * (kBlock / 64) + wv_id) * LPW;       // first learner of this wave
     const int64_t i = wbase + q;
-    float* __restrict__ img = lds + wv_id * IMG;
+    float* __restrict__ img = lds + wv_id * IMGP;
     const int64_t remain = N - wbase;
     const uint32_t img_bytes = (uint32_t)((remain < LPW ? (remain < 0 ? 0 : remain) : LPW) * AF * 4);
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(c.W + wbase * AF), 0, (int)img_bytes, 0x00020000);
@@ -74,10 +75,16 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
         qc1 = c.qcache[N + il];
         if constexpr (A > 2) qc2 = c.qcache[2 * N + il];
     }
+#if RSRL_K1_LDS_DMA
+#pragma unroll
+    for (int m = 0; m < NLD; ++m)         // straight into the wave's LDS image (wave-uniform LDS base + lane * 16); beyond the image: zeros into the pad
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + 64 * 4 * m), 16, lane * 16, 64 * 16 * m, 0, RSRL_Q4_AUX_LD);
+#else
     f4 ld[NLD];
 #pragma unroll
     for (int m = 0; m < NLD; ++m)
         ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * m) * 16, 0, RSRL_Q4_AUX_LD));
+#endif
 
     PolicyParams pol = c.pol; pol.kind = POLICY;
     AlgoParams alg = c.alg; alg.kind = ALGO;
@@ -96,9 +103,13 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
     const U4 x = draw(c.seed, gid, t, BLK_STEP);
 
+#if RSRL_K1_LDS_DMA
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): the issuing wave's covering wait orders its ds_reads
+#else
 #pragma unroll
     for (int m = 0; m < NLD; ++m)
         if (m + 1 < NLD || lane + 64 * m < IMG4) *reinterpret_cast<f4*>(img + (lane + 64 * m) * 4) = ld[m];
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // the image is private to this wave: no block barrier
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

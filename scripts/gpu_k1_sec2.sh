@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3: k_step_reg_lm with cooperative whole-sector stores (variant hoist) against the default
+# round 3: k_step_reg_lm with cooperative whole-sector stores (variant dma) against the default
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-RSRL_HIP_LIB=rsrl_amd/lib/variants/hoist.so RSRL_K1_QUAD=0 python -m pytest tests/test_gpu_parity_mc.py -x -q -m gpu -k "single_step" 2>&1 | tail -3
-for v in hoist base; do
+RSRL_HIP_LIB=rsrl_amd/lib/variants/dma.so RSRL_K1_QUAD=0 python -m pytest tests/test_gpu_parity_mc.py -x -q -m gpu -k "single_step" 2>&1 | tail -3
+for v in dma base; do
   for n in 65536 131072 262144 1048576; do
     lib=rsrl_amd/lib/variants/$v.so
     [ $v = base ] && lib=rsrl_amd/lib/librsrl_hip.so
@@ -21,4 +21,4 @@ print(json.dumps({"variant": "$v", "n": n, "kernel": kn, "us_per_step_wall": rou
 c.close()
 PY
   done
-done 2>&1 | tee gpurun_out/k1_hoist.txt
+done 2>&1 | tee gpurun_out/k1_dma.txt
