@@ -62,8 +62,9 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
 /* rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}
  *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66
  * the eligibility-trace agents {SARSALambda, QLambda}
- *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights; register-family Fourier bases, or tile coding with one
- *   dense trace table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12)
+ *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights; register-family Fourier bases, the order-7 Fourier bases of
+ *   the 4-D domains with f32 weights (W and the trace streamed from memory every step), or tile coding with one dense trace
+ *   table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12)
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights, register-family Fourier bases */
