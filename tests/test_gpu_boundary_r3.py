@@ -274,3 +274,31 @@ def test_persistent_kernel_equals_one_launch_per_step_on_every_shape(ra, cfg, N)
     assert np.abs(ref[0]).max() > 0
     assert all(np.array_equal(a, b) for a, b in zip(ref[:3], got[:3]))
     assert ref[3] == got[3] and ref[4] == got[4]
+
+
+def test_empty_oversized_and_ragged_batches(ra):
+    # the granular calls take 1 <= M <= n_envs items; an empty or an oversized batch is refused with EINVAL and changes nothing,
+    # a ragged one (M < n_envs) touches learners 0..M-1 only; train(0) is a no-op
+    N = 200
+    with ra.Context(n_envs=N, policy=1, epsilon=0.1, seed=2) as c:
+        c.reset(); c.train(10)
+        before = c.checksum(); s0 = c.states.copy()
+        L, h = c._L, c._h
+        buf = np.zeros((2, N + 8), np.float32); out = np.zeros((3, N + 8), np.float32)
+        idx = np.zeros(N + 8, np.int32)
+        p = lambda a: a.ctypes.data_as(__import__("ctypes").c_void_p)       # noqa: E731
+        for M in (0, -3, N + 1):
+            assert L.rsrl_hip_q_evaluate(h, p(buf), M, p(out)) != 0
+            assert L.rsrl_hip_policy_sample(h, p(buf), M, p(idx)) != 0
+            assert L.rsrl_hip_handle(h, p(buf), p(idx), p(out), p(buf), p(idx), M, p(out)) != 0
+        assert c.checksum() == before and np.array_equal(c.states, s0)
+        st = c.train(0)
+        assert st["env_steps"] == 0 and c.checksum() == before
+        # ragged handle: 7 transitions move 7 learners
+        a = c.actions[:7].copy()
+        frm = c.states[:, :7].copy()
+        w8 = c.get_weights(8).copy(); w3 = c.get_weights(3).copy()
+        td = c.handle(frm, a, np.full(7, -1.0, np.float32), frm, np.zeros(7, np.uint8))
+        assert td.shape == (7,) and np.array_equal(c.get_weights(8), w8) and not np.array_equal(c.get_weights(3), w3)
+        with pytest.raises(ra.RsrlHipError):
+            c.train(-1)
