@@ -18,6 +18,8 @@ CONFIGS = {
                                                                  n_envs=2048, policy=1, epsilon=0.2, gamma=0.99, alpha=0.0125, lam=0.7, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 128, 16, 1048576 + 208),
     "L3 2048 Acrobot SARSA(lambda) Fourier(7) wave family, f32 W + Z streamed (240 KiB per learner-step)": (dict(domain=2, order=7, algo=ra.SARSA_LAMBDA, n_envs=2048, policy=1, epsilon=0.2, gamma=0.99,
                                                                  alpha=0.0005, lam=0.8, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 64, 8, 5 * 49152 + 64),
+    "L3b 16384 Acrobot SARSA(lambda) Fourier(7) wave family (1.6 GB of W + Z: HBM-resident)": (dict(domain=2, order=7, algo=ra.SARSA_LAMBDA, n_envs=16384, policy=1, epsilon=0.2, gamma=0.99,
+                                                                 alpha=0.0005, lam=0.8, trace=ra.TRACE_SATURATE, max_episode_steps=1000), 32, 4, 5 * 49152 + 64),
     "P1 2048 CartPole TD(lambda) tiles 8x8^4, per-learner dense trace (256 KiB of Z + W swept per learner-step)": (dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.TD_LAMBDA,
                                                                  n_envs=2048, policy=ra.RANDOM, gamma=0.9, alpha=0.05, lam=0.3, max_episode_steps=1000), 128, 16, 4 * 131072 + 64),
     "K1 262144 MountainCar QL Fourier(5), 1 step per launch (four lanes per learner)": (dict(n_envs=262144, policy=1, epsilon=0.1, max_episode_steps=1000, steps_per_launch=1), 2000, 300, 608),
