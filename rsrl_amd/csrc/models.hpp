@@ -173,6 +173,16 @@ struct TileModel {
             for (int b = 0; b < A; ++b) q[b] = q[b] + (float)(ft.idx[t] + b) * 1e-6f;
         return;
 #endif
+#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 4)          // A/B builds only (timing of a folded apply): one 64-bit table entry gathered and converted per weight
+        {
+            const long long* __restrict__ tab = reinterpret_cast<const long long*>(c.qcache);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int b = 0; b < A; ++b) q[b] = q[b] + (c.W[widx(c, wi, g, ft.idx[t], b)] + (float)tab[(int64_t)ft.idx[t] * A + b] * 1e-9f);
+            return;
+        }
+#endif
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll

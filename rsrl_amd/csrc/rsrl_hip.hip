@@ -1522,7 +1522,8 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-    if (!fused_apply) {
+    static const bool skip_apply = getenv("RSRL_TILE_SKIP_APPLY") != nullptr;      // A/B timing only: the table is never applied
+    if (!fused_apply && !skip_apply) {
         hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
                            tile_lsb((float)c->cfg.lr));
         KCHECK();
