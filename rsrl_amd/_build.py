@@ -104,6 +104,9 @@ def _build_to(lib_path, extra_flags, verbose):
     if os.path.abspath(lib_path) == os.path.abspath(LIB_PATH):
         with open(STAMP_PATH, "w") as f:
             f.write(source_digest() + "\n")
+    else:
+        import shutil
+        shutil.rmtree(obj_dir, ignore_errors=True)      # an A/B variant's objects are of no further use (16 MB each in every gpurun snapshot)
     return lib_path
 
 
