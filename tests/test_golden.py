@@ -157,3 +157,40 @@ def test_device_matches_golden_r02_bitwise():
         W = np.stack([c.get_weights(i) for i in range(2)])
         assert _bits(W).tolist() == g["W_after_f32d_bits"]
         assert np.max(np.abs(W - np.array(g["W_after_f64"]))) <= 2e-5 * (1 + np.abs(np.array(g["W_after_f64"])).max())
+
+
+# ---- round 3: trace / prediction agents on tile coding and on the wave family, tests/golden/vectors_r03.json (make_golden_r03.py) ----
+G3 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors_r03.json")))["oracle"]
+
+
+def _check_r03(g, states_t, actions, weights, traces, st):
+    n = g["n_envs"]
+    assert _bits(states_t).tolist() == g["states"] and list(actions) == g["actions"]
+    assert st["episodes"] == g["episodes"] and st["episodes_truncated"] == g["episodes_truncated"]
+    assert [_digest(weights(i)) for i in range(n)] == g["w_digest"]
+    assert [_digest(traces(i)) for i in range(n)] == g["z_digest"]
+
+
+def test_oracle_reproduces_golden_r03(orc):
+    for key, wave in (("sarsa_lambda_tiles", False), ("td_lambda_tiles", False), ("q_lambda_wave", True)):
+        g = G3[key]
+        run = orc.Run(orc.make_agent(**g["config"]), g["n_envs"], "f32d")
+        if wave:
+            run.reset_wave(); st = run.train_wave(g["steps"])
+        else:
+            run.reset(); st = run.train(g["steps"])
+        _check_r03(g, run.state, run.action.tolist(), lambda i: run.weights[i], lambda i: run.traces[i], st)
+
+
+@pytest.mark.gpu
+def test_device_matches_golden_r03_bitwise():
+    # the HIP path against the committed vectors, without the live oracle: states, actions, weights and traces bit for bit
+    import rsrl_amd as ra
+    for key in ("sarsa_lambda_tiles", "td_lambda_tiles", "q_lambda_wave"):
+        g = G3[key]
+        with ra.Context(n_envs=g["n_envs"], **g["config"]) as c:
+            c.reset()
+            a, b = g["steps"] // 3, g["steps"] - g["steps"] // 3
+            s1, s2 = c.train(a), c.train(b)                    # two launches: the boundary is invisible
+            st = {k: s1[k] + s2[k] for k in ("episodes", "episodes_truncated")}
+            _check_r03(g, c.states.T, c.actions.tolist(), c.get_weights, c.get_traces, st)
