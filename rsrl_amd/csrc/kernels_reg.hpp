@@ -394,6 +394,9 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 #ifndef RSRL_ACTION_MASKS
 #define RSRL_ACTION_MASKS 1
 #endif
+#ifndef RSRL_LOOP_ENTRY_WAIT
+#define RSRL_LOOP_ENTRY_WAIT 1
+#endif
 #ifndef RSRL_K1_STORE_ALL
 #define RSRL_K1_STORE_ALL 1
 #endif
@@ -464,6 +467,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         }
         typename Dom::Pre pre_s = Dom::pre(s);
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
+#if RSRL_LOOP_ENTRY_WAIT
+        // every load of the prologue retires HERE: otherwise the compiler, which sees the weight loads pending on the loop's entry edge
+        // only, places their waits at the first uses INSIDE the loop -- ~19 s_waitcnt per pair of steps that wait for nothing
+        __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+#endif
 
         // x = this batch-step's behaviour-policy draw, xin = the agent's own (SARSA): halves of Philox blocks shared by two steps
         auto one_step = [&](const Phi& phi_s, Phi& phi_n, const U4& x, const U4& xin) {
