@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 5
+#define RSRL_HIP_ABI_VERSION 6
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -288,7 +288,15 @@ int rsrl_hip_train(rsrl_hip_ctx* ctx, int64_t n_steps, rsrl_hip_stats* stats_out
  *   call (the fused loop carries Q(s,.) between launches and addresses the RNG by the batch-step); RSRL_NO_COALESCE=1 in the
  *   environment disables it.  On a caller-supplied stream nothing is ever held back.
  *   Shared dense weights (RSRL_W_SHARED on a register-family Fourier basis, at most one 512-learner block per CU): the whole
- *   call is ONE persistent launch; the ranks of a peer group exchange inside it (RSRL_NO_PERSIST=1: one launch per batch-step). */
+ *   call is ONE persistent launch; the ranks of a peer group exchange inside it (RSRL_NO_PERSIST=1: one launch per batch-step).
+ *   That kernel needs every block of its grid -- and of its peers' grids -- resident at once.  The library guarantees it: the grid
+ *   is checked against the device's occupancy (and once per ctx by a cooperative launch); a peer group decides COLLECTIVELY in
+ *   rsrl_hip_peer_connect (ranks that share a device must fit together; RSRL_NO_PERSIST on any rank counts for all), so that no
+ *   two ranks ever take different paths; unrelated persistent ctxs of one process take turns on a device.  Whenever the guarantee
+ *   cannot be given the per-step path runs instead -- same results, bit for bit.
+ *   Launch coalescing contract: steps a call has ACCEPTED but not launched (rsrl_hip_pending_steps) are launched by the next call
+ *   on the ctx, whichever it is; a host that stops calling and wants them to run calls rsrl_hip_sync (as with any asynchronous
+ *   queue, acceptance is not completion). */
 /* batch-steps executed so far by rsrl_hip_train and rsrl_hip_handle (the RNG counter) */
 uint64_t rsrl_hip_step_count(const rsrl_hip_ctx* ctx);
 /* batch-steps rsrl_hip_train has accepted but not enqueued yet (launch coalescing); always 0 on a caller-supplied stream */
@@ -349,6 +357,14 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* ctx, const uint8_t* handles /*[world_siz
  * later call blocks on a rank the same thread has not driven yet.  Afterwards the host calls rsrl_hip_train(ctxs[i], ..)
  * for each i in turn (the calls only enqueue) and rsrl_hip_sync(ctxs[i]) at the end. */
 int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n);
+/* Step every rank of such a group from that one thread: n_steps batch-steps on ctxs[0..n) (exactly the group's ranks, in rank
+ * order); results are those of rsrl_hip_train on every rank from a thread of its own, bit for bit.
+ *   RCCL: REQUIRED for n > 1 -- a thread driving several communicators must issue each collective for all of them inside one
+ *         ncclGroupStart / End, so the ranks advance in lock-step here and rsrl_hip_train / rsrl_hip_handle on a rank of such a group
+ *         return RSRL_HIP_ESTATE.
+ *   PEER: feeds the ranks in turns of at most 32 batch-steps, so that no rank's launch queue fills up in front of a peer whose
+ *         kernels the same thread has not enqueued yet (calling rsrl_hip_train rank by rank stays valid for short calls). */
+int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps);
 /* what is attached: world size and rank as the exchange itself reports them (ncclCommCount / ncclCommUserRank for RCCL),
  * exchange = -1 (none), RSRL_EXCHANGE_RCCL or RSRL_EXCHANGE_PEER.  Any output pointer may be NULL. */
 int rsrl_hip_comm_info(rsrl_hip_ctx* ctx, int* world_size, int* rank, int* exchange);

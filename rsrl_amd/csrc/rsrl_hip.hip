@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <unistd.h>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -375,6 +377,14 @@ struct rsrl_hip_ctx {
     unsigned long long** d_px_Bptrs = nullptr; // device array [world] of every rank's hop-2 buffer
     uint64_t px_seq = 0;                       // batch-steps exchanged through px_A / px_B so far (tags and parity)
     int n_cu = 256;
+    // ---- co-residency of the persistent kernel (every block of the grid -- and of every peer rank -- must be resident at once)
+    int persist_occ = -1;                      // blocks of k_shared_persist one CU admits (occupancy query; -1 = not asked yet, 0 = none)
+    bool group_persist = false;                // PEER group: the COLLECTIVE decision of rsrl_hip_peer_connect (every rank takes the same path)
+    bool coop_allowed = true;                  // no rank of this ctx's group shares (process, device) with it: a cooperative launch cannot queue behind a peer's
+    bool coop_validated = false;               // one cooperative launch of this ctx's persistent grid has been accepted by the runtime
+    bool persist_refused = false;              // ... or refused (single rank: the per-step path takes over for good)
+    uint64_t group_token = 0;                  // identifies the peer group (same on every rank); 0 = a lone ctx
+    bool st_rccl_group = false;                // member of a single-thread RCCL group of more than one rank: stepped by rsrl_hip_group_train only
 };
 
 static Common make_common(const rsrl_hip_ctx* c) {
@@ -1097,6 +1107,8 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     CHECK_CTX(c); FLUSH(c);
     if (!from_states || !actions || !rewards || !to_states || !terminal) return fail(RSRL_HIP_EINVAL, "null argument");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch size");
+    if (c->st_rccl_group) return fail(RSRL_HIP_ESTATE, "this ctx is a rank of a single-thread RCCL group: handle() all-reduces the mini-batch delta, and one thread "
+                                                       "cannot issue that for one rank at a time -- use one thread / process per rank, or RSRL_EXCHANGE_PEER");
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(check_host_actions(actions, (size_t)M, c->A));
     const float *d_from, *d_rew, *d_to; const int32_t* d_act; const uint8_t* d_term; OutBuf<float> otd;
@@ -1461,11 +1473,14 @@ static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom&
     if (fold) c->sh_par ^= 1;
     return RSRL_HIP_OK;
 }
+// xpart: 0 = the whole batch-step; 1 = everything BEFORE the RCCL all-reduce; 2 = what FOLLOWS it.  (1, 2: rsrl_hip_group_train issues
+// the all-reduces of all ranks of a single-thread group between the two parts, inside one ncclGroupStart / End.)
 static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int do_c, uint64_t t,
-                               const uint64_t* t_dev) {
+                               const uint64_t* t_dev, int xpart = 0) {
     const dim3 grid(grid_for(k.n_envs)), block(kBlock);
     const bool dense = c->cfg.basis == RSRL_FOURIER;
     if (dense) {
+        if (xpart == 2) return RSRL_HIP_OK;                              // the next launch's prologue folds the all-reduced delta
         const int n = (int)c->dw_elems;
         const int fold = do_c ? fold_in_step(c) : 0;
         TRY(enqueue_dense_step(c, k, g, d_stats, (do_c ? 1 : 0) | 2, fold, t, t_dev));
@@ -1480,11 +1495,11 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         }
         hipLaunchKernelGGL(k_tab_finalize, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr, c->dW, t, t_dev);
         KCHECK();
-        TRY(exchange_dw(c, t, t_dev, k.xdelta));
+        if (xpart == 0) TRY(exchange_dw(c, t, t_dev, k.xdelta));
         return RSRL_HIP_OK;
     }
     bool fused_apply = false;
-    if (!for_model(c, [&](auto tag) {
+    if (xpart != 2 && !for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
             int slice = 0; size_t lds = 0;
@@ -1503,7 +1518,9 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
                     // the apply rides in the scatter kernel when its blocks can meet: single rank, the whole grid resident
                     // -- measured SLOWER than the third launch (24.4 against 23.7 us per batch-step at 262 144 learners: the wait for the flush
                     // atomics, the returning arrival and the poll are three fabric round trips; round 2's ticket version: 34.6): A/B knob only
+#ifdef RSRL_AB_KNOBS
                     fused_apply = !c->multi && getenv("RSRL_TILE_FUSED_APPLY") && chunks * (unsigned)c->cfg.n_tilings <= (unsigned)c->n_cu;
+#endif
                     hipLaunchKernelGGL(k_tile_scatter, dim3(chunks, (unsigned)c->cfg.n_tilings), dim3(1024), (size_t)slice * 8, c->stream, c->sc_keys, c->sc_terms,
                                        (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb,
                                        fused_apply ? c->W : (float*)nullptr, c->tile_arrive, tile_lsb((float)c->cfg.lr), c->d_peer_err, c->peer_timeout);
@@ -1522,16 +1539,22 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-    static const bool skip_apply = getenv("RSRL_TILE_SKIP_APPLY") != nullptr;      // A/B timing only: the table is never applied
-    if (!fused_apply && !skip_apply) {
+#ifdef RSRL_AB_KNOBS
+    static const bool skip_apply = getenv("RSRL_TILE_SKIP_APPLY") != nullptr;      // A/B builds only (-DRSRL_AB_KNOBS): the table is never applied
+#else
+    constexpr bool skip_apply = false;                                 // (the product library has no knob that drops the update)
+#endif
+    if (xpart != 2 && !fused_apply && !skip_apply) {
         hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
                            tile_lsb((float)c->cfg.lr));
         KCHECK();
     }
     if (multi) {
-        TRY(exchange_dw(c, t, t_dev, k.xdelta));
-        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
-        KCHECK();
+        if (xpart == 0) TRY(exchange_dw(c, t, t_dev, k.xdelta));
+        if (xpart != 1) {
+            hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+            KCHECK();
+        }
     }
     return RSRL_HIP_OK;
 }
@@ -1617,14 +1640,57 @@ static inline int64_t fuse_depth(const rsrl_hip_ctx* c) {
     return reg ? (reg_depth > 0 ? reg_depth : 4096) : 256;
 }
 
-// shared weights, dense basis: the whole train call as ONE persistent launch (kernels_persist.hpp) when every 512-learner block
-// can be resident at once (one per CU) -- single rank, or ranks exchanging through the one-hop peer buffers.  RSRL_NO_PERSIST=1
-// keeps one launch per batch-step (k_shared_step), which is also what larger shards and RCCL-attached ctxs run.
-static bool persist_ok(const rsrl_hip_ctx* c) {
+// ---- co-residency of the persistent kernel ----------------------------------------------------------------------------------
+// Shared weights, dense basis: the whole train call as ONE persistent launch (kernels_persist.hpp).  k_shared_persist spins on
+// granules written by the other blocks of its grid and by the grids of its peer ranks: every one of those blocks must be RESIDENT
+// at the same time, or the resident ones wait for blocks that cannot start.  Three guards make that true by construction:
+//  (1) the grid itself: sh_rows <= one 512-learner block per CU, provided the occupancy query admits at least one -- and, once per
+//      ctx, ONE cooperative launch of the very same grid: the runtime's own check of the grid against that query (refused: the
+//      per-step path takes over for good; a plain launch of the same grid has the same residency, so the later launches are plain);
+//  (2) ranks of one peer group on one device: the SUM of their grids must fit.  Decided once and COLLECTIVELY in
+//      rsrl_hip_peer_connect from what every rank put into its handle (rows, budgets, device identity, RSRL_NO_PERSIST): every
+//      rank takes the same path -- the persistent and the per-step kernels exchange through different buffers and tags, so ranks
+//      on different paths would never meet;
+//  (3) unrelated ctxs of THIS process on one device: persist_admit() below -- one persistent group per device at a time (a lone
+//      ctx that finds the device taken runs this call on the per-step path, which is bit-identical; a group waits on its stream).
+// Persistent ctxs of OTHER processes that are not peers of this one cannot be seen from here: the bounded waits
+// (config.peer_timeout_ms) are the backstop, and one process per GPU is the deployment.  RSRL_NO_PERSIST=1 keeps one launch per
+// batch-step (k_shared_step), which is also what larger shards and RCCL-attached ctxs run.
+static int persist_blocks_per_cu(rsrl_hip_ctx* c) {
+    if (c->persist_occ >= 0) return c->persist_occ;
+    int nb = 0;
+    (void)hipSetDevice(c->cfg.device);
+    for_model(c, [&](auto tag) {
+        using M = typename decltype(tag)::type;
+        if constexpr (M::kDense) {
+            int a = 0, b = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void*>(&k_shared_persist<M, kSharedBlock, true>), kSharedBlock, 0) != hipSuccess) a = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void*>(&k_shared_persist<M, kSharedBlock, false>), kSharedBlock, 0) != hipSuccess) b = 0;
+            nb = a < b ? a : b;
+        }
+    });
+    (void)hipGetLastError();
+    c->persist_occ = nb < 0 ? 0 : nb;
+    return c->persist_occ;
+}
+// blocks of the persistent kernel the device may hold for ONE grid (a lone ctx, or one rank alone on its device): one per CU
+static unsigned persist_budget_single(rsrl_hip_ctx* c) { return persist_blocks_per_cu(c) >= 1 ? (unsigned)c->n_cu : 0u; }
+// ... and for the SUM of the grids of several ranks on one device.  The occupancy query over-reports by one block per CU for some
+// kernels on this runtime (MI355X_MICROARCH.md, "Residency and cooperative launch"), so one block per CU is held back
+static unsigned persist_budget_shared(rsrl_hip_ctx* c) {
+    const int nb = persist_blocks_per_cu(c);
+    return nb >= 1 ? (unsigned)c->n_cu * (unsigned)(nb > 1 ? nb - 1 : 1) : 0u;
+}
+// this rank alone: could it run the persistent kernel?  (multi-rank: what goes into the handle; the group decides)
+static bool persist_capable(rsrl_hip_ctx* c) {
     if (c->cfg.weight_mode != RSRL_W_SHARED || !c->sh_tab) return false;
-    if (c->multi && c->cfg.exchange != RSRL_EXCHANGE_PEER) return false;
     if (getenv("RSRL_NO_PERSIST")) return false;
-    return c->sh_rows <= (unsigned)c->n_cu;
+    return c->sh_rows <= persist_budget_single(c);
+}
+static bool persist_ok(rsrl_hip_ctx* c) {
+    if (c->cfg.weight_mode != RSRL_W_SHARED || !c->sh_tab || c->persist_refused) return false;
+    if (c->multi) return c->cfg.exchange == RSRL_EXCHANGE_PEER && c->group_persist;      // the GROUP's decision, never this rank's own
+    return persist_capable(c);
 }
 static int ensure_persist_buffers(rsrl_hip_ctx* c) {
     const size_t pairs = (c->dw_elems + 1) / 2;
@@ -1644,26 +1710,94 @@ static int ensure_persist_buffers(rsrl_hip_ctx* c) {
     }
     return RSRL_HIP_OK;
 }
-static int enqueue_persist(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
+
+// (3) one persistent group per device at a time, within this process.  An entry = one persistent launch in flight: who owns it (a
+// lone ctx, or a peer group by its token), which round of the group it belongs to (the exchange sequence number at its start: the
+// ranks of a group agree on it), and which foreign launches its stream was made to wait for.  The ranks of one round must make
+// the SAME waits: a rank that started while a foreign grid still held CUs, spinning for a peer that waits for that grid to end,
+// could keep the foreign grid from ever becoming resident.
+namespace {
+struct PersistEntry { uint64_t id; hipEvent_t ev; uint64_t owner; uint64_t round; std::vector<uint64_t> waited; };
+struct PersistGate { std::mutex mu; uint64_t next_id = 1; std::map<int, std::vector<PersistEntry>> by_dev; };
+PersistGate* persist_gate() { static PersistGate* g = new PersistGate(); return g; }      // never destroyed: ctxs may outlive static destructors
+}
+enum { PERSIST_LAUNCHED = 0, PERSIST_FALLBACK = 1 };
+// Launch one chunk of the persistent kernel under the gate.  *outcome = PERSIST_FALLBACK: nothing was launched, the caller (a lone
+// ctx only) runs this call on the per-step path.
+static int persist_launch(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats, bool may_fall_back, int* outcome) {
+    *outcome = PERSIST_LAUNCHED;
     TRY(ensure_persist_buffers(c));
     PersistExch x{};
     x.A = c->px_A; x.B = c->d_px_Bptrs; x.B_self = c->px_B; x.err = c->d_peer_err;
     x.world = c->multi ? c->world_size : 1; x.rank = c->multi ? c->rank : 0; x.timeout_ticks = c->peer_timeout;
+    PersistGate& gate = *persist_gate();
+    std::lock_guard<std::mutex> lock(gate.mu);                          // admission, launch and registration are one step
+    std::vector<PersistEntry>& live = gate.by_dev[c->cfg.device];
+    for (auto it = live.begin(); it != live.end();) {                   // launches that have ended leave the gate
+        if (hipEventQuery(it->ev) == hipSuccess) { (void)hipEventDestroy(it->ev); it = live.erase(it); }
+        else { (void)hipGetLastError(); ++it; }
+    }
+    const uint64_t owner = c->group_token ? c->group_token : (uint64_t)(uintptr_t)c;
+    const uint64_t round = c->px_seq;
+    std::vector<uint64_t> waited;
+    auto wait_for = [&](uint64_t id) -> int {
+        for (const PersistEntry& e : live)
+            if (e.id == id) { HIP_TRY(hipStreamWaitEvent(c->stream, e.ev, 0)); waited.push_back(id); }
+        return RSRL_HIP_OK;                                             // (an entry that has left the gate has ended: nothing to wait for)
+    };
+    const PersistEntry* opener = nullptr;
+    if (c->group_token)
+        for (const PersistEntry& e : live) if (e.owner == owner && e.round == round) { opener = &e; break; }
+    if (opener) {                                                       // a peer of this round is already in: make its waits, nothing else
+        const std::vector<uint64_t> ids = opener->waited;
+        for (uint64_t id : ids) TRY(wait_for(id));
+    } else {
+        std::vector<uint64_t> foreign;
+        for (const PersistEntry& e : live) if (e.owner != owner) foreign.push_back(e.id);
+        if (!foreign.empty() && may_fall_back) { *outcome = PERSIST_FALLBACK; return RSRL_HIP_OK; }
+        for (uint64_t id : foreign) TRY(wait_for(id));
+    }
+    // (1) the runtime's own check of this grid, once per ctx: a cooperative launch (+15-19 us of host time, paid once).  Not when a
+    // peer rank shares this process AND device: cooperative launches of one process go through one queue per device, and a rank
+    // queued behind the peer it exchanges with would wait for itself.
+    static const bool no_coop = getenv("RSRL_PERSIST_NO_COOP") != nullptr;
+    const bool coop = !c->coop_validated && c->coop_allowed && !no_coop;
     bool ok = false;
+    hipError_t coop_err = hipSuccess;
     for_model(c, [&](auto tag) {
         using M = typename decltype(tag)::type;
         if constexpr (M::kDense) {
-            if (c->multi)
-                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, true>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, c->t, c->px_seq, (int)n_steps,
-                                   c->W, x, d_stats);
-            else
-                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, false>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, k, g, c->t, c->px_seq, (int)n_steps,
-                                   c->W, x, d_stats);
+            Common kk = k; BasisGeom gg = g; uint64_t t0 = c->t, xs0 = c->px_seq; int n = (int)n_steps; float* W = c->W; PersistExch xx = x; DevStats* st = d_stats;
+            void* args[] = {&kk, &gg, &t0, &xs0, &n, &W, &xx, &st};
+            if (coop) {
+                const void* fn = c->multi ? reinterpret_cast<const void*>(&k_shared_persist<M, kSharedBlock, true>)
+                                          : reinterpret_cast<const void*>(&k_shared_persist<M, kSharedBlock, false>);
+                coop_err = hipLaunchCooperativeKernel(fn, dim3(c->sh_rows), dim3(kSharedBlock), args, 0, c->stream);
+            } else if (c->multi) {
+                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, true>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, kk, gg, t0, xs0, n, W, xx, st);
+            } else {
+                hipLaunchKernelGGL((k_shared_persist<M, kSharedBlock, false>), dim3(c->sh_rows), dim3(kSharedBlock), 0, c->stream, kk, gg, t0, xs0, n, W, xx, st);
+            }
             ok = true;
         }
     });
     if (!ok) return NO_MODEL(c);
+    if (coop) {
+        if (coop_err != hipSuccess) {
+            (void)hipGetLastError();
+            if (may_fall_back) { c->persist_refused = true; *outcome = PERSIST_FALLBACK; return RSRL_HIP_OK; }
+            return fail(RSRL_HIP_ERCCL, "the runtime refused the persistent shared-W grid of rank %d (%u blocks of %d threads on device %d: %s); the other ranks "
+                                        "of the group were told it fits -- set RSRL_NO_PERSIST=1 on every rank", c->rank, c->sh_rows, kSharedBlock, c->cfg.device,
+                        hipGetErrorString(coop_err));
+        }
+        c->coop_validated = true;
+    }
     KCHECK();
+    PersistEntry e;
+    e.id = gate.next_id++; e.owner = owner; e.round = round; e.waited = waited;
+    HIP_TRY(hipEventCreateWithFlags(&e.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e.ev, c->stream));
+    live.push_back(std::move(e));
     return RSRL_HIP_OK;
 }
 
@@ -1686,20 +1820,22 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     int64_t done = 0;
     // the delta tables rotate with the batch-step counter: a counter that did not simply continue (reset, restored checkpoint)
     // finds them in another phase -- start from clean tables then
-    const bool persist = shared && n_steps > 0 && persist_ok(c);
-    const bool peer_steps = shared && c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER && !persist;   // per-step exchanges on peer_recv
+    bool persist = shared && n_steps > 0 && persist_ok(c);
     if (persist) {
         for (int64_t left = n_steps; left > 0;) {                       // (the kernel's step count is an int)
             const int64_t chunk = left < (int64_t)1 << 30 ? left : (int64_t)1 << 30;
             TRY(timing_begin(c));
-            TRY(enqueue_persist(c, k, g, chunk, d_stats));
+            int outcome = PERSIST_LAUNCHED;
+            // only a LONE ctx may change its mind here (its two paths are bit-identical and self-contained), and only before its first chunk
+            TRY(persist_launch(c, k, g, chunk, d_stats, !c->multi && left == n_steps, &outcome));
+            if (outcome == PERSIST_FALLBACK) { persist = false; break; }
             TRY(timing_end(c, (uint32_t)chunk));
             c->t += (uint64_t)chunk; c->px_seq += (uint64_t)chunk; left -= chunk;
             k = make_common(c);
         }
-        c->kernel_name = "k_shared_persist";
-        done = n_steps;
+        if (persist) { c->kernel_name = "k_shared_persist"; done = n_steps; }
     }
+    const bool peer_steps = shared && c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER && !persist;   // per-step exchanges on peer_recv
     if (shared && !persist && c->sh_tab && n_steps > 0 && c->t != c->sh_tab_t)
         HIP_TRY(hipMemsetAsync(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems, c->stream));
     while (done < n_steps) {
@@ -1840,9 +1976,12 @@ static bool coalescable(const rsrl_hip_ctx* c) {
 // or as soon as anything observes or changes the ctx (every other entry point flushes first, rsrl_hip_sync included), or
 // when a call finds the stream idle (then nothing is gained by waiting).  Invisible to the caller: same results bit for bit,
 // same ordering; 5 000 back-to-back train(20) calls run as ~400 launches instead of 5 000.  RSRL_NO_COALESCE=1 disables it.
+#define ST_RCCL_GUARD(c) do { if ((c)->st_rccl_group) return fail(RSRL_HIP_ESTATE, "this ctx is a rank of a single-thread RCCL group: its collectives must be " \
+    "issued for all ranks together -- step the group with rsrl_hip_group_train (or use one thread / process per rank, or RSRL_EXCHANGE_PEER)"); } while (0)
 int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     CHECK_CTX(c);
     if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
+    ST_RCCL_GUARD(c);
     if (stats_out || !coalescable(c)) {
         FLUSH(c);
         return train_now(c, n_steps, stats_out);
@@ -1990,7 +2129,19 @@ int rsrl_hip_comm_info(rsrl_hip_ctx* c, int* world_size, int* rank, int* exchang
 }
 
 // ---- RSRL_EXCHANGE_PEER set-up: export this rank's receive buffer, connect to everybody's -----------------------------
-struct PeerBlob { uint32_t magic; int32_t pid; uint64_t ptr; uint64_t bytes; int32_t world; int32_t pad; hipIpcMemHandle_t h; };
+// what a rank tells the others about itself: where its receive buffer is -- and what rsrl_hip_peer_connect needs to decide, the same way
+// on every rank, whether the group runs the persistent kernel: the rank's grid (rows), what its device admits (budgets), which
+// physical device that is (ranks of one node may share one), and whether it could run the kernel at all (flags bit 0)
+struct PeerBlob { uint32_t magic; int32_t pid; uint64_t ptr; uint64_t bytes; int32_t world; uint32_t sh_rows; hipIpcMemHandle_t h;
+                  uint64_t dev_id; uint32_t budget_shared; uint32_t flags; };
+// identity of the physical device behind a ctx, the same in every process of the node (ordinals are not: HIP_VISIBLE_DEVICES)
+static uint64_t device_identity(int device) {
+    int dom = 0, bus = 0, dev = 0;
+    if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device) != hipSuccess) { (void)hipGetLastError(); dom = 0; }
+    if (hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device) != hipSuccess) { (void)hipGetLastError(); bus = device; }
+    if (hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return ((uint64_t)(uint32_t)dom << 32) | ((uint64_t)(uint32_t)(bus & 0xffff) << 16) | (uint64_t)(uint32_t)(dev & 0xffff) | (1ull << 63);
+}
 static_assert(sizeof(PeerBlob) <= RSRL_HIP_PEER_HANDLE_BYTES, "peer handle blob must fit the ABI slot");
 int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     CHECK_CTX(c); FLUSH(c);
@@ -2012,6 +2163,9 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     c->peer_world = world_size;
     PeerBlob b; memset(&b, 0, sizeof(b));
     b.magic = 0x52504552u; b.pid = (int32_t)getpid(); b.ptr = (uint64_t)(uintptr_t)c->peer_recv; b.bytes = c->peer_recv_bytes; b.world = world_size;
+    b.sh_rows = c->sh_rows; b.dev_id = device_identity(c->cfg.device);
+    b.budget_shared = persist_budget_shared(c);
+    b.flags = persist_capable(c) ? 1u : 0u;                            // (RSRL_NO_PERSIST in this rank's environment included: it travels to the others)
     HIP_TRY(hipIpcGetMemHandle(&b.h, c->peer_recv));
     memset(handle_out, 0, RSRL_HIP_PEER_HANDLE_BYTES);
     memcpy(handle_out, &b, sizeof(b));
@@ -2064,6 +2218,29 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
         c->px_seq = 0;                                      // a fresh (cleared) hop-2 buffer: the sequence restarts, on every rank alike
         if (c->px_A) { HIP_TRY(hipFree(c->px_A)); c->px_A = nullptr; }
     }
+    {   // (2) the persistent kernel or the per-step kernels: ONE decision for the whole group, computed by every rank from the same
+        // handles.  Persistent iff every rank could run it alone AND, on every device that hosts several ranks, the sum of their grids
+        // fits the smallest budget any of them reported for it.
+        std::vector<PeerBlob> bl((size_t)world_size);
+        for (int r = 0; r < world_size; ++r) memcpy(&bl[(size_t)r], handles + (size_t)r * RSRL_HIP_PEER_HANDLE_BYTES, sizeof(PeerBlob));
+        bool all = true;
+        uint64_t token = 1469598103934665603ull;
+        for (int r = 0; r < world_size; ++r) {
+            const PeerBlob& b = bl[(size_t)r];
+            if (!(b.flags & 1u)) all = false;
+            uint64_t rows = 0, budget = ~0ull; int here = 0;
+            for (int q = 0; q < world_size; ++q)
+                if (bl[(size_t)q].dev_id == b.dev_id) { rows += bl[(size_t)q].sh_rows; if (bl[(size_t)q].budget_shared < budget) budget = bl[(size_t)q].budget_shared; ++here; }
+            if (here > 1 && rows > budget) all = false;
+            for (uint64_t v : {(uint64_t)(uint32_t)b.pid, b.ptr}) { token ^= v; token *= 1099511628211ull; }
+        }
+        c->group_persist = all;
+        c->group_token = token | 1ull;
+        c->coop_allowed = true;
+        for (int r = 0; r < world_size; ++r)
+            if (r != rank && bl[(size_t)r].pid == bl[(size_t)rank].pid && bl[(size_t)r].dev_id == bl[(size_t)rank].dev_id) c->coop_allowed = false;
+        c->coop_validated = false; c->persist_refused = false;
+    }
     c->world_size = world_size; c->rank = rank; c->multi = true;
     return RSRL_HIP_OK;
 }
@@ -2101,7 +2278,7 @@ int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
     }
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     NCCL_TRY(ncclCommInitAll(comms.data(), n, devs.data()));
-    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[(size_t)i]; ctxs[i]->world_size = n; ctxs[i]->rank = i; ctxs[i]->multi = true; }
+    for (int i = 0; i < n; ++i) { ctxs[i]->comm = comms[(size_t)i]; ctxs[i]->world_size = n; ctxs[i]->rank = i; ctxs[i]->multi = true; ctxs[i]->st_rccl_group = n > 1; }
     // warm-up: dW is zero between operations, so the grouped all-reduce leaves it zero
     NCCL_TRY(ncclGroupStart());
     for (int i = 0; i < n; ++i) {
@@ -2111,6 +2288,71 @@ int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
     }
     NCCL_TRY(ncclGroupEnd());
     for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(ctxs[i]->cfg.device)); HIP_TRY(hipStreamSynchronize(ctxs[i]->stream)); }
+    return RSRL_HIP_OK;
+}
+
+// One thread stepping every rank of a group it created with rsrl_hip_group_create.  What makes this an entry point of its own:
+//  * RCCL: a thread that drives several communicators must issue each collective for ALL of them inside one ncclGroupStart / End;
+//    un-grouped, an all-reduce of rank 0 may wait for a rank the same thread has not reached yet, and a train call enqueues hundreds
+//    of them.  So the batch-steps advance in lock-step here -- every rank's step kernels, then every rank's all-reduce in ONE group,
+//    then what follows the exchange -- and rsrl_hip_train / rsrl_hip_handle refuse such a ctx (RSRL_HIP_ESTATE).
+//  * PEER: a rank's exchange kernels wait (bounded) for its peers' kernels, which this same thread has yet to enqueue: the ranks
+//    are therefore fed in turns of at most 32 batch-steps, so that no rank's launch queue can fill up in front of a peer that has
+//    nothing enqueued (the persistent kernel is one launch per rank and call: no turns needed).
+// Results are those of rsrl_hip_train on every rank from a thread of its own, bit for bit.
+int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps) {
+    if (!ctxs || n < 1 || n > 64) return fail(RSRL_HIP_EINVAL, "bad group arguments");
+    if (n_steps < 0) return fail(RSRL_HIP_EINVAL, "n_steps < 0");
+    for (int i = 0; i < n; ++i) {
+        rsrl_hip_ctx* c = ctxs[i];
+        if (!c) return fail(RSRL_HIP_EINVAL, "null ctx in the group");
+        if (!c->multi || c->world_size != n || c->rank != i || c->cfg.exchange != ctxs[0]->cfg.exchange ||
+            (c->cfg.exchange == RSRL_EXCHANGE_PEER && c->group_token != ctxs[0]->group_token))
+            return fail(RSRL_HIP_ESTATE, "ctxs[0..%d) must be exactly the ranks of one group made by rsrl_hip_group_create, in rank order", n);
+        FLUSH(c);
+    }
+    if (n_steps == 0) return RSRL_HIP_OK;
+    if (ctxs[0]->cfg.exchange == RSRL_EXCHANGE_PEER) {
+        const int64_t turn = persist_ok(ctxs[0]) ? n_steps : kStepsPerGraph;
+        for (int64_t done = 0; done < n_steps; done += turn)
+            for (int i = 0; i < n; ++i) TRY(train_now(ctxs[i], n_steps - done < turn ? n_steps - done : turn, nullptr));
+        return RSRL_HIP_OK;
+    }
+    // RCCL: lock-step, the all-reduces of a batch-step grouped
+    std::vector<Common> ks((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        rsrl_hip_ctx* c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        if (c->sh_tab && c->t != c->sh_tab_t) HIP_TRY(hipMemsetAsync(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems, c->stream));
+    }
+    for (int64_t j = 0; j < n_steps; ++j) {
+        for (int i = 0; i < n; ++i) {
+            rsrl_hip_ctx* c = ctxs[i];
+            HIP_TRY(hipSetDevice(c->cfg.device));
+            ks[(size_t)i] = make_common(c);
+            TRY(enqueue_shared_step(c, ks[(size_t)i], make_geom(c), nullptr, j == 0 ? 0 : 1, c->t, nullptr, 1));
+        }
+        NCCL_TRY(ncclGroupStart());
+        for (int i = 0; i < n; ++i) {
+            rsrl_hip_ctx* c = ctxs[i];
+            HIP_TRY(hipSetDevice(c->cfg.device));
+            NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+        }
+        NCCL_TRY(ncclGroupEnd());
+        for (int i = 0; i < n; ++i) {
+            rsrl_hip_ctx* c = ctxs[i];
+            HIP_TRY(hipSetDevice(c->cfg.device));
+            TRY(enqueue_shared_step(c, ks[(size_t)i], make_geom(c), nullptr, j == 0 ? 0 : 1, c->t, nullptr, 2));
+            c->t += 1;
+            c->kernel_name = c->cfg.basis == RSRL_FOURIER ? "k_shared_step" : "k_shared_ca";
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        rsrl_hip_ctx* c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        TRY(enqueue_shared_c(c, make_common(c), make_geom(c), c->t - 1));
+        c->sh_tab_t = c->t;
+    }
     return RSRL_HIP_OK;
 }
 
