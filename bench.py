@@ -75,6 +75,8 @@ def pmc_traffic(kernel, envs, steps_per_launch):
     kernel / configuration.  bench.py cannot run rocprofv3 on itself."""
     rec = (_profiles_json("pmc_traffic.json") or {}).get(kernel)
     recs = [r for r in (rec if isinstance(rec, list) else [rec] if rec else []) if r.get("envs") == envs]
+    if steps_per_launch is None:                     # a kernel whose bytes per launch do not depend on the launch's depth, or that has one depth only
+        return recs[0]["traffic_bytes_per_launch"] if recs else None
     for r in recs:
         if abs(r.get("steps_per_launch", -1) - steps_per_launch) < 1e-9:
             return r["traffic_bytes_per_launch"]
@@ -178,8 +180,10 @@ def guarded(fn, timeout_s):
 
 
 def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
-    """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg_lm), i.e. the 608 B/env-step
-    streaming formulation the HBM roofline of SURVEY 8(d) is defined on -- every byte of it really moves.  Never part of `value`."""
+    """Secondary measurement: the SAME workload with one batch-step per launch (k_step_reg_lm / k_step_reg_q4), i.e. the 608 B/env-step
+    streaming formulation the HBM roofline of SURVEY 8(d) is defined on -- every byte of it really moves.  Never part of `value`.
+    At 65 536 learners the 28 MB of weights stay in L2 / the Infinity Cache between launches; the HBM-resident figure is the one at
+    1 048 576 learners (453 MB of weights: beyond the 256 MiB Infinity Cache), reported beside it (roofline_streaming_hbm)."""
     try:
         ctx = rsrl_amd.Context(domain=rsrl_amd.MOUNTAIN_CAR, order=5, algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY,
                                epsilon=0.1, gamma=0.9, lr=0.001, n_envs=envs, env_offset=rank * envs, seed=0,
@@ -196,9 +200,12 @@ def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
         ctx.close()
         avg = ms * 1e-3 / max(1, n)
         ach = BYTES_PER_ENV_STEP * envs / avg
+        working_set = envs * (432 + 8 + 4 + 4 + 12)
         return {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                "traffic": pmc_traffic(kn, envs, 1), "avg_launch_ms": avg * 1e3, "launches": n,
-                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
+                "traffic": pmc_traffic(kn, envs, 1), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * envs, "avg_launch_ms": avg * 1e3, "launches": n,
+                "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "learners": envs, "working_set_bytes": working_set,
+                "resident_in": "HBM" if working_set > 256 * 2 ** 20 else ("Infinity Cache / L2 between launches" if working_set > 32 * 2 ** 20 else "L2 between launches"),
                 "env_steps_per_s_this_rank": envs * steps / dt}
     except Exception as e:
         return {"error": repr(e)}
@@ -236,14 +243,44 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
                 "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
                 "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
                 "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
-                "roofline": {"bound": "hbm", "achieved": 32 * envs_per_gpu * steps / dt / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                             "frac": 32 * envs_per_gpu * steps / dt / HBM_PEAK, "algorithmic_bytes_per_env_step": 32, "traffic": None,
-                             "what": "SURVEY 8(d): 32 B/env-step (state, action, episode counter; W stays on the chip) -- a lower bound that does "
-                                     "not bind: the batch-step is bound by the two fabric hops of the delta all-reduce (~3.2 us of it, "
-                                     "profiles/r03_ubench_granule_allreduce.txt) plus ~700 VALU instructions per learner at two waves per SIMD"},
+                "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu, ms * 1e-3 / max(1, n_l), n_l, 32,
+                                         "SURVEY 8(d): C4 is VALU / latency bound (W stays on the chip: 32 B/env-step of state stream); the batch-step = two fabric hops "
+                                         "of the delta all-reduce (~3.2 us, profiles/r03_ubench_granule_allreduce.txt) + the learners' arithmetic at two waves per SIMD"),
                 "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
     except Exception as e:                       # never let the secondary leg take the headline down
         return {"error": repr(e)}
+
+
+def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_bytes_per_env_step, what):
+    """roofline object of a secondary leg: every `frac` is a fraction of a PUBLISHED peak and follows from a file under profiles/.
+    bound "valu": flop per env-step (profiles/isa_mix.json: rocprofv3 instruction-class counters of this kernel) x the kernel's env-steps/s by HIP
+    events / 157.3 TFLOP/s; `issue_slots`: VALU instructions per env-step at the guide's 2 cycles each (a LOWER bound of the slots used: packed
+    instructions take 4) against 1024 SIMDs x 2.4 GHz; `traffic` = HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json), `hbm` = that
+    traffic over the launch duration against 8 TB/s.  SURVEY 8(d)'s algorithmic bytes x rate are kept under a name that is not `frac`."""
+    mix = (_profiles_json("isa_mix.json") or {}).get(kname) or {}
+    flop = mix.get("flop_per_env_step")
+    n_valu = mix.get("valu_wave_instr_per_env_step")
+    rl = {"bound": "valu", "kernel": kname, "unit": "TFLOP/s", "peak": FP32_VECTOR_PEAK / 1e12, "env_steps_per_s_kernel": per_gpu_steps_per_s,
+          "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "what": what}
+    if flop:
+        rl.update({"achieved": flop * per_gpu_steps_per_s / 1e12, "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK, "flop_per_env_step": flop,
+                   "source": "profiles/isa_mix.json (rocprofv3 SQ_INSTS_VALU_* class counters of this kernel per env-step) x HIP-event kernel rate of this run"})
+    else:
+        rl.update({"achieved": None, "frac": None, "error": f"profiles/isa_mix.json has no flop count for {kname}"})
+    if n_valu:
+        cyc = n_valu * SPEC_CYCLES["other"]                          # SIMD cycles per env-step if every wave-instruction took 2
+        peak = N_SIMD * CLOCK_HZ / cyc
+        rl["issue_slots"] = {"valu_wave_instr_per_env_step": n_valu, "frac_lower_bound": per_gpu_steps_per_s / peak, "peak_env_steps_per_s": peak,
+                             "what": "every VALU wave-instruction priced at 2 cycles (MI355X_MICROARCH.md), 1024 SIMDs x 2.4 GHz; packed fp32 instructions take 4, "
+                                     "so the slots really used are more"}
+    tr = pmc_traffic(kname, envs, None)
+    rl["traffic"] = tr
+    rl["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json)"
+    if tr and avg_launch_s > 0:
+        rl["hbm"] = {"achieved": tr / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": tr / avg_launch_s / HBM_PEAK, "what": "REAL traffic of the launch / its duration"}
+    rl["algorithmic_bytes_equivalent"] = {"bytes_per_env_step": alg_bytes_per_env_step, "equivalent_GBps": alg_bytes_per_env_step * per_gpu_steps_per_s / 1e9,
+                                          "note": "SURVEY 8(d)'s algorithmic bytes x rate: NOT moved bytes and not a roofline fraction"}
+    return rl
 
 
 def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
@@ -294,11 +331,10 @@ def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extr
         ms, n, kn = ctx.timing_read()
         ctx.close()
         per_step = ms * 1e-3 / max(1, steps)              # seconds of kernel time per batch-step (all launches of the call / its steps)
-        ach = bytes_per_env_step * kw["n_envs"] / per_step if per_step > 0 else 0.0
+        rate = kw["n_envs"] / per_step if per_step > 0 else 0.0
         rec = {"workload": name, "value": kw["n_envs"] * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
-               "roofline": {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                            "algorithmic_bytes_per_env_step": bytes_per_env_step, "kernel_us_per_batch_step": per_step * 1e6,
-                            "traffic": None, "what": what}}
+               "kernel_us_per_batch_step": per_step * 1e6,
+               "roofline": leg_roofline(kn, rate, kw["n_envs"], ms * 1e-3 / max(1, n), n, bytes_per_env_step, what)}
         if extra:
             rec["roofline"].update(extra)
         return rec
@@ -424,6 +460,9 @@ def main():
     # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
     streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None
+    # ... and at an HBM-resident size: 1 048 576 learners = 453 MB of weights (the 28 MB of 65 536 learners never leave L2 / the Infinity Cache)
+    streaming_hbm = guarded(lambda: streaming_leg(rsrl_amd, 1048576, rank, device, steps=160, warmup=32), 120) \
+        if (args.steps_per_launch != 1 and not args.no_streaming_leg and world <= ndev) else None
     c3 = c5 = None
     if not args.no_config_legs and world <= ndev:
         c3 = guarded(lambda: config_leg(
@@ -441,10 +480,16 @@ def main():
             "the whole launch, so the figure is an equivalent, not moved bytes: the kernel is VALU-issue bound at one wave per SIMD"), 180)
     shared = shared_peer = None
     if not args.no_shared_leg:
-        shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
+        if world > ndev:
+            # RCCL admits one rank per device (ncclCommInitRank: "invalid usage" for a duplicate GPU): on an oversubscribed test box the leg
+            # has nothing to measure.  The peer exchange runs: ranks that share a device decide together which kernels fit it.
+            shared = {"skipped": f"{world} ranks on {ndev} device(s): RCCL refuses ranks that share a device (the peer exchange below runs)"}
+        else:
+            shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
         if not (isinstance(shared, dict) and shared.get("error") == "timeout"):
-            shared_peer = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_PEER), 240)
-    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, shared, shared_peer, c3, c5))
+            shared_peer = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_PEER,
+                                                       envs_per_gpu=131072 if world <= ndev else max(512, min(131072, args.envs))), 240)
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_peer, c3, c5))
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -509,6 +554,8 @@ def main():
             out["value_no_coalesce"] = no_coalesce
         if streaming is not None:
             out["roofline_streaming"] = streaming
+        if streaming_hbm is not None:
+            out["roofline_streaming_hbm"] = streaming_hbm
         if c3 is not None:
             out["c3_shared_tiles"] = c3
         if c5 is not None:
@@ -517,11 +564,16 @@ def main():
             out["shared_w"] = shared
         if shared_peer is not None:
             out["shared_w_peer"] = shared_peer
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # the other ranks are idle by now (they wait in the closing barrier below): the host cores are rank 0's
             out["cpu_baseline"] = cpu_baseline()
+            if world > 1:
+                out["cpu_baseline"]["measured_with_ranks"] = world
         print(json.dumps(out), flush=True)
     if hung:
         os._exit(0)          # a secondary leg is stuck in a collective: do not wait for it in the destructors
+    if world > 1:
+        guarded(cp.barrier, 120)          # the ranks leave together (rank 0 was timing the CPU baseline on the host cores)
     ctx.close()
     cp.close()
 

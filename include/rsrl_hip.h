@@ -149,6 +149,18 @@ typedef struct {
     int32_t  peer_timeout_ms;    /* ABI 5 (was reserved0): bound of every in-kernel wait for a peer / block of the shared-W exchange, in
                                     milliseconds; 0 = RSRL_PEER_TIMEOUT_MS from the environment, else 4000.  Make it longer than the
                                     longest time one rank may spend away from the others (a rollout, a checkpoint) */
+    /* ---- ABI 6 ---- */
+    double   epsilon_decay;      /* the reference drivers' epsilon schedule, `agent.policy.epsilon *= 0.995` once per EPISODE of the learner
+                                    (examples/sarsa_lambda.rs:48-75, :68; the pub field epsilon_greedy.rs:19).  1.0 (default) = no
+                                    schedule: one epsilon for the whole ctx (rsrl_hip_set_epsilon).  In (0, 1): EpsilonGreedy.epsilon is
+                                    a field of every LEARNER; whenever an episode of learner i ends (terminal transition or step cap),
+                                    after that episode's last handle and before the next episode's initial sample,
+                                    eps_i <- max(eps_i * epsilon_decay, epsilon_min).  One learner reproduces the reference loop's
+                                    schedule step for step.  The agent's policy follows when it IS the behaviour policy object
+                                    (agent_policy = -1, as in the example).  Needs policy = RSRL_EPSILON_GREEDY, per-learner weights and a
+                                    fused driver loop: the one-step agents and SARSALambda / QLambda on a register-family Fourier basis,
+                                    or any one-step agent on tile coding / a generic Fourier order. */
+    double   epsilon_min;        /* floor of the schedule (0 = none) */
 } rsrl_hip_config;
 /* size of the ABI 3 struct: the oldest layout rsrl_hip_create accepts */
 #define RSRL_HIP_CONFIG_SIZE_V3 ((uint32_t)offsetof(rsrl_hip_config, agent_policy))
@@ -240,8 +252,11 @@ int rsrl_hip_policy_probs(rsrl_hip_ctx* ctx, const float* states, int64_t M, flo
  *   (greedy.rs:46-60, epsilon_greedy.rs:49-63, random.rs:28-32) and -- faithfully -- the raw action value Q(s, a) for Softmax
  *   (softmax.rs:84-92 forwards to the approximator).  actions int32[M] in [0, A), prob_out f32[M]. */
 int rsrl_hip_policy_prob(rsrl_hip_ctx* ctx, const float* states, const int32_t* actions, int64_t M, float* prob_out);
-/* the pub field EpsilonGreedy.epsilon (decayed by drivers, examples/sarsa_lambda.rs:68) */
+/* the pub field EpsilonGreedy.epsilon (decayed by drivers, examples/sarsa_lambda.rs:68); with config.epsilon_decay it sets every
+ * learner's field */
 int rsrl_hip_set_epsilon(rsrl_hip_ctx* ctx, double epsilon);
+/* every learner's current epsilon, f32[N] (config.epsilon_decay: each learner's own field; otherwise N copies of the ctx's) */
+int rsrl_hip_get_epsilons(rsrl_hip_ctx* ctx, float* eps_out /*[N]*/);
 
 /* Parameterised::weights / weights_view_mut               rsrl/src/params/mod.rs:116-134
  * w is row-major f32[F][A] (ndarray Array2 (F, A), fa/linear.rs:293-301); env_index is
@@ -271,6 +286,8 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v
  *              if aux_kind is 3 (file version 3): u32 head[N], u32 len[N], f32 entries[D + 5][n_steps][N] -- every learner's
  *              Backup ring {s, a, q, residual, pi, mu} (q_sigma.rs:30-63), so that a QSigma run with n_steps > 1 resumes
  *              bit-identically too.  Files of version 2 (no aux_kind 3) are still read.
+ *              A ctx with config.epsilon_decay writes file version 4: everything above, then f32 eps[N], every learner's current
+ *              epsilon (the schedule's state), so that a resumed run continues the schedule.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header
  * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run resumes bit-identically. */
 int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
@@ -316,6 +333,16 @@ int rsrl_hip_rollout_greedy(rsrl_hip_ctx* ctx, int64_t step_limit,
  * total_reward_out, n_states (:340) = n_states_out, n_transitions = n_states - 1. */
 int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* ctx, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out,
                                 float* states_out, int32_t* actions_out, float* rewards_out, uint8_t* terminal_out);
+
+/* Domain::rollout with ANY of the four policies as the closure, s -> policy.sample(rng, s)  (lib.rs:448-479 takes any
+ * FnMut(&S) -> A; policies/mod.rs:65-78): an epsilon-greedy or softmax evaluation run next to the greedy one.  `policy` is an
+ * rsrl_policy over the ctx's Q function with its own parameters (epsilon for RSRL_EPSILON_GREEDY, tau for RSRL_SOFTMAX; the ctx's
+ * behaviour policy is not touched).  Outputs as rsrl_hip_rollout_trajectory (every one but n_states_out optional).  The draws
+ * are a stream of their own, addressed by (number of rollout_policy calls made on the ctx so far, action selection k, global
+ * learner id): a call is reproducible, successive calls are independent samples. */
+int rsrl_hip_rollout_policy(rsrl_hip_ctx* ctx, int policy, double epsilon, double tau, int64_t step_limit, int64_t M,
+                            uint32_t* n_states_out, float* total_reward_out, float* states_out, int32_t* actions_out,
+                            float* rewards_out, uint8_t* terminal_out);
 
 /* Order-independent 64-bit checksums of the ctx's device state (sum of the 32-bit words, each multiplied by an odd
  * function of its index): out[0] weights (+traces), out[1] env states/actions/episode counters.  For determinism /

@@ -39,7 +39,8 @@ class Agent(C.Structure):
                 ("eps_thr", C.c_uint32), ("max_episode_steps", C.c_uint32),
                 ("lam", C.c_double), ("trace", C.c_int), ("lr_td", C.c_double),
                 ("apolicy", C.c_int), ("aepsilon", C.c_double), ("atau", C.c_double), ("aeps_thr", C.c_uint32),
-                ("sigma", C.c_double), ("n_steps", C.c_int)]
+                ("sigma", C.c_double), ("n_steps", C.c_int),
+                ("apol_same", C.c_int), ("eps_decay", C.c_double), ("eps_min", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -133,6 +134,8 @@ def _declare(L):
         g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
         g("orc_run_reset").argtypes = [C.c_void_p]
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_eps").restype = Rp
+        g("orc_run_eps").argtypes = [C.c_void_p]
         g("orc_handle_lambda").restype = R
         g("orc_handle_lambda").argtypes = [C.POINTER(Agent), Rp, Rp, Rp, C.c_int, R, Rp, C.c_int, u32p]
         g("orc_handle_gq").restype = R
@@ -163,6 +166,8 @@ def _declare(L):
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
         g("orc_run_rollout_greedy").restype = C.c_int
         g("orc_run_rollout_greedy").argtypes = [C.c_void_p, C.c_int64, u32p, Rp]
+        g("orc_run_rollout_policy").restype = C.c_int
+        g("orc_run_rollout_policy").argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int64, u32p, Rp, C.POINTER(C.c_int32)]
 
 
 def _np_dtype(prec):
@@ -180,7 +185,8 @@ def _ptr(a, ct):
 def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_per_dim=8,
                algo=QLEARNING, policy=EGREEDY, shared_w=False, seed=0, env_offset=0,
                gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0, max_episode_steps=1000, lam=0.0,
-               trace=TRACE_ACCUMULATE, lr_td=0.0, agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, sigma=0.0, n_steps=1):
+               trace=TRACE_ACCUMULATE, lr_td=0.0, agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, sigma=0.0, n_steps=1,
+               epsilon_decay=1.0, epsilon_min=0.0):
     ag = Agent()
     lib().orc_agent_init(C.byref(ag), domain, basis, order, n_tilings, tiles_per_dim, algo, policy,
                          int(bool(shared_w)), seed, env_offset, gamma, lr, alpha, epsilon, tau,
@@ -190,6 +196,9 @@ def make_agent(domain=MOUNTAIN_CAR, basis=FOURIER, order=5, n_tilings=8, tiles_p
     if agent_policy is not None:      # the agent's own policy object (sarsa.rs:35-41, expected_sarsa.rs:22-29); default: the behaviour policy
         ag.apolicy, ag.aepsilon, ag.atau = agent_policy, agent_epsilon, agent_tau
         ag.aeps_thr = lib().orc_eps_threshold(agent_epsilon)
+        ag.apol_same = 0
+    # the drivers' schedule `agent.policy.epsilon *= decay` once per episode of a learner (examples/sarsa_lambda.rs:68)
+    ag.eps_decay, ag.eps_min = epsilon_decay, epsilon_min
     return ag
 
 
@@ -435,6 +444,10 @@ class Run:
         return np.ctypeslib.as_array(self._f("orc_run_traces")(self._h), shape=(self.n, self.F, self.A))
 
     @property
+    def eps(self):        # (N,) view: every learner's EpsilonGreedy.epsilon
+        return np.ctypeslib.as_array(self._f("orc_run_eps")(self._h), shape=(self.n,))
+
+    @property
     def t(self):
         return int(self._f("orc_run_t")(self._h))
 
@@ -502,6 +515,19 @@ class Run:
         cb = CB(_cb)
         self._f("orc_run_train_hook")(self._h, int(n_steps), C.byref(st), C.cast(cb, C.c_void_p), None)
         return st.as_dict()
+
+    def rollout_policy(self, policy, step_limit, epsilon=0.1, tau=1.0, call=0):
+        """Domain::rollout with the closure s -> policy.sample(rng, s) (any of the four policies); `call` = how many such rollouts
+        came before (the draws' stream) -> (n_states, total_reward, actions (step_limit - 1, N))"""
+        n_states = np.zeros(self.n, dtype=np.uint32)
+        tot = np.zeros(self.n, dtype=self._dt)
+        acts = np.zeros((max(int(step_limit) - 1, 0), self.n), dtype=np.int32)
+        rc = self._f("orc_run_rollout_policy")(self._h, int(policy), float(epsilon), float(tau), int(call), int(step_limit),
+                                               n_states.ctypes.data_as(C.POINTER(C.c_uint32)), _ptr(tot, self._ct),
+                                               acts.ctypes.data_as(C.POINTER(C.c_int32)) if acts.size else None)
+        if rc != 0:
+            raise ValueError("rollout_policy: invalid step_limit / policy")
+        return n_states, tot, acts
 
     def rollout_greedy(self, step_limit):
         n_states = np.zeros(self.n, dtype=np.uint32)

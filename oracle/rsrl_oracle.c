@@ -170,6 +170,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     ag->lambda = 0.0; ag->trace = ORC_TRACE_ACCUMULATE; ag->lr_td = 0.0;
     ag->apolicy = policy; ag->aepsilon = epsilon; ag->atau = tau; ag->aeps_thr = ag->eps_thr;
     ag->sigma = 0.0; ag->n_steps = 1;
+    ag->apol_same = 1; ag->eps_decay = 1.0; ag->eps_min = 0.0;
 }
 
 /* ------------------------------------------------------------------ */

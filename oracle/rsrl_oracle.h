@@ -26,7 +26,7 @@ enum { ORC_QLEARNING = 0, ORC_SARSA = 1, ORC_EXPECTED_SARSA = 2, ORC_SARSA_LAMBD
 enum { ORC_TRACE_ACCUMULATE = 0, ORC_TRACE_SATURATE = 1, ORC_TRACE_DUTCH = 2 };
 enum { ORC_GREEDY = 0, ORC_EGREEDY = 1, ORC_SOFTMAX = 2, ORC_RANDOM = 3 };
 /* RNG draw blocks (counter word 3) */
-enum { ORC_BLK_STEP = 0, ORC_BLK_RESET = 1, ORC_BLK_INNER = 2, ORC_BLK_INIT = 3, ORC_BLK_API = 4 };
+enum { ORC_BLK_STEP = 0, ORC_BLK_RESET = 1, ORC_BLK_INNER = 2, ORC_BLK_INIT = 3, ORC_BLK_API = 4, ORC_BLK_ROLLOUT = 5 };
 
 #define ORC_MAX_ACTIONS 8
 #define ORC_MAX_TILINGS 32
@@ -56,6 +56,12 @@ typedef struct {
     /* QSigma{.., sigma, backup: Backup::new(n_steps)}  (q_sigma.rs:80-105) */
     double sigma;
     int n_steps;
+    /* the drivers' epsilon schedule (examples/sarsa_lambda.rs:48-75): `agent.policy.epsilon *= eps_decay` (floored at eps_min) once
+     * per episode of a learner, after the episode's last handle / sample and before the next episode's initial sample (:68).
+     * eps_decay == 1 (or 0, the memset default): no schedule.  apol_same: the agent's policy IS the behaviour policy object (what the
+     * examples build with make_shared), so the schedule moves both. */
+    int apol_same;
+    double eps_decay, eps_min;
 } orc_agent;
 #define ORC_MAX_NSTEPS 32
 
@@ -127,10 +133,12 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     R     orc_handle_qsigma_##S(const orc_agent* ag, R* W, void* backup, const R* s, int a, R r, const R* ns,     \
                                 int term, const uint32_t x_inner[4]);                                             \
     R*    orc_run_traces_##S(void* h);                                                                  \
+    R*    orc_run_eps_##S(void* h);                                                                     \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
                                  void (*dw_hook)(R* dW, int n, void* user), void* user);                \
-    int   orc_run_rollout_greedy_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward);
+    int   orc_run_rollout_greedy_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward); \
+    int   orc_run_rollout_policy_##S(void* h, int policy, double eps, double tau, uint64_t call, int64_t step_limit, uint32_t* n_states, R* total_reward, int32_t* actions);
 
 ORC_DECLARE(double, f64)
 ORC_DECLARE(float, f32)

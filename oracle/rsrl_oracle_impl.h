@@ -771,6 +771,8 @@ typedef struct {
     R* Z;            /* per-env [N][F][A]: eligibility traces (lambda agents) or fa_td weights (GreedyGQ) */
     uint64_t t;      /* global batch-step counter */
     FN(qs_backup)* qs; /* [N] QSigma backups */
+    R* eps;          /* [N] EpsilonGreedy.epsilon of every learner (the pub field, epsilon_greedy.rs:19): one value each, decayed per
+                      * episode when the agent carries a schedule (orc_agent.eps_decay) */
     R* qc;           /* [N][A] Q(s,.) of the current state carried between orc_run_train_dev calls (the device's qcache) */
     int q_valid;     /* 0: qc is stale -> recompute from W at the next orc_run_train_dev call */
 } FN(orc_run);
@@ -787,6 +789,28 @@ static void FN(run_q)(FN(orc_run)* run, int64_t i, const R* s, R* q) {
     FN(orc_q_evaluate)(&run->ag.basis, FN(run_W)(run, i), A, s, q);
 }
 
+/* ---- the per-learner epsilon schedule ------------------------------------------------------------------------------------------
+ * sched: the agent carries one.  The value lives in R (f64: the reference's; float instantiations: the device's fp32 field), and
+ * gen_bool's threshold is taken from it as orc_eps_threshold takes it from the configured value (R * 2^24 is exact). */
+static int FN(eps_sched)(const orc_agent* ag) { return ag->eps_decay > 0.0 && ag->eps_decay != 1.0; }
+/* the agent as learner i sees it: its own epsilon in the behaviour policy -- and in the agent's policy when that is the same object */
+static orc_agent FN(agent_of)(const FN(orc_run)* run, int64_t i) {
+    orc_agent a = run->ag;
+    if (FN(eps_sched)(&run->ag)) {
+        a.epsilon = (double)run->eps[i]; a.eps_thr = orc_eps_threshold((double)run->eps[i]);
+        if (a.apol_same) { a.aepsilon = a.epsilon; a.aeps_thr = a.eps_thr; }
+    }
+    return a;
+}
+/* an episode of learner i has ended: agent.policy.epsilon *= decay  (examples/sarsa_lambda.rs:68), floored */
+static void FN(eps_episode_end)(FN(orc_run)* run, int64_t i) {
+    if (FN(eps_sched)(&run->ag)) {
+        R e = run->eps[i] * (R)run->ag.eps_decay;
+        run->eps[i] = (e > (R)run->ag.eps_min) ? e : (R)run->ag.eps_min;
+    }
+}
+R* FN(orc_run_eps)(void* h) { return ((FN(orc_run)*)h)->eps; }
+
 void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     FN(orc_run)* run = (FN(orc_run)*)calloc(1, sizeof(*run));
     size_t FA = (size_t)orc_basis_nfeat(&ag->basis) * (size_t)ORC_N_OUT(ag);
@@ -798,6 +822,8 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
     run->Z = ORC_HAS_AUX(ag->algo) ? (R*)calloc(FA * (size_t)n_envs, sizeof(R)) : NULL;
     run->t = 0;
     run->qc = (R*)calloc((size_t)n_envs * ORC_MAX_ACTIONS, sizeof(R)); run->q_valid = 0;
+    run->eps = (R*)calloc((size_t)n_envs, sizeof(R));
+    { int64_t i; for (i = 0; i < n_envs; i++) run->eps[i] = (R)ag->epsilon; }
     run->qs = NULL;
     if (ag->algo == ORC_Q_SIGMA) {
         int64_t i; run->qs = (FN(qs_backup)*)calloc((size_t)n_envs, sizeof(FN(qs_backup)));
@@ -807,7 +833,7 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
 }
 void FN(orc_run_destroy)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h;
-    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run->qs); free(run);
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run->eps); free(run->qs); free(run);
 }
 R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
 int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
@@ -816,7 +842,10 @@ R* FN(orc_run_weights)(void* h) { return ((FN(orc_run)*)h)->W; }
 R* FN(orc_run_traces)(void* h) { return ((FN(orc_run)*)h)->Z; }
 uint64_t FN(orc_run_t)(void* h) { return ((FN(orc_run)*)h)->t; }
 void FN(orc_run_set_epsilon)(void* h, double eps) {
-    FN(orc_run)* run = (FN(orc_run)*)h; run->ag.epsilon = eps; run->ag.eps_thr = orc_eps_threshold(eps);
+    FN(orc_run)* run = (FN(orc_run)*)h; int64_t i;
+    run->ag.epsilon = eps; run->ag.eps_thr = orc_eps_threshold(eps);
+    if (run->ag.apol_same) { run->ag.aepsilon = eps; run->ag.aeps_thr = run->ag.eps_thr; }     /* one policy object: the agent's moves too */
+    for (i = 0; i < run->n_envs; i++) run->eps[i] = (R)eps;
 }
 
 /* per-episode `Domain::default()` + initial `policy.sample`   examples/q_learning.rs:37-38 */
@@ -830,7 +859,7 @@ void FN(orc_run_reset)(void* h) {
         FN(orc_domain_reset)(ag->domain, s);
         FN(run_q)(run, i, s, q);
         orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INIT, x);
-        run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+        run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, FN(agent_of)(run, i).eps_thr, (R)ag->tau, x);
         run->ep_step[i] = 0;
     }
 }
@@ -868,6 +897,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
         for (i = 0; i < N; i++) {
             R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
             R r, delta; int a = run->action[i], term; uint32_t xi[4];
+            const orc_agent agl = FN(agent_of)(run, i); const orc_agent* ag = &agl;      /* (shadows: learner i's own epsilon, when scheduled) */
             memcpy(ns, s, sizeof(R) * D);
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
             term_all[i] = (uint8_t)term;
@@ -904,17 +934,18 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             R q[ORC_MAX_ACTIONS]; uint32_t x[4]; int na;
             FN(run_q)(run, i, ns, q);                                       /* projection #4, UPDATED W */
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_STEP, x);
-            na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+            na = FN(orc_policy_sample)(ag->policy, q, A, FN(agent_of)(run, i).eps_thr, (R)ag->tau, x);
             run->ep_step[i] += 1;
             acc.env_steps += 1;
             if (term_all[i] || (ag->max_episode_steps > 0 && run->ep_step[i] >= ag->max_episode_steps)) {
                 acc.episodes += 1;
                 if (!term_all[i]) acc.episodes_truncated += 1;
                 acc.sum_episode_steps += run->ep_step[i];
+                FN(eps_episode_end)(run, i);                                /* agent.policy.epsilon *= 0.995  examples/sarsa_lambda.rs:68 */
                 FN(orc_domain_reset)(ag->domain, ns);
                 FN(run_q)(run, i, ns, q);
                 orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_RESET, x);
-                na = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+                na = FN(orc_policy_sample)(ag->policy, q, A, FN(agent_of)(run, i).eps_thr, (R)ag->tau, x);
                 run->ep_step[i] = 0;
             }
             memcpy(s, ns, sizeof(R) * D);
@@ -938,7 +969,7 @@ int FN(orc_run_train_fast)(void* h, int64_t n_steps, orc_stats* st) {
     int64_t N = run->n_envs, i, k;
     R *phi_s, *phi_n, *tmp;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
-    if (ag->algo != ORC_QLEARNING || b->kind != ORC_FOURIER || ag->shared_w) return -1;
+    if (ag->algo != ORC_QLEARNING || b->kind != ORC_FOURIER || ag->shared_w || FN(eps_sched)(ag)) return -1;
     phi_s = (R*)malloc(sizeof(R) * (size_t)F); phi_n = (R*)malloc(sizeof(R) * (size_t)F);
     for (i = 0; i < N; i++) {
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
@@ -1037,6 +1068,7 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i); R* qc = run->qc + (size_t)i * ORC_MAX_ACTIONS;
         R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
         int a = run->action[i]; uint32_t ep = run->ep_step[i];
+        orc_agent agl = FN(agent_of)(run, i); const orc_agent* ag = &agl;          /* (shadows: learner i's own epsilon, when scheduled) */
         FN(orc_fourier_project)(b->order, D, FN(basis_lo)(b), FN(basis_hi)(b), s, phi_s);
         if (run->q_valid) { for (j = 0; j < A; j++) q_s[j] = qc[j]; }
         else FN(dot_columns)(phi_s, W, A, F, q_s);
@@ -1061,6 +1093,7 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
             }
             q_n[a] = FN(fma_)(scale, dot, q_n[a]);
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, term ? ORC_BLK_RESET : ORC_BLK_STEP, x);
+            if (term || trunc) { FN(eps_episode_end)(run, i); agl = FN(agent_of)(run, i); }      /* examples/sarsa_lambda.rs:68 */
             na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
             acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
             if (term) { acc.episodes += 1; acc.sum_episode_steps += ep; ep = 0; }
@@ -1157,6 +1190,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
     int64_t N = run->n_envs, i, k;
     R *phi_s, *phi_n, *tmp;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (FN(eps_sched)(ag)) return -1;
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
           (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z))) return -1;
@@ -1290,6 +1324,7 @@ int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
     R *phi, *W, *terms, *phis; uint8_t* flags; int* acts; int64_t* qsum;
     float lsb_f, inv_lsb_f;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (FN(eps_sched)(ag)) return -1;
     if (b->kind != ORC_FOURIER || !ag->shared_w || n_steps < 1 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL)) return -1;
     AF = A * F; n_rows = (int)((N + BLOCK - 1) / BLOCK); W = run->W;
@@ -1385,6 +1420,40 @@ int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, 
             if (steps >= step_limit - 1) break;
             FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
             a = FN(orc_policy_mode)(ag->policy, q, A, (R)ag->tau);
+            term = FN(orc_domain_step)(ag->domain, s, a, &r);
+        }
+        n_states[i] = (uint32_t)(steps + 1);
+        if (total_reward) total_reward[i] = tot;
+    }
+    return 0;
+}
+
+/* Domain::rollout with ANY policy as the closure: pi = |s| policy.sample(rng, s)     rsrl_domains/src/lib.rs:448-479 takes any FnMut(&S) -> A
+ * (policies/mod.rs:65-78).  policy / eps / tau: the sampling policy and its parameters; the k-th action selection of learner i in
+ * rollout call `call` draws the whole Philox block (counter (call << 32) | k, block ORC_BLK_ROLLOUT): word 0 = explore?, word 1 =
+ * the random action, word 2 = tie-break / softmax u -- what orc_policy_sample expects. */
+int FN(orc_run_rollout_policy)(void* h, int policy, double eps, double tau, uint64_t call, int64_t step_limit, uint32_t* n_states, R* total_reward,
+                               int32_t* actions /* [step_limit-1][N] or NULL */) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
+    int A = ag->n_actions; int64_t i;
+    const uint32_t thr = orc_eps_threshold(eps);
+    if (step_limit < 1 || ORC_IS_PRED(ag->algo) || policy < 0 || policy > ORC_RANDOM) return -1;
+    for (i = 0; i < run->n_envs; i++) {
+        R s[8], q[ORC_MAX_ACTIONS], r, tot = 0; int a, term; int64_t steps = 0; uint32_t x[4]; uint64_t k = 0;
+        const R* W = FN(run_W)(run, i);
+        FN(orc_domain_reset)(ag->domain, s);
+        FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+        orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), (call << 32) | (k++ & 0xffffffffu), ORC_BLK_ROLLOUT, x);
+        a = FN(orc_policy_sample)(policy, q, A, thr, (R)tau, x);
+        term = FN(orc_domain_step)(ag->domain, s, a, &r);
+        while (steps < step_limit - 1) {
+            if (actions) actions[steps * run->n_envs + i] = a;
+            steps++; tot += r;
+            if (term) break;
+            if (steps >= step_limit - 1) break;
+            FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), (call << 32) | (k++ & 0xffffffffu), ORC_BLK_ROLLOUT, x);
+            a = FN(orc_policy_sample)(policy, q, A, thr, (R)tau, x);
             term = FN(orc_domain_step)(ag->domain, s, a, &r);
         }
         n_states[i] = (uint32_t)(steps + 1);

@@ -20,6 +20,7 @@ class Config(C.Structure):
         ("lr_td", C.c_double),
         ("agent_policy", C.c_int32), ("exchange", C.c_int32), ("agent_epsilon", C.c_double), ("agent_tau", C.c_double),
         ("sigma", C.c_double), ("n_steps", C.c_int32), ("peer_timeout_ms", C.c_int32),
+        ("epsilon_decay", C.c_double), ("epsilon_min", C.c_double),
     ]
 
 
@@ -65,6 +66,7 @@ SYMBOLS = {
     "rsrl_hip_policy_mode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_policy_probs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_epsilon": (C.c_int, [C.c_void_p, C.c_double]),
+    "rsrl_hip_get_epsilons": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_get_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "rsrl_hip_set_weights_all": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -79,6 +81,7 @@ SYMBOLS = {
     "rsrl_hip_pending_steps": (C.c_int64, [C.c_void_p]),
     "rsrl_hip_rollout_greedy": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rsrl_hip_rollout_trajectory": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
+    "rsrl_hip_rollout_policy": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int64] + [C.c_void_p] * 6),
     "rsrl_hip_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_fx_saturations": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rsrl_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -86,6 +89,7 @@ SYMBOLS = {
     "rsrl_hip_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rsrl_hip_peer_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rsrl_hip_group_train": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),
     "rsrl_hip_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rsrl_hip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rsrl_hip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),

@@ -67,7 +67,8 @@ class Context:
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
                  max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0,
-                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1, peer_timeout_ms=0):
+                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1, peer_timeout_ms=0,
+                 epsilon_decay=1.0, epsilon_min=0.0):
         self._L = _abi.lib()
         cfg = _abi.Config()
         _abi.check(self._L.rsrl_hip_config_init(C.byref(cfg)))
@@ -84,6 +85,8 @@ class Context:
         cfg.agent_epsilon, cfg.agent_tau, cfg.exchange = agent_epsilon, agent_tau, exchange
         cfg.sigma, cfg.n_steps = sigma, n_steps                   # QSigma{sigma, Backup::new(n_steps)}
         cfg.peer_timeout_ms = int(peer_timeout_ms)                # bound of the in-kernel waits of the shared-W exchange (0 = default)
+        # the reference drivers' schedule `agent.policy.epsilon *= 0.995` once per episode of a learner (examples/sarsa_lambda.rs:68)
+        cfg.epsilon_decay, cfg.epsilon_min = float(epsilon_decay), float(epsilon_min)
         self.cfg = cfg
         self._h = C.c_void_p()
         _abi.check(self._L.rsrl_hip_create(C.byref(cfg), C.byref(self._h)))
@@ -241,6 +244,13 @@ class Context:
     def set_epsilon(self, eps):
         _abi.check(self._L.rsrl_hip_set_epsilon(self._h, float(eps)))
 
+    @property
+    def epsilons(self):
+        """every learner's current EpsilonGreedy.epsilon (N,): its own field under `epsilon_decay`, else N copies of the ctx's"""
+        out = np.empty(self.N, dtype=np.float32)
+        _abi.check(self._L.rsrl_hip_get_epsilons(self._h, _p(out)))
+        return out
+
     # ---- Parameterised
     def get_weights(self, env_index=0):
         out = np.empty((self.F, self.n_out), dtype=np.float32)
@@ -310,6 +320,19 @@ class Context:
                                                        _p(out["terminal"])))
         return out
 
+    def rollout_policy(self, policy, step_limit, M=None, epsilon=0.1, tau=1.0):
+        """Domain::rollout with the closure s -> policy.sample(rng, s) for ANY of the four policies over the ctx's Q function
+        (lib.rs:448-479 takes any FnMut(&S) -> A) -> the same dict as rollout_trajectory"""
+        M = self.N if M is None else int(M)
+        L = int(step_limit)
+        out = dict(n_states=np.empty(M, dtype=np.uint32), total_reward=np.empty(M, dtype=np.float32),
+                   states=np.zeros((L, self.D, M), dtype=np.float32), actions=np.zeros((max(L - 1, 0), M), dtype=np.int32),
+                   rewards=np.zeros((max(L - 1, 0), M), dtype=np.float32), terminal=np.empty(M, dtype=np.uint8))
+        _abi.check(self._L.rsrl_hip_rollout_policy(self._h, int(policy), float(epsilon), float(tau), L, M, _p(out["n_states"]),
+                                                   _p(out["total_reward"]), _p(out["states"]), _p(out["actions"]) if L > 1 else None,
+                                                   _p(out["rewards"]) if L > 1 else None, _p(out["terminal"])))
+        return out
+
     def checksum(self):
         """(weights(+traces), env state) 64-bit checksums computed on the device"""
         out = (C.c_uint64 * 2)()
@@ -352,6 +375,13 @@ class Context:
         """all ranks in this process (rank = position in `ctxs`): attach the exchange the ctxs were configured with"""
         arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
         _abi.check(_abi.lib().rsrl_hip_group_create(arr, len(ctxs)))
+
+    @staticmethod
+    def group_train(ctxs, n_steps):
+        """one thread stepping every rank of a group made by group_create (required for RCCL groups of more than one rank:
+        each batch-step's all-reduces are issued for all ranks inside one ncclGroupStart / End)"""
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        _abi.check(_abi.lib().rsrl_hip_group_train(arr, len(ctxs), int(n_steps)))
 
     def comm_info(self):
         """(world_size, rank, exchange) as the attached exchange reports them; exchange -1 = none"""

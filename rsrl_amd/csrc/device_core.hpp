@@ -60,7 +60,7 @@ __host__ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, u
     }
     return U4{c0, c1, c2, c3};
 }
-enum : uint32_t { BLK_STEP = 0, BLK_RESET = 1, BLK_INNER = 2, BLK_INIT = 3, BLK_API = 4 };
+enum : uint32_t { BLK_STEP = 0, BLK_RESET = 1, BLK_INNER = 2, BLK_INIT = 3, BLK_API = 4, BLK_ROLLOUT = 5 };
 // key = (seed_lo, seed_hi); counter = (t_lo, t_hi, env_id, block): the whole 128-bit block
 __host__ __device__ __forceinline__ U4 draw_block(uint64_t seed, uint32_t env_id, uint64_t t, uint32_t block) {
     return philox4x32_10((uint32_t)t, (uint32_t)(t >> 32), env_id, block, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -561,6 +561,15 @@ __device__ __forceinline__ void policy_probs(const PolicyParams& pp, const float
 #pragma unroll
         for (int i = 0; i < A; ++i) p[i] = pr + p[i] * (1.0f - pp.eps);
     }
+}
+
+// Domain::rollout's closure (lib.rs:448-479 takes any FnMut(&S) -> A): sample = 0 -> the ctx's policy.mode (the README's greedy
+// evaluation); 1 -> policy.sample of `pp`, the k-th selection of a learner drawing the whole Philox block ((call << 32) | k, BLK_ROLLOUT)
+struct RolloutPolicy { int sample; PolicyParams pp; uint64_t call; };
+template <int A>
+__device__ __forceinline__ int rollout_action(const PolicyParams& mode_pol, const RolloutPolicy& rp, const float (&q)[A], uint64_t seed, uint32_t gid, uint64_t k) {
+    if (!rp.sample) return policy_mode<A>(mode_pol, q);
+    return policy_sample<A>(rp.pp, q, draw_block(seed, gid, (rp.call << 32) | (k & 0xffffffffull), BLK_ROLLOUT));
 }
 
 struct AlgoParams { int kind; float gamma, lr, alpha; };

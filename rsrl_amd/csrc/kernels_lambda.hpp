@@ -45,6 +45,8 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
     double sum_abs = 0.0, sum_r = 0.0;
     if (i < N) {
         PolicyParams pol = c.pol; pol.kind = POLICY;
+        const bool esched = c.eps != nullptr;                          // wave-uniform: the per-learner epsilon schedule (examples/sarsa_lambda.rs:68)
+        if (esched) learner_eps_load(c, i, pol);
         AlgoParams alg = c.alg; alg.kind = (ALGO == ALG_SARSA_LAMBDA) ? ALG_SARSA : ALG_QLEARNING;   // the TD target formula
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
             // ---- policy.sample with the UPDATED weights (every column moved: recompute)
             w.q(phi_n, q_n);
             const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            if (esched) learner_eps_step(c, term | trunc, pol);        // agent.policy.epsilon *= decay after the episode's last handle (:68)
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_train_lambda(Common c, LambdaParams 
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
+        if (esched) c.eps[i] = pol.eps;
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(kBlock) void k_handle_lambda(Common c, LambdaParams
     U4 xin = U4{0, 0, 0, 0};
     if (sarsa) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
     float e;
-    const float delta = td_error<A>(alg, c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+    PolicyParams apol = c.apol;
+    if (c.apol_same) learner_eps_load(c, i, apol);                     // the shared policy object: this learner's epsilon
+    const float delta = td_error<A>(alg, apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
     const float scale = lp.alpha * delta;
 #pragma unroll
     for (int b = 0; b < A; ++b)

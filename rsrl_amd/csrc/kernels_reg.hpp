@@ -38,12 +38,35 @@ struct Common {
     int shared;            // one approximator for all learners (weight_mode == RSRL_W_SHARED)
     float* qcache;         // [A][N] Q(s,.) of the CURRENT state with the current weights, carried between launches
     int q_valid;           // 0: qcache is stale (weights/states were changed from outside) -> recompute from W
+    float* eps;            // [N] or null.  Non-null: EpsilonGreedy.epsilon is a field of every LEARNER (as it is of the reference's one
+                           // learner, epsilon_greedy.rs:19) and the driver-loop kernels run the reference drivers' schedule on it --
+                           // eps_i <- max(eps_i * eps_decay, eps_min) at every episode end of learner i (examples/sarsa_lambda.rs:68)
+    float eps_decay, eps_min;
     int64_t xdelta;        // multi-rank peer exchange: (exchanges this ctx has performed on its receive buffer) - (batch-step counter).
                            // Slot parity and granule tags follow t + xdelta, a sequence number that only ever grows, whatever happens
                            // to the batch-step counter (a restored checkpoint sets it back; other exchange paths advance it alone)
 };
 
 constexpr int kBlock = 256;
+
+// ---- EpsilonGreedy.epsilon per learner (Common::eps).  The reference's driver decays the pub field once per episode of its one
+// learner, AFTER the episode's last handle / sample and BEFORE the next episode's initial sample (examples/sarsa_lambda.rs:48-75,
+// :68); vectorised, every learner carries its own value.  fp32 on the device (eps_i * decay rounded once per episode; the f64
+// oracle keeps the reference's f64 product); gen_bool's threshold is taken from it exactly as make_common takes it from the config.
+__device__ __forceinline__ uint32_t eps_threshold(float eps) {
+    const float v = eps * 16777216.0f;                                 // exact (a power of two)
+    return v <= 0.0f ? 0u : (v >= 16777216.0f ? 16777216u : (uint32_t)v);
+}
+__device__ __forceinline__ void learner_eps_load(const Common& c, int64_t i, PolicyParams& pol) {
+    if (c.eps) { const float e = c.eps[i]; pol.eps = e; pol.eps_thr = eps_threshold(e); }
+}
+// at the end of a step: the episode ended (terminal or step cap) -> the learner's epsilon decays; `pol` then samples the new episode's
+// first action with the new value
+__device__ __forceinline__ void learner_eps_step(const Common& c, bool episode_ended, PolicyParams& pol) {
+    const float e2 = fmaxf(pol.eps * c.eps_decay, c.eps_min);
+    pol.eps = episode_ended ? e2 : pol.eps;
+    pol.eps_thr = eps_threshold(pol.eps);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -414,7 +437,9 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 // co-resident waves one per 2.7 / 4.8 / 5.9 / 4.3 (profiles/r01_ubench_valu_issue.txt).  The loop itself needs ~225 registers;
 // what had pushed the first version to 460 (one wave per SIMD at EVERY size) was its prologue / epilogue: per-element 64-bit
 // addresses, CSE'd between the loads and the stores and kept alive across the loop.
-template <int DOMAIN, int ORDER, int ALGO, int POLICY>
+// ESCHED: the per-learner epsilon schedule (Common::eps) -- an instantiation of its own, so that the schedule-free loop (the bench's)
+// keeps its threshold in a scalar register and not one instruction more.
+template <int DOMAIN, int ORDER, int ALGO, int POLICY, bool ESCHED = false>
 __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
     using Dom = Domain<DOMAIN>;
     using Bas = FourierReg<DOMAIN, ORDER>;
@@ -434,6 +459,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
 
     if (i < N) {
         PolicyParams pol = c.pol; pol.kind = POLICY;
+        if constexpr (ESCHED) learner_eps_load(c, i, pol);
         AlgoParams alg = c.alg; alg.kind = ALGO;
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
@@ -535,6 +561,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
 #else
             w.q(phi_n, q_n);
 #endif
+            if constexpr (ESCHED) learner_eps_step(c, term | trunc, pol);        // the episode's last handle is done: its end decays epsilon
             int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta);
             facc_r += r;
@@ -580,6 +607,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
+        if constexpr (ESCHED) c.eps[i] = pol.eps;
         c.qcache[i] = q_s.v0;
         if constexpr (A > 1) c.qcache[N + i] = q_s.v1;
         if constexpr (A > 2) c.qcache[2 * N + i] = q_s.v2;

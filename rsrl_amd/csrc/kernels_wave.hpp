@@ -501,12 +501,15 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
 
 template <int DOMAIN, class WT>
 __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __restrict__ Wbase, int64_t step_limit,
-                                                         uint32_t* __restrict__ n_states, float* __restrict__ total_reward, int64_t Mn, TrajOut tr) {
+                                                         uint32_t* __restrict__ n_states, float* __restrict__ total_reward, int64_t Mn, TrajOut tr,
+                                                         RolloutPolicy rp) {
     using WF = WaveFourier<DOMAIN>; using Dom = Domain<DOMAIN>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (i >= Mn) return;
+    const uint32_t gid = (uint32_t)(c.env_offset + i);
+    uint64_t kk = 0;
     float w[A][8][8];
     WF::template load_w<WT>(Wbase + i * (int64_t)(A * F), lane, w);
     float s[D]; Dom::reset(s);
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __r
     WF::project(s, lane, phi);
 #pragma unroll
     for (int b = 0; b < A; ++b) q[b] = WF::dot(phi, w[b]);
-    int a = policy_mode<A>(c.pol, q);
+    int a = rollout_action<A>(c.pol, rp, q, c.seed, gid, kk++);
     bool term = Dom::step(s, a, r);
     int64_t steps = 0;
     while (steps < step_limit - 1) {
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_rollout(Common c, const WT* __r
         WF::project(s, lane, phi);
 #pragma unroll
         for (int b = 0; b < A; ++b) q[b] = WF::dot(phi, w[b]);
-        a = policy_mode<A>(c.pol, q);
+        a = rollout_action<A>(c.pol, rp, q, c.seed, gid, kk++);
         term = Dom::step(s, a, r);
     }
     if (lane == 0) {

@@ -68,7 +68,9 @@ bool launch_qsigma(int domain, int order, dim3 grid, dim3 block, hipStream_t st,
             else return false;                                                                              \
         } else if (chunk == -1)                                                                             \
             hipLaunchKernelGGL((k_step_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, stats, t_dev);              \
-        else                                                                                                \
+        else if (PO == POL_EGREEDY && k.eps) {      /* per-learner epsilon schedule: an instantiation of its own (EpsilonGreedy only) */ \
+            if constexpr (PO == POL_EGREEDY) hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO, true>), grid, block, 0, st, k, t, chunk, stats); \
+        } else                                                                                              \
             hipLaunchKernelGGL((k_train_reg<DM, OR, AL, PO>), grid, block, 0, st, k, t, chunk, stats);            \
         return true;                                                                                        \
     }

@@ -370,7 +370,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(Common c, BasisGeom g, uint64_
     const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
 #pragma unroll
     for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
-    c.action[i] = policy_sample<A>(c.pol, q, x);
+    PolicyParams pol = c.pol;
+    learner_eps_load(c, i, pol);                     // per-learner epsilon, when configured (a reset is not an episode end: no decay)
+    c.action[i] = policy_sample<A>(pol, q, x);
     c.ep_step[i] = 0;
 }
 
@@ -384,6 +386,8 @@ template <int A>
 __device__ __forceinline__ void qop_finish(const Common& c, int op, const float (&q)[A], int64_t Mn, int64_t i, uint64_t call,
                                            float* __restrict__ fout, int32_t* __restrict__ iout, const float* __restrict__ fin,
                                            const int32_t* __restrict__ iin) {
+    PolicyParams pol = c.pol;
+    learner_eps_load(c, i, pol);                     // item i is evaluated with learner i's policy object (its own epsilon, when configured)
     if (op == QOP_EVALUATE) {
 #pragma unroll
         for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = q[b];
@@ -393,18 +397,18 @@ __device__ __forceinline__ void qop_finish(const Common& c, int op, const float 
         if (fout) fout[i] = v;
     } else if (op == QOP_SAMPLE) {
         const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
-        iout[i] = policy_sample<A>(c.pol, q, x);
+        iout[i] = policy_sample<A>(pol, q, x);
     } else if (op == QOP_MODE) {
-        iout[i] = policy_mode<A>(c.pol, q);
+        iout[i] = policy_mode<A>(pol, q);
     } else if (op == QOP_EXPECTED) {
         float p[A];
 #pragma unroll
         for (int b = 0; b < A; ++b) p[b] = fin[(int64_t)b * Mn + i];
         fout[i] = expected_value<A>(q, p);
     } else if (op == QOP_PROB_SA) {
-        fout[i] = policy_eval_sa<A>(c.pol, q, clamp_action<A>(iin[i]));
+        fout[i] = policy_eval_sa<A>(pol, q, clamp_action<A>(iin[i]));
     } else {
-        float p[A]; policy_probs<A>(c.pol, q, p);
+        float p[A]; policy_probs<A>(pol, q, p);
 #pragma unroll
         for (int b = 0; b < A; ++b) fout[(int64_t)b * Mn + i] = p[b];
     }
@@ -462,7 +466,9 @@ __global__ __launch_bounds__(kBlock) void k_handle(Common c, BasisGeom g, const 
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
         float e;
-        const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+        PolicyParams apol = c.apol;
+        if (c.apol_same) learner_eps_load(c, i, apol);             // the agent shares the behaviour policy object: this learner's epsilon
+        const float delta = td_dispatch<A>(c.alg, apol, q_s, a, q_n, r, term, xin, e);
         scale = c.alg.lr * e;
         if (!shared) M::update(c, wi, g, fs, a, scale);
         if (td_out) td_out[i] = delta;
@@ -487,11 +493,13 @@ __device__ __forceinline__ void traj_record(const TrajOut& tr, int64_t i, int64_
 }
 template <class M>
 __global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64_t step_limit, uint32_t* __restrict__ n_states,
-                                                    float* __restrict__ total_reward, int64_t Mn, TrajOut tr) {
+                                                    float* __restrict__ total_reward, int64_t Mn, TrajOut tr, RolloutPolicy rp) {
     constexpr int D = M::D, A = M::A;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Mn) return;
     const int64_t wi = c.shared ? 0 : i;
+    const uint32_t gid = (uint32_t)(c.env_offset + i);
+    uint64_t kk = 0;                                 // action selections so far
     float s[D]; M::Dom::reset(s);
     if (tr.states) {
 #pragma unroll
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64
     }
     typename M::Feat ft; float q[A], r, tot = 0.0f;
     M::features(s, g, ft); M::q_all(c, wi, g, ft, q);
-    int a = policy_mode<A>(c.pol, q);
+    int a = rollout_action<A>(c.pol, rp, q, c.seed, gid, kk++);
     bool term = M::Dom::step(s, a, r);               // the first step is taken eagerly (lib.rs:457-459)
     int64_t steps = 0;
     while (steps < step_limit - 1) {
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(Common c, BasisGeom g, int64
         if (term) break;                             // successors() stops after a Terminal observation
         if (steps >= step_limit - 1) break;
         M::features(s, g, ft); M::q_all(c, wi, g, ft, q);
-        a = policy_mode<A>(c.pol, q);
+        a = rollout_action<A>(c.pol, rp, q, c.seed, gid, kk++);
         term = M::Dom::step(s, a, r);
     }
     n_states[i] = (uint32_t)(steps + 1);
@@ -540,6 +548,9 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
         typename M::Feat fs, fn;
         M::features(s, g, fs);
         float facc_abs = 0.0f, facc_r = 0.0f;
+        PolicyParams pol = c.pol, apol = c.apol;
+        const bool esched = c.eps != nullptr;        // per-learner epsilon schedule (examples/sarsa_lambda.rs:68)
+        if (esched) { learner_eps_load(c, i, pol); if (c.apol_same) apol = pol; }
         for (int k = 0; k < n_steps; ++k) {
             const uint64_t t = t0 + (uint64_t)k;
             float ns[D];
@@ -557,11 +568,12 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+            const float delta = td_dispatch<A>(c.alg, apol, q_s, a, q_n, r, term, xin, e);
             M::update(c, i, g, fs, a, c.alg.lr * e);
             M::q_all(c, i, g, fn, q_n);                              // UPDATED weights
             const U4 x = draw(c.seed, gid, t, BLK_STEP);
-            int na = policy_sample<A>(c.pol, q_n, x);
+            if (esched) { learner_eps_step(c, term | trunc, pol); if (c.apol_same) apol = pol; }
+            int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
             if (trunc) {
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
                 M::features(ns, g, fn);
                 M::q_all(c, i, g, fn, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr);
+                na = policy_sample<A>(pol, q_n, xr);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
@@ -582,6 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
+        if (esched) c.eps[i] = pol.eps;
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_tab_exchange_apply(const long long* __r
         __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     W[j] += peer_sum(recv, n, world, j, xs, err, timeout);
 }
+__global__ void k_fill_f32(float* __restrict__ p, int64_t n, float v) { const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_set_dyn(DynParams* __restrict__ d, DynParams v) { *d = v; }
 __global__ void k_set_t(uint64_t* __restrict__ t_dev, uint64_t v) { *t_dev = v; }
 __global__ void k_advance_t(uint64_t* __restrict__ t_dev, uint64_t d) { *t_dev += d; }
@@ -330,6 +331,7 @@ struct rsrl_hip_ctx {
     unsigned sh_rows = 0;            // rows per buffer = blocks of k_shared_step
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
     float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
+    float* eps = nullptr;            // [N] per-learner EpsilonGreedy.epsilon (config.epsilon_decay != 1), else null
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
@@ -342,6 +344,7 @@ struct rsrl_hip_ctx {
     uint64_t t = 0;          // batch-steps executed (RNG counter)
     int64_t pending = 0;     // batch-steps accepted by rsrl_hip_train but not launched yet (launch coalescing, see rsrl_hip_train)
     uint64_t api_calls = 0;  // RNG counter of rsrl_hip_policy_sample
+    uint64_t rollout_calls = 0;   // ... and of rsrl_hip_rollout_policy (one stream of draws per call)
     Scratch scratch[8];
     // timing of train launches
     bool timing = false;
@@ -407,6 +410,7 @@ static Common make_common(const rsrl_hip_ctx* c) {
     k.max_episode_steps = c->cfg.max_episode_steps;
     k.state = c->state; k.action = c->action; k.ep_step = c->ep_step; k.W = c->W; k.w_stride = c->w_stride; k.w_ls = c->w_ls; k.shared = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : 0;
     k.qcache = c->qcache; k.q_valid = c->q_valid ? 1 : 0;
+    k.eps = c->eps; k.eps_decay = (float)c->cfg.epsilon_decay; k.eps_min = (float)c->cfg.epsilon_min;
     k.xdelta = (int64_t)c->peer_seq - (int64_t)c->t;
     return k;
 }
@@ -633,6 +637,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0; cfg->lr_td = 0.0;
     cfg->agent_policy = -1; cfg->agent_epsilon = 0.1; cfg->agent_tau = 1.0; cfg->exchange = RSRL_EXCHANGE_RCCL;
     cfg->sigma = 0.0; cfg->n_steps = 1;
+    cfg->epsilon_decay = 1.0; cfg->epsilon_min = 0.0;
     return RSRL_HIP_OK;
 }
 
@@ -663,6 +668,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->d_dyn) (void)hipFree(c->d_dyn);
     if (c->qcache) (void)hipFree(c->qcache);
     if (c->Z) (void)hipFree(c->Z);
+    if (c->eps) (void)hipFree(c->eps);
     if (c->flags) (void)hipFree(c->flags);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
@@ -755,6 +761,18 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
     }
+    if (!(cfg->epsilon_decay > 0.0 && cfg->epsilon_decay <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon_decay must be in (0, 1] (1 = no schedule)");
+    if (!(cfg->epsilon_min >= 0.0 && cfg->epsilon_min <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon_min must be in [0, 1]");
+    if (cfg->epsilon_decay != 1.0) {
+        // the kernels that run the schedule: k_train_reg<.., ESCHED>, k_train_lambda, k_train_mem
+        const bool reg = cfg->basis == RSRL_FOURIER && !is_wave(*cfg) && !is_generic_fourier(*cfg);
+        const bool one_step = cfg->algo == RSRL_QLEARNING || cfg->algo == RSRL_SARSA || cfg->algo == RSRL_EXPECTED_SARSA || cfg->algo == RSRL_PAL;
+        const bool ok = cfg->policy == RSRL_EPSILON_GREEDY && cfg->weight_mode == RSRL_W_PER_ENV && cfg->steps_per_launch != 1 &&
+                        ((reg && (one_step || is_lambda(cfg->algo))) || (!reg && !is_wave(*cfg) && one_step));
+        if (!ok) return fail(RSRL_HIP_EINVAL, "epsilon_decay (the per-learner epsilon schedule) needs policy = EpsilonGreedy, per-learner weights, steps_per_launch != 1 and "
+                                              "a one-step agent or SARSALambda / QLambda on a register-family Fourier basis, or a one-step agent on tile coding / a "
+                                              "generic Fourier order");
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(RSRL_HIP_EHIP, "no HIP device");
@@ -803,6 +821,11 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         HIP_TRY(hipMemsetAsync(c->qs_buf, 0, sizeof(float) * nf, c->stream));
         HIP_TRY(hipMemsetAsync(c->qs_head, 0, sizeof(uint32_t) * (size_t)N, c->stream));
         HIP_TRY(hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)N, c->stream));          // Backup::new: empty
+    }
+    if (cfg->epsilon_decay != 1.0) {
+        HIP_TRY(hipMalloc((void**)&c->eps, sizeof(float) * (size_t)N));
+        hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(N)), dim3(kBlock), 0, c->stream, c->eps, N, (float)cfg->epsilon);
+        KCHECK();
     }
     if (has_aux(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
@@ -907,6 +930,27 @@ int rsrl_hip_set_epsilon(rsrl_hip_ctx* c, double eps) {
     CHECK_CTX(c); FLUSH(c);
     if (!(eps >= 0.0 && eps <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon must be in [0,1]");   // gen_bool panics otherwise
     c->cfg.epsilon = eps;
+    if (c->eps) {                                                       // the field of every learner
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->eps, c->cfg.n_envs, (float)eps);
+        KCHECK();
+    }
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_get_epsilons(rsrl_hip_ctx* c, float* eps_out) {
+    CHECK_CTX(c); FLUSH(c); if (!eps_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t N = c->cfg.n_envs;
+    if (c->eps) {
+        HIP_TRY(hipMemcpyAsync(eps_out, c->eps, sizeof(float) * (size_t)N, hipMemcpyDefault, c->stream));
+    } else {
+        OutBuf<float> ob;
+        TRY(stage_out(c, 0, eps_out, (size_t)N, &ob));
+        hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(N)), dim3(kBlock), 0, c->stream, ob.dev, N, (float)c->cfg.epsilon);
+        KCHECK();
+        bool sync = false; TRY(flush_out(c, &ob, &sync));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 
@@ -1263,10 +1307,12 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) 
 // The header is serialised FIELD BY FIELD (little-endian, no implicit padding); layout in include/rsrl_hip.h.
 namespace {
 constexpr uint32_t kCkptVersion = 3;          // files carrying aux_kind 3 (QSigma's n-step backups); every other file is still written as version 2
+constexpr uint32_t kCkptVersionEps = 4;       // ... or as version 4 when the ctx runs the per-learner epsilon schedule: f32 eps[N] follows the payload
 constexpr size_t kCkptHeaderBytes = 72;
 struct Ckpt {
     int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A, algo, weight_dtype, aux_kind;
     int64_t n_learners; uint64_t step_count;
+    bool has_eps;                                 // (not a header field: the file version says it)
 };
 // 1 = eligibility traces, 2 = fa_td weights (both: a second matrix of W's shape), 3 = QSigma's per-learner n-step backups
 int aux_kind_of(const rsrl_hip_ctx* c) { return c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1)); }
@@ -1277,6 +1323,7 @@ Ckpt ckpt_of(const rsrl_hip_ctx* c) {
     h.tiles_per_dim = c->cfg.tiles_per_dim; h.weight_mode = c->cfg.weight_mode; h.F = c->F; h.A = c->Aw;
     h.algo = c->cfg.algo; h.weight_dtype = c->cfg.weight_dtype; h.aux_kind = aux_kind_of(c);
     h.n_learners = c->cfg.weight_mode == RSRL_W_SHARED ? 1 : c->cfg.n_envs; h.step_count = c->t;
+    h.has_eps = c->eps != nullptr;
     return h;
 }
 void put32(uint8_t*& p, uint32_t v) { for (int i = 0; i < 4; ++i) *p++ = (uint8_t)(v >> (8 * i)); }
@@ -1286,7 +1333,7 @@ uint64_t get64(const uint8_t*& p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) 
 void ckpt_encode(const Ckpt& h, uint8_t (&buf)[kCkptHeaderBytes]) {
     uint8_t* p = buf;
     memcpy(p, "RSRLHIPW", 8); p += 8;
-    put32(p, h.aux_kind == 3 ? kCkptVersion : 2u);
+    put32(p, h.has_eps ? kCkptVersionEps : (h.aux_kind == 3 ? kCkptVersion : 2u));
     const int32_t f[11] = {h.domain, h.basis, h.order, h.n_tilings, h.tiles_per_dim, h.weight_mode, h.F, h.A, h.algo, h.weight_dtype, h.aux_kind};
     for (int32_t v : f) put32(p, (uint32_t)v);
     put64(p, (uint64_t)h.n_learners); put64(p, h.step_count);
@@ -1299,6 +1346,7 @@ bool ckpt_decode(const uint8_t (&buf)[kCkptHeaderBytes], Ckpt* h, uint32_t* vers
     int32_t* f[11] = {&h->domain, &h->basis, &h->order, &h->n_tilings, &h->tiles_per_dim, &h->weight_mode, &h->F, &h->A, &h->algo, &h->weight_dtype, &h->aux_kind};
     for (int32_t* v : f) *v = (int32_t)get32(p);
     h->n_learners = (int64_t)get64(p); h->step_count = get64(p);
+    h->has_eps = *version == kCkptVersionEps;
     return true;
 }
 }  // namespace
@@ -1328,6 +1376,11 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
         if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the QSigma backups: %s", hipGetErrorString(e));
         else if (fwrite(hl.data(), 4, 2 * N, f) != 2 * N || fwrite(buf.data(), 4, nf, f) != nf) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
     }
+    if (rc == RSRL_HIP_OK && h.has_eps) {                              // the schedule's state: every learner's current epsilon
+        std::vector<float> e((size_t)c->cfg.n_envs);
+        rc = rsrl_hip_get_epsilons(c, e.data());
+        if (rc == RSRL_HIP_OK && fwrite(e.data(), 4, e.size(), f) != e.size()) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+    }
     if (fclose(f) != 0 && rc == RSRL_HIP_OK) rc = fail(RSRL_HIP_EINVAL, "closing %s failed", path);
     return rc;
 }
@@ -1341,15 +1394,23 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     Ckpt h{}; uint32_t version = 0; uint8_t hdr[kCkptHeaderBytes];
     int rc = RSRL_HIP_OK;
     if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || !ckpt_decode(hdr, &h, &version)) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
-    else if (version != kCkptVersion && version != 2u) rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2 and %u", path, version, kCkptVersion);
-    else if (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
-             h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
-             h.algo != want.algo || h.weight_dtype != want.weight_dtype || h.aux_kind != want.aux_kind || h.n_learners != want.n_learners)
-        rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration", path);
+    else if (version != kCkptVersion && version != 2u && version != kCkptVersionEps)
+        rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2, %u and %u", path, version, kCkptVersion, kCkptVersionEps);
+    // a QSigma file written before the backups travelled (version 2, aux_kind 0) is still read: the weights are loaded and the run
+    // resumes from EMPTY n-step backups, as after a terminal transition (q_sigma.rs:154)
+    const bool old_qsigma = rc == RSRL_HIP_OK && want.aux_kind == 3 && h.aux_kind == 0 && version == 2u;
+    if (rc == RSRL_HIP_OK &&
+        (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
+         h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
+         h.algo != want.algo || h.weight_dtype != want.weight_dtype || (h.aux_kind != want.aux_kind && !old_qsigma) || h.n_learners != want.n_learners ||
+         h.has_eps != want.has_eps))
+        rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration%s", path,
+                  h.has_eps != want.has_eps ? " (the per-learner epsilon schedule, config.epsilon_decay, is part of it)" : "");
     const size_t per = (size_t)c->F * c->Aw;
     if (rc == RSRL_HIP_OK) {                                             // a truncated file is refused before anything is touched
         const long long expect = (long long)kCkptHeaderBytes + (long long)((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1) * h.n_learners * (long long)per * 4 +
-                                 (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0);
+                                 (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0) +
+                                 (h.has_eps ? (long long)c->cfg.n_envs * 4 : 0);
         if (fseek(f, 0, SEEK_END) != 0 || ftell(f) != expect || fseek(f, (long)kCkptHeaderBytes, SEEK_SET) != 0)
             rc = fail(RSRL_HIP_EINVAL, "%s is truncated or has trailing bytes (expected %lld bytes)", path, expect);
     }
@@ -1382,8 +1443,25 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         for (size_t i = 0; rc == RSRL_HIP_OK && i < N; ++i)
             if (hl[i] >= (uint32_t)c->cfg.n_steps || hl[N + i] > (uint32_t)c->cfg.n_steps) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt QSigma backup of learner %zu", path, i);
     }
+    std::vector<float> eps_in;
+    if (rc == RSRL_HIP_OK && h.has_eps) {
+        eps_in.resize((size_t)c->cfg.n_envs);
+        if (fread(eps_in.data(), 4, eps_in.size(), f) != eps_in.size()) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
+        for (size_t i = 0; rc == RSRL_HIP_OK && i < eps_in.size(); ++i)
+            if (!(eps_in[i] >= 0.0f && eps_in[i] <= 1.0f)) rc = fail(RSRL_HIP_EINVAL, "%s: epsilon of learner %zu is outside [0, 1]", path, i);
+    }
     fclose(f);
     (void)hipStreamSynchronize(c->stream);
+    if (rc == RSRL_HIP_OK && old_qsigma) {                             // old file: no backups in it -> empty ones
+        hipError_t e2 = hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
+        if (e2 == hipSuccess) e2 = hipMemsetAsync(c->qs_head, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
+        if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "clearing the QSigma backups: %s", hipGetErrorString(e2));
+    }
+    if (rc == RSRL_HIP_OK && h.has_eps) {
+        hipError_t e2 = hipMemcpyAsync(c->eps, eps_in.data(), 4 * eps_in.size(), hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the learners' epsilons: %s", hipGetErrorString(e2));
+    }
     if (rc == RSRL_HIP_OK && h.aux_kind == 3) {
         const size_t N = (size_t)c->cfg.n_envs;
         hipError_t e2 = hipMemcpyAsync(c->qs_head, hl.data(), 4 * N, hipMemcpyHostToDevice, c->stream);
@@ -2002,12 +2080,13 @@ int rsrl_hip_train(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) 
 }
 
 static int rollout_impl(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out, float* states_out,
-                        int32_t* actions_out, float* rewards_out, uint8_t* terminal_out) {
+                        int32_t* actions_out, float* rewards_out, uint8_t* terminal_out, const RolloutPolicy& rp) {
     CHECK_CTX(c); FLUSH(c);
     if (!n_states_out) return fail(RSRL_HIP_EINVAL, "null argument");
     if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1 (unbounded rollouts are not offered)");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M, (long long)c->cfg.n_envs);
-    if (c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
+    if (is_pred(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "a prediction agent has a state-value function only: no action values to roll out with");
+    if (!rp.sample && c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (step_limit == 1) { actions_out = nullptr; rewards_out = nullptr; }      // Trajectory.steps is empty
     OutBuf<uint32_t> on; OutBuf<float> ot, os, orw; OutBuf<int32_t> oa; OutBuf<uint8_t> otm;
@@ -2028,11 +2107,11 @@ static int rollout_impl(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using T = decltype(tag); using WT = typename T::wt;
-            hipLaunchKernelGGL((k_wave_rollout<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, step_limit, on.dev, ot.dev, M, tr);
+            hipLaunchKernelGGL((k_wave_rollout<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, (const WT*)c->W, step_limit, on.dev, ot.dev, M, tr, rp);
         });
     } else if (!for_model(c, [&](auto tag) {
             using Mo = typename decltype(tag)::type;
-            hipLaunchKernelGGL((k_rollout<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev, M, tr);
+            hipLaunchKernelGGL((k_rollout<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, k, g, step_limit, on.dev, ot.dev, M, tr, rp);
         })) return NO_MODEL(c);
     KCHECK();
     bool sync = false;
@@ -2043,11 +2122,27 @@ static int rollout_impl(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t
 }
 int rsrl_hip_rollout_greedy(rsrl_hip_ctx* c, int64_t step_limit, uint32_t* n_states_out, float* total_reward_out) {
     CHECK_CTX(c);
-    return rollout_impl(c, step_limit, c->cfg.n_envs, n_states_out, total_reward_out, nullptr, nullptr, nullptr, nullptr);
+    return rollout_impl(c, step_limit, c->cfg.n_envs, n_states_out, total_reward_out, nullptr, nullptr, nullptr, nullptr, RolloutPolicy{});
 }
 int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t* n_states_out, float* total_reward_out,
                                 float* states_out, int32_t* actions_out, float* rewards_out, uint8_t* terminal_out) {
-    return rollout_impl(c, step_limit, M, n_states_out, total_reward_out, states_out, actions_out, rewards_out, terminal_out);
+    return rollout_impl(c, step_limit, M, n_states_out, total_reward_out, states_out, actions_out, rewards_out, terminal_out, RolloutPolicy{});
+}
+int rsrl_hip_rollout_policy(rsrl_hip_ctx* c, int policy, double epsilon, double tau, int64_t step_limit, int64_t M, uint32_t* n_states_out,
+                            float* total_reward_out, float* states_out, int32_t* actions_out, float* rewards_out, uint8_t* terminal_out) {
+    CHECK_CTX(c);
+    if (policy < 0 || policy > RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "unknown policy %d", policy);
+    if (policy == RSRL_EPSILON_GREEDY && !(epsilon >= 0.0 && epsilon <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon must be in [0,1]");      // gen_bool panics otherwise
+    if (policy == RSRL_SOFTMAX && std::fabs(tau) < 1e-7) return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");     // softmax.rs:63-66
+    RolloutPolicy rp{};
+    rp.sample = 1; rp.pp.kind = policy;
+    const double v = epsilon * 16777216.0;
+    rp.pp.eps_thr = v <= 0.0 ? 0u : (v >= 16777216.0 ? 16777216u : (uint32_t)v);
+    rp.pp.eps = (float)epsilon; rp.pp.tau = (float)tau;
+    rp.call = c->rollout_calls;
+    const int rc = rollout_impl(c, step_limit, M, n_states_out, total_reward_out, states_out, actions_out, rewards_out, terminal_out, rp);
+    if (rc == RSRL_HIP_OK) c->rollout_calls++;
+    return rc;
 }
 
 int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {

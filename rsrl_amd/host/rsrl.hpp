@@ -87,7 +87,12 @@ struct LFA {                              // LFA::vector(basis, SGD(lr), n_actio
 
 // ---- rsrl::policies --------------------------------------------------------------------------------
 namespace policies {
-struct Policy { int kind; double epsilon = 0.0, tau = 1.0; };
+struct Policy {
+    int kind; double epsilon = 0.0, tau = 1.0;
+    // the reference drivers' schedule on the pub field: `agent.policy.epsilon *= decay` after every EPISODE of a learner
+    // (examples/sarsa_lambda.rs:68); with N learners in one ctx every learner carries its own field.  1.0 = no schedule.
+    double epsilon_decay = 1.0, epsilon_min = 0.0;
+};
 struct Random : Policy { explicit Random(int /*n_actions*/) : Policy{RSRL_RANDOM} {} };
 struct Greedy : Policy {
     Shared<fa::linear::LFA> q;
@@ -96,6 +101,8 @@ struct Greedy : Policy {
 struct EpsilonGreedy : Policy {           // EpsilonGreedy::new(greedy, random, epsilon)  (epsilon_greedy.rs:22-31)
     Shared<fa::linear::LFA> q;
     EpsilonGreedy(const Greedy& g, const Random&, double eps) : Policy{RSRL_EPSILON_GREEDY, eps}, q(g.q) {}
+    // the driver's per-episode `policy.epsilon *= decay` (floored at `floor`) as part of the policy object
+    EpsilonGreedy& decayed_per_episode(double decay, double floor = 0.0) { epsilon_decay = decay; epsilon_min = floor; return *this; }
 };
 struct Softmax : Policy {                 // Softmax::new(fa, tau) panics for |tau| < 1e-7 (softmax.rs:63-66)
     Shared<fa::linear::LFA> q;
@@ -193,6 +200,7 @@ public:
         cfg.algo = agent.algo; cfg.gamma = agent.gamma; cfg.alpha = agent.alpha;
         cfg.trace = agent.trace; cfg.lambda = agent.lambda; cfg.lr_td = agent.lr_td;
         cfg.policy = policy.kind; cfg.epsilon = policy.epsilon; cfg.tau = policy.tau;
+        cfg.epsilon_decay = policy.epsilon_decay; cfg.epsilon_min = policy.epsilon_min;
         // an agent-owned policy equal to the behaviour policy IS the shared object of the reference's examples
         if (agent.owns_policy && (agent.policy.kind != policy.kind || agent.policy.epsilon != policy.epsilon || agent.policy.tau != policy.tau)) {
             cfg.agent_policy = agent.policy.kind; cfg.agent_epsilon = agent.policy.epsilon; cfg.agent_tau = agent.policy.tau;
@@ -260,6 +268,7 @@ public:
         std::vector<float> p(N_); check(rsrl_hip_policy_prob(ctx_, states.data(), actions.data(), N_, p.data())); return p;
     }
     void set_epsilon(double eps) { check(rsrl_hip_set_epsilon(ctx_, eps)); }      // pub field EpsilonGreedy.epsilon
+    std::vector<float> epsilons() { std::vector<float> e(N_); check(rsrl_hip_get_epsilons(ctx_, e.data())); return e; }   // ... of every learner
     // Parameterised::weights()                                                    (params/mod.rs:118)
     std::vector<float> weights(int64_t env = 0) {
         std::vector<float> w((size_t)F_ * O_); check(rsrl_hip_get_weights(ctx_, env, w.data())); return w;
@@ -289,6 +298,16 @@ public:
         tr.actions.assign((size_t)(step_limit - 1) * N_, 0); tr.rewards.assign((size_t)(step_limit - 1) * N_, 0.0f);
         check(rsrl_hip_rollout_trajectory(ctx_, step_limit, N_, tr.n_states.data(), tr.total_reward.data(), tr.states.data(),
                                           step_limit > 1 ? tr.actions.data() : nullptr, step_limit > 1 ? tr.rewards.data() : nullptr, tr.terminal.data()));
+        return tr;
+    }
+    // Domain::rollout(|s| policy.sample(rng, s), Some(limit)) for any policy over this session's Q function   (lib.rs:448-479)
+    domains::Trajectory rollout(const policies::Policy& pi, int64_t step_limit) {
+        domains::Trajectory tr;
+        tr.n_states.resize(N_); tr.total_reward.resize(N_); tr.terminal.resize(N_);
+        tr.states.assign((size_t)step_limit * D_ * N_, 0.0f);
+        tr.actions.assign((size_t)(step_limit - 1) * N_, 0); tr.rewards.assign((size_t)(step_limit - 1) * N_, 0.0f);
+        check(rsrl_hip_rollout_policy(ctx_, pi.kind, pi.epsilon, pi.tau, step_limit, N_, tr.n_states.data(), tr.total_reward.data(), tr.states.data(),
+                                      step_limit > 1 ? tr.actions.data() : nullptr, step_limit > 1 ? tr.rewards.data() : nullptr, tr.terminal.data()));
         return tr;
     }
     rsrl_hip_ctx* raw() { return ctx_; }

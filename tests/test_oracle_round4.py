@@ -1,0 +1,111 @@
+"""CPU tests of the oracle's round-4 additions (test infrastructure checked against the reference's own lines):
+  * the drivers' epsilon schedule, `agent.policy.epsilon *= 0.995` once per episode of a learner (rsrl/examples/sarsa_lambda.rs:48-75,
+    :68; the pub field policies/epsilon_greedy.rs:19) -- against an independent transcription of that loop;
+  * Domain::rollout with an arbitrary policy closure (rsrl_domains/src/lib.rs:448-479)."""
+import numpy as np
+import pytest
+
+EX = dict(domain=0, order=5, algo=3, policy=1, trace=1, gamma=0.99, alpha=0.01, lam=0.7, epsilon=0.2)      # examples/sarsa_lambda.rs:19-45
+
+
+def test_schedule_is_the_reference_drivers(orc):
+    # ONE learner, f64: an independent transcription of examples/sarsa_lambda.rs:48-75 -- episode loop, `epsilon *= 0.995` after the
+    # episode's last sample (:68) -- driven by the oracle's single-transition functions, against the oracle's vectorised loop
+    ag = orc.make_agent(seed=11, max_episode_steps=30, epsilon_decay=0.995, **EX)
+    run = orc.Run(ag, 1, "f64")
+    run.reset()
+    K = 400
+    F, A = orc.n_features(ag), 3
+    W, Z = np.zeros((F, A)), np.zeros((F, A))
+    eps, t = 0.2, 0
+    s = orc.domain_reset(0)
+    a = orc.policy_sample(orc.EGREEDY, orc.q_evaluate(ag, W, s), orc.draw(11, 0, 0, orc.BLK_INIT), eps=eps)
+    episodes, ep_len, eps_hist = 0, 0, []
+    for t in range(K):
+        ns, r, term = orc.domain_step(0, s, a)
+        agl = orc.make_agent(seed=11, max_episode_steps=30, **{**EX, "epsilon": eps})        # agent.policy is the shared object: SARSALambda's own draw too
+        orc.handle_lambda(agl, W, Z, s, a, r, ns, term, orc.draw(11, 0, t, orc.BLK_INNER))
+        ep_len += 1
+        done = term or ep_len >= 30
+        if done:
+            eps = eps * 0.995                                     # :68
+            episodes += 1; ep_len = 0
+            ns = orc.domain_reset(0)
+        a = orc.policy_sample(orc.EGREEDY, orc.q_evaluate(ag, W, ns), orc.draw(11, 0, t, orc.BLK_RESET if done else orc.BLK_STEP), eps=eps)
+        s = ns
+        eps_hist.append(eps)
+    st = run.train(K)
+    assert st["episodes"] == episodes >= 10
+    assert run.eps[0] == eps                                      # the very same f64 products
+    assert np.array_equal(run.state[0], s) and run.action[0] == a
+    assert np.max(np.abs(run.weights[0] - W)) == 0.0 and np.max(np.abs(run.traces[0] - Z)) == 0.0
+    e = 0.2
+    for _ in range(episodes):
+        e *= 0.995
+    assert e == eps
+
+
+def test_schedule_properties(orc):
+    N, K = 24, 600
+    ag = orc.make_agent(seed=2, max_episode_steps=12, epsilon_decay=0.9, epsilon_min=0.04, **EX)
+    run = orc.Run(ag, N, "f64"); run.reset()
+    assert np.all(run.eps == 0.2)
+    run.train(K)
+    assert run.eps.min() == 0.04 and run.eps.max() <= 0.2 * 0.9 ** 3          # floored; every learner finished >= 50 episodes
+    # no schedule: the per-learner field never moves; set_epsilon writes every learner's field (and the agent's shared policy object)
+    plain = orc.Run(orc.make_agent(seed=2, max_episode_steps=12, **EX), N, "f64"); plain.reset(); plain.train(50)
+    assert np.all(plain.eps == 0.2)
+    plain.set_epsilon(0.5)
+    assert np.all(plain.eps == 0.5)
+    # decay 1.0 == no schedule, bit for bit
+    one = orc.Run(orc.make_agent(seed=2, max_episode_steps=12, epsilon_decay=1.0, **EX), N, "f32d"); one.reset(); one.train(100)
+    ref = orc.Run(orc.make_agent(seed=2, max_episode_steps=12, **EX), N, "f32d"); ref.reset(); ref.train(100)
+    assert np.array_equal(one.weights, ref.weights) and np.array_equal(one.state, ref.state)
+    # the float instantiations keep the field in fp32 (the device's): one rounding per episode away from the f64 schedule
+    f32 = orc.Run(orc.make_agent(seed=2, max_episode_steps=12, epsilon_decay=0.995, **EX), 4, "f32d"); f32.reset(); f32.train(240)
+    f64 = orc.Run(orc.make_agent(seed=2, max_episode_steps=12, epsilon_decay=0.995, **EX), 4, "f64"); f64.reset(); f64.train(240)
+    assert f32.eps.dtype == np.float32 and np.max(np.abs(f32.eps - f64.eps)) <= 25 * 6e-8 * 0.2
+
+
+@pytest.mark.parametrize("algo,apol", [(0, None), (1, None), (2, None), (1, 0)])
+def test_schedule_device_order_loop_follows_the_reference_order_loop(orc, algo, apol):
+    kw = dict(algo=algo, policy=1, gamma=0.9, lr=0.001, alpha=0.7, epsilon=0.3, seed=21, max_episode_steps=20, epsilon_decay=0.97, epsilon_min=0.01)
+    if apol is not None:
+        kw["agent_policy"] = apol
+    ag = orc.make_agent(**kw)
+    N, K = 32, 500
+    ref = orc.Run(ag, N, "f64"); ref.reset(); st = ref.train(K)
+    dev = orc.Run(ag, N, "f64"); dev.reset(); dev.train_dev(200); dev.train_dev(K - 200)
+    assert np.array_equal(ref.eps, dev.eps) and st["episodes"] >= 25 * N
+    same = np.all(np.abs(ref.state - dev.state) <= 1e-9, axis=1) & (ref.action == dev.action)
+    assert same.mean() >= 0.95 and np.max(np.abs(ref.weights[same] - dev.weights[same])) <= 1e-10
+    with pytest.raises(ValueError):
+        dev.train_fast(1)                                         # (the optimised-CPU loop has no schedule)
+
+
+def test_rollout_policy(orc):
+    N, L = 64, 150
+    ag = orc.make_agent(policy=orc.EGREEDY, seed=4, lr=0.002, max_episode_steps=100)
+    run = orc.Run(ag, N, "f64"); run.reset(); run.train(500)
+    n_g, tot_g = run.rollout_greedy(L)
+    # epsilon = 0: Greedy::sample == Greedy::mode unless two action values are within 1e-7 of each other (utils.rs:6-21 vs core.rs:96-105)
+    n0, tot0, a0 = run.rollout_policy(orc.EGREEDY, L, epsilon=0.0)
+    assert (n0 == n_g).mean() >= 0.98 and np.array_equal(tot0[n0 == n_g], tot_g[n0 == n_g])
+    # reproducible per call number, another stream for another call
+    n1, _, a1 = run.rollout_policy(orc.EGREEDY, L, epsilon=0.5, call=0)
+    n2, _, a2 = run.rollout_policy(orc.EGREEDY, L, epsilon=0.5, call=0)
+    n3, _, a3 = run.rollout_policy(orc.EGREEDY, L, epsilon=0.5, call=1)
+    assert np.array_equal(a1, a2) and np.array_equal(n1, n2) and not np.array_equal(a1, a3)
+    # Random: uniform actions, whatever the action values (random.rs:43-45)
+    _, _, ar = run.rollout_policy(orc.RANDOM, L)
+    fr = np.bincount(ar[:20].ravel(), minlength=3) / ar[:20].size
+    assert np.abs(fr - 1 / 3).max() < 0.05
+    # n_states = 1 + transitions <= limit; total reward = -(transitions) unless the goal was reached (MountainCar: 0 on the last one)
+    assert n1.max() <= L and np.all(n1 >= 2)
+    # limit 1: no transition is kept (lib.rs:457-479)
+    n, tot, acts = run.rollout_policy(orc.SOFTMAX, 1, tau=0.5)
+    assert np.all(n == 1) and np.all(tot == 0) and acts.shape == (0, N)
+    with pytest.raises(ValueError):
+        run.rollout_policy(orc.EGREEDY, 0)
+    with pytest.raises(ValueError):
+        run.rollout_policy(9, 10)
