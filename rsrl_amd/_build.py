@@ -58,7 +58,23 @@ def source_digest(extra_flags=()):
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
     h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags))).encode())
+    h.update(hipcc_version().encode())
     return h.hexdigest()
+
+
+_HIPCC_VERSION = None
+
+
+def hipcc_version():
+    """`hipcc --version` (cached): a compiler upgrade makes the stamped library stale.  A box without hipcc (it only runs the prebuilt
+    library) contributes the empty string -- there is_stale() is never asked to rebuild anyway."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+        except Exception:
+            _HIPCC_VERSION = ""
+    return _HIPCC_VERSION
 
 
 def is_stale():
