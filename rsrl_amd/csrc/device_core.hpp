@@ -245,6 +245,25 @@ template <> struct Domain<0> {
     }
 };
 
+// x / d for a COMPILE-TIME constant d, bit for bit the correctly rounded fp32 quotient the reference's `/` is (ode.rs:36 `/ 6.0`,
+// cart_pole.rs:60 `/ TOTAL_MASS`, the tile coder's (s - lo) / (hi - lo)): through f64 -- convert, ONE multiplication by RN64(1 / d),
+// convert back: three instructions where the IEEE fp32 division expands to ~11 (v_div_scale x 2, v_rcp, four fmas, v_div_fmas,
+// v_div_fixup).  The double product is within 2^-52 of x / d, and x / d is never that close to a rounding boundary of fp32 unless it is
+// representable (d x midpoint has more than 24 significant bits), so the second rounding decides as the first would have.  PROVEN for
+// every divisor on the path by trying all 2^32 inputs -- zeros of both signs, denormals, infinities, NaNs -- on the CPU:
+// oracle/check_constdiv.c, tests/test_oracle_round4.py::test_constant_division_is_the_ieee_quotient.  The oracle keeps the `/`.
+__device__ __forceinline__ float div_const(float x, float d) { return (float)((double)x * (1.0 / (double)d)); }
+// (int)floorf(x), saturating, NaN -> 0: ONE instruction (v_cvt_flr_i32_f32) instead of v_floor_f32 + v_cvt_i32_f32
+__device__ __forceinline__ int floor_to_int(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return (int)floorf(x);
+#endif
+}
+
 // classical RK4, f ignores time      rsrl_domains/src/ode.rs:1-43
 template <class Grad>
 __device__ __forceinline__ void rk4(const Grad& f, float (&y)[4], float dx) {
@@ -262,7 +281,7 @@ __device__ __forceinline__ void rk4(const Grad& f, float (&y)[4], float dx) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         k4[i] *= dx;
-        y[i] += (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]) / 6.0f;
+        y[i] += div_const(k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i], 6.0f);      // (/ 6.0: the same bits, a third of the instructions)
     }
 }
 
@@ -293,7 +312,7 @@ template <> struct Domain<1> {
             const float dx = y[1], theta = y[2], dtheta = y[3];
             float sin_t, cos_t;
             sincos_cw(theta, sin_t, cos_t);
-            const float z = (force + POLE_MOMENT * dtheta * dtheta * sin_t) / TOTAL_MASS;
+            const float z = div_const(force + POLE_MOMENT * dtheta * dtheta * sin_t, TOTAL_MASS);
             const float numer = G * sin_t - cos_t * z;
             const float denom = FOUR_THIRDS * POLE_COM - POLE_MOMENT * cos_t * cos_t;
             const float ddtheta = numer / denom;

@@ -141,10 +141,13 @@ struct TileModel {
             constexpr int i = Ii;
             constexpr float lo = (float)Dom::lo_d(i), hi = (float)Dom::hi_d(i);
             const float num = s[i] - lo;
-            const float den = hi - lo;
-            const float sc = num / den;
+            constexpr float den = hi - lo;
+            const float sc = div_const(num, den);                       // num / den, the same bits (device_core.hpp div_const)
             u[i] = sc * (float)(B - 1);
         });
+        // cell = clamp((int)floorf(v), 0, B-1) == (int)floorf(clamp(v, 0, B-1)) for every v (the bounds are integers; a NaN gives 0 either
+        // way: v_med3_f32 returns the minimum then): one v_med3_f32 + one v_cvt_flr_i32_f32 instead of floor, convert, max, min
+        const float top = (float)(B - 1);
         static_for<0, T>([&](auto Tt) {
             constexpr int t = Tt;
             int lin = 0, stride = 1;
@@ -152,10 +155,9 @@ struct TileModel {
                 constexpr int i = Ii;
                 constexpr float off = (float)((t * (2 * i + 1)) % T) / (float)T;
                 const float v = u[i] + off;
-                int cell = (int)floorf(v);
-                cell = cell < 0 ? 0 : cell;
-                cell = cell > B - 1 ? B - 1 : cell;
-                lin += cell * stride; stride *= B;
+                const int cell = floor_to_int(__builtin_amdgcn_fmed3f(v, 0.0f, top));
+                lin = (int)__umul24((unsigned)cell, (unsigned)stride) + lin;          // cell < 64, stride <= 2^24: v_mad_u32_u24
+                stride *= B;
             });
             ft.idx[t] = t * BD + lin;
         });
@@ -193,6 +195,36 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) acc = acc + c.W[widx(c, wi, g, ft.idx[t], a)];
         return acc;
+    }
+    // Q(s,.) from ONE SHARED table: the table is addressed through a buffer descriptor (wave-uniform base in SGPRs) + a 32-bit byte
+    // offset per lane -- one shift and one A-dword buffer load per tiling, no 64-bit address arithmetic (the per-learner form above
+    // spends ~6 VALU instructions per gather on it).  Same loads, same order of additions: the same bits.
+    // Precondition (host): the table is smaller than 2 GiB.
+    __device__ static __forceinline__ void q_all_shared(const float* __restrict__ W, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, g.F * A * 4, 0x00020000);
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = 0.0f;
+        float w[T][A];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int off = ft.idx[t] * (A * 4);
+            if constexpr (A == 2) {
+                typedef int i2v __attribute__((ext_vector_type(2)));
+                const i2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+                w[t][0] = __builtin_bit_cast(float, v.x); w[t][1] = __builtin_bit_cast(float, v.y);
+            } else if constexpr (A == 3) {
+                typedef int i3v __attribute__((ext_vector_type(3)));
+                const i3v v = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
+                w[t][0] = __builtin_bit_cast(float, v.x); w[t][1] = __builtin_bit_cast(float, v.y); w[t][2] = __builtin_bit_cast(float, v.z);
+            } else {
+#pragma unroll
+                for (int b = 0; b < A; ++b) w[t][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * b, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int b = 0; b < A; ++b) q[b] = q[b] + w[t][b];          // acc + w, tilings in order
     }
     __device__ static __forceinline__ void update(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a, float scale) {
 #pragma unroll
@@ -644,7 +676,9 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         if (done) { M::Dom::reset(s); ep = 0; }
         else load_state<M>(c.state, N, i, s);
         M::features(s, g, fs);
-        if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s); else M::q_all(c, 0, g, fs, q_s);
+        if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s);
+        else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fs, q_s);
+        else M::q_all(c, 0, g, fs, q_s);
         if (do_c) {                                                     // ---- phase C of batch-step t-1
             const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
@@ -661,7 +695,9 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         typename M::Feat fn;
         M::features(ns, g, fn);
         float q_n[A];
-        if constexpr (M::kDense) M::q_all_lds(sh_w, fn, q_n); else M::q_all(c, 0, g, fn, q_n);
+        if constexpr (M::kDense) M::q_all_lds(sh_w, fn, q_n);
+        else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fn, q_n);
+        else M::q_all(c, 0, g, fn, q_n);
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         float e;

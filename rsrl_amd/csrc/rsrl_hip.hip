@@ -721,6 +721,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (cfg->tiles_per_dim < 1 || cfg->tiles_per_dim > 64) return fail(RSRL_HIP_EINVAL, "tiles_per_dim must be in [1, 64]");
         int64_t cells = 1; for (int i = 0; i < c->D; ++i) cells *= cfg->tiles_per_dim;
         if (cells * cfg->n_tilings > (int64_t)1 << 30) return fail(RSRL_HIP_EINVAL, "tile table too large");
+        // (a shared table is gathered through one 32-bit buffer descriptor)
+        if (cfg->weight_mode == RSRL_W_SHARED && cells * cfg->n_tilings * c->A * 4 >= (int64_t)1 << 31) return fail(RSRL_HIP_EINVAL, "a shared tile table must be smaller than 2 GiB");
         c->F = (int)(cells * cfg->n_tilings);
     } else {
         return fail(RSRL_HIP_EINVAL, "unknown basis %d", cfg->basis);

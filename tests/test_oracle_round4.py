@@ -109,3 +109,31 @@ def test_rollout_policy(orc):
         run.rollout_policy(orc.EGREEDY, 0)
     with pytest.raises(ValueError):
         run.rollout_policy(9, 10)
+
+
+def test_constant_division_is_the_ieee_quotient(orc, tmp_path):
+    # The HIP path divides by compile-time constants through f64 -- (float)((double)x * (1.0 / (double)d)), three instructions instead of
+    # the ~11 of an IEEE fp32 division (rsrl_amd/csrc/device_core.hpp div_const) -- while the oracle keeps the reference's `/`
+    # (ode.rs:36 `/ 6.0`, cart_pole.rs:60 `/ TOTAL_MASS`, the tile coder's (s - lo) / (hi - lo)).  They are the same function: shown here
+    # by trying EVERY fp32 input (zeros of both signs, denormals, infinities, NaNs) for every divisor on the path.
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    exe = str(tmp_path / "check_constdiv")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-pthread", "-o", exe,
+                           os.path.join(here, "check_constdiv.c"), "-lm"])
+    divisors = {np.float32(6.0), np.float32(1.0) + np.float32(0.1)}                    # RK4's / 6.0; TOTAL_MASS = 1.0 + 0.1 (consts.rs:4-7)
+    for dom in (0, 1, 2):
+        lo, hi = orc.domain_bounds(dom)
+        for a, b in zip(lo.astype(np.float32), hi.astype(np.float32)):
+            divisors.add(np.float32(b - a))                                            # hi - lo in fp32, as the device's constexpr evaluates it
+    assert np.float32(1.1) in divisors and len(divisors) >= 10
+    n = min(16, len(os.sched_getaffinity(0)))
+    args = [exe, "0", "1", str(n), "0", "3.5e38"] + [f"{float(d):.9g}" for d in sorted(divisors)]
+    out = subprocess.run(args, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout
+    rows = [ln for ln in out.stdout.splitlines() if ln.startswith("d=")]
+    assert len(rows) == len(divisors) and all("4294967296 inputs, 0 mismatches" in ln for ln in rows), out.stdout
+    # the checker does find a sequence that is NOT the quotient: Markstein's fp32 correction step fails where its residual underflows
+    bad = subprocess.run([exe, "1", "1", str(n), "0", "1e-36", "1.10000002"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 1 and "mismatches" in bad.stdout and " 0 mismatches" not in bad.stdout
