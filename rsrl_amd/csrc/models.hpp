@@ -208,14 +208,16 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int off = ft.idx[t] * (A * 4);
+            // (the builtin's result goes through __builtin_bit_cast: assigned to an int vector of the same size it is silently narrowed to
+            // its first element -- a one-dword load)
             if constexpr (A == 2) {
-                typedef int i2v __attribute__((ext_vector_type(2)));
-                const i2v v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
-                w[t][0] = __builtin_bit_cast(float, v.x); w[t][1] = __builtin_bit_cast(float, v.y);
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                const f2v v = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+                w[t][0] = v.x; w[t][1] = v.y;
             } else if constexpr (A == 3) {
-                typedef int i3v __attribute__((ext_vector_type(3)));
-                const i3v v = __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0);
-                w[t][0] = __builtin_bit_cast(float, v.x); w[t][1] = __builtin_bit_cast(float, v.y); w[t][2] = __builtin_bit_cast(float, v.z);
+                typedef float f3v __attribute__((ext_vector_type(3)));
+                const f3v v = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
+                w[t][0] = v.x; w[t][1] = v.y; w[t][2] = v.z;
             } else {
 #pragma unroll
                 for (int b = 0; b < A; ++b) w[t][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * b, 0, 0));
