@@ -243,7 +243,8 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
                 "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
                 "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
                 "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
-                "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu, ms * 1e-3 / max(1, n_l), n_l, 32,
+                "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu,
+                                         ms * 1e-3 if kn == "k_shared_persist" else ms * 1e-3 / max(1, n_l), 1 if kn == "k_shared_persist" else n_l, 32,
                                          "SURVEY 8(d): C4 is VALU / latency bound (W stays on the chip: 32 B/env-step of state stream); the batch-step = two fabric hops "
                                          "of the delta all-reduce (~3.2 us, profiles/r03_ubench_granule_allreduce.txt) + the learners' arithmetic at two waves per SIMD"),
                 "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
@@ -251,15 +252,20 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
         return {"error": repr(e)}
 
 
-def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_bytes_per_env_step, what):
+def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_bytes_per_env_step, what, also=()):
     """roofline object of a secondary leg: every `frac` is a fraction of a PUBLISHED peak and follows from a file under profiles/.
     bound "valu": flop per env-step (profiles/isa_mix.json: rocprofv3 instruction-class counters of this kernel) x the kernel's env-steps/s by HIP
     events / 157.3 TFLOP/s; `issue_slots`: VALU instructions per env-step at the guide's 2 cycles each (a LOWER bound of the slots used: packed
     instructions take 4) against 1024 SIMDs x 2.4 GHz; `traffic` = HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json), `hbm` = that
     traffic over the launch duration against 8 TB/s.  SURVEY 8(d)'s algorithmic bytes x rate are kept under a name that is not `frac`."""
-    mix = (_profiles_json("isa_mix.json") or {}).get(kname) or {}
+    mixes = _profiles_json("isa_mix.json") or {}
+    mix = mixes.get(kname) or {}
     flop = mix.get("flop_per_env_step")
     n_valu = mix.get("valu_wave_instr_per_env_step")
+    for k in also:                                       # the batch-step's other kernels (`also`): their instructions and bytes count too
+        if flop and mixes.get(k, {}).get("flop_per_env_step") is not None:
+            flop += mixes[k]["flop_per_env_step"]
+            n_valu += mixes[k].get("valu_wave_instr_per_env_step", 0.0)
     rl = {"bound": "valu", "kernel": kname, "unit": "TFLOP/s", "peak": FP32_VECTOR_PEAK / 1e12, "env_steps_per_s_kernel": per_gpu_steps_per_s,
           "avg_launch_ms": avg_launch_s * 1e3, "launches": launches, "what": what}
     if flop:
@@ -273,11 +279,28 @@ def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_b
         rl["issue_slots"] = {"valu_wave_instr_per_env_step": n_valu, "frac_lower_bound": per_gpu_steps_per_s / peak, "peak_env_steps_per_s": peak,
                              "what": "every VALU wave-instruction priced at 2 cycles (MI355X_MICROARCH.md), 1024 SIMDs x 2.4 GHz; packed fp32 instructions take 4, "
                                      "so the slots really used are more"}
-    tr = pmc_traffic(kname, envs, None)
-    rl["traffic"] = tr
-    rl["traffic_unit"] = "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json)"
-    if tr and avg_launch_s > 0:
-        rl["hbm"] = {"achieved": tr / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": tr / avg_launch_s / HBM_PEAK, "what": "REAL traffic of the launch / its duration"}
+    tfile = _profiles_json("pmc_traffic.json") or {}
+    rec = tfile.get(kname)
+    rec = rec[0] if isinstance(rec, list) and rec else rec
+    if isinstance(rec, dict) and also:
+        rec = dict(rec)
+        for k in also:
+            o = tfile.get(k)
+            if isinstance(o, dict) and o.get("envs") == rec.get("envs"):
+                rec["bytes_per_env_step"] += o["bytes_per_env_step"]
+                rec["traffic_bytes_per_launch"] += o["traffic_bytes_per_launch"]
+    rl["traffic"], rl["traffic_unit"] = None, "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes; profiles/pmc_traffic.json)"
+    if isinstance(rec, dict) and rec.get("envs") == envs and avg_launch_s > 0:
+        if rec.get("scales") == "per_launch":            # W in + out once per launch, whatever its depth: the profiled launch's bytes are this launch's
+            tr = rec["traffic_bytes_per_launch"]
+            bps = tr / avg_launch_s
+        else:                                            # bytes follow the batch-steps: scale the profiled launch to this one's depth
+            steps_here = per_gpu_steps_per_s * avg_launch_s / envs
+            tr = rec["bytes_per_env_step"] * envs * steps_here
+            bps = rec["bytes_per_env_step"] * per_gpu_steps_per_s
+        rl["traffic"] = tr
+        rl["traffic_profiled"] = {"bytes_per_launch": rec["traffic_bytes_per_launch"], "steps_per_launch": rec.get("steps_per_launch"), "scales": rec.get("scales")}
+        rl["hbm"] = {"achieved": bps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bps / HBM_PEAK, "what": "REAL traffic (PMC) over the kernel's time"}
     rl["algorithmic_bytes_equivalent"] = {"bytes_per_env_step": alg_bytes_per_env_step, "equivalent_GBps": alg_bytes_per_env_step * per_gpu_steps_per_s / 1e9,
                                           "note": "SURVEY 8(d)'s algorithmic bytes x rate: NOT moved bytes and not a roofline fraction"}
     return rl
@@ -314,7 +337,7 @@ def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
             "source": "profiles/isa_mix.json (rocprofv3 SQ_INSTS_VALU_* class counters per env-step) x HIP-event kernel rate of this run"}
 
 
-def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extra=None):
+def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extra=None, also=()):
     """Secondary measurement of another BASELINE.json configuration's per-GPU share (a parity-test configuration, never part of
     `value`): env-steps/s, the dominant kernel's HIP-event time per batch-step, and a roofline object on SURVEY 8(d)'s
     algorithmic bytes per env-step against the 8 TB/s of MI355X_MICROARCH.md."""
@@ -334,7 +357,9 @@ def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extr
         rate = kw["n_envs"] / per_step if per_step > 0 else 0.0
         rec = {"workload": name, "value": kw["n_envs"] * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
                "kernel_us_per_batch_step": per_step * 1e6,
-               "roofline": leg_roofline(kn, rate, kw["n_envs"], ms * 1e-3 / max(1, n), n, bytes_per_env_step, what)}
+               "roofline": leg_roofline(kn, rate, kw["n_envs"], ms * 1e-3 / max(1, n), n, bytes_per_env_step, what, also)}
+        if also:
+            rec["roofline"]["kernels"] = [kn] + list(also)
         if extra:
             rec["roofline"].update(extra)
         return rec
@@ -471,7 +496,8 @@ def main():
                  policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99, lr=0.0125 / 262144, weight_mode=rsrl_amd.W_SHARED, max_episode_steps=1000,
                  env_offset=rank * 262144, device=device), 960, 64, 208,
             "SURVEY 8(d): 208 B/env-step, of which 48 B are the HBM stream (state, action, counter) and 160 B are gathers / atomic "
-            "read-modify-writes of the shared table served by L2; the batch-step is bound by the scatter (device atomics) and its dependent launches"), 120)
+            "read-modify-writes of the shared table served by L2; the batch-step is three DEPENDENT launches (step, scatter, apply): latency-bound, "
+            "none of the three fractions binds", also=("k_tile_scatter", "k_apply_rep")), 120)
         c5 = guarded(lambda: config_leg(
             rsrl_amd, "BASELINE.json configs[4], one GPU's share: 32768 Acrobot envs, ExpectedSARSA + Fourier(7) + Softmax, bf16 weights, per-env W",
             dict(domain=rsrl_amd.ACROBOT, order=7, algo=rsrl_amd.EXPECTED_SARSA, policy=rsrl_amd.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,

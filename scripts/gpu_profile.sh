@@ -10,20 +10,24 @@ set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
-rm -rf $O; mkdir -p $O
-LEGS=${*:-fused stream stream1m persist tile wave}
+[ "${PROFILE_LEGS_ONLY:-0}" = "1" ] || rm -rf $O
+mkdir -p $O
+LEGS=${*:-fused stream stream1m persist perstep tile wave}
 cd /tmp
+if [ "${PROFILE_LEGS_ONLY:-0}" = "1" ]; then SKIP_BENCH=1; else SKIP_BENCH=0; fi
+[ $SKIP_BENCH = 1 ] || {
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_driver -o k -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-config-legs --no-shared-leg --no-streaming-leg > $O/bench_driver_profiled.json 2> $O/kt_driver.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_1024 -o k -- python $R/bench.py --gpus 1 --steps 1024 --warmup 5 --no-cpu-baseline --no-config-legs --no-shared-leg --no-streaming-leg --no-nocoalesce-leg > $O/bench_1024_profiled.json 2> $O/kt_1024.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_legs -o k -- python $R/bench.py --gpus 1 --steps 1024 --warmup 5 --no-cpu-baseline --regions 1 --region-seconds 0.2 --no-nocoalesce-leg > $O/bench_legs_profiled.json 2> $O/kt_legs.log
+}
 G1="FETCH_SIZE"
 G2="WRITE_SIZE"
 G3="SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT"
 G4="SQ_WAVES SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"
 G5="SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_FLOPS_FP32_TRANS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_FLOPS_FP64"
 for leg in $LEGS; do
-  mkdir -p $O/$leg
+  rm -rf $O/$leg; mkdir -p $O/$leg
   # plain launches under counter collection (graph replays crashed the profiler's host side in round 3)
   CMD="env RSRL_NO_GRAPH=1 python $R/scripts/profile_leg.py $leg"
   python $R/scripts/profile_leg.py $leg > $O/$leg/plain.json 2> $O/$leg/plain.err
