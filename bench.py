@@ -238,7 +238,7 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
         lo, hi = -cp.max_over_ranks(-chk), cp.max_over_ranks(chk)
         ctx.close()
         return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step "
-                            f"{'peer-write' if exchange else 'RCCL all-reduce'} exchange of the 432 B delta", "ranks": cp.world, "steps": steps,
+                            f"{ {0: 'RCCL all-reduce of the fixed-point delta table', 1: 'one-hop peer-write exchange of the delta'}.get(comm_kind, 'exchange') }", "ranks": cp.world, "steps": steps,
                 "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
                 "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
                 "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
@@ -504,18 +504,19 @@ def main():
                  n_envs=32768, weight_dtype=rsrl_amd.W_BF16, max_episode_steps=1000, env_offset=rank * 32768, device=device), 512, 64, 32816,
             "SURVEY 8(d): 32 816 B/env-step if W (24 KiB bf16 per learner) were streamed every step; the wave-family kernel keeps W in registers for "
             "the whole launch, so the figure is an equivalent, not moved bytes: the kernel is VALU-issue bound at one wave per SIMD"), 180)
-    shared = shared_peer = None
+    # shared-W legs: `shared_w` = what a user gets (exchange AUTO: the one-hop peer exchange whenever every rank's device reaches every
+    # other's, and then the persistent kernel); `shared_w_rccl` = the any-topology fallback asked for explicitly
+    shared = shared_rccl = None
     if not args.no_shared_leg:
+        shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_AUTO,
+                                              envs_per_gpu=131072 if world <= ndev else max(512, min(131072, args.envs))), 240)
         if world > ndev:
             # RCCL admits one rank per device (ncclCommInitRank: "invalid usage" for a duplicate GPU): on an oversubscribed test box the leg
-            # has nothing to measure.  The peer exchange runs: ranks that share a device decide together which kernels fit it.
-            shared = {"skipped": f"{world} ranks on {ndev} device(s): RCCL refuses ranks that share a device (the peer exchange below runs)"}
-        else:
-            shared = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
-        if not (isinstance(shared, dict) and shared.get("error") == "timeout"):
-            shared_peer = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_PEER,
-                                                       envs_per_gpu=131072 if world <= ndev else max(512, min(131072, args.envs))), 240)
-    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_peer, c3, c5))
+            # has nothing to measure.  The peer exchange above runs: ranks that share a device decide together which kernels fit it.
+            shared_rccl = {"skipped": f"{world} ranks on {ndev} device(s): RCCL refuses ranks that share a device (shared_w, the peer exchange, runs)"}
+        elif not (isinstance(shared, dict) and shared.get("error") == "timeout"):
+            shared_rccl = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_rccl, c3, c5))
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -588,8 +589,8 @@ def main():
             out["c5_wave_bf16"] = c5
         if shared is not None:
             out["shared_w"] = shared
-        if shared_peer is not None:
-            out["shared_w_peer"] = shared_peer
+        if shared_rccl is not None:
+            out["shared_w_rccl"] = shared_rccl
         if not args.no_cpu_baseline:
             # the other ranks are idle by now (they wait in the closing barrier below): the host cores are rank 0's
             out["cpu_baseline"] = cpu_baseline()

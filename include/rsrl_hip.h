@@ -92,8 +92,12 @@ typedef enum { RSRL_W_F32 = 0, RSRL_W_BF16 = 1 } rsrl_weight_dtype;
  *   RCCL : ncclAllReduce(sum) on the ctx's stream (one process per GPU, any topology)
  *   PEER : one-hop peer-write -- every rank stores its delta into a slot of every other rank's receive buffer
  *          (hipIpc-mapped memory: xGMI stores across GPUs) and each rank sums the slots in rank order: deterministic,
- *          ring-free, one fabric hop (single node) */
-typedef enum { RSRL_EXCHANGE_RCCL = 0, RSRL_EXCHANGE_PEER = 1 } rsrl_exchange;
+ *          ring-free, one fabric hop (single node)
+ *   AUTO : (the default) decided when the exchange is attached: rsrl_hip_comm_init makes it RCCL, rsrl_hip_peer_export makes it PEER,
+ *          rsrl_hip_group_create takes PEER whenever every device of the group can access every other one's memory (one hop over xGMI
+ *          beats a ring of latency-bound all-reduces at 432 B; the persistent kernel exchanges inside its one launch) and RCCL, the
+ *          any-topology fallback, otherwise.  rsrl_hip_can_access_peer lets a multi-process host make the same choice. */
+typedef enum { RSRL_EXCHANGE_RCCL = 0, RSRL_EXCHANGE_PEER = 1, RSRL_EXCHANGE_AUTO = 2 } rsrl_exchange;
 
 typedef struct rsrl_hip_ctx rsrl_hip_ctx;
 
@@ -376,6 +380,9 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* ctx, const uint8_t* id_bytes, int world_siz
  * (rsrl_hip_load_weights sets the counter back) cannot make a stale slot look current. */
 #define RSRL_HIP_PEER_HANDLE_BYTES 128
 int rsrl_hip_peer_export(rsrl_hip_ctx* ctx, int world_size, uint8_t* handle_out /*[128]*/);
+/* 1 if `device` can read and write `peer_device`'s memory directly (hipDeviceCanAccessPeer; a device can always access itself), 0 if not,
+ * a negative status on error: what a host needs to choose RSRL_EXCHANGE_PEER for its ranks (every pair must say 1) */
+int rsrl_hip_can_access_peer(int device, int peer_device);
 int rsrl_hip_peer_connect(rsrl_hip_ctx* ctx, const uint8_t* handles /*[world_size][128]*/, int world_size, int rank);
 
 /* All ranks in ONE process (a single-threaded host, like the reference's Rc<RefCell> owner graph, rsrl/src/core.rs:13-15):

@@ -13,7 +13,7 @@ TRACE_ACCUMULATE, TRACE_SATURATE, TRACE_DUTCH = 0, 1, 2
 GREEDY, EPSILON_GREEDY, SOFTMAX, RANDOM = 0, 1, 2, 3
 W_PER_ENV, W_SHARED = 0, 1
 W_F32, W_BF16 = 0, 1
-EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1
+EXCHANGE_RCCL, EXCHANGE_PEER, EXCHANGE_AUTO = 0, 1, 2
 PEER_HANDLE_BYTES = 128
 
 
@@ -33,6 +33,14 @@ def _in(a, dtype, shape=None):
     if shape is not None and tuple(a.shape) != tuple(shape):
         raise ValueError(f"expected shape {shape}, got {a.shape}")
     return a
+
+
+def can_access_peer(device, peer_device):
+    """True if `device` reads and writes `peer_device`'s memory directly (what the one-hop peer exchange needs of every pair of ranks)"""
+    rc = _abi.lib().rsrl_hip_can_access_peer(int(device), int(peer_device))
+    if rc < 0:
+        _abi.check(rc)
+    return rc == 1
 
 
 def device_count():
@@ -67,7 +75,7 @@ class Context:
                  algo=QLEARNING, policy=GREEDY, weight_mode=W_PER_ENV, weight_dtype=W_F32,
                  n_envs=1, env_offset=0, seed=0, gamma=0.9, lr=0.001, alpha=1.0, epsilon=0.1, tau=1.0,
                  max_episode_steps=0, steps_per_launch=0, device=0, stream=None, lam=0.0, trace=TRACE_ACCUMULATE, lr_td=0.0,
-                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_RCCL, sigma=0.0, n_steps=1, peer_timeout_ms=0,
+                 agent_policy=None, agent_epsilon=0.1, agent_tau=1.0, exchange=EXCHANGE_AUTO, sigma=0.0, n_steps=1, peer_timeout_ms=0,
                  epsilon_decay=1.0, epsilon_min=0.0):
         self._L = _abi.lib()
         cfg = _abi.Config()

@@ -635,7 +635,7 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
     cfg->gamma = 0.9; cfg->lr = 0.001; cfg->alpha = 1.0; cfg->epsilon = 0.1; cfg->tau = 1.0;
     cfg->max_episode_steps = 0; cfg->steps_per_launch = 0;
     cfg->trace = RSRL_TRACE_ACCUMULATE; cfg->lambda = 0.0; cfg->lr_td = 0.0;
-    cfg->agent_policy = -1; cfg->agent_epsilon = 0.1; cfg->agent_tau = 1.0; cfg->exchange = RSRL_EXCHANGE_RCCL;
+    cfg->agent_policy = -1; cfg->agent_epsilon = 0.1; cfg->agent_tau = 1.0; cfg->exchange = RSRL_EXCHANGE_AUTO;
     cfg->sigma = 0.0; cfg->n_steps = 1;
     cfg->epsilon_decay = 1.0; cfg->epsilon_min = 0.0;
     return RSRL_HIP_OK;
@@ -713,7 +713,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "Tau parameter in Softmax must be non-zero.");
     if (cfg->agent_policy == RSRL_EPSILON_GREEDY && !(cfg->agent_epsilon >= 0.0 && cfg->agent_epsilon <= 1.0))
         return fail(RSRL_HIP_EINVAL, "agent_epsilon must be in [0,1]");
-    if (cfg->exchange != RSRL_EXCHANGE_RCCL && cfg->exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_EINVAL, "unknown exchange %d", cfg->exchange);
+    if (cfg->exchange != RSRL_EXCHANGE_RCCL && cfg->exchange != RSRL_EXCHANGE_PEER && cfg->exchange != RSRL_EXCHANGE_AUTO) return fail(RSRL_HIP_EINVAL, "unknown exchange %d", cfg->exchange);
     if (cfg->basis == RSRL_FOURIER) {
         if (cfg->order < 1 || cfg->order > 7) return fail(RSRL_HIP_EINVAL, "Fourier order must be in [1, 7]");
         c->F = 1; for (int i = 0; i < c->D; ++i) c->F *= (cfg->order + 1);
@@ -1532,7 +1532,21 @@ static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
 // t_dev != nullptr: the launch is a graph node, t is its offset to the device-side batch-step counter.
 // what the step kernel's prologue folds into the weights: 1 = this rank's own delta table (single rank), 2 = the float delta the
 // all-reduce left in dW (RCCL), 0 = nothing (peer exchange: its kernel applies the sum itself)
-static inline int fold_in_step(const rsrl_hip_ctx* c) { return !c->multi ? 1 : (c->cfg.exchange == RSRL_EXCHANGE_PEER ? 0 : 2); }
+// RCCL (round 4): the ranks all-reduce the FIXED-POINT TABLE of the batch-step itself (kTabRep copies of A*F 64-bit integers, ncclInt64 /
+// ncclSum, in place) and the next launch's prologue folds it exactly as it folds a single rank's own table (fold = 1): no table -> float
+// kernel between the step and the collective (one dependent launch less per batch-step: 12.2 -> ~9.7 us at a size-1 communicator), and
+// the sum over the ranks is an exact integer -- a run sharded in whole 512-learner blocks equals the unsharded run bit for bit, as it
+// already did on the peer path.  fold = 2 (the float delta in dW) is no longer produced by the dense path.
+static inline int fold_in_step(const rsrl_hip_ctx* c) { return !c->multi ? 1 : (c->cfg.exchange == RSRL_EXCHANGE_PEER ? 0 : 1); }
+// the set of the rotating delta tables batch-step t accumulates into (models.hpp DeltaTab: t mod 3)
+static inline long long* tab_set_of(const rsrl_hip_ctx* c, uint64_t t) { return c->sh_tab + (size_t)kTabRep * c->dw_elems * (size_t)(t % 3u); }
+// the dense RCCL exchange: all-reduce of batch-step t's table set, in place.  Inside a captured graph t is the node's offset to a device-side
+// counter that is a MULTIPLE OF 3 whenever a graph is replayed (train_now starts replaying only at such a step, graphs are 30 steps long),
+// so t mod 3 is the set there too.
+static int exchange_table(rsrl_hip_ctx* c, uint64_t t) {
+    NCCL_TRY(ncclAllReduce(tab_set_of(c, t), tab_set_of(c, t), (size_t)kTabRep * c->dw_elems, ncclInt64, ncclSum, c->comm, c->stream));
+    return RSRL_HIP_OK;
+}
 // dense basis, shared weights: ONE launch per batch-step (k_shared_step, models.hpp).  fold: add the previous batch-step's delta to
 // the weights first.
 static int enqueue_dense_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int mode, int fold, uint64_t t,
@@ -1573,9 +1587,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             KCHECK();
             return RSRL_HIP_OK;
         }
-        hipLaunchKernelGGL(k_tab_finalize, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, c->sh_tab, n, k.alg.lr, c->dW, t, t_dev);
-        KCHECK();
-        if (xpart == 0) TRY(exchange_dw(c, t, t_dev, k.xdelta));
+        if (xpart == 0) TRY(exchange_table(c, t));
         return RSRL_HIP_OK;
     }
     bool fused_apply = false;
@@ -1643,7 +1655,6 @@ static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g
         // closing launch: fold the last batch-step's delta, phase C; the result goes back to the canonical buffer
         const int fold = fold_in_step(c);
         TRY(enqueue_dense_step(c, k, g, nullptr, 1, fold, t_last + 1, nullptr));
-        if (fold == 2) HIP_TRY(hipMemsetAsync(c->dW, 0, sizeof(float) * c->dw_elems, c->stream));      // consumed: dW is zero between operations
         if (c->sh_par) {
             HIP_TRY(hipMemcpyAsync(c->W, c->W2, c->w_bytes, hipMemcpyDeviceToDevice, c->stream));
             c->sh_par = 0;
@@ -1679,15 +1690,19 @@ static int enqueue_k1_step(rsrl_hip_ctx* c, const Common& k, DevStats* d_stats, 
 // as the graph's last node), so one executable graph serves every replay.  Any change of the kernel arguments (epsilon,
 // pointers) re-captures.
 constexpr int kStepsPerGraph = 32;
+// the dense RCCL path all-reduces the table set of its batch-step (t mod 3): its graphs are 30 steps long and start at t = 0 mod 3
+static inline bool rccl_dense(const rsrl_hip_ctx* c) { return c->multi && c->cfg.exchange == RSRL_EXCHANGE_RCCL && c->cfg.weight_mode == RSRL_W_SHARED && c->sh_tab != nullptr; }
+static inline int steps_per_graph(const rsrl_hip_ctx* c) { return rccl_dense(c) ? 30 : kStepsPerGraph; }
 static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int kind) {
     if (c->step_graph_exec && c->step_graph_kind == kind && memcmp(&c->step_graph_key, &k, sizeof(Common)) == 0) return RSRL_HIP_OK;
     if (c->step_graph_exec) { (void)hipGraphExecDestroy(c->step_graph_exec); c->step_graph_exec = nullptr; }
     if (c->step_graph) { (void)hipGraphDestroy(c->step_graph); c->step_graph = nullptr; }
     HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = RSRL_HIP_OK;
-    for (int j = 0; j < kStepsPerGraph && rc == RSRL_HIP_OK; ++j)
+    const int spg = steps_per_graph(c);
+    for (int j = 0; j < spg && rc == RSRL_HIP_OK; ++j)
         rc = kind == 1 ? enqueue_k1_step(c, k, nullptr, (uint64_t)j, c->d_t) : enqueue_shared_step(c, k, g, nullptr, 1, (uint64_t)j, c->d_t);
-    if (rc == RSRL_HIP_OK) hipLaunchKernelGGL(k_advance_t, dim3(1), dim3(1), 0, c->stream, c->d_t, (uint64_t)kStepsPerGraph);
+    if (rc == RSRL_HIP_OK) hipLaunchKernelGGL(k_advance_t, dim3(1), dim3(1), 0, c->stream, c->d_t, (uint64_t)spg);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc != RSRL_HIP_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1920,7 +1935,8 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         HIP_TRY(hipMemsetAsync(c->sh_tab, 0, sizeof(long long) * 3 * kTabRep * c->dw_elems, c->stream));
     while (done < n_steps) {
         // (dense shared W: the W / row buffers alternate every batch-step, the graph is captured at the parity of an odd step count)
-        if (graph_ok && n_steps - done >= kStepsPerGraph && (shared ? (done > 0 && (!fourier || (done & 1))) : c->q_valid)) {
+        const int spg = steps_per_graph(c);
+        if (graph_ok && n_steps - done >= spg && (shared ? (done > 0 && (!fourier || (done & 1)) && (!rccl_dense(c) || c->t % 3u == 0)) : c->q_valid)) {
             // the graph's nodes read the policy parameters from device memory: set_epsilon between calls (the reference's drivers
             // decay epsilon every episode, examples/sarsa_lambda.rs:68) refreshes 48 bytes instead of re-instantiating 32+ nodes
             Common kg = k; kg.q_valid = stream_k1 ? 1 : k.q_valid;
@@ -1934,11 +1950,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (!t_dev_set) { hipLaunchKernelGGL(k_set_t, dim3(1), dim3(1), 0, c->stream, c->d_t, c->t); KCHECK(); t_dev_set = true; }
             TRY(timing_begin(c));
             HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
-            TRY(timing_end(c, kStepsPerGraph));
+            TRY(timing_end(c, (uint32_t)spg));
             c->kernel_name = stream_k1 ? (c->w_ls != 1 ? (c->k1_quad ? "k_step_reg_q4" : "k_step_reg_lm") : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
-            c->t += (uint64_t)kStepsPerGraph;
-            if (peer_steps) c->peer_seq += (uint64_t)kStepsPerGraph;
-            done += kStepsPerGraph;
+            c->t += (uint64_t)spg;
+            if (peer_steps) c->peer_seq += (uint64_t)spg;
+            done += spg;
             continue;
         }
         t_dev_set = false;                  // plain launches advance the host counter only
@@ -2203,7 +2219,8 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
     if (c->multi) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
-    if (c->cfg.exchange != RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
+    if (c->cfg.exchange == RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
+    c->cfg.exchange = RSRL_EXCHANGE_RCCL;                              // (AUTO: attaching a communicator decides)
     NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
     c->world_size = world_size; c->rank = rank; c->multi = true;
     // warm-up: RCCL sets its connections up lazily, at the first collective -- which must not be the one inside the step graph's
@@ -2244,8 +2261,9 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     CHECK_CTX(c); FLUSH(c);
     if (!handle_out || world_size < 1 || world_size > 64) return fail(RSRL_HIP_EINVAL, "bad peer arguments");
     if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no exchange: shard by env_offset instead");
-    if (c->cfg.exchange != RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
+    if (c->cfg.exchange == RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
     if (c->multi || c->peer_recv) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
+    c->cfg.exchange = RSRL_EXCHANGE_PEER;                              // (AUTO: exporting a receive buffer decides)
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->peer_old_bytes = sizeof(uint2) * 2 * (size_t)world_size * c->dw_elems;
     // second region: the hop-2 buffer of the persistent kernel, [2 (parity)][world][A*F rounded up to even] granules
@@ -2267,6 +2285,15 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     memset(handle_out, 0, RSRL_HIP_PEER_HANDLE_BYTES);
     memcpy(handle_out, &b, sizeof(b));
     return RSRL_HIP_OK;
+}
+int rsrl_hip_can_access_peer(int device, int peer_device) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n || peer_device < 0 || peer_device >= n) return fail(RSRL_HIP_EINVAL, "device out of range (%d devices)", n);
+    if (device == peer_device) return 1;
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, device, peer_device));
+    return can ? 1 : 0;
 }
 int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_size, int rank) {
     CHECK_CTX(c); FLUSH(c);
@@ -2361,6 +2388,21 @@ int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
         if (c->cfg.exchange != ctxs[0]->cfg.exchange || c->dw_elems != ctxs[0]->dw_elems || c->cfg.basis != ctxs[0]->cfg.basis)
             return fail(RSRL_HIP_EINVAL, "the ctxs of a group must share the approximator's shape and the exchange kind");
     }
+    if (ctxs[0]->cfg.exchange == RSRL_EXCHANGE_AUTO) {
+        // PEER whenever every device of the group reaches every other one's memory (one hop, exact integer sums, the persistent kernel);
+        // RCCL, the any-topology fallback, otherwise -- or when ranks share a device but RCCL was not asked for explicitly (it needs one
+        // device per rank)
+        bool peer = true;
+        for (int i = 0; i < n && peer; ++i)
+            for (int j = 0; j < n && peer; ++j) {
+                const int a = ctxs[i]->cfg.device, b = ctxs[j]->cfg.device;
+                if (a == b) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+                if (!can) peer = false;
+            }
+        for (int i = 0; i < n; ++i) ctxs[i]->cfg.exchange = peer ? RSRL_EXCHANGE_PEER : RSRL_EXCHANGE_RCCL;
+    }
     if (ctxs[0]->cfg.exchange == RSRL_EXCHANGE_PEER) {
         std::vector<uint8_t> handles((size_t)n * RSRL_HIP_PEER_HANDLE_BYTES);
         for (int i = 0; i < n; ++i) TRY(rsrl_hip_peer_export(ctxs[i], n, handles.data() + (size_t)i * RSRL_HIP_PEER_HANDLE_BYTES));
@@ -2433,7 +2475,8 @@ int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps) {
         for (int i = 0; i < n; ++i) {
             rsrl_hip_ctx* c = ctxs[i];
             HIP_TRY(hipSetDevice(c->cfg.device));
-            NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+            if (c->sh_tab) TRY(exchange_table(c, c->t));                  // dense basis: the batch-step's fixed-point table
+            else NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));      // tile coding: the float delta
         }
         NCCL_TRY(ncclGroupEnd());
         for (int i = 0; i < n; ++i) {

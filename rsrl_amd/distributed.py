@@ -109,7 +109,16 @@ def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=Non
     ctx = context_cls(n_envs=count, env_offset=cfg.pop("env_offset", 0) + offset, **cfg)
     shared = cfg.get("weight_mode", 0) == 1
     if shared and (control.world > 1 or force_exchange):
-        if cfg.get("exchange", 0) == 1:        # one-hop peer-write: all-gather the receive-buffer handles
+        exchange = cfg.get("exchange", 2)
+        if exchange == 2:                      # AUTO: the peer exchange whenever EVERY rank's device reaches every other rank's (decided by all
+            peer = False                       # ranks alike from the all-gathered devices), RCCL -- any topology -- otherwise
+            if context_cls.__name__ == "Context":
+                from .context import can_access_peer
+                devs = control.all_gather_bytes(cfg["device"])
+                mine = all(can_access_peer(cfg["device"], d) for d in devs)
+                peer = all(control.all_gather_bytes(bool(mine)))
+            exchange = 1 if peer else 0
+        if exchange == 1:                      # one-hop peer-write: all-gather the receive-buffer handles
             handles = control.all_gather_bytes(ctx.peer_export(control.world))
             ctx.peer_connect(handles, control.rank)
         else:                                  # RCCL: rank 0 draws the ncclUniqueId, the control plane broadcasts it

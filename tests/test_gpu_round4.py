@@ -379,7 +379,31 @@ def test_bench_two_ranks_on_one_gpu_has_no_error_leg(tmp_path):
     if any("timed out" in e for e in errors(d)):
         pytest.skip("processes are time-sliced exclusively on this GPU: " + repr(list(errors(d))))
     assert not list(errors(d)), list(errors(d))
-    assert d["shared_w_peer"]["replicas_consistent"] and d["shared_w_peer"]["exchange_world_size"] == 2 and d["shared_w_peer"]["ranks"] == 2
-    assert "skipped" in d["shared_w"]
+    assert d["shared_w"]["replicas_consistent"] and d["shared_w"]["exchange_world_size"] == 2 and d["shared_w"]["ranks"] == 2
+    assert d["shared_w"]["exchange_kind"] == "peer" and "skipped" in d["shared_w_rccl"]
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["measured_with_ranks"] == 2
     assert d["roofline"]["frac"] is not None and 0 < d["roofline"]["frac"] <= 1
+
+
+def test_exchange_auto_prefers_the_peer_exchange(ra):
+    # config.exchange defaults to AUTO: group_create takes the one-hop peer exchange whenever every device reaches every other's memory
+    # (trivially so on one device), comm_init makes the ctx an RCCL rank, peer_export a PEER rank -- and all three are the plain run
+    N = 8192
+    kw = dict(C4, n_envs=N, lr=0.001 / N)
+    assert ra.can_access_peer(0, 0)
+    with pytest.raises(ra.RsrlHipError):
+        ra.can_access_peer(0, 99)
+    with ra.Context(**kw) as plain, ra.Context(**kw) as grp, ra.Context(**kw) as rccl, ra.Context(**kw) as peer:
+        assert grp.cfg.exchange == ra.EXCHANGE_AUTO and grp.comm_info() == (1, 0, -1)
+        ra.Context.group_create([grp])
+        assert grp.comm_info() == (1, 0, ra.EXCHANGE_PEER)
+        rccl.comm_init(ra.Context.comm_unique_id(), 1, 0)
+        assert rccl.comm_info() == (1, 0, ra.EXCHANGE_RCCL)
+        peer.peer_connect([peer.peer_export(1)], 0)
+        assert peer.comm_info() == (1, 0, ra.EXCHANGE_PEER)
+        ref = _run(plain, (40, 75))                              # (75: plain steps, then 30-step graph replays at t = 0 mod 3 on the RCCL path)
+        for other in (grp, rccl, peer):
+            got = _run(other, (40, 75))
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+        with pytest.raises(ra.RsrlHipError):
+            rccl.peer_export(1)                                  # decided
