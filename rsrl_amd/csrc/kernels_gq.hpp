@@ -176,4 +176,94 @@ __global__ __launch_bounds__(kBlock) void k_handle_gq(Common c, GqParams gp, con
     if (td_out) td_out[i] = delta;
 }
 
+// ---- GreedyGQ over ANY model (tile coding with per-learner tables, the generic Fourier orders): both approximators in memory.
+// The reference's agent is generic over the approximator (greedy_gq.rs:49-71: `Q` and `W` are type parameters); fa_td lives in the ctx's
+// auxiliary matrix, addressed like fa_q (a Common whose weight pointer is the auxiliary matrix).  Operation by operation the register
+// family's step -- and the oracle's orc_handle_gq, which is basis-generic: fa_q's column a moves by lr*td_error*phi(s) FIRST, then
+// column na by lr*(-gamma*td_est)*phi(s') (non-terminal), fa_td's column a by lr_td*(td_error - td_est)*phi(s).
+template <class M>
+__device__ __forceinline__ float gq_handle_mem(const Common& c, const Common& cv, const GqParams& gp, const BasisGeom& g, int64_t i, const typename M::Feat& fs,
+                                               int a, float r, const typename M::Feat& fn, bool term) {
+    constexpr int A = M::A;
+    float q_s[A], e_s[A], q_n[A];
+    M::q_all(c, i, g, fs, q_s);
+    M::q_all(cv, i, g, fs, e_s);
+    M::q_all(c, i, g, fn, q_n);                               // (a terminal transition does not read it: the select below drops it)
+    const float qsa = select_a<A>(q_s, a), td_est = select_a<A>(e_s, a);
+    float qmax;
+    const int na_star = find_max<A>(q_n, qmax);
+    const float delta = term ? (r - qsa) : (r + c.alg.gamma * qmax - qsa);
+    M::update(c, i, g, fs, a, c.alg.lr * delta);
+    if (!term) M::update(c, i, g, fn, na_star, c.alg.lr * (-c.alg.gamma * td_est));
+    M::update(cv, i, g, fs, a, gp.lr_td * (delta - td_est));
+    return delta;
+}
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_train_gq_mem(Common c, GqParams gp, BasisGeom g, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        Common cv = c; cv.W = gp.V;                            // fa_td: the same layout, the auxiliary matrix
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float s[D]; load_state<M>(c.state, N, i, s);
+        int a = c.action[i];
+        uint32_t ep = c.ep_step[i];
+        typename M::Feat fs, fn;
+        M::features(s, g, fs);
+        float facc_abs = 0.0f, facc_r = 0.0f;
+        for (int k = 0; k < n_steps; ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            const bool term = M::Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            M::features(ns, g, fn);
+            const float delta = gq_handle_mem<M>(c, cv, gp, g, i, fs, a, r, fn, term);
+            if (term || trunc) {
+                n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; ep = 0;
+                M::Dom::reset(ns);
+                M::features(ns, g, fn);
+            }
+            float q_n[A];
+            M::q_all(c, i, g, fn, q_n);                        // behaviour policy: the UPDATED fa_q, at s' or at the restart state
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            a = policy_sample<A>(c.pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+            fs = fn;
+        }
+        sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+        c.action[i] = a;
+        c.ep_step[i] = ep;
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_handle_gq_mem(Common c, GqParams gp, BasisGeom g, const float* __restrict__ from, const int32_t* __restrict__ act,
+                                                          const float* __restrict__ rew, const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                          int64_t Mn, float* __restrict__ td_out) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    Common cv = c; cv.W = gp.V;
+    float s[D], ns[D];
+    load_state<M>(from, Mn, i, s);
+    load_state<M>(to, Mn, i, ns);
+    typename M::Feat fs, fn;
+    M::features(s, g, fs);
+    M::features(ns, g, fn);
+    const float delta = gq_handle_mem<M>(c, cv, gp, g, i, fs, clamp_action<A>(act[i]), rew[i], fn, termf[i] != 0);
+    if (td_out) td_out[i] = delta;
+}
+
 }  // namespace rsrl

@@ -56,6 +56,18 @@ bool launch_qsigma(int domain, int order, dim3 grid, dim3 block, hipStream_t st,
                    int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                    int64_t Mn, float* td_out);
 
+// the same two agents on the models without a register-family kernel (tile coding, generic Fourier orders); false if the configuration
+// has a register-family kernel (use the launchers above) or none at all
+}  // namespace rsrl
+#include "../../include/rsrl_hip.h"
+namespace rsrl {
+bool launch_gq_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const GqParams& gp, const BasisGeom& g, uint64_t t,
+                     int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                     int64_t Mn, float* td_out);
+bool launch_qsigma_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const QsParams& qp, const BasisGeom& g, uint64_t t,
+                         int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
+                         int64_t Mn, float* td_out);
+
 #define RSRL_TRAIN_CASE(DM, OR, AL, PO)                                                                     \
     if (order == OR && algo == AL && policy == PO) {                                                        \
         if (chunk == -3) {                                                                                  \

@@ -19,6 +19,7 @@
 #include "../../include/rsrl_hip.h"
 #include "launch.hpp"
 #include "models.hpp"
+#include "model_list.hpp"
 #include "kernels_wave.hpp"
 #include "kernels_lambda.hpp"
 #include "kernels_gq.hpp"
@@ -457,27 +458,7 @@ static inline float tile_lsb(float lr) {
 }
 constexpr int kSharedBlock = 512;    // learners per block of k_shared_step: 256 blocks = one per CU for a 131 072-env shard
 
-// ---- (basis, domain, parameter) -> Model type ---------------------------------------------------
-// Fourier register family: F = (order+1)^D <= 36 features per learner held in VGPRs.
-// Tile coding: T tilings as a template parameter (indices in VGPRs), tiles_per_dim at run time.
-#define RSRL_MODELS(X)                                                                       \
-    X((FourierModel<0, 1>), RSRL_FOURIER, 0, 1) X((FourierModel<0, 2>), RSRL_FOURIER, 0, 2)  \
-    X((FourierModel<0, 3>), RSRL_FOURIER, 0, 3) X((FourierModel<0, 4>), RSRL_FOURIER, 0, 4)  \
-    X((FourierModel<0, 5>), RSRL_FOURIER, 0, 5)                                              \
-    X((FourierModel<1, 1>), RSRL_FOURIER, 1, 1) X((FourierModel<2, 1>), RSRL_FOURIER, 2, 1)  \
-    X((TileModel<0, 4>), RSRL_TILE_CODING, 0, 4) X((TileModel<0, 8>), RSRL_TILE_CODING, 0, 8) X((TileModel<0, 16>), RSRL_TILE_CODING, 0, 16) \
-    X((TileModel<1, 4>), RSRL_TILE_CODING, 1, 4) X((TileModel<1, 8>), RSRL_TILE_CODING, 1, 8) X((TileModel<1, 16>), RSRL_TILE_CODING, 1, 16) \
-    X((TileModel<2, 4>), RSRL_TILE_CODING, 2, 4) X((TileModel<2, 8>), RSRL_TILE_CODING, 2, 8) X((TileModel<2, 16>), RSRL_TILE_CODING, 2, 16) \
-    X((FourierGenericModel<0>), RSRL_FOURIER, 0, -1) X((FourierGenericModel<1>), RSRL_FOURIER, 1, -1) X((FourierGenericModel<2>), RSRL_FOURIER, 2, -1)
-
-template <class T> struct Tag { using type = T; };
-#define RSRL_UNPAREN(...) __VA_ARGS__
-// param -1: the generic-order Fourier model (any order 1..7 without a specialised kernel; listed last)
-static bool model_match(const rsrl_hip_config& cfg, int basis, int domain, int param) {
-    if (cfg.basis != basis || cfg.domain != domain) return false;
-    if (param == -1) return cfg.order >= 1 && cfg.order <= 7;
-    return (basis == RSRL_FOURIER ? cfg.order : cfg.n_tilings) == param;
-}
+// ---- (basis, domain, parameter) -> Model type: model_list.hpp
 static bool is_generic_fourier(const rsrl_hip_config& cfg) {
     if (cfg.basis != RSRL_FOURIER) return false;
 #define X(TYPE, BS, DM, P) if (P != -1 && model_match(cfg, BS, DM, P)) return false;
@@ -698,8 +679,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "global env ids must fit 32 bits");
     if (cfg->algo < 0 || cfg->algo > RSRL_Q_SIGMA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->algo == RSRL_Q_SIGMA) {
-        if (cfg->basis != RSRL_FOURIER || cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32 || (cfg->order == kWaveOrder && cfg->domain != RSRL_MOUNTAIN_CAR))
-            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights on a register-family Fourier basis (MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        // any basis but the order-7 wave family: register-family Fourier, the generic Fourier orders, tile coding (per-learner tables)
+        if (cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32 || (cfg->basis == RSRL_FOURIER && cfg->order == kWaveOrder && cfg->domain != RSRL_MOUNTAIN_CAR))
+            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights (any Fourier order but 7 on CartPole / Acrobot, or tile coding)");
         if (!(cfg->sigma >= 0.0 && cfg->sigma <= 1.0)) return fail(RSRL_HIP_EINVAL, "sigma must be in [0, 1]");
         if (cfg->n_steps < 1 || cfg->n_steps > 32) return fail(RSRL_HIP_EINVAL, "n_steps must be in [1, 32]");
     }
@@ -748,9 +730,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         }
     }
     if (cfg->algo == RSRL_GREEDY_GQ) {
-        if (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
-            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
+            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights (any Fourier order but 7 on CartPole / Acrobot, or tile coding)");
         if (!(cfg->lr_td >= 0.0)) return fail(RSRL_HIP_EINVAL, "lr_td must be >= 0");
     }
     if (is_lambda(cfg->algo)) {
@@ -814,8 +795,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
     if (cfg->algo == RSRL_Q_SIGMA) {
-        if (is_wave(*cfg) || is_generic_fourier(*cfg))
-            return fail(RSRL_HIP_EINVAL, "QSigma needs a register-family Fourier basis (MountainCar orders 1-5, CartPole/Acrobot order 1)");
+        if (is_wave(*cfg)) return fail(RSRL_HIP_EINVAL, "QSigma is not available on the order-7 wave family");
         const size_t nf = (size_t)(c->D + 5) * (size_t)cfg->n_steps * (size_t)N;
         HIP_TRY(hipMalloc((void**)&c->qs_buf, sizeof(float) * nf));
         HIP_TRY(hipMalloc((void**)&c->qs_head, sizeof(uint32_t) * (size_t)N));
@@ -1173,11 +1153,17 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
                               d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
     } else if (c->cfg.algo == RSRL_Q_SIGMA) {
-        if (!launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, 0, nullptr,
-                           d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+        const bool reg = c->cfg.basis == RSRL_FOURIER && !is_generic_fourier(c->cfg);
+        if (!(reg ? launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, 0, nullptr,
+                                  d_from, d_act, d_rew, d_to, d_term, M, otd.dev)
+                  : launch_qsigma_model(c->cfg, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, 0, nullptr,
+                                        d_from, d_act, d_rew, d_to, d_term, M, otd.dev))) return NO_MODEL(c);
     } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
-        if (!launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
-                              d_from, d_act, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+        const bool reg = c->cfg.basis == RSRL_FOURIER && !is_generic_fourier(c->cfg);
+        if (!(reg ? launch_handle_gq(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c),
+                                     d_from, d_act, d_rew, d_to, d_term, M, otd.dev)
+                  : launch_gq_model(c->cfg, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_gq(c), g, c->t, 0, nullptr,
+                                    d_from, d_act, d_rew, d_to, d_term, M, otd.dev))) return NO_MODEL(c);
     } else if (is_lambda(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, M, c->stream, k, g, make_lambda(c), c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
                                 M, otd.dev)) return NO_MODEL(c);
@@ -1974,14 +1960,20 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             c->kernel_name = "k_train_td";
             KCHECK();
         } else if (c->cfg.algo == RSRL_Q_SIGMA) {
-            if (!launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, chunk, d_stats,
-                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr)) return NO_MODEL(c);
+            const bool reg = fourier && !is_generic_fourier(c->cfg);
+            if (!(reg ? launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, chunk, d_stats,
+                                      nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr)
+                      : launch_qsigma_model(c->cfg, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, chunk, d_stats,
+                                            nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr))) return NO_MODEL(c);
             c->kernel_name = "k_train_qsigma";
             KCHECK();
         } else if (c->cfg.algo == RSRL_GREEDY_GQ) {
-            if (!launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
-                                 make_gq(c), c->t, chunk, d_stats)) return NO_MODEL(c);
-            c->kernel_name = "k_train_gq";
+            const bool reg = fourier && !is_generic_fourier(c->cfg);
+            if (!(reg ? launch_train_gq(c->cfg.domain, c->cfg.order, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
+                                        make_gq(c), c->t, chunk, d_stats)
+                      : launch_gq_model(c->cfg, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_gq(c), g, c->t, chunk, d_stats,
+                                        nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr))) return NO_MODEL(c);
+            c->kernel_name = reg ? "k_train_gq" : "k_train_gq_mem";
             KCHECK();
         } else if (is_lambda(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
             if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, k.n_envs, c->stream, k, g, make_lambda(c), c->t, chunk, d_stats, nullptr, nullptr,

@@ -407,3 +407,63 @@ def test_exchange_auto_prefers_the_peer_exchange(ra):
             assert all(np.array_equal(a, b) for a, b in zip(ref, got))
         with pytest.raises(ra.RsrlHipError):
             rccl.peer_export(1)                                  # decided
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GreedyGQ and QSigma off the register family: tile coding (per-learner tables) and the generic Fourier orders.  The reference's agents
+# are generic over the approximator (greedy_gq.rs:49-71, q_sigma.rs:80-105).
+# ---------------------------------------------------------------------------------------------------------------------------
+WIDE = [
+    ("greedy_gq, CartPole tiles 8 x 8^4", dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=6, policy=1, gamma=0.99, lr=0.0125, lr_td=0.001, epsilon=0.1)),
+    ("greedy_gq, MountainCar tiles 4 x 6^2", dict(domain=0, basis=1, n_tilings=4, tiles_per_dim=6, algo=6, policy=1, gamma=0.99, lr=0.025, lr_td=0.002, epsilon=0.1)),
+    ("greedy_gq, MountainCar Fourier(6)", dict(domain=0, order=6, algo=6, policy=1, gamma=0.99, lr=0.05, lr_td=0.001, epsilon=0.1)),
+    ("greedy_gq, CartPole Fourier(2)", dict(domain=1, order=2, algo=6, policy=2, tau=0.5, gamma=0.99, lr=0.02, lr_td=0.001)),
+    ("q_sigma n=3, CartPole tiles 8 x 8^4", dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=9, policy=1, gamma=0.95, lr=0.0125, alpha=0.5, sigma=0.5, n_steps=3, epsilon=0.2)),
+    ("q_sigma n=1 sigma=1, Acrobot tiles 4 x 4^4", dict(domain=2, basis=1, n_tilings=4, tiles_per_dim=4, algo=9, policy=1, gamma=0.95, lr=0.025, alpha=1.0, sigma=1.0, n_steps=1, epsilon=0.2)),
+    ("q_sigma n=4 tree backup, MountainCar Fourier(7)", dict(domain=0, order=7, algo=9, policy=1, gamma=0.9, lr=0.01, alpha=0.5, sigma=0.0, n_steps=4, epsilon=0.2)),
+    ("q_sigma n=2, Acrobot Fourier(2)", dict(domain=2, order=2, algo=9, policy=3, gamma=0.9, lr=0.01, alpha=0.5, sigma=0.5, n_steps=2)),
+]
+
+
+@pytest.mark.parametrize("name,kw", WIDE, ids=[c[0] for c in WIDE])
+def test_gq_and_qsigma_off_the_register_family_bitwise(ra, orc, name, kw, tmp_path):
+    N, K = 40, 260
+    ag = orc.make_agent(seed=13, max_episode_steps=30, **kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    ost = run.train(K)
+    with ra.Context(n_envs=N, seed=13, max_episode_steps=30, **kw) as c:
+        c.reset()
+        st = [c.train(k) for k in (90, 1, K - 91)]
+        assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
+        for i in (0, 1, 19, N - 1):
+            assert np.array_equal(c.get_weights(i), run.weights[i]), i
+            if kw["algo"] == 6:
+                assert np.array_equal(c.get_td_weights(i), run.traces[i]), i
+        assert sum(s["episodes"] for s in st) == ost["episodes"] > 0
+        assert np.abs(run.weights).max() > 0 and np.all(np.isfinite(run.weights))
+        # Handler::handle on caller-supplied transitions goes through the same code (teacher forcing): once more, bit for bit
+        s, a = c.states, c.actions
+        frm, nxt, rew, term = c.domain_step(a)
+        term[::4] = 1
+        Wb = [c.get_weights(i) for i in range(N)]
+        Vb = [c.get_td_weights(i) for i in range(N)] if kw["algo"] == 6 else None
+        td = c.handle(frm, a, rew, nxt, term)
+        if kw["algo"] == 6:
+            for i in (0, 7, N - 1):
+                W, V = Wb[i].copy(), Vb[i].copy()
+                d = orc.handle_gq(ag, W, V, frm[:, i], a[i], rew[i], nxt[:, i], term[i], "f32d")
+                assert np.float32(d) == td[i] and np.array_equal(c.get_weights(i), W) and np.array_equal(c.get_td_weights(i), V), i
+        # checkpoint: the second approximator / the n-step backups travel, a resumed run is the uninterrupted one
+        path = str(tmp_path / "wide.ckpt")
+        c.save_weights(path)
+        c.reset(); c.train(40)
+        ref = (c.states, [c.get_weights(i) for i in (0, N - 1)])
+        with ra.Context(n_envs=N, seed=13, max_episode_steps=30, **kw) as d2:
+            d2.load_weights(path)
+            d2.reset(); d2.train(40)
+            assert np.array_equal(d2.states, ref[0]) and all(np.array_equal(d2.get_weights(i), w) for i, w in zip((0, N - 1), ref[1]))
+    for bad in (dict(algo=6, lr_td=0.01, domain=2, order=7), dict(algo=9, domain=1, order=7), dict(algo=6, lr_td=0.01, basis=1, weight_mode=1),
+                dict(algo=9, basis=1, weight_mode=1)):
+        with pytest.raises(ra.RsrlHipError):
+            ra.Context(n_envs=8, policy=1, **bad)
