@@ -80,9 +80,13 @@ def test_gq_fused_equals_stepwise_and_resume(ra, tmp_path):
             c1.get_traces(0)                       # GreedyGQ has no eligibility trace
 
 
-def test_gq_needs_register_family(ra):
-    with pytest.raises(ra.RsrlHipError):
-        ra.Context(n_envs=8, algo=6, basis=ra.TILE_CODING)
+def test_gq_configurations(ra):
+    with ra.Context(n_envs=8, algo=6, basis=ra.TILE_CODING):                # tile coding: built in round 4 (tests/test_gpu_round4.py)
+        pass
+    with pytest.raises(ra.RsrlHipError):                                    # ... with per-learner tables only
+        ra.Context(n_envs=8, algo=6, basis=ra.TILE_CODING, weight_mode=ra.W_SHARED)
+    with pytest.raises(ra.RsrlHipError):                                    # not on the order-7 wave family
+        ra.Context(n_envs=8, algo=6, domain=2, order=7)
     with ra.Context(n_envs=8, algo=0) as c:
         with pytest.raises(ra.RsrlHipError):
             c.get_td_weights(0)

@@ -78,7 +78,8 @@ def test_qsigma_free_running_bitwise(ra, orc, domain, order, n_steps, sigma, pol
 
 
 def test_qsigma_rejects_what_it_cannot_run(ra):
-    for bad in (dict(weight_mode=ra.W_SHARED), dict(basis=ra.TILE_CODING), dict(sigma=1.5), dict(n_steps=0), dict(n_steps=33),
+    # (tile coding and the generic Fourier orders: built in round 4, tests/test_gpu_round4.py)
+    for bad in (dict(weight_mode=ra.W_SHARED), dict(basis=ra.TILE_CODING, weight_mode=ra.W_SHARED), dict(sigma=1.5), dict(n_steps=0), dict(n_steps=33),
                 dict(domain=2, order=7)):
         with pytest.raises(ra.RsrlHipError):
             ra.Context(n_envs=8, algo=ra.Q_SIGMA, **bad)
