@@ -128,6 +128,7 @@ struct TileModel {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, A = Dom::A;
     static constexpr bool kDense = false, kSparse = true;
+    static constexpr int kT = T;
     struct Feat { int idx[T]; };
     __host__ __device__ static constexpr int F_or_1() { return 1; }
     __device__ static __forceinline__ void q_all_lds(const float*, const Feat&, float (&)[A]) {}
@@ -200,11 +201,8 @@ struct TileModel {
     // offset per lane -- one shift and one A-dword buffer load per tiling, no 64-bit address arithmetic (the per-learner form above
     // spends ~6 VALU instructions per gather on it).  Same loads, same order of additions: the same bits.
     // Precondition (host): the table is smaller than 2 GiB.
-    __device__ static __forceinline__ void q_all_shared(const float* __restrict__ W, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
+    __device__ static __forceinline__ void gather_shared(const float* __restrict__ W, const BasisGeom& g, const Feat& ft, float (&w)[T][A]) {
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, g.F * A * 4, 0x00020000);
-#pragma unroll
-        for (int b = 0; b < A; ++b) q[b] = 0.0f;
-        float w[T][A];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int off = ft.idx[t] * (A * 4);
@@ -223,10 +221,19 @@ struct TileModel {
                 for (int b = 0; b < A; ++b) w[t][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * b, 0, 0));
             }
         }
+    }
+    __device__ static __forceinline__ void sum_gathered(const float (&w)[T][A], float (&q)[A]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int b = 0; b < A; ++b) q[b] = q[b] + w[t][b];          // acc + w, tilings in order
+    }
+    __device__ static __forceinline__ void q_all_shared(const float* __restrict__ W, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
+        float w[T][A];
+        gather_shared(W, g, ft, w);
+        sum_gathered(w, q);
     }
     __device__ static __forceinline__ void update(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, int a, float scale) {
 #pragma unroll
@@ -633,6 +640,17 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
+// k_shared_ca evaluates the transition of BOTH actions speculatively (see the kernel) for: tile coding, two actions
+template <class M> struct SpecTraits { static constexpr bool value = false; };
+template <int DOMAIN, int T> struct SpecTraits<TileModel<DOMAIN, T>> { static constexpr bool value = Domain<DOMAIN>::A == 2; };
+// MEASURED AND SWITCHED OFF (round 4, 262 144 CartPole learners): one memory round trip less, but 1 174 instead of ~810 instructions per
+// learner-step -- 23.0 -> 26.2 us per batch-step.  The step kernel is issue-bound at its four waves per SIMD, not latency-bound: the
+// speculation costs more than the round trip it hides.  Kept as an A/B build option (-DRSRL_TILE_SPECULATE=1; bitwise either way).
+#ifndef RSRL_TILE_SPECULATE
+#define RSRL_TILE_SPECULATE 0
+#endif
+template <class M> constexpr bool kSpeculate = (RSRL_TILE_SPECULATE != 0) && SpecTraits<M>::value;
+
 // shared weights, phases C(t-1) + A(t) in ONE launch.  Both read the same weights W_t: phase C finishes the previous
 // batch-step (policy.sample with the just-updated weights; finished episodes restart from Domain::default()), phase A
 // runs the transition and takes the TD error of this step against W_t and adds the learner's term lr*e*phi(s) to the
@@ -678,6 +696,47 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         if (done) { M::Dom::reset(s); ep = 0; }
         else load_state<M>(c.state, N, i, s);
         M::features(s, g, fs);
+        float r = 0.0f; bool term = false;
+        typename M::Feat fn;
+        float q_n[A];
+        bool spec_done = false;
+        if constexpr (kSpeculate<M>) {
+            // TWO actions (CartPole) and a table in memory: the action of phase C hangs on a gather (Q(s,.) from the shared table), the
+            // transition on the action, Q(s',.) on a SECOND gather -- two dependent memory round trips with the whole RK4 step between
+            // them.  Here the transition and the tile indices are computed for BOTH actions while the first gather is in flight, and
+            // both candidates' gathers go out before the action is known: one round trip instead of two, the extra RK4 step runs in
+            // its shadow.  The taken candidate is exactly what the sequential code computes: the same bits.
+            if (do_c) {
+                float w_s[M::kT][A], w_n[A][M::kT][A];
+                M::gather_shared(c.W, g, fs, w_s);
+                float ns_b[A][D], r_b[A]; bool term_b[A]; typename M::Feat fn_b[A];
+#pragma unroll
+                for (int b = 0; b < A; ++b) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) ns_b[b][d] = s[d];
+                    term_b[b] = M::Dom::step(ns_b[b], b, r_b[b]);
+                    M::features(ns_b[b], g, fn_b[b]);
+                    M::gather_shared(c.W, g, fn_b[b], w_n[b]);
+                }
+                M::sum_gathered(w_s, q_s);
+                const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
+                a = policy_sample<A>(c.pol, q_s, x);                    // ---- phase C of batch-step t-1
+                const bool one = a != 0;                                // ---- phase A of batch-step t: the taken candidate
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = one ? ns_b[1][d] : ns_b[0][d];
+                r = one ? r_b[1] : r_b[0]; term = one ? term_b[1] : term_b[0];
+#pragma unroll
+                for (int tt = 0; tt < M::kT; ++tt) fn.idx[tt] = one ? fn_b[1].idx[tt] : fn_b[0].idx[tt];
+                float w_sel[M::kT][A];
+#pragma unroll
+                for (int tt = 0; tt < M::kT; ++tt)
+#pragma unroll
+                    for (int b = 0; b < A; ++b) w_sel[tt][b] = one ? w_n[1][tt][b] : w_n[0][tt][b];
+                M::sum_gathered(w_sel, q_n);
+                spec_done = true;
+            }
+        }
+        if (!spec_done) {
         if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s);
         else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fs, q_s);
         else M::q_all(c, 0, g, fs, q_s);
@@ -690,16 +749,14 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         // ---- phase A of batch-step t
 #pragma unroll
         for (int d = 0; d < D; ++d) ns[d] = s[d];
-        float r;
-        const bool term = M::Dom::step(ns, a, r);
-        ep += 1;
-        const bool trunc = !term && cap > 0 && ep >= cap;
-        typename M::Feat fn;
+        term = M::Dom::step(ns, a, r);
         M::features(ns, g, fn);
-        float q_n[A];
         if constexpr (M::kDense) M::q_all_lds(sh_w, fn, q_n);
         else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fn, q_n);
         else M::q_all(c, 0, g, fn, q_n);
+        }
+        ep += 1;
+        const bool trunc = !term && cap > 0 && ep >= cap;
         U4 xin = U4{0, 0, 0, 0};
         if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
         float e;
