@@ -806,6 +806,106 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
+// ---- Shared tile coding, the step kernel SPLIT in two (round 4; used inside the captured step graph).  k_shared_ca is issue-bound
+// (~810 VALU instructions per learner-step at four waves per SIMD), the scatter and apply launches that follow it are latency-bound
+// (one LDS sweep, a few device atomics, a 2 MB table pass) -- and all three are strictly dependent through the weights.  But most of the
+// step kernel's instructions do not need the weights: the transition (RK4) and the tile indices of the successor depend on the action
+// only, and an action is one of A values.  So:
+//   k_tile_pre (t+1)   for every learner: the restart of a finished episode, the tile indices of s, and -- for EVERY action -- the
+//                      transition, its reward / terminal flag and the successor's tile indices.  Needs the state POST(t) left, no weights:
+//                      it runs on a second stream UNDER scatter(t) + apply(t).
+//   k_tile_post (t+1)  gathers Q(s,.), samples the action (phase C of step t), picks that action's candidate, gathers Q(s',.), takes the TD
+//                      error, hands keys and term to the scatter.  ~250 instructions: the critical path per batch-step becomes
+//                      post + scatter + apply.
+// Candidate b is exactly what k_shared_ca computes when the action is b: same functions, same order -- bit-identical (C3 bitwise tests).
+// STATUS: measured and OFF by default (RSRL_TILE_SPLIT=1 enables it) -- the fork / join per batch-step costs more in the graph runtime
+// than the overlap gains (34.4 us on the GPU's clock, 195 us wall, vs 22.0 us for the linear graph); see rsrl_hip.hip create_impl.
+// 16-bit keys: a tiling has at most 65 536 / A cells on this path (what the scatter kernel's keys need anyway).
+struct TilePre {
+    uint16_t* keys_s;   // [T][N]       slice-relative cell of s per tiling
+    uint16_t* keys_n;   // [A][T][N]    ... of the successor under action b
+    float* ns;          // [A][D][N]    successor under action b (before any restart)
+    float* r;           // [A][N]
+    uint8_t* term;      // [A][N]
+};
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_tile_pre(Common c, BasisGeom g, const uint8_t* __restrict__ flags, TilePre p) {
+    constexpr int D = M::D, A = M::A, T = M::kT;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float s[D];
+    if (flags[i] != 0) M::Dom::reset(s);                          // the episode ended at the previous batch-step: it restarts (as k_shared_ca's phase C does)
+    else load_state<M>(c.state, N, i, s);
+    const int cells = g.F / T;
+    typename M::Feat fs;
+    M::features(s, g, fs);
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) p.keys_s[(int64_t)tt * N + i] = (uint16_t)(fs.idx[tt] - tt * cells);
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+        float ns[D], r;
+#pragma unroll
+        for (int d = 0; d < D; ++d) ns[d] = s[d];
+        const bool term = M::Dom::step(ns, b, r);
+        typename M::Feat fn;
+        M::features(ns, g, fn);
+#pragma unroll
+        for (int d = 0; d < D; ++d) p.ns[((int64_t)b * D + d) * N + i] = ns[d];
+        p.r[(int64_t)b * N + i] = r;
+        p.term[(int64_t)b * N + i] = term ? 1 : 0;
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) p.keys_n[((int64_t)b * T + tt) * N + i] = (uint16_t)(fn.idx[tt] - tt * cells);
+    }
+}
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_tile_post(Common c, BasisGeom g, uint64_t t, uint8_t* __restrict__ flags, TilePre p, uint16_t* __restrict__ keys,
+                                                      float* __restrict__ terms, const uint64_t* __restrict__ t_dev) {
+    if (t_dev) t += *t_dev;
+    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
+    constexpr int D = M::D, A = M::A, T = M::kT;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t gid = (uint32_t)(c.env_offset + i);
+    const uint32_t cap = c.max_episode_steps;
+    const int cells = g.F / T;
+    uint32_t ep = flags[i] != 0 ? 0u : c.ep_step[i];
+    int rel_s[T];
+    typename M::Feat fs;
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) { rel_s[tt] = (int)p.keys_s[(int64_t)tt * N + i]; fs.idx[tt] = tt * cells + rel_s[tt]; }
+    float q_s[A];
+    M::q_all_shared(c.W, g, fs, q_s);
+    const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
+    const int a = policy_sample<A>(c.pol, q_s, x);                // ---- phase C of batch-step t-1
+    // ---- phase A of batch-step t: the candidate of the action taken
+    float ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ns[d] = p.ns[((int64_t)a * D + d) * N + i];
+    const float r = p.r[(int64_t)a * N + i];
+    const bool term = p.term[(int64_t)a * N + i] != 0;
+    typename M::Feat fn;
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) fn.idx[tt] = tt * cells + (int)p.keys_n[((int64_t)a * T + tt) * N + i];
+    float q_n[A];
+    M::q_all_shared(c.W, g, fn, q_n);
+    ep += 1;
+    const bool trunc = !term && cap > 0 && ep >= cap;
+    U4 xin = U4{0, 0, 0, 0};
+    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+    float e;
+    (void)td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+#pragma unroll
+    for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
+    c.action[i] = a;
+    c.ep_step[i] = ep;
+    flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) keys[(int64_t)tt * N + i] = (uint16_t)(rel_s[tt] * A + a);
+    terms[i] = c.alg.lr * e;
+}
+
 // ---------------------------------------------------------------------------------------
 // Shared weights, dense basis: ONE launch per batch-step (k_shared_step).
 // A dependent kernel costs ~4 us on this machine whatever it does, so the delta reduction no longer has a kernel of its

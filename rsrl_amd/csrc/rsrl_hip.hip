@@ -324,6 +324,12 @@ struct rsrl_hip_ctx {
     long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
     bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
     unsigned long long* tile_arrive = nullptr;     // shared tile coding: one arrival counter per tiling (apply folded into the scatter kernel)
+    // shared tile coding, the step kernel split in two inside the step graph (models.hpp k_tile_pre / k_tile_post)
+    TilePre pre{};                   // what k_tile_pre hands to k_tile_post
+    hipStream_t stream2 = nullptr;   // k_tile_pre runs here, under the scatter + apply of the previous batch-step
+    std::vector<hipEvent_t> split_events;
+    bool split_now = false, split_fork = false;    // set by ensure_step_graph around the capture
+    int split_j = 0;
     uint16_t* sc_keys = nullptr;     // shared tile coding, separate scatter kernel: slice-relative entries [T][N]
     float* sc_terms = nullptr;       //   and terms lr*e [N] handed from the step kernel to k_tile_scatter
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
@@ -637,6 +643,9 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->h_fx) (void)hipFree(c->h_fx);
     if (c->sc_keys) (void)hipFree(c->sc_keys);
+    for (void* q : {(void*)c->pre.keys_s, (void*)c->pre.keys_n, (void*)c->pre.ns, (void*)c->pre.r, (void*)c->pre.term}) if (q) (void)hipFree(q);
+    for (hipEvent_t e : c->split_events) (void)hipEventDestroy(e);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->tile_arrive) (void)hipFree(c->tile_arrive);
     if (c->sc_terms) (void)hipFree(c->sc_terms);
     if (c->W2) (void)hipFree(c->W2);
@@ -842,6 +851,20 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         if (c->tile_slice && !fused_scatter) {                           // the scatter as a kernel of its own (A/B knob: the fused one)
             HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
             HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(float) * (size_t)N));
+            // The split step (k_tile_pre / k_tile_post, models.hpp) inside the step graph: MEASURED AND OFF (round 4, 262 144 CartPole learners).
+            // Bit-identical (C3 bitwise tests with RSRL_TILE_SPLIT=1), but a hipGraph with a fork / join per batch-step runs its branches on
+            // separate queues: 34.4 us per batch-step on the GPU's own clock and 195 us wall (the host side of a 32-step, two-stream graph
+            // launch), against 22.0 for the linear three-launch graph.  hipExtAnyOrderLaunch (overlap inside ONE queue) is not supported on
+            // gfx9.  RSRL_TILE_SPLIT=1 keeps it reachable for A/B runs on a later runtime.
+            if (c->own_stream && getenv("RSRL_TILE_SPLIT")) {
+                const size_t Tn = (size_t)cfg->n_tilings, An = (size_t)c->A, Dn = (size_t)c->D;
+                HIP_TRY(hipMalloc((void**)&c->pre.keys_s, sizeof(uint16_t) * Tn * (size_t)N));
+                HIP_TRY(hipMalloc((void**)&c->pre.keys_n, sizeof(uint16_t) * An * Tn * (size_t)N));
+                HIP_TRY(hipMalloc((void**)&c->pre.ns, sizeof(float) * An * Dn * (size_t)N));
+                HIP_TRY(hipMalloc((void**)&c->pre.r, sizeof(float) * An * (size_t)N));
+                HIP_TRY(hipMalloc((void**)&c->pre.term, An * (size_t)N));
+                HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            }
             HIP_TRY(hipMalloc((void**)&c->tile_arrive, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings));
             HIP_TRY(hipMemsetAsync(c->tile_arrive, 0, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings, c->stream));
         }
@@ -1587,6 +1610,17 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             if constexpr (M::kSparse) {
                 if (c->sc_keys) {
                     // step kernel (terms + entries per learner) -> scatter kernel: block (chunk, tiling), 8 192 learners per chunk
+                    if (c->split_now) {
+                        // inside the step graph: k_tile_pre of this batch-step has run (under the previous step's scatter + apply)
+                        hipLaunchKernelGGL((k_tile_post<M>), grid, block, 0, c->stream, k, g, t, c->flags, c->pre, c->sc_keys, c->sc_terms, t_dev);
+                        if (c->split_fork) {                             // ... and the next one's starts now, on the second stream
+                            hipEvent_t e_post = c->split_events[(size_t)(2 * c->split_j)], e_pre = c->split_events[(size_t)(2 * c->split_j + 1)];
+                            (void)hipEventRecord(e_post, c->stream);
+                            (void)hipStreamWaitEvent(c->stream2, e_post, 0);
+                            hipLaunchKernelGGL((k_tile_pre<M>), grid, block, 0, c->stream2, k, g, c->flags, c->pre);
+                            (void)hipEventRecord(e_pre, c->stream2);
+                        }
+                    } else
                     hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, 0, nrep,
                                        (int64_t)c->dw_elems, t_dev, c->sc_keys, c->sc_terms);
                     static const int chunks_env = getenv("RSRL_SCATTER_CHUNKS") ? atoi(getenv("RSRL_SCATTER_CHUNKS")) : 32;
@@ -1634,6 +1668,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             KCHECK();
         }
     }
+    if (c->split_now && c->split_fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->split_events[(size_t)(2 * c->split_j + 1)], 0));   // join: the next k_tile_post needs it
     return RSRL_HIP_OK;
 }
 static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
@@ -1686,8 +1721,25 @@ static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = RSRL_HIP_OK;
     const int spg = steps_per_graph(c);
-    for (int j = 0; j < spg && rc == RSRL_HIP_OK; ++j)
+    const bool split = kind == 2 && c->pre.keys_s != nullptr;          // shared tile coding: the step kernel split in two (models.hpp k_tile_pre / _post)
+    if (split) {
+        while (c->split_events.size() < (size_t)(2 * spg)) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(RSRL_HIP_EHIP, "hipEventCreate failed"); break; }
+            c->split_events.push_back(e);
+        }
+        // the first batch-step's k_tile_pre opens the graph on the main stream; every later one forks under the step before it
+        if (rc == RSRL_HIP_OK && !for_model(c, [&](auto tag) {
+                using M = typename decltype(tag)::type;
+                if constexpr (M::kSparse) hipLaunchKernelGGL((k_tile_pre<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, c->flags, c->pre);
+            })) rc = NO_MODEL(c);
+        c->split_now = true;
+    }
+    for (int j = 0; j < spg && rc == RSRL_HIP_OK; ++j) {
+        c->split_fork = split && j + 1 < spg; c->split_j = j;
         rc = kind == 1 ? enqueue_k1_step(c, k, nullptr, (uint64_t)j, c->d_t) : enqueue_shared_step(c, k, g, nullptr, 1, (uint64_t)j, c->d_t);
+    }
+    c->split_now = false; c->split_fork = false;
     if (rc == RSRL_HIP_OK) hipLaunchKernelGGL(k_advance_t, dim3(1), dim3(1), 0, c->stream, c->d_t, (uint64_t)spg);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
