@@ -213,43 +213,66 @@ def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
 
 def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=131072, steps=320, warmup=64):
     """Secondary measurement (BASELINE.json configs[3]): 131 072 MountainCar envs per GPU, ONE shared Fourier(5)
-    approximator, per-batch-step exchange of the 432 B weight delta (RCCL all-reduce, or the one-hop peer-write).  The
-    exchange is attached for a single rank too (communicator of size 1: same sequence).  Never part of `value`."""
+    approximator, per-batch-step exchange of the weight delta (exchange AUTO: the one-hop peer exchange whenever every device
+    reaches every other's memory; RCCL: the any-topology fallback).  The exchange is attached for a single rank too (a group of
+    size 1 runs the same sequence).  Never part of `value`.  The ranks FAIL TOGETHER: after every phase they tell each other
+    whether it worked, so a rank that hit an error never leaves the others waiting in a collective."""
+    import numpy as np
+
+    def together(err, what):
+        oks = cp.all_gather_bytes(err is None)
+        if all(oks):
+            return None
+        return {"error": (repr(err) if err is not None else f"rank(s) {[r for r, ok in enumerate(oks) if not ok]} failed while {what}"), "failed_while": what}
     try:
         ctx = make_sharded_context(envs_per_gpu * cp.world, cp, force_exchange=True, domain=rsrl_amd.MOUNTAIN_CAR, order=5,
                                    algo=rsrl_amd.QLEARNING, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.9,
                                    lr=0.001 / (envs_per_gpu * cp.world), weight_mode=rsrl_amd.W_SHARED, seed=0,
                                    max_episode_steps=1000, exchange=exchange)
+    except Exception as e:                       # (make_sharded_context fails on every rank together)
+        return {"error": repr(e), "failed_while": "setting the exchange up"}
+    err = None
+    try:
         comm_world, comm_rank, comm_kind = ctx.comm_info()      # what the attached exchange itself reports (ncclCommCount for RCCL)
         ctx.reset()
         ctx.train(warmup, want_stats=False)
         ctx.sync()
-        cp.barrier()
+    except Exception as e:      # noqa: BLE001
+        err = e
+    bad = together(err, "warming up")
+    if bad:
+        ctx.close()
+        return bad
+    cp.barrier()
+    dt_own, ms, n_l, kn, w = 0.0, 0.0, 1, "", None
+    try:
         ctx.timing_enable(True)
         t0 = time.perf_counter()
         ctx.train(steps, want_stats=False)
         ctx.sync()
         dt_own = time.perf_counter() - t0
-        dt = cp.max_over_ranks(dt_own)
         ms, n_l, kn = ctx.timing_read()
         w = ctx.get_weights()
-        import numpy as np
-        chk = float(np.abs(w).sum())
-        lo, hi = -cp.max_over_ranks(-chk), cp.max_over_ranks(chk)
-        ctx.close()
-        return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step "
-                            f"{ {0: 'RCCL all-reduce of the fixed-point delta table', 1: 'one-hop peer-write exchange of the delta'}.get(comm_kind, 'exchange') }", "ranks": cp.world, "steps": steps,
-                "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
-                "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
-                "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
-                "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
-                "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu,
-                                         ms * 1e-3 if kn == "k_shared_persist" else ms * 1e-3 / max(1, n_l), 1 if kn == "k_shared_persist" else n_l, 32,
-                                         "SURVEY 8(d): C4 is VALU / latency bound (W stays on the chip: 32 B/env-step of state stream); the batch-step = two fabric hops "
-                                         "of the delta all-reduce (~3.2 us, profiles/r03_ubench_granule_allreduce.txt) + the learners' arithmetic at two waves per SIMD"),
-                "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
-    except Exception as e:                       # never let the secondary leg take the headline down
-        return {"error": repr(e)}
+    except Exception as e:      # noqa: BLE001
+        err = e
+    bad = together(err, "timing the batch-steps")
+    ctx.close()
+    if bad:
+        return bad
+    dt = cp.max_over_ranks(dt_own)
+    chk = float(np.abs(w).sum())
+    lo, hi = -cp.max_over_ranks(-chk), cp.max_over_ranks(chk)
+    return {"workload": f"{envs_per_gpu} MountainCar envs per GPU, shared-W QLearning Fourier(5), per-step "
+                        f"{ {0: 'RCCL all-reduce of the fixed-point delta table', 1: 'one-hop peer-write exchange of the delta'}.get(comm_kind, 'exchange') }", "ranks": cp.world, "steps": steps,
+            "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
+            "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
+            "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
+            "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
+            "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu,
+                                     ms * 1e-3 if kn == "k_shared_persist" else ms * 1e-3 / max(1, n_l), 1 if kn == "k_shared_persist" else n_l, 32,
+                                     "SURVEY 8(d): C4 is VALU / latency bound (W stays on the chip: 32 B/env-step of state stream); the batch-step = two fabric hops "
+                                     "of the delta all-reduce (~3.2 us, profiles/r03_ubench_granule_allreduce.txt) + the learners' arithmetic at two waves per SIMD"),
+            "replicas_consistent": bool(lo == hi), "sum_abs_w": hi}
 
 
 def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_bytes_per_env_step, what, also=()):

@@ -94,9 +94,14 @@ class ControlPlane:
 
 def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=None, force_exchange=False, **cfg):
     """Create this rank's Context for its shard of `total_envs` environments.  In shared-weight mode with more
-    than one rank the exchange of the weight delta is set up (RCCL communicator, or the peer-write buffers when
-    cfg has exchange=EXCHANGE_PEER); force_exchange attaches it for a single rank too (a communicator of size 1 runs
-    the same finalize -> exchange -> apply sequence: how the multi-rank path is exercised on a one-GPU box)."""
+    than one rank the exchange of the weight delta is set up: exchange=EXCHANGE_AUTO (default) takes the one-hop peer
+    exchange whenever every rank's device reaches every other rank's memory and RCCL otherwise; EXCHANGE_PEER / _RCCL
+    force one.  force_exchange attaches it for a single rank too (a group of size 1 runs the same sequence: how the
+    multi-rank path is exercised on a one-GPU box).
+
+    FAILS TOGETHER: a rank whose local step fails (ctx creation, export, connect) still joins every control-plane
+    collective of the set-up with a marker, and then every rank raises -- no rank is left waiting in a collective
+    (an all-gather, ncclCommInitRank) for a peer that has already given up."""
     if context_cls is None:
         from .context import Context as context_cls
     if total_envs < control.world:
@@ -106,23 +111,63 @@ def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=Non
     if "device" not in cfg:
         from .context import device_count
         cfg["device"] = control.info.local_rank % max(1, device_count()) if context_cls.__name__ == "Context" else control.info.local_rank
-    ctx = context_cls(n_envs=count, env_offset=cfg.pop("env_offset", 0) + offset, **cfg)
     shared = cfg.get("weight_mode", 0) == 1
-    if shared and (control.world > 1 or force_exchange):
+    attach = shared and (control.world > 1 or force_exchange)
+    err, ctx = None, None
+    try:
+        ctx = context_cls(n_envs=count, env_offset=cfg.pop("env_offset", 0) + offset, **cfg)
+    except Exception as e:      # noqa: BLE001
+        if not attach:
+            raise
+        err = e
+
+    def together(what):
+        """every rank learns whether any rank failed so far; all raise together"""
+        oks = control.all_gather_bytes(err is None)
+        if not all(oks):
+            bad = [r for r, ok in enumerate(oks) if not ok]
+            if ctx is not None and hasattr(ctx, "close"):
+                ctx.close()
+            raise err if err is not None else RuntimeError(f"shared-W exchange set-up ({what}) failed on rank(s) {bad}; this rank gives up with them")
+
+    if attach:
         exchange = cfg.get("exchange", 2)
         if exchange == 2:                      # AUTO: the peer exchange whenever EVERY rank's device reaches every other rank's (decided by all
-            peer = False                       # ranks alike from the all-gathered devices), RCCL -- any topology -- otherwise
-            if context_cls.__name__ == "Context":
-                from .context import can_access_peer
-                devs = control.all_gather_bytes(cfg["device"])
-                mine = all(can_access_peer(cfg["device"], d) for d in devs)
-                peer = all(control.all_gather_bytes(bool(mine)))
-            exchange = 1 if peer else 0
+            mine = False                       # ranks alike from the all-gathered devices), RCCL -- any topology -- otherwise
+            devs = control.all_gather_bytes(cfg["device"])
+            if err is None and context_cls.__name__ == "Context":
+                try:
+                    from .context import can_access_peer
+                    mine = all(can_access_peer(cfg["device"], d) for d in devs)
+                except Exception:      # noqa: BLE001
+                    mine = False
+            exchange = 1 if all(control.all_gather_bytes(bool(mine))) else 0
+        together("creating the ctxs")
         if exchange == 1:                      # one-hop peer-write: all-gather the receive-buffer handles
-            handles = control.all_gather_bytes(ctx.peer_export(control.world))
-            ctx.peer_connect(handles, control.rank)
+            h = None
+            try:
+                h = ctx.peer_export(control.world)
+            except Exception as e:      # noqa: BLE001
+                err = e
+            handles = control.all_gather_bytes(h)
+            together("exporting the receive buffers")
+            try:
+                ctx.peer_connect(handles, control.rank)
+            except Exception as e:      # noqa: BLE001
+                err = e
+            together("connecting the receive buffers")
         else:                                  # RCCL: rank 0 draws the ncclUniqueId, the control plane broadcasts it
-            fn = unique_id_fn or context_cls.comm_unique_id
-            uid = control.broadcast_bytes(fn() if control.rank == 0 else None, src=0)
-            ctx.comm_init(uid, control.world, control.rank)
+            uid = None
+            if control.rank == 0:
+                try:
+                    uid = (unique_id_fn or context_cls.comm_unique_id)()
+                except Exception as e:      # noqa: BLE001
+                    err = e
+            uid = control.broadcast_bytes(uid, src=0)
+            together("drawing the communicator id")          # (ncclCommInitRank blocks until every rank joins: nobody enters it alone)
+            try:
+                ctx.comm_init(uid, control.world, control.rank)
+            except Exception as e:      # noqa: BLE001
+                err = e
+            together("initialising the communicator")
     return ctx

@@ -37,6 +37,25 @@ ctx = make_sharded_context(1001, cp, context_cls=FakeCtx, weight_mode=1, seed=3)
 out["shard"] = [ctx.kw["env_offset"], ctx.kw["n_envs"], ctx.kw["device"]]
 out["comm"] = [(u == b"U" * 128, w, r) for (u, w, r) in FakeCtx.calls]
 
+# a rank whose LOCAL set-up step fails must not leave the other one waiting in a collective: both raise, together
+class HalfBroken(FakeCtx):
+    def peer_export(self, world):
+        if self.kw["env_offset"] > 0:
+            raise RuntimeError("export failed on this rank")
+        return b"H" * 128
+    def peer_connect(self, handles, rank): raise AssertionError("never reached: a peer could not export")
+    def close(self): pass
+try:
+    make_sharded_context(64, cp, context_cls=HalfBroken, weight_mode=1, exchange=1)
+    out["fails_together"] = "no error"
+except RuntimeError as e:
+    out["fails_together"] = str(e)
+class PeerOk(FakeCtx):
+    def peer_export(self, world): return bytes([self.kw["env_offset"] % 251]) * 128
+    def peer_connect(self, handles, rank): self.connected = (handles, rank)
+pc = make_sharded_context(64, cp, context_cls=PeerOk, weight_mode=1, exchange=1)
+out["peer_connected"] = [len(pc.connected[0]), pc.connected[1], pc.connected[0][1][0]]
+
 # the sharding scheme, exercised with the oracle
 N, K = 24, 40
 off, cnt = shard_range(N, cp.world, cp.rank)
@@ -107,6 +126,12 @@ def test_world2_gloo_sharding_and_control_plane(tmp_path, orc):
     for r in (0, 1):
         assert res[r]["uid_ok"] and res[r]["max"] == 2.5 and res[r]["world"] == 2
         assert res[r]["comm"] == [[True, 2, r]]
+        assert res[r]["peer_connected"] == [2, r, 32 % 251]              # both handles, in rank order (rank 1's shard starts at 32)
+    # the rank whose export failed raises its own error, the other one gives up WITH it instead of waiting for its handle
+    assert "export failed on this rank" in res[1]["fails_together"]
+    assert "failed on rank(s) [1]" in res[0]["fails_together"]
+    for r in (0, 1):
+        pass
     assert res[0]["shard"] == [0, 501, 0] and res[1]["shard"] == [501, 500, 1]
 
     # unsharded reference runs
