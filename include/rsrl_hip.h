@@ -72,7 +72,8 @@ typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL
                RSRL_PAL = 5, RSRL_GREEDY_GQ = 6,
                /* prediction (state-value function on a ScalarLFA, ONE weight column; behaviour policy RSRL_RANDOM):
                 *   TD prediction/td/td.rs:25-59 (SGD(lr)), TDLambda prediction/td/td_lambda.rs:25-78 (step = the TD error);
-                *   per-learner weights, on a register-family Fourier basis or on tile coding (one block per learner) */
+                *   per-learner weights: register-family Fourier bases (fused, register-resident), the other Fourier orders (one thread
+                *   per learner, w and z in memory) or tile coding (one block per learner); not the order-7 wave family */
                RSRL_TD = 7, RSRL_TD_LAMBDA = 8,
                /* QSigma, the n-step Q(sigma) agent (control/td/q_sigma.rs:80-202; config.sigma, config.n_steps, alpha, gamma, and the
                 * agent's own policy).  The reference panics at its first full backup -- Backup::propagate reads entries[n_steps]

@@ -174,6 +174,106 @@ __global__ __launch_bounds__(kBlock) void k_v_evaluate(Common c, const float* __
     out[i] = v[0];
 }
 
+// TD / TDLambda on a model WITHOUT a register-family kernel (the generic Fourier orders): one thread per learner, w and z in memory
+// ([F][N], learner fastest), phi recomputed per feature (M::phi_at).  from == nullptr: the driver loop; otherwise Handler::handle on
+// one caller-supplied transition per learner.  Same arithmetic as orc_handle_td (oracle/rsrl_oracle_impl.h): V(s) by M::q_index on
+// column 0, the trace merged before the weights move, a terminal transition zeroing the trace.
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_td_mem(Common c, TdParams tp, BasisGeom g, int lambda, uint64_t t0, int n_steps, DevStats* __restrict__ stats,
+                                                   const float* __restrict__ from, const float* __restrict__ rew, const float* __restrict__ to,
+                                                   const uint8_t* __restrict__ termf, int64_t Mn, float* __restrict__ td_out) {
+    constexpr int D = M::D, A = M::A;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = c.n_envs;
+    const bool driver = from == nullptr;
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < (driver ? N : Mn)) {
+        PolicyParams pol = c.pol; pol.kind = POL_RANDOM;
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        const float q0[A] = {};
+        float s[D];
+        int a = 0; uint32_t ep = 0;
+        if (driver) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+            a = c.action[i]; ep = c.ep_step[i];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = from[(int64_t)d * Mn + i];
+        }
+        for (int k = 0; k < (driver ? n_steps : 1); ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D], r;
+            bool term, trunc = false;
+            if (driver) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = s[d];
+                term = M::Dom::step(ns, a, r);
+                ep += 1;
+                trunc = !term && cap > 0 && ep >= cap;
+                if (term) M::Dom::reset(ns);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = to[(int64_t)d * Mn + i];
+                r = rew[i]; term = termf[i] != 0;
+            }
+            typename M::Feat fs, fn;
+            M::features(s, g, fs);
+            M::features(ns, g, fn);
+            const float v_s = M::q_index(c, i, g, fs, 0);
+            const float v_n = M::q_index(c, i, g, fn, 0);
+            const float td = term ? (r - v_s) : (r + c.alg.gamma * v_n - v_s);
+            if (lambda) {
+                for (int f = 0; f < g.F; ++f) {
+                    const int64_t j = M::widx(c, i, g, 0, f);
+                    const float zz = trace_merge(tp.trace, tp.rate, tp.Z[j], M::phi_at(g, fs, f));
+                    c.W[j] = fmaf(td, zz, c.W[j]);
+                    tp.Z[j] = term ? 0.0f : zz;
+                }
+            } else {
+                M::update(c, i, g, fs, 0, c.alg.lr * td);
+            }
+            if (!driver) { if (td_out) td_out[i] = td; break; }
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            int na = policy_sample<A>(pol, q0, x);
+            sum_abs += (double)fabsf(td); sum_r += (double)r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                M::Dom::reset(ns);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(pol, q0, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+            a = na;
+        }
+        if (driver) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+            c.action[i] = a;
+            c.ep_step[i] = ep;
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// Function<(S,)>::evaluate of the ScalarLFA on such a model
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_v_mem(Common c, BasisGeom g, const float* __restrict__ states, int64_t Mn, float* __restrict__ out) {
+    constexpr int D = M::D;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * Mn + i];
+    typename M::Feat ft;
+    M::features(s, g, ft);
+    out[i] = M::q_index(c, i, g, ft, 0);
+}
+
 // per-episode Domain::default() + the first Random.sample (the control path's k_reset evaluates Q, which does not exist here)
 template <int DOMAIN>
 __global__ __launch_bounds__(kBlock) void k_reset_td(Common c, uint64_t t) {

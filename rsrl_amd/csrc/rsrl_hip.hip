@@ -729,9 +729,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     if (is_pred(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;
-        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
-            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1) or on tile coding");
+        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
+            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights (any Fourier order but 7 on CartPole / Acrobot, "
+                                         "or tile coding)");
         if (cfg->policy != RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "prediction agents have no Q function: the behaviour policy must be RSRL_RANDOM");
         if (cfg->algo == RSRL_TD_LAMBDA) {
             if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
@@ -1085,6 +1085,9 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, false, 0, c->stream, k, g, make_td(c), 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M_,
                             of.dev, d_states)) return NO_MODEL(c);
+    } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && is_generic_fourier(c->cfg)) {
+        if (!launch_td_model(c->cfg, dim3(grid_for(M_)), dim3(kBlock), c->stream, k, make_td(c), g, false, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M_,
+                             of.dev, d_states)) return NO_MODEL(c);
     } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE) {
         if (!launch_v_evaluate(c->cfg.domain, c->cfg.order, dim3(grid_for(M_)), dim3(kBlock), c->stream, k, d_states, M_, of.dev)) return NO_MODEL(c);
     } else if (is_wave(c->cfg)) {
@@ -1172,6 +1175,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, M, c->stream, k, g, make_td(c), c->t, 1, nullptr, d_from, d_rew,
                             d_to, d_term, M, otd.dev, nullptr)) return NO_MODEL(c);
+    } else if (is_pred(c->cfg.algo) && is_generic_fourier(c->cfg)) {
+        if (!launch_td_model(c->cfg, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c), g, c->cfg.algo == RSRL_TD_LAMBDA, c->t, 1, nullptr, d_from, d_rew,
+                             d_to, d_term, M, otd.dev, nullptr)) return NO_MODEL(c);
     } else if (is_pred(c->cfg.algo)) {
         if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
                               d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
@@ -2005,6 +2011,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, k.n_envs, c->stream, k, g, make_td(c), c->t, chunk, d_stats,
                                 nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return NO_MODEL(c);
             c->kernel_name = "k_td_tile";
+            KCHECK();
+        } else if (is_pred(c->cfg.algo) && is_generic_fourier(c->cfg)) {
+            if (!launch_td_model(c->cfg, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_td(c), g, c->cfg.algo == RSRL_TD_LAMBDA, c->t, chunk, d_stats,
+                                 nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return NO_MODEL(c);
+            c->kernel_name = "k_td_mem";
             KCHECK();
         } else if (is_pred(c->cfg.algo)) {
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,

@@ -33,6 +33,21 @@ bool launch_v_evaluate(int domain, int order, dim3 grid, dim3 block, hipStream_t
     RSRL_VEV_CASE(0, 1) RSRL_VEV_CASE(0, 2) RSRL_VEV_CASE(0, 3) RSRL_VEV_CASE(0, 4) RSRL_VEV_CASE(0, 5) RSRL_VEV_CASE(1, 1) RSRL_VEV_CASE(2, 1)
     return false;
 }
+// TD / TDLambda / V-evaluate on the generic Fourier orders: states != nullptr -> evaluate, from != nullptr -> handle, else the driver loop
+bool launch_td_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const TdParams& tp, const BasisGeom& g, bool lambda,
+                     uint64_t t, int chunk, DevStats* stats, const float* from, const float* rew, const float* to, const uint8_t* termf, int64_t Mn,
+                     float* out, const float* states) {
+#define RSRL_TDM_CASE(DM)                                                                                                                  \
+    if (cfg.domain == DM) {                                                                                                                \
+        using M = FourierGenericModel<DM>;                                                                                                 \
+        if (states) hipLaunchKernelGGL((k_v_mem<M>), grid, block, 0, st, k, g, states, Mn, out);                                           \
+        else hipLaunchKernelGGL((k_td_mem<M>), grid, block, 0, st, k, tp, g, lambda ? 1 : 0, t, chunk, stats, from, rew, to, termf, Mn, out); \
+        return true;                                                                                                                       \
+    }
+    if (cfg.basis != RSRL_FOURIER || cfg.order < 1 || cfg.order > 7) return false;
+    RSRL_TDM_CASE(0) RSRL_TDM_CASE(1) RSRL_TDM_CASE(2)
+    return false;
+}
 bool launch_reset_td(int domain, dim3 grid, dim3 block, hipStream_t st, const Common& k, uint64_t t) {
     if (domain == 0) { hipLaunchKernelGGL((k_reset_td<0>), grid, block, 0, st, k, t); return true; }
     if (domain == 1) { hipLaunchKernelGGL((k_reset_td<1>), grid, block, 0, st, k, t); return true; }

@@ -467,3 +467,66 @@ def test_gq_and_qsigma_off_the_register_family_bitwise(ra, orc, name, kw, tmp_pa
                 dict(algo=9, basis=1, weight_mode=1)):
         with pytest.raises(ra.RsrlHipError):
             ra.Context(n_envs=8, policy=1, **bad)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# TD / TDLambda on the generic Fourier orders (any order without a register-family kernel): rsrl_amd/csrc/kernels_td.hpp k_td_mem.
+# The reference's prediction agents are generic over the approximator (prediction/td/td.rs:25-59, td_lambda.rs:25-78).
+@pytest.mark.parametrize("algo,trace,domain,order", [(7, 0, 0, 6), (7, 0, 1, 2), (8, 0, 0, 7), (8, 1, 2, 2), (8, 2, 0, 6)])
+def test_td_generic_fourier_train_bitwise(ra, orc, algo, trace, domain, order):
+    # TDLambda steps with the raw TD error (td_lambda.rs:59-62: no learning rate), which grows geometrically on a dense basis of many
+    # features: a short run and short episodes keep every number finite, so that the comparison is of numbers
+    N, K, cap = (40, 96, 19) if algo == 7 else (40, 12, 5)
+    kw = dict(gamma=0.9, lr=0.01, alpha=0.05, lam=0.3)
+    ag = orc.make_agent(domain=domain, order=order, algo=algo, policy=orc.RANDOM, seed=13, trace=trace, max_episode_steps=cap, env_offset=3, **kw)
+    run = orc.Run(ag, N, "f32d"); run.reset()
+    ost = run.train(K)
+    with ra.Context(domain=domain, order=order, n_envs=N, algo=algo, policy=ra.RANDOM, seed=13, trace=trace, max_episode_steps=cap, env_offset=3, **kw) as c:
+        assert c.n_out == 1 and c.F == (order + 1) ** c.D
+        c.reset()
+        st = [c.train(k) for k in (K // 3, 1, K - K // 3 - 1)]
+        assert c.timing_read()[2] == "k_td_mem"
+        assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
+        for i in range(N):
+            assert np.array_equal(c.get_weights(i).reshape(-1), run.weights[i].reshape(-1)), i
+            if algo == 8:
+                assert np.array_equal(c.get_traces(i).reshape(-1), run.traces[i].reshape(-1)), i
+        assert np.abs(run.weights).max() > 0 and np.all(np.isfinite(run.weights))
+        assert sum(s["episodes"] for s in st) == ost["episodes"] > 0
+        assert sum(s["episodes_truncated"] for s in st) == ost["episodes_truncated"]
+        assert abs(sum(s["sum_abs_td_error"] for s in st) - ost["sum_abs_td_error"]) <= 1e-6 * ost["sum_abs_td_error"]
+
+
+@pytest.mark.parametrize("algo,trace", [(7, 0), (8, 0), (8, 1), (8, 2)])
+def test_td_generic_fourier_handle_and_evaluate_bitwise(ra, orc, algo, trace):
+    M, domain, order = 48, 1, 2
+    rng = np.random.default_rng(algo * 5 + trace)
+    kw = dict(gamma=0.97, lr=0.02, alpha=0.1, lam=0.9)
+    ag = orc.make_agent(domain=domain, order=order, algo=algo, policy=orc.RANDOM, seed=4, trace=trace, **kw)
+    lo, hi = orc.domain_bounds(domain)
+    s = (lo[:, None] + (hi - lo)[:, None] * rng.random((len(lo), M))).astype(np.float32) * 0.5
+    a = rng.integers(0, 2, M).astype(np.int32)
+    with ra.Context(domain=domain, order=order, n_envs=M, algo=algo, policy=ra.RANDOM, seed=4, trace=trace, **kw) as c:
+        F = c.F
+        c.states = s
+        frm, nxt, rew, term = c.domain_step(a)
+        term[::7] = 1
+        Ws = (rng.normal(size=(M, F)) * 0.1).astype(np.float32)
+        Zs = (rng.normal(size=(M, F)) * 0.4).astype(np.float32)
+        for i in range(M):
+            c.set_weights(Ws[i].reshape(F, 1), i)
+            if algo == 8:
+                c.set_traces(Zs[i].reshape(F, 1), i)
+        v = c.q_evaluate(s)
+        assert v.shape == (1, M)
+        td = c.handle(frm, a, rew, nxt, term)
+        for i in range(M):
+            assert v[0, i] == np.float32(orc.v_evaluate(ag, Ws[i], s[:, i], "f32d")), i
+            W, Z = Ws[i].copy(), Zs[i].copy()
+            d = orc.handle_td(ag, W, Z if algo == 8 else None, frm[:, i], rew[i], nxt[:, i], term[i], "f32d")
+            assert td[i] == np.float32(d), (i, td[i], d)
+            assert np.array_equal(c.get_weights(i).reshape(-1), W), i
+            if algo == 8:
+                assert np.array_equal(c.get_traces(i).reshape(-1), Z), i
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(domain=1, order=7, n_envs=8, algo=7, policy=ra.RANDOM)            # the order-7 wave family has no prediction kernels
