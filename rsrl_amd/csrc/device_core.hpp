@@ -120,14 +120,29 @@ __device__ __forceinline__ uint32_t sign_mask(int x) {
 __device__ __forceinline__ float bitsel(uint32_t m, float x, float y) {          // m ? x : y for an all-ones / all-zeros m
     return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, x) & m) | (__builtin_bit_cast(uint32_t, y) & ~m));
 }
+// (sin, cos) of the reduced argument -> (sin, cos) of the angle in quadrant q: swapped when q is odd, sin negated in quadrants 2, 3, cos
+// in quadrants 1, 2.  Seven integer instructions, written as the instructions: the mask by v_bfe_i32 (bit 0 sign-extended), each select ONE
+// v_bitop3_b32 (bitfield insert, truth table 0xca), each sign flip ONE v_bitop3_b32 (x ^ (t & 0x80000000), 0x78) -- the generic
+// (x & m) | (y & ~m) spelling compiled to twelve.  The same bits: integer logic only.
 __device__ __forceinline__ void quadrant_select(int q, float s, float c, float& sn, float& cs) {
-    const uint32_t swap = sign_mask(q << 31);                           // q odd
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t su = __builtin_bit_cast(uint32_t, s), cu = __builtin_bit_cast(uint32_t, c);
+    const uint32_t swap = (uint32_t)__builtin_amdgcn_sbfe(q, 0, 1);     // q odd
+    const uint32_t a = __builtin_amdgcn_bitop3_b32(swap, cu, su, 0xca);  // swap ? c : s
+    const uint32_t b = __builtin_amdgcn_bitop3_b32(swap, su, cu, 0xca);  // swap ? s : c
+    const uint32_t ta = (uint32_t)q << 30;                              // bit 31 = q & 2       : sin negative in quadrants 2, 3
+    const uint32_t tb = ((uint32_t)q << 30) + 0x40000000u;              // bit 31 = (q + 1) & 2 : cos negative in quadrants 1, 2
+    sn = __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(a, ta, 0x80000000u, 0x78));
+    cs = __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(b, tb, 0x80000000u, 0x78));
+#else
+    const uint32_t swap = sign_mask(q << 31);
     const float a = bitsel(swap, c, s);
     const float b = bitsel(swap, s, c);
-    const uint32_t sa = ((uint32_t)q & 2u) << 30;                       // sin negative in quadrants 2, 3
-    const uint32_t sb = (((uint32_t)q + 1u) & 2u) << 30;                // cos negative in quadrants 1, 2
+    const uint32_t sa = ((uint32_t)q & 2u) << 30;
+    const uint32_t sb = (((uint32_t)q + 1u) & 2u) << 30;
     sn = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, a) ^ sa);
     cs = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, b) ^ sb);
+#endif
 }
 // sin(pi x), cos(pi x) for x in [0, 1] (scaled states s~): q = rint(2x), r = x - q/2 in [-1/4, 1/4]
 __device__ __forceinline__ void sincospi01(float x, float& sn, float& cs) {
