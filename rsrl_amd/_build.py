@@ -42,7 +42,7 @@ def sources():
 
 def deps():
     inc = os.path.join(os.path.dirname(HERE), "include", "rsrl_hip.h")
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc, os.path.abspath(__file__)]
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc, os.path.abspath(__file__), os.path.join(HERE, "_asmfilter.py")]
 
 
 STAMP_PATH = LIB_PATH + ".sha256"
@@ -57,7 +57,8 @@ def source_digest(extra_flags=()):
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
-    h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags))).encode())
+    h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags), nop_filter_enabled())).encode())
+    h.update(open(os.path.join(HERE, "_asmfilter.py"), "rb").read())
     h.update(hipcc_version().encode())
     return h.hexdigest()
 
@@ -84,14 +85,51 @@ def is_stale():
     return open(STAMP_PATH).read().strip() != source_digest()
 
 
+def nop_filter_enabled():
+    """the assembly post-pass of _asmfilter.py (drops the compiler's false-positive wait states behind packed fp32 instructions);
+    RSRL_NOP_FILTER=0 compiles every source in one hipcc call instead (A/B)"""
+    return os.environ.get("RSRL_NOP_FILTER", "1") != "0"
+
+
+def _tool(name):
+    return subprocess.run([hipcc(), "-print-prog-name=" + name], capture_output=True, text=True, check=True).stdout.strip()
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 def _compile_one(args):
     src, obj, verbose, extra = args
     flags = [f for f in HIPCC_FLAGS if f != "-shared" and not (f == "-fno-slp-vectorize" and "-fslp-vectorize" in extra)]
     per_src = [] if any("amdgpu-sched-strategy" in e for e in extra) else PER_SOURCE_FLAGS.get(os.path.basename(src), [])
-    cmd = [hipcc()] + flags + per_src + list(extra) + ["-c", src, "-o", obj]
+    base = [hipcc()] + flags + per_src + list(extra)
+    if not nop_filter_enabled():
+        _run(base + ["-c", src, "-o", obj], verbose)
+        return obj
+    # hipcc's own steps, taken apart so that the device assembly can be filtered in between:
+    #   device: .hip -> .s (clang) -> filtered .s -> .o (assembler) -> code object (lld) -> fat binary (clang-offload-bundler)
+    #   host  : .hip -> .o with the fat binary embedded
+    from . import _asmfilter
+    stem = obj[:-2] if obj.endswith(".o") else obj
+    asm, dev_o, code, fatbin = stem + ".gfx950.s", stem + ".gfx950.o", stem + ".gfx950.co", stem + ".hipfb"
+    _run(base + ["-Wno-unused-command-line-argument", "--cuda-device-only", "-S", src, "-o", asm], verbose)
+    text, removed = _asmfilter.filter_asm(open(asm).read())
+    with open(asm, "w") as f:
+        f.write(text)
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(f"# {os.path.basename(src)}: {removed} wait states behind packed fp32 instructions removed")
+    _run([_tool("clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm, "-o", dev_o], verbose)
+    _run([_tool("lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", dev_o, "-o", code], verbose)
+    _run([_tool("clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + code,
+          "-output=" + fatbin], verbose)
+    _run(base + ["-Wno-unused-command-line-argument", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin,
+                 "-c", src, "-o", obj], verbose)
+    for tmp in (asm, dev_o, code, fatbin):
+        os.remove(tmp)
     return obj
 
 

@@ -448,7 +448,17 @@ template <int A>
 __device__ __forceinline__ uint32_t argmaxima_mask(const float (&q)[A]) {
     // i = 0 against mx = -FLT_MAX, folded: the tolerance test can only hit q[0] == -FLT_MAX itself, so q[0] joins the set
     // iff q[0] >= -FLT_MAX (not NaN, not -inf) and the running max becomes max(q[0], -FLT_MAX) either way
-    float mx = fmaxf(q[0], -FLT_MAX); uint32_t mask = (q[0] >= -FLT_MAX) ? 1u : 0u;
+    // (v_med3_f32 with +inf: fmaxf's value for every input, NaN included -- the median of three returns min3 when an operand is NaN --
+    // without the canonicalising v_max_f32 x, x the compiler puts in front of fmaxf when x comes out of a bitwise select)
+#ifndef RSRL_MED3_ARGMAX
+#define RSRL_MED3_ARGMAX 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RSRL_MED3_ARGMAX
+    float mx = __builtin_amdgcn_fmed3f(q[0], -FLT_MAX, __builtin_inff());
+#else
+    float mx = fmaxf(q[0], -FLT_MAX);
+#endif
+    uint32_t mask = (q[0] >= -FLT_MAX) ? 1u : 0u;
 #pragma unroll
     for (int i = 1; i < A; ++i) {                                     // selects only: no exec-mask branches
         const float qi = q[i];
@@ -557,11 +567,23 @@ struct PolicyParams { int kind; uint32_t eps_thr; float eps; float tau; };
 //   EpsilonGreedy::sample  epsilon_greedy.rs:74-80 (gen_bool(eps) ? Random : Greedy)
 //   Random::sample         random.rs:43-45         (Uniform(0, A))
 //   Softmax::sample        softmax.rs:131-139
-template <int A>
+// YZ: the caller guarantees x.y == x.z (the per-step draws, half_block).  EpsilonGreedy then needs ONE scaled pick instead of two:
+// a random action is the pick among the full set {0..A-1}, kth_set_bit(2^A - 1, k) = k -- the same action as mulhi(x.y, A) -- and
+// the empty set of maxima already took that route.  One quarter-rate multiply and two selects less per sample; the same results.
+template <int A, bool YZ = false>
 __device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float (&q)[A], const U4& x, int ulane = -1) {
     switch (pp.kind) {
     case POL_GREEDY: return greedy_sample<A>(q, x.z);
     case POL_EGREEDY: {
+#ifndef RSRL_EGREEDY_FUSED
+#define RSRL_EGREEDY_FUSED 1
+#endif
+        if constexpr (YZ && (RSRL_EGREEDY_FUSED != 0)) {
+            const uint32_t m0 = argmaxima_mask<A>(q);
+            const bool explore = (x.x >> 8) < pp.eps_thr;
+            const uint32_t mask = (explore | (m0 == 0u)) ? ((1u << A) - 1u) : m0;
+            return kth_set_bit<A>(mask, (int)mulhi_u32(x.y, (uint32_t)__popc(mask)));
+        }
         const int g = greedy_sample<A>(q, x.z), u = (int)mulhi_u32(x.y, (uint32_t)A);
         const bool explore = (x.x >> 8) < pp.eps_thr;
         return explore ? u : g;

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             w.q(phi_n, q_n);
 #endif
             if constexpr (ESCHED) learner_eps_step(c, term | trunc, pol);        // the episode's last handle is done: its end decays epsilon
-            int na = policy_sample<A>(pol, q_n, x);
+            int na = policy_sample<A, true>(pol, q_n, x);               // (x is a half block: y == z)
             facc_abs += fabsf(delta);
             facc_r += r;
             n_ep += term ? 1u : 0u; ep = term ? 0u : ep;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
                 pre_s = Dom::pre(ns);
                 { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
                 w.q(phi_n, q_n);
-                na = policy_sample<A>(pol, q_n, x);          // the step's one behaviour sample: the same draw (BLK_RESET == BLK_STEP)
+                na = policy_sample<A, true>(pol, q_n, x);    // the step's one behaviour sample: the same draw (BLK_RESET == BLK_STEP)
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];

@@ -104,3 +104,47 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     assert out["value"] > 0 and out["optimised"]["value"] > out["value"]           # fewer projections, no heap traffic
     assert "sample" in out and abs(out["per_core"] * out["cores"] - out["value"]) < 1e-6 * out["value"]
     assert bench.BYTES_PER_ENV_STEP == 2 * 2 * 4 + 8 + 8 + 36 * 3 * 4 + 36 * 4   # 608 B per env-step
+
+
+def test_asm_filter_removes_only_the_packed_fp32_wait_states():
+    # rsrl_amd/_asmfilter.py: `s_nop 0` goes only between a packed fp32 instruction and an ordinary VALU consumer of its result
+    from rsrl_amd import _asmfilter
+    src = "\n".join([
+        "k:",
+        "\tv_pk_fma_f32 v[10:11], v[10:11], v[4:5], s[2:3] op_sel_hi:[1,1,0]",
+        "\ts_nop 0",                                               # 1: consumer reads v[10:11] -> removed
+        "\tv_pk_fma_f32 v[10:11], v[10:11], v[4:5], s[6:7] op_sel_hi:[1,1,0]",
+        "\ts_nop 0",                                               # 2: consumer reads v11 as a single register -> removed
+        "\tv_mul_f32_e32 v1, v11, v2",
+        "\tv_pk_mul_f32 v[20:21], v[4:5], v[6:7]",
+        "\ts_nop 0",                                               # 3: next instruction does not read v[20:21] -> stays
+        "\tv_add_f32_e32 v3, v1, v2",
+        "\tv_pk_add_f32 v[30:31], v[4:5], v[6:7]",
+        "\ts_nop 1",                                               # 4: two wait states: some other hazard -> stays
+        "\tv_add_f32_e32 v3, v30, v2",
+        "\tv_pk_add_f32 v[30:31], v[4:5], v[6:7]",
+        "\ts_nop 0",                                               # 5: v_readlane is not an ordinary consumer -> stays
+        "\tv_readlane_b32 s0, v30, 3",
+        "\tv_cmp_gt_f32_e64 s[0:1], v1, v2",
+        "\ts_nop 0",                                               # 6: not behind a packed instruction -> stays
+        "\tv_cndmask_b32_e64 v1, v2, v3, s[0:1]",
+        "\tv_pk_mul_f32 v[40:41], v[4:5], v[6:7]",
+        "\ts_nop 0",                                               # 7: a label before the consumer -> stays
+        ".LBB0_1:",
+        "\tv_add_f32_e32 v3, v40, v2",
+        "\tv_pk_mul_f32 v[50:51], v[4:5], v[6:7]",
+        "\ts_nop 0",                                               # 8: the destination only WRITTEN by the next instruction -> stays
+        "\tv_mov_b32_e32 v50, v2",
+        "\tv_pk_fma_f32 v[60:61], v[4:5], v[6:7], v[8:9]",
+        "\t; a comment line",
+        "\ts_nop 0",                                               # 9: comments in between do not hide the producer -> removed
+        "\tv_pk_mul_f32 v[62:63], v[0:1], v[60:61]",
+    ])
+    out, removed = _asmfilter.filter_asm(src)
+    assert removed == 3
+    kept = [ln for ln in out.split("\n")]
+    assert len(kept) == len(src.split("\n")) - 3
+    assert out.count("s_nop 0") == 5 and out.count("s_nop 1") == 1
+    # every instruction but the removed wait states is still there, in order
+    assert [ln for ln in src.split("\n") if ln.strip() != "s_nop 0"] == [ln for ln in out.split("\n") if ln.strip() != "s_nop 0"]
+    assert _asmfilter.filter_asm(out) == (out, 0)                  # idempotent
