@@ -30,8 +30,9 @@ LEG_KERNELS = {
     "tile": ["k_shared_ca", "k_tile_scatter", "k_apply_rep"], "wave": ["k_train_wave"],
 }
 # static counts of the executed path of k_train_reg's steady-state loop (scripts/isa_stats.py on train_reg_d0b.hip): v_pk_fma_f32 314 per
-# pair of steps; v_pk_mul_f32 42 + v_pk_add_f32 4; v_cndmask_b32 34
-K_TRAIN_REG_STATIC = {"pk_fma": 157.0, "pk_other": 23.0, "cndmask": 17.0}
+# pair of steps; v_pk_mul_f32 42 + v_pk_add_f32 4; v_cndmask_b32 30 (after the assembly post-pass of rsrl_amd/_asmfilter.py: 719 instructions per
+# pair of steps, 26 of them scalar)
+K_TRAIN_REG_STATIC = {"pk_fma": 157.0, "pk_other": 23.0, "cndmask": 15.0}
 
 
 def first_json(path):
