@@ -8,7 +8,9 @@ instruction writes two whole dwords; there is no partial write to forward, and t
 pair.  In the fused driver loop every instruction of the single resident wave takes an issue slot, `s_nop` included: the Horner chains of
 sincospi and the harmonic recurrences carried ~8 of them per env-step (2 % of the slots).
 
-What it leaves alone.  Only `s_nop 0` (one wait state) whose PREVIOUS instruction is one of the three packed fp32 opcodes and whose NEXT
+What it leaves alone.  Only `s_nop 0` (one wait state) whose previous COMPILER-EMITTED instruction is one of the three packed fp32 opcodes
+(inline-asm instructions in between -- the sources' v_pk_mov_b32 / v_ashrrev_i32 -- are skipped as the recogniser skips them: with one of
+those in between the wait state exists whether or not the rule applies) and whose NEXT
 instruction is an ordinary VALU instruction (not v_readlane / v_readfirstlane / v_writelane / v_div_fmas / v_permlane, no DPP, no SDWA) that
 reads a register the packed instruction wrote.  Every other wait state (VALU-writes-SGPR before VMEM or v_readlane, trans-op forwarding,
 s_nop with a larger count, ...) stays where the compiler put it.
@@ -45,28 +47,40 @@ def _reads(instr, lo, hi):
 def filter_asm(text):
     """returns (filtered text, number of `s_nop 0` lines removed)"""
     lines = text.split("\n")
-    out, removed, prev = [], 0, None
+    out, removed = [], 0
+    prev = None            # the last instruction the COMPILER emitted (what its hazard recogniser counts from)
+    asm_between = 0        # inline-asm instructions (;;#ASMSTART .. ;;#ASMEND) since `prev`: the recogniser does not count them as wait states
+    in_app = False
     n = len(lines)
     for i, line in enumerate(lines):
         t = line.strip()
-        if t == "s_nop 0" and prev is not None:
+        if t.startswith(";;#ASMSTART"):
+            in_app = True
+        elif t.startswith(";;#ASMEND"):
+            in_app = False
+        if t == "s_nop 0" and prev is not None and not in_app:
             m = _PK.match(prev)
             if m:
                 lo, hi = int(m.group(1)), int(m.group(2))
                 j = i + 1
                 while j < n and not _is_instr(lines[j]):
-                    if lines[j].strip().endswith(":"):          # a label: the consumer is in another block, leave the wait state
-                        j = n
+                    if lines[j].strip().endswith(":") and not lines[j].strip().startswith(";"):
+                        j = n                                   # a label: the consumer is in another block, leave the wait state
                         break
                     j += 1
                 nxt = lines[j].strip() if j < n else ""
                 plain = nxt.startswith("v_") and not _NOT_PLAIN.match(nxt) and "dpp" not in nxt and "sdwa" not in nxt
+                # asm_between == 0: the false positive described above.  asm_between >= 1: an instruction the recogniser did not count
+                # already sits between producer and consumer -- the wait state is there whatever the rule is worth.
                 if plain and _reads(nxt, lo, hi):
                     removed += 1
                     continue
         if _is_instr(line):
-            prev = t
+            if in_app:
+                asm_between += 1
+            else:
+                prev, asm_between = t, 0
         elif t.endswith(":") and not t.startswith(";"):
-            prev = None                                         # block boundary: the previous instruction is not known
+            prev, asm_between = None, 0                         # block boundary: the previous instruction is not known
         out.append(line)
     return "\n".join(out), removed

@@ -187,6 +187,27 @@ __device__ __forceinline__ void sincospi01_x2(f2 x, f2& sn, f2& cs) {
     quadrant_select((int)q.y, s.y, c.y, s1, c1);
     sn = f2{s0, s1}; cs = f2{c0, c1};
 }
+// {a[SA], b[SB]}: a register pair assembled from halves of two others by ONE v_pk_mov_b32 (D.lo = S0[op_sel[0]], D.hi = S1[op_sel[1]]);
+// the compiler spells the same build_vector as two v_mov_b32.  A move: the same bits.
+// MEASURED AND SWITCHED OFF (round 4): nine instructions fewer per env-step in k_train_reg (14 v_mov -> 5 v_pk_mov), and 1 % SLOWER on the
+// same box (9.38-9.43e10 against 9.48-9.53e10): a lone wave issues a packed instruction every ~5.2 cycles and a plain one every ~3.4, so
+// one packed move buys little over two plain ones, and the asm statements pin the schedule.  -DRSRL_PK_MOV=1 builds it (bitwise either way).
+#ifndef RSRL_PK_MOV
+#define RSRL_PK_MOV 0
+#endif
+template <int SA, int SB>
+__device__ __forceinline__ f2 pk_pick(f2 a, f2 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && RSRL_PK_MOV
+    f2 r;
+    if constexpr (SA == 0 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+    else if constexpr (SA == 0 && SB == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else if constexpr (SA == 1 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return f2{SA ? a.y : a.x, SB ? b.y : b.x};
+#endif
+}
 // sin(x), cos(x) for |x| <= 100: Cody-Waite reduction by pi/2 (two-term, fma), polynomials on [-pi/4, pi/4]
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     const float n = rintf(x * 0.6366197466850281f);
@@ -788,8 +809,15 @@ struct FourierReg {
                     constexpr int j = Jj, ka = 2 * j + 1, kb = 2 * j + 2;
                     constexpr int a0 = ka / N1, a1 = ka % N1, b0 = kb / N1, b1 = kb % N1;
                     if constexpr (kb < F && a0 == b0 && a0 >= 1 && a1 >= 1 && b1 >= 1) {
-                        const f2 c1 = f2{tb.c(1, a1), tb.c(1, b1)}, s1 = f2{tb.s(1, a1), tb.s(1, b1)};
+                        const f2 c1 = pk_pick<1, 1>(tb.ct[0][a1], tb.ct[0][b1]), s1 = pk_pick<1, 1>(tb.st[0][a1], tb.st[0][b1]);
                         const f2 v = __builtin_elementwise_fma(splat2(-tb.s(0, a0)), s1, splat2(tb.c(0, a0)) * c1);
+                        phi[2 * j] = v.x; phi[2 * j + 1] = v.y;
+                    } else if constexpr (kb < F && a0 == 0 && b0 == 0) {
+                        // row 0: the dimension-1 harmonics themselves -- the very pair the rows below multiply by
+                        const f2 v = pk_pick<1, 1>(tb.ct[0][a1], tb.ct[0][b1]);
+                        phi[2 * j] = v.x; phi[2 * j + 1] = v.y;
+                    } else if constexpr (kb < F && a0 == 0 && b0 == 1 && b1 == 0) {
+                        const f2 v = pk_pick<1, 0>(tb.ct[0][a1], tb.ct[0][1]);      // (cos of the last dimension-1 harmonic, cos of dimension 0's first)
                         phi[2 * j] = v.x; phi[2 * j + 1] = v.y;
                     } else {
                         phi[2 * j] = feature<ka>(tb);

@@ -139,12 +139,24 @@ def test_asm_filter_removes_only_the_packed_fp32_wait_states():
         "\t; a comment line",
         "\ts_nop 0",                                               # 9: comments in between do not hide the producer -> removed
         "\tv_pk_mul_f32 v[62:63], v[0:1], v[60:61]",
+        "\tv_pk_mul_f32 v[70:71], v[4:5], v[6:7]",
+        "\t;;#ASMSTART",
+        "\tv_pk_mov_b32 v[72:73], v[0:1], v[2:3] op_sel:[1,1]",     # inline asm: the recogniser does not count it ...
+        "\t;;#ASMEND",
+        "\ts_nop 0",                                              # 10: ... so this one is redundant a fortiori -> removed
+        "\tv_pk_fma_f32 v[74:75], v[70:71], v[4:5], v[6:7]",
+        "\tv_cmp_gt_f32_e32 vcc, v1, v2",
+        "\t;;#ASMSTART",
+        "\tv_ashrrev_i32_e32 v80, 31, v3",
+        "\t;;#ASMEND",
+        "\ts_nop 0",                                              # 11: not a packed producer -> stays
+        "\tv_cndmask_b32_e32 v1, v2, v3, vcc",
     ])
     out, removed = _asmfilter.filter_asm(src)
-    assert removed == 3
+    assert removed == 4
     kept = [ln for ln in out.split("\n")]
-    assert len(kept) == len(src.split("\n")) - 3
-    assert out.count("s_nop 0") == 5 and out.count("s_nop 1") == 1
+    assert len(kept) == len(src.split("\n")) - 4
+    assert out.count("s_nop 0") == 6 and out.count("s_nop 1") == 1
     # every instruction but the removed wait states is still there, in order
     assert [ln for ln in src.split("\n") if ln.strip() != "s_nop 0"] == [ln for ln in out.split("\n") if ln.strip() != "s_nop 0"]
     assert _asmfilter.filter_asm(out) == (out, 0)                  # idempotent
