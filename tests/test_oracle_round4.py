@@ -137,3 +137,36 @@ def test_constant_division_is_the_ieee_quotient(orc, tmp_path):
     # the checker does find a sequence that is NOT the quotient: Markstein's fp32 correction step fails where its residual underflows
     bad = subprocess.run([exe, "1", "1", str(n), "0", "1e-36", "1.10000002"], capture_output=True, text=True, timeout=300)
     assert bad.returncode == 1 and "mismatches" in bad.stdout and " 0 mismatches" not in bad.stdout
+
+
+# The independent leg of the chain for the round-4 families: the device is compared BITWISE with the oracle's f32d
+# instantiation (tests/test_gpu_round4.py), which restates the device's own polynomials and evaluation order -- so f32d itself has to be
+# held to the reference's arithmetic: the f64 run of the same agent, same seeds, within a tolerance.
+R4_FAMILIES = [
+    ("greedy_gq, CartPole tiles", dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=6, policy=1, gamma=0.99, lr=0.0125, lr_td=0.001, epsilon=0.1), 0.95, 3e-8),
+    ("greedy_gq, MountainCar Fourier(6)", dict(domain=0, order=6, algo=6, policy=1, gamma=0.99, lr=0.05, lr_td=0.001, epsilon=0.1), 0.95, 1e-5),
+    ("q_sigma n=3, CartPole tiles", dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=9, policy=1, gamma=0.95, lr=0.0125, alpha=0.5, sigma=0.5, n_steps=3,
+                                         epsilon=0.2), 0.95, 5e-9),
+    ("q_sigma n=4, MountainCar Fourier(7)", dict(domain=0, order=7, algo=9, policy=1, gamma=0.9, lr=0.01, alpha=0.5, sigma=0.0, n_steps=4, epsilon=0.2), 0.95, 1e-6),
+    ("td, MountainCar Fourier(6)", dict(domain=0, order=6, algo=7, policy=3, gamma=0.9, lr=0.01), 1.0, 2e-6),
+    ("td, CartPole Fourier(2)", dict(domain=1, order=2, algo=7, policy=3, gamma=0.9, lr=0.01), 1.0, 2e-7),
+    ("sarsa + epsilon schedule", dict(domain=0, order=3, algo=1, policy=1, gamma=0.9, lr=0.002, epsilon=0.4, epsilon_decay=0.97, epsilon_min=0.01), 0.95, 2e-7),
+]
+
+
+@pytest.mark.parametrize("name,kw,min_same,tol", R4_FAMILIES, ids=[c[0] for c in R4_FAMILIES])
+def test_round4_families_f32d_follows_the_f64_reference_run(orc, name, kw, min_same, tol):
+    N, K = 48, 160
+    ag = orc.make_agent(seed=17, max_episode_steps=25, **kw)
+    d = orc.Run(ag, N, "f32d"); d.reset(); sd = d.train(K)
+    r = orc.Run(ag, N, "f64"); r.reset(); sr = r.train(K)
+    same = np.all(np.abs(r.state - d.state) <= 1e-4 * (1 + np.abs(r.state)), axis=1) & (r.action == d.action)
+    assert same.mean() >= min_same, same.mean()                  # (fp32 argmax flips move a learner to another trajectory: inherent)
+    scale = max(1.0, float(np.abs(r.weights[same]).max()))
+    assert np.max(np.abs(r.weights[same] - d.weights[same])) <= tol * scale
+    if kw["algo"] == 6:
+        assert np.max(np.abs(r.traces[same] - d.traces[same])) <= tol * max(1.0, float(np.abs(r.traces[same]).max()))
+    assert abs(sd["episodes"] - sr["episodes"]) <= max(2, int((1 - same.mean()) * N * K / 10))
+    assert np.abs(r.weights).max() > 0
+    if "epsilon_decay" in kw:
+        assert np.max(np.abs(r.eps[same] - d.eps[same])) <= 30 * 6e-8 * 0.4
