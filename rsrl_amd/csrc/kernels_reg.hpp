@@ -611,10 +611,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         c.qcache[i] = q_s.v0;
         if constexpr (A > 1) c.qcache[N + i] = q_s.v1;
         if constexpr (A > 2) c.qcache[2 * N + i] = q_s.v2;
+        // the row addresses are computed AGAIN here (the base laundered through an empty asm statement): kept from the loads they are
+        // 216 scalar registers that live across the whole loop -- spilled into VGPR lanes (370 v_writelane before the loop, 370
+        // v_readlane after it) and, at 256 VGPRs, pushing vector registers into scratch
+        char* wblk_e = wblk;
+        int64_t wrow_e = wrow;
+        asm volatile("" : "+s"(wblk_e), "+s"(wrow_e));
 #pragma unroll
         for (int b = 0; b < A; ++b)
 #pragma unroll
-            for (int f = 0; f < F; ++f) row_store(wblk + (int64_t)(b * F + f) * wrow, wlane, w.get(b, f));
+            for (int f = 0; f < F; ++f) row_store(wblk_e + (int64_t)(b * F + f) * wrow_e, wlane, w.get(b, f));
     }
 
     // per-launch statistics: block-level reduction into this block's own slot (no atomics: a slot
