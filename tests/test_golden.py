@@ -194,3 +194,65 @@ def test_device_matches_golden_r03_bitwise():
             s1, s2 = c.train(a), c.train(b)                    # two launches: the boundary is invisible
             st = {k: s1[k] + s2[k] for k in ("episodes", "episodes_truncated")}
             _check_r03(g, c.states.T, c.actions.tolist(), c.get_weights, c.get_traces, st)
+
+
+# ---- round 4: the per-learner epsilon schedule, rollouts under a sampling policy, GreedyGQ / QSigma / TD off the register family:
+# tests/golden/vectors_r04.json (make_golden_r04.py) ----
+G4 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vectors_r04.json")))["oracle"]
+R4_TRAIN = ("sarsa_lambda_eps_schedule", "qlearning_eps_schedule", "greedy_gq_tiles", "q_sigma_generic_fourier", "td_generic_fourier")
+
+
+def _check_r04(g, states_t, actions, weights, aux, eps, st):
+    n = g["n_envs"]
+    assert _bits(states_t).tolist() == g["states"] and list(actions) == g["actions"]
+    assert st["episodes"] == g["episodes"] > 0 and st["episodes_truncated"] == g["episodes_truncated"]
+    assert [_digest(weights(i)) for i in range(n)] == g["w_digest"]
+    if g["aux"]:
+        assert [_digest(aux(i)) for i in range(n)] == g["z_digest"]
+    if "eps_bits" in g:
+        assert _bits(eps()).tolist() == g["eps_bits"]
+        if g["config"]["domain"] == 1:
+            assert len(set(g["eps_bits"])) > 1                   # CartPole: the learners' episodes end at different steps -> different epsilons
+
+
+def _check_rollouts(g, call_fn):
+    for k, rec in enumerate(g["calls"]):
+        n_states, total, acts = call_fn(rec["policy"], g["limit"], rec["kw"], k)
+        assert n_states.tolist() == rec["n_states"] and _bits(total).tolist() == rec["total_reward_bits"]
+        ref = np.array(rec["actions"])
+        for i, ns in enumerate(rec["n_states"]):                 # the actions actually taken: ns - 1 of them
+            assert acts[:ns - 1, i].tolist() == ref[:ns - 1, i].tolist(), (k, i)
+
+
+def test_oracle_reproduces_golden_r04(orc):
+    for key in R4_TRAIN:
+        g = G4[key]
+        run = orc.Run(orc.make_agent(**g["config"]), g["n_envs"], "f32d"); run.reset()
+        st = (run.train_dev if g["loop"] == "dev" else run.train)(g["steps"])
+        _check_r04(g, run.state, run.action.tolist(), lambda i: run.weights[i], lambda i: run.traces[i], lambda: run.eps, st)
+    g = G4["rollout_policy"]
+    run = orc.Run(orc.make_agent(**g["config"]), g["n_envs"], "f32d"); run.reset(); run.train_dev(g["steps"])
+    _check_rollouts(g, lambda policy, limit, kw, k: run.rollout_policy(policy, limit, call=k, **kw))
+
+
+@pytest.mark.gpu
+def test_device_matches_golden_r04_bitwise():
+    # the HIP path against the committed vectors, without the live oracle
+    import rsrl_amd as ra
+    for key in R4_TRAIN:
+        g = G4[key]
+        with ra.Context(n_envs=g["n_envs"], **g["config"]) as c:
+            c.reset()
+            a, b = g["steps"] // 3, g["steps"] - g["steps"] // 3
+            s1, s2 = c.train(a), c.train(b)
+            st = {k: s1[k] + s2[k] for k in ("episodes", "episodes_truncated")}
+            aux = c.get_td_weights if g["config"]["algo"] == 6 else c.get_traces
+            _check_r04(g, c.states.T, c.actions.tolist(), c.get_weights, aux, lambda: c.epsilons, st)
+    g = G4["rollout_policy"]
+    with ra.Context(n_envs=g["n_envs"], **g["config"]) as c:
+        c.reset(); c.train(g["steps"])
+
+        def call(policy, limit, kw, k):
+            r = c.rollout_policy(policy, limit, **kw)            # (the ctx numbers its sampling rollouts itself: 0, 1, 2)
+            return r["n_states"], r["total_reward"], r["actions"]
+        _check_rollouts(g, call)
