@@ -85,19 +85,23 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restric
                                                        uint32_t* __restrict__ err, uint64_t timeout) {
     extern __shared__ long long scatter_slice[];
     const int t = blockIdx.y;
-    for (int j = threadIdx.x; j < S; j += blockDim.x) scatter_slice[j] = 0;
-    __syncthreads();
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = keys + (int64_t)t * N;
-    for (int64_t ib = i0; ib < i1; ib += 8 * (int64_t)blockDim.x) {      // eight learners per thread, their loads in flight together
-        float sc[8]; uint16_t kk[8];
+    float sc[8]; uint16_t kk[8];
+    auto fetch = [&](int64_t ib) {                                       // eight learners per thread, their loads in flight together
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t i = ib + e * (int64_t)blockDim.x + threadIdx.x;
             sc[e] = i < i1 ? terms[i] : 0.0f;
             kk[e] = i < i1 ? kt[i] : (uint16_t)0;
         }
+    };
+    fetch(i0);                                                           // the first (usually the only) batch is on its way while the slice is cleared
+    for (int j = threadIdx.x; j < S; j += blockDim.x) scatter_slice[j] = 0;
+    __syncthreads();
+    for (int64_t ib = i0; ib < i1; ib += 8 * (int64_t)blockDim.x) {
+        if (ib != i0) fetch(ib);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned long long q = fx_quantise(sc[e], inv_lsb);      // the learner's term as ONE integer, the same for all its tilings
