@@ -134,6 +134,7 @@ def _declare(L):
         g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
         g("orc_run_reset").argtypes = [C.c_void_p]
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_teacher").argtypes = [C.c_void_p, C.POINTER(Stats), Rp, C.POINTER(C.c_int32), Rp, Rp, C.POINTER(C.c_uint8), Rp]
         g("orc_run_eps").restype = Rp
         g("orc_run_eps").argtypes = [C.c_void_p]
         g("orc_handle_lambda").restype = R
@@ -461,6 +462,20 @@ class Run:
         st = Stats()
         self._f("orc_run_train")(self._h, int(n_steps), C.byref(st))
         return st.as_dict()
+
+    def teacher_step(self):
+        """ONE batch-step of train() as a teacher: successor states rounded to fp32, the handled transitions returned ->
+        dict(from (N, D), action (N,), reward (N,), to (N, D), terminal (N,) uint8, td (N,), stats).  Replayed through the device's
+        Handler::handle (its k-th call draws what this run's k-th batch-step drew) both sides learn from identical inputs."""
+        st = Stats()
+        out = dict(frm=np.empty((self.n, self.D), dtype=self._dt), action=np.empty(self.n, dtype=np.int32),
+                   reward=np.empty(self.n, dtype=self._dt), to=np.empty((self.n, self.D), dtype=self._dt),
+                   terminal=np.empty(self.n, dtype=np.uint8), td=np.empty(self.n, dtype=self._dt))
+        self._f("orc_run_teacher")(self._h, C.byref(st), _ptr(out["frm"], self._ct), out["action"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                   _ptr(out["reward"], self._ct), _ptr(out["to"], self._ct),
+                                   out["terminal"].ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(out["td"], self._ct))
+        out["stats"] = st.as_dict()
+        return out
 
     def train_fast(self, n_steps):
         """Same results as train() with the repeated projections / heap traffic of the reference's call pattern removed

@@ -775,6 +775,11 @@ typedef struct {
                       * episode when the agent carries a schedule (orc_agent.eps_decay) */
     R* qc;           /* [N][A] Q(s,.) of the current state carried between orc_run_train_dev calls (the device's qcache) */
     int q_valid;     /* 0: qc is stale -> recompute from W at the next orc_run_train_dev call */
+    /* teacher forcing (orc_run_teacher): when round32 is set every successor state is rounded to fp32 before anything uses it, so the
+     * transitions this run handles are fp32-representable and can be replayed, value for value, through the device's
+     * Handler::handle; tape_* (may be NULL) receive the batch-step's transitions as the agent saw them */
+    int round32;
+    R* tape_from; int32_t* tape_act; R* tape_rew; R* tape_to; uint8_t* tape_term; R* tape_td;
 } FN(orc_run);
 
 static R* FN(run_W)(FN(orc_run)* run, int64_t i) {
@@ -901,6 +906,11 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             memcpy(ns, s, sizeof(R) * D);
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);              /* Domain::transition lib.rs:436-446 */
             term_all[i] = (uint8_t)term;
+            if (run->round32) { int d; for (d = 0; d < D; d++) ns[d] = (R)(float)ns[d]; }
+            if (run->tape_from) {
+                memcpy(run->tape_from + (size_t)i * D, s, sizeof(R) * D); memcpy(run->tape_to + (size_t)i * D, ns, sizeof(R) * D);
+                run->tape_act[i] = a; run->tape_rew[i] = r; run->tape_term[i] = (uint8_t)term;
+            }
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xi);
             if (ORC_IS_PRED(ag->algo)) {
                 delta = FN(orc_handle_td)(ag, FN(run_W)(run, i), run->Z ? run->Z + (size_t)i * F : NULL, s, r, ns, term);
@@ -925,6 +935,7 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
             }
             acc.sum_abs_td_error += fabs((double)delta);
             acc.sum_reward += (double)r;
+            if (run->tape_td) run->tape_td[i] = delta;
         }
         if (fixed) { int j; for (j = 0; j < F * A; j++) dW[j] = (R)((float)qacc[j] * lsb_f); }
         if (dW && dw_hook) dw_hook(dW, F * A, user);
@@ -957,6 +968,20 @@ void FN(orc_run_train_hook)(void* h, int64_t n_steps, orc_stats* st, void (*dw_h
 }
 
 void FN(orc_run_train)(void* h, int64_t n_steps, orc_stats* st) { FN(orc_run_train_hook)(h, n_steps, st, NULL, NULL); }
+
+/* ONE batch-step of orc_run_train as a TEACHER: successor states are rounded to fp32 (the reset states are fp32-exact), and the
+ * transitions the agents handled -- from [N][D], action, reward, to [N][D], terminal flag -- and their TD errors are written out.
+ * A test replays them through the device's rsrl_hip_handle (whose k-th call uses the same agent-side draws as this run's k-th
+ * batch-step) and compares weights: both sides have then learned from identical fp32-representable inputs, which is the
+ * "teacher-forced" comparison of SURVEY 8(d).  The run's own arithmetic stays R throughout. */
+void FN(orc_run_teacher)(void* h, orc_stats* st, R* from, int32_t* act, R* rew, R* to, uint8_t* term, R* td) {
+    FN(orc_run)* run = (FN(orc_run)*)h;
+    run->round32 = 1;
+    run->tape_from = from; run->tape_act = act; run->tape_rew = rew; run->tape_to = to; run->tape_term = term; run->tape_td = td;
+    FN(orc_run_train_hook)(h, 1, st, NULL, NULL);
+    run->tape_from = NULL; run->tape_act = NULL; run->tape_rew = NULL; run->tape_to = NULL; run->tape_term = NULL; run->tape_td = NULL;
+    run->round32 = 0;
+}
 
 /* The same driver loop with the work the reference repeats removed -- phi(s) and Q(s,.) carried over from the previous
  * step, phi(s') projected once, no heap traffic, learners walked one after the other (they are independent): the
