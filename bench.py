@@ -161,6 +161,15 @@ def parity_sample(m=2048):
     spec.loader.exec_module(mod)
     out = mod.measure(m)
     out["sample"] = f"{m} uniformly random in-range states per quantity, device (fp32) vs oracle f64"
+    # every BASELINE.json configuration against the f64 oracle: teacher-forced learning (identical fp32-representable inputs), bf16 + SR vs fp32
+    # weights vs f64, free-running population statistics -- a shortened live sample of what tests/test_gpu_parity_f64.py asserts at full
+    # length (profiles/r05_parity_configs.json: the full-length worst cases)
+    try:
+        out["configs"] = mod.measure_configs(scale=0.25)
+        out["configs"]["sample"] = ("a quarter of the asserted lengths: 250 teacher-forced steps (configs[4]: 50), 500 free-running steps; "
+                                    "keys as in scripts/measure_parity.py")
+    except Exception as e:      # noqa: BLE001
+        out["configs"] = {"error": repr(e)}
     return out
 
 
@@ -504,7 +513,7 @@ def main():
         finally:
             os.environ.pop("RSRL_NO_COALESCE", None)
     rollout = guarded(lambda: greedy_rollout_check(ctx), 120) if rank == 0 else None
-    parity = guarded(parity_sample, 120) if (rank == 0 and not args.no_cpu_baseline) else None
+    parity = guarded(parity_sample, 180) if (rank == 0 and not args.no_cpu_baseline) else None
     # secondary legs run under a watchdog: whatever happens to them, rank 0 still prints the headline line
     streaming = guarded(lambda: streaming_leg(rsrl_amd, args.envs, rank, device), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg) else None

@@ -1,0 +1,82 @@
+"""Every BASELINE.json configuration held to the f64 oracle (the REFERENCE's precision) on the GPU -- not only C2.
+
+The bitwise suites compare the HIP path with `f32d`, an oracle instantiation that restates the device's own polynomials and evaluation
+order; this file is the link to the reference's arithmetic itself (scripts/measure_parity.py: teacher_forced / free_running; the measured
+worst cases are committed as profiles/r05_parity_configs.json and bench.py prints a live sample as `parity.configs`):
+
+* teacher-forced: the f64 oracle runs the configuration's driver loop with successor states rounded to fp32 and hands every batch-step's
+  transitions to rsrl_hip_handle, so device and oracle learn from IDENTICAL inputs for K steps ("teacher-forced 1 000 steps --
+  max|dW| <= 1e-3 max(1, max|W|)"; asserted here ~1000x tighter, and relative to max|W| itself).
+* bf16 (configs[4]): the same tape through bf16+SR weights and fp32 weights: max|W_bf16 - W_f32| <= sqrt(K) 2^-8 max|W| (K unbiased roundings of
+  at most one bf16 ulp: a random walk; measured 0.4-0.55 of it), Q and TD errors against f64 bounded beside it.
+* free-running population statistics over 2 000 steps (episodes, sum|delta|, sum of rewards) within a stated % of the f64 oracle.
+
+Bounds are ~2-3x the measured worst case (the runs are deterministic: same seed, same bits)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mp():
+    spec = importlib.util.spec_from_file_location("measure_parity", os.path.join(ROOT, "scripts", "measure_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# config -> (|d delta| / (1+|delta|), |dW| / max|W|, |dW| / max(1, max|W|), |dQ| / (1+|Q|)) after K teacher-forced steps, fp32 weights vs f64
+F32_BOUNDS = {
+    "c2": (5e-6, 3e-6, 1e-6, 3e-6),        # measured 1.7e-6, 8.4e-7, 2.4e-7, 7.4e-7   (1 000 steps, 256 learners)
+    "c3": (5e-7, 2e-6, 1e-8, 1e-8),        # measured 9.9e-8, 4.7e-7, 3.2e-9, 1.4e-9   (1 000 steps, 512 learners on one table: exact fixed-point sums)
+    "c4": (6e-6, 3e-6, 1e-6, 4e-6),        # measured 1.9e-6, 9.7e-7, 2.6e-7, 1.2e-6   (1 000 steps, 512 learners on one W)
+    "c5": (1e-4, 6e-6, 5e-7, 2e-5),        # measured 3.2e-5, 2.2e-6, 1.5e-7, 5.9e-6   (200 steps, lr 1e-3: past SGD's stability limit, errors feed back)
+    "c5s": (1e-5, 1.5e-6, 3e-8, 4e-6),     # measured 2.5e-6, 3.5e-7, 6.0e-9, 1.1e-6   (200 steps, lr 2.5e-4)
+}
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c5s"])
+def test_teacher_forced_vs_f64(mp, name):
+    r = mp.teacher_forced(name)
+    b = F32_BOUNDS[name]
+    f = r["f32"]
+    assert r["max_abs_w_f64"] > 1e-3                     # something was learned
+    assert f["td_max_rel"] <= b[0], f
+    assert f["w_rel_to_maxw"] <= b[1], f
+    assert f["w_rel_to_max1"] <= b[2] and f["w_rel_to_max1"] <= 1e-3, f       # SURVEY 8(d)'s contract is the 1e-3
+    assert f["q_max_rel"] <= b[3], f
+    if name in ("c5", "c5s"):
+        # ---- bf16 + stochastic rounding against fp32 weights on the same tape, and against the f64 oracle
+        x, bf = r["bf16_vs_f32"], r["bf16"]
+        assert 0 < x["w_max_abs"] <= x["model_bound_w"], x               # sqrt(K) 2^-8 max|W|; measured 0.55 (lr 1e-3) / 0.42 (lr 2.5e-4) of it
+        assert bf["w_rel_to_maxw"] <= (0.06 if name == "c5" else 0.05), bf     # measured 0.030 / 0.023 of max|W|
+        assert bf["q_max_rel"] <= (0.03 if name == "c5" else 5e-3), bf         # measured 9.8e-3 / 1.5e-3
+        assert bf["td_max_rel"] <= (0.15 if name == "c5" else 8e-3), bf        # measured 4.8e-2 / 2.6e-3
+
+
+# config -> bounds on the relative differences of (episodes, sum |delta|, sum of rewards), device vs f64 oracle, 2 000 free-running steps
+FREE_BOUNDS = {
+    "c2": (0.01, 1e-3, 0.01),              # measured 0, 1.9e-4, 0
+    "c3": (0.05, 0.08, 0.08),              # measured 2.1e-2, 3.2e-2, 3.3e-2  (CartPole: a flipped greedy action ends an episode earlier or later)
+    "c4": (0.01, 0.02, 0.01),              # measured 0, 7.4e-3, 0
+    "c5s": (0.02, 0.01, 0.005),            # measured 1.9e-3, 1.6e-3, 3.2e-4
+}
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5s"])
+def test_population_statistics_vs_f64(mp, name):
+    r = mp.free_running(name)
+    b = FREE_BOUNDS[name]
+    assert r["episodes_f64"] > 100
+    assert r["episodes_rel"] <= b[0] and r["sum_abs_td_rel"] <= b[1] and r["sum_reward_rel"] <= b[2], r
+
+
+def test_population_statistics_bf16_vs_f64(mp):
+    # configs[4]'s weight format: bf16 + stochastic rounding learns what the f64 reference learns, as a population
+    r = mp.free_running("c5s", bf16=True)
+    assert r["episodes_rel"] <= 0.10 and r["sum_abs_td_rel"] <= 0.01 and r["sum_reward_rel"] <= 0.01, r     # measured 4.6e-2, 2.6e-3, 1.7e-3
