@@ -69,6 +69,58 @@ def _profiles_json(name):
         return None
 
 
+_LIVE_DIGESTS = {}
+
+
+def profile_digest(kname, tables=("isa_mix.json", "pmc_traffic.json")):
+    """Do the committed per-kernel constants (profiles/isa_mix.json: flop per env-step; pmc_traffic.json: HBM bytes) belong to the binary this
+    process runs?  scripts/summarize_profile.py stamps every entry with the sha256 of the profiled kernel's machine code; this recomputes it from
+    the library bench.py loaded (rsrl_amd/_kdigest.py: every instantiation of the kernel template inside librsrl_hip.so's gfx950 code objects).
+    -> {"profile_digest_matches": bool, "kernel_code_sha256": live, "profiled_code_sha256": {table: stamped}}.  A kernel edit without a
+    re-profile flips the flag, and every fraction that multiplies a live rate by those constants is then printed as null."""
+    from rsrl_amd import _build, _kdigest
+    lib = os.environ.get("RSRL_HIP_LIB", _build.LIB_PATH)
+    if kname not in _LIVE_DIGESTS:
+        try:
+            _LIVE_DIGESTS[kname] = _kdigest.kernel_digests(lib, [kname])[kname]
+        except Exception:      # noqa: BLE001
+            _LIVE_DIGESTS[kname] = None
+    live, stamped = _LIVE_DIGESTS[kname], {}
+    for t in tables:
+        rec = (_profiles_json(t) or {}).get(kname)
+        rec = rec[0] if isinstance(rec, list) and rec else rec
+        stamped[t] = rec.get("code_sha256") if isinstance(rec, dict) else None
+    ok = live is not None and all(v == live for v in stamped.values())
+    return {"profile_digest_matches": bool(ok), "kernel_code_sha256": live, "profiled_code_sha256": stamped}
+
+
+def gate_on_profile(rl, kernels):
+    """stamp a roofline object with the digest check of its kernels; when the committed profile is not of this binary, every fraction derived from it
+    is withheld (null) and survives only under a name that says so"""
+    checks = {k: profile_digest(k) for k in kernels}
+    ok = all(c["profile_digest_matches"] for c in checks.values())
+    rl["profile_digest_matches"] = ok
+    rl["profile_digest"] = checks if len(checks) > 1 else next(iter(checks.values()))
+    if not ok:
+        stale = {}
+        for key in ("frac", "useful_frac"):
+            if rl.get(key) is not None:
+                stale[key] = rl[key]
+                rl[key] = None
+        for sub in ("hbm", "issue_slots"):
+            if isinstance(rl.get(sub), dict):
+                for key in ("frac", "frac_lower_bound"):
+                    if rl[sub].get(key) is not None:
+                        stale[f"{sub}.{key}"] = rl[sub][key]
+                        rl[sub][key] = None
+        if rl.get("traffic") is not None:
+            stale["traffic"] = rl["traffic"]
+            rl["traffic"] = None
+        rl["from_stale_profile"] = dict(stale, note="profiles/isa_mix.json / pmc_traffic.json were taken from OTHER machine code than this library's: "
+                                                    "re-run scripts/gpu_profile.sh + scripts/summarize_profile.py")
+    return rl
+
+
 def pmc_traffic(kernel, envs, steps_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), or None when no pass was collected for this
@@ -210,8 +262,11 @@ def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
         avg = ms * 1e-3 / max(1, n)
         ach = BYTES_PER_ENV_STEP * envs / avg
         working_set = envs * (432 + 8 + 4 + 4 + 12)
+        chk = profile_digest(kn, tables=("pmc_traffic.json",))
         return {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                "traffic": pmc_traffic(kn, envs, 1), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
+                "frac_what": "algorithmic bytes (608 B per env-step, SURVEY 8(d)) x live HIP-event rate / 8 TB/s: no profiled constant in it",
+                "profile_digest_matches": chk["profile_digest_matches"], "profile_digest": chk,
+                "traffic": pmc_traffic(kn, envs, 1) if chk["profile_digest_matches"] else None, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/pmc_traffic.json)",
                 "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * envs, "avg_launch_ms": avg * 1e3, "launches": n,
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP, "learners": envs, "working_set_bytes": working_set,
                 "resident_in": "HBM" if working_set > 256 * 2 ** 20 else ("Infinity Cache / L2 between launches" if working_set > 32 * 2 ** 20 else "L2 between launches"),
@@ -335,7 +390,7 @@ def leg_roofline(kname, per_gpu_steps_per_s, envs, avg_launch_s, launches, alg_b
         rl["hbm"] = {"achieved": bps / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bps / HBM_PEAK, "what": "REAL traffic (PMC) over the kernel's time"}
     rl["algorithmic_bytes_equivalent"] = {"bytes_per_env_step": alg_bytes_per_env_step, "equivalent_GBps": alg_bytes_per_env_step * per_gpu_steps_per_s / 1e9,
                                           "note": "SURVEY 8(d)'s algorithmic bytes x rate: NOT moved bytes and not a roofline fraction"}
-    return rl
+    return gate_on_profile(rl, [kname] + list(also))
 
 
 def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
@@ -358,7 +413,11 @@ def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
     ub_cyc = sum(mix[k] * ub[k] for k in ub)
     ub_peak = N_SIMD * 64 * CLOCK_HZ / ub_cyc
     tf = flop * per_gpu_steps_per_s / 1e12
+    useful = mix.get("useful_flop_per_env_step", flop - 4.0 * mix.get("pk_fma_masked_zero", 36.0))
     return {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK,
+            "useful_frac": useful * per_gpu_steps_per_s / FP32_VECTOR_PEAK, "useful_flop_per_env_step": useful,
+            "useful_what": "frac counts EXECUTED flop; useful_frac leaves out the masked column update's multiplies by zero (36 packed fmas per env-step: the action "
+                           "is per lane, registers cannot be indexed by a lane value -- DESIGN 4.1)",
             "flop_per_env_step": flop, "env_steps_per_s_per_gpu": per_gpu_steps_per_s,
             "issue_slots": {"valu_instr_per_env_step": n_valu, "packed": mix["pk"], "cycles_per_env_step_at_spec_rates": spec_cyc,
                             "peak_env_steps_per_s": spec_peak, "frac": per_gpu_steps_per_s / spec_peak,
@@ -595,6 +654,7 @@ def main():
             if traffic and avg_launch_s > 0:
                 rl["hbm"] = {"achieved": traffic / avg_launch_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": traffic / avg_launch_s / HBM_PEAK, "what": "REAL traffic of the launch / its duration"}
+            gate_on_profile(rl, [kname])
             rl["streaming_formulation_equivalent"] = {
                 "algorithmic_bytes_per_env_step": BYTES_PER_ENV_STEP,
                 "equivalent_GBps": BYTES_PER_ENV_STEP * per_gpu_kernel_rate / 1e9,

@@ -32,7 +32,10 @@ LEG_KERNELS = {
 # static counts of the executed path of k_train_reg's steady-state loop (scripts/isa_stats.py on train_reg_d0b.hip): v_pk_fma_f32 314 per
 # pair of steps; v_pk_mul_f32 42 + v_pk_add_f32 4; v_cndmask_b32 30 (after the assembly post-pass of rsrl_amd/_asmfilter.py: 719 instructions per
 # pair of steps, 26 of them scalar)
-K_TRAIN_REG_STATIC = {"pk_fma": 157.0, "pk_other": 23.0, "cndmask": 15.0}
+K_TRAIN_REG_STATIC = {"pk_fma": 157.0, "pk_other": 23.0, "cndmask": 15.0,
+                      # of the 54 packed fmas of the column update only the taken action's 18 change a weight: the other 36 multiply by zero because
+                      # the action is per lane and registers cannot be indexed by a lane value -- executed, not useful
+                      "pk_fma_masked_zero": 36.0}
 
 
 def first_json(path):
@@ -171,6 +174,13 @@ def main():
                 mix[sub] = e
         # (k_train_reg keeps its established fields below)
     json.dump(raw, open(os.path.join(P, f"{tag}_pmc_raw.json"), "w"), indent=1)
+    # the profile belongs to the BINARY it was taken from: the sha256 of every profiled kernel's machine code (all instantiations), computed on the
+    # GPU box from the library the profiled processes loaded (scripts/gpu_profile.sh -> kernel_digests.json; rsrl_amd/_kdigest.py).  bench.py prints a
+    # roofline fraction from these constants only while the library it loaded carries the same code (`profile_digest_matches`).
+    digests = first_json(os.path.join(G, "kernel_digests.json")) or {}
+    for table in (mix, traffic):
+        for k, e in table.items():
+            e["code_sha256"] = digests.get(k)
     old_traffic = json.load(open(tp)) if os.path.exists(tp) else {}
     if "k_train_reg" in traffic:                                    # keep the list form (entries per launch depth) bench.py reads
         keep = [x for x in old_traffic.get("k_train_reg", []) if isinstance(x, dict) and x.get("steps_per_launch") != traffic["k_train_reg"]["steps_per_launch"]]
@@ -196,6 +206,8 @@ def main():
         e = mix["k_train_reg"]
         known = e["pk_fma"] * 4 + (e["pk"] - e["pk_fma"]) * 2 + e["fp_fma"] * 2 + e["fp_other"]
         e["flop_per_env_step"] = known
+        e["useful_flop_per_env_step"] = known - 4.0 * K_TRAIN_REG_STATIC["pk_fma_masked_zero"]
+        e["useful_flop_how"] = "flop_per_env_step minus the masked column update's multiplies by zero (36 packed fmas x 4 flop)"
         e["flop_how"] = "static packed counts + class counters (the established k_train_reg accounting)"
         rawc = e.get("flops_counter_raw_per_env_step", 0.0)
         for cand, label in ((64.0, "per-lane flops per wave-instruction (x 64 lanes)"), (1.0, "flops of all lanes")):
