@@ -15,13 +15,33 @@ instruction is an ordinary VALU instruction (not v_readlane / v_readfirstlane / 
 reads a register the packed instruction wrote.  Every other wait state (VALU-writes-SGPR before VMEM or v_readlane, trans-op forwarding,
 s_nop with a larger count, ...) stays where the compiler put it.
 
-Safety net: the GPU tests compare every kernel family bit for bit with the oracle; a missed wait state would read a stale register and
-fail them (tests/test_gpu_*.py, 290 cases, all green with the pass on).  tests/test_abi_cpu.py checks the pass itself on CPU.
-RSRL_NOP_FILTER=0 builds without it (A/B)."""
+Where the rule lives (recalled from LLVM's AMDGPU backend; the image ships no LLVM sources or ISA manual to quote): GCNHazardRecognizer::
+checkVALUHazards, the `ST.hasDstSelForwardingHazard()` block -- "VALU writes vdst with dst_sel / op_sel[3], next VALU reads it: 1 wait state"
+-- decides "op_sel[3]" by `src0_modifiers & SISrcMods::DST_OP_SEL`; SIDefines.h has OP_SEL_1 = DST_OP_SEL = 1 << 3, and for a VOP3P instruction
+bit 3 of src0_modifiers is op_sel_hi[0].  gfx940/gfx950's "VALU write SGPR/VCC -> VMEM/v_readlane", trans-op and VMEM-store-data rules are
+other functions of the same recogniser and their wait states are not touched here.
+
+A wait state can also be the LAST slot of a longer hazard counted from an earlier instruction (a VMEM / FLAT store of more than 64 bits
+needs 2 wait states before a VALU overwrites its data registers; a VALU that wrote an SGPR / VCC, a trans op or a readlane a few slots back have
+their own counts).  So the `s_nop 0` is kept whenever one of the four compiler-emitted instructions before the packed producer is such an
+instruction (_LONG_HAZARD_SOURCE): the pass only removes a wait state that nothing but the forwarding rule can have asked for.
+
+Scope: rsrl_amd/_build.py applies the pass only to the translation units where its gain was measured (NOP_FILTER_SOURCES) and only under the
+`hipcc --version` it was validated with (anything else builds in one plain hipcc call).  Evidence that the hardware interlocks the pair:
+scripts/ubench/pk_forward.hip (tests/test_gpu_round5.py: 10^6 random producer -> consumer pairs back to back inside one asm statement, with and
+without the wait state, bit for bit), the GPU suites (every kernel family bitwise against the oracle with the pass on) and scripts/ab_bits.py.
+tests/test_abi_cpu.py checks the pass itself and the per-translation-unit removal counts on CPU.  RSRL_NOP_FILTER=0 builds without it (A/B)."""
 import re
 
 _PK = re.compile(r"v_pk_(?:fma|mul|add)_f32\s+v\[(\d+):(\d+)\]")
 _NOT_PLAIN = re.compile(r"v_(?:readlane|readfirstlane|writelane|div_fmas|permlane)")
+# instructions whose own hazards span more than one slot and could own the wait state: wide stores (data registers live for 2 wait states), VALU
+# that writes an SGPR / VCC / EXEC (compares, carries, readlanes, div_scale), transcendental ops, MFMA, any VALU whose destination is an SGPR / VCC / EXEC, scalar writes of exec
+_LONG_HAZARD_SOURCE = re.compile(
+    r"(?:global|flat|scratch|buffer)_store_(?:dwordx[34]|b96|b128)|buffer_atomic|global_atomic|flat_atomic|ds_(?:write|store)_b(?:96|128)|"
+    r"v_cmp|v_cmpx|v_readlane|v_readfirstlane|v_writelane|v_div_scale|v_add_co|v_sub_co|v_subrev_co|v_addc_co|v_subb_co|v_mad_u64_u32|v_mad_i64_i32|"
+    r"v_(?:exp|log|rcp|rsq|sqrt|sin|cos)_|v_mfma|v_smfmac|v_permlane|s_\S*saveexec|s_.*\bexec\b|v_\S+\s+(?:s\[?\d|vcc|exec)")
+LOOKBACK = 4
 
 
 def _is_instr(line):
@@ -49,6 +69,7 @@ def filter_asm(text):
     lines = text.split("\n")
     out, removed = [], 0
     prev = None            # the last instruction the COMPILER emitted (what its hazard recogniser counts from)
+    hist = []              # the instructions before `prev`, newest last (at most LOOKBACK; emptied at labels)
     asm_between = 0        # inline-asm instructions (;;#ASMSTART .. ;;#ASMEND) since `prev`: the recogniser does not count them as wait states
     in_app = False
     n = len(lines)
@@ -72,15 +93,20 @@ def filter_asm(text):
                 plain = nxt.startswith("v_") and not _NOT_PLAIN.match(nxt) and "dpp" not in nxt and "sdwa" not in nxt
                 # asm_between == 0: the false positive described above.  asm_between >= 1: an instruction the recogniser did not count
                 # already sits between producer and consumer -- the wait state is there whatever the rule is worth.
-                if plain and _reads(nxt, lo, hi):
+                if plain and _reads(nxt, lo, hi) and not any(_LONG_HAZARD_SOURCE.match(h) for h in hist[-LOOKBACK:]):
                     removed += 1
                     continue
         if _is_instr(line):
             if in_app:
                 asm_between += 1
+                hist.append(t)                                  # (an inline-asm instruction can be a hazard source like any other)
             else:
+                if prev is not None:
+                    hist.append(prev)
                 prev, asm_between = t, 0
+            del hist[:-LOOKBACK - 1]
         elif t.endswith(":") and not t.startswith(";"):
             prev, asm_between = None, 0                         # block boundary: the previous instruction is not known
+            hist = []
         out.append(line)
     return "\n".join(out), removed

@@ -57,7 +57,7 @@ def source_digest(extra_flags=()):
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
-    h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags), nop_filter_enabled())).encode())
+    h.update(repr((HIPCC_FLAGS, sorted(PER_SOURCE_FLAGS.items()), list(extra_flags), nop_filter_enabled(), NOP_FILTER_SOURCES)).encode())
     h.update(open(os.path.join(HERE, "_asmfilter.py"), "rb").read())
     h.update(hipcc_version().encode())
     return h.hexdigest()
@@ -85,10 +85,33 @@ def is_stale():
     return open(STAMP_PATH).read().strip() != source_digest()
 
 
+# The assembly post-pass is applied ONLY where its gain was measured (k_train_reg +1.0-1.3 %, k_train_wave +6 %, k_shared_persist
+# ~+10 %; the last two live in rsrl_hip.hip) and ONLY under the compiler whose hazard recogniser it was validated against: any other
+# `hipcc --version` compiles every source in one plain hipcc call (fail closed -- a new recogniser may place wait states for other reasons).
+NOP_FILTER_SOURCES = ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip", "rsrl_hip.hip")
+NOP_FILTER_VALIDATED_HIPCC = "roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5"     # substring of `hipcc --version` (AMD clang 22.0.0git)
+NOP_COUNTS_PATH = LIB_PATH.replace(".so", ".nop_filter.json")
+_warned_version = False
+
+
 def nop_filter_enabled():
     """the assembly post-pass of _asmfilter.py (drops the compiler's false-positive wait states behind packed fp32 instructions);
-    RSRL_NOP_FILTER=0 compiles every source in one hipcc call instead (A/B)"""
-    return os.environ.get("RSRL_NOP_FILTER", "1") != "0"
+    RSRL_NOP_FILTER=0, or a compiler other than the validated one, compiles every source in one hipcc call instead"""
+    global _warned_version
+    if os.environ.get("RSRL_NOP_FILTER", "1") == "0":
+        return False
+    if NOP_FILTER_VALIDATED_HIPCC not in hipcc_version():
+        if not _warned_version:
+            import sys
+            print("rsrl_amd._build: this hipcc is not the one the assembly post-pass was validated with (" + NOP_FILTER_VALIDATED_HIPCC +
+                  "): building WITHOUT it", file=sys.stderr)
+            _warned_version = True
+        return False
+    return True
+
+
+def nop_filter_applies(src):
+    return nop_filter_enabled() and os.path.basename(src) in NOP_FILTER_SOURCES
 
 
 def _tool(name):
@@ -106,9 +129,9 @@ def _compile_one(args):
     flags = [f for f in HIPCC_FLAGS if f != "-shared" and not (f == "-fno-slp-vectorize" and "-fslp-vectorize" in extra)]
     per_src = [] if any("amdgpu-sched-strategy" in e for e in extra) else PER_SOURCE_FLAGS.get(os.path.basename(src), [])
     base = [hipcc()] + flags + per_src + list(extra)
-    if not nop_filter_enabled():
+    if not nop_filter_applies(src):
         _run(base + ["-c", src, "-o", obj], verbose)
-        return obj
+        return obj, None
     # hipcc's own steps, taken apart so that the device assembly can be filtered in between:
     #   device: .hip -> .s (clang) -> filtered .s -> .o (assembler) -> code object (lld) -> fat binary (clang-offload-bundler)
     #   host  : .hip -> .o with the fat binary embedded
@@ -120,7 +143,7 @@ def _compile_one(args):
         import sys
         print(f"rsrl_amd._build: assembly post-pass unavailable for {os.path.basename(src)} ({e}); compiling it in one hipcc call", file=sys.stderr)
         _run(base + ["-c", src, "-o", obj], verbose)
-        return obj
+        return obj, None
 
 
 def _compile_filtered(base, src, obj, verbose):
@@ -142,7 +165,7 @@ def _compile_filtered(base, src, obj, verbose):
                  "-c", src, "-o", obj], verbose)
     for tmp in (asm, dev_o, code, fatbin):
         os.remove(tmp)
-    return obj
+    return obj, removed
 
 
 def build(force=False, verbose=False, out=None, extra_flags=()):
@@ -162,7 +185,8 @@ def _build_to(lib_path, extra_flags, verbose):
     os.makedirs(obj_dir, exist_ok=True)
     jobs = [(s, os.path.join(obj_dir, os.path.basename(s) + ".o"), verbose, extra_flags) for s in sources()]
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        objs = list(ex.map(_compile_one, jobs))
+        results = list(ex.map(_compile_one, jobs))
+    objs = [r[0] for r in results]
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-L/opt/rocm/lib", "-lrccl", "-o", lib_path]
     if verbose:
         print(" ".join(cmd))
@@ -170,10 +194,29 @@ def _build_to(lib_path, extra_flags, verbose):
     if os.path.abspath(lib_path) == os.path.abspath(LIB_PATH):
         with open(STAMP_PATH, "w") as f:
             f.write(source_digest() + "\n")
+        # how many wait states the post-pass removed per translation unit (null = compiled in one plain hipcc call): tests/test_abi_cpu.py
+        # holds the expected counts, so a toolchain or source change that moves them is noticed
+        import json
+        with open(NOP_COUNTS_PATH, "w") as f:
+            json.dump({os.path.basename(j[0]): r[1] for j, r in zip(jobs, results)}, f, indent=1, sort_keys=True)
+            f.write("\n")
     else:
         import shutil
         shutil.rmtree(obj_dir, ignore_errors=True)      # an A/B variant's objects are of no further use (16 MB each in every gpurun snapshot)
     return lib_path
+
+
+PK_FORWARD_SRC = os.path.join(os.path.dirname(HERE), "scripts", "ubench", "pk_forward.hip")
+PK_FORWARD_BIN = PK_FORWARD_SRC[:-4]
+
+
+def build_pk_forward(force=False):
+    """scripts/ubench/pk_forward: the micro-test behind the assembly post-pass (does the hardware interlock a packed-fp32 producer and its
+    next-slot consumer?), run by tests/test_gpu_round5.py.  Built in-tree so that it travels to the GPU box."""
+    if not force and os.path.exists(PK_FORWARD_BIN) and os.path.getmtime(PK_FORWARD_BIN) >= os.path.getmtime(PK_FORWARD_SRC):
+        return PK_FORWARD_BIN
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-Wno-unused-command-line-argument", "-o", PK_FORWARD_BIN, PK_FORWARD_SRC])
+    return PK_FORWARD_BIN
 
 
 if __name__ == "__main__":

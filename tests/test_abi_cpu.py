@@ -160,3 +160,55 @@ def test_asm_filter_removes_only_the_packed_fp32_wait_states():
     # every instruction but the removed wait states is still there, in order
     assert [ln for ln in src.split("\n") if ln.strip() != "s_nop 0"] == [ln for ln in out.split("\n") if ln.strip() != "s_nop 0"]
     assert _asmfilter.filter_asm(out) == (out, 0)                  # idempotent
+
+
+def test_asm_filter_keeps_a_wait_state_that_may_belong_to_an_earlier_instruction():
+    # one wait state can be the LAST slot of a longer hazard counted from an instruction before the packed producer (a wide store whose data
+    # registers the consumer overwrites, a VALU that wrote an SGPR / VCC, a trans op, an MFMA): within four slots of such an instruction nothing is removed
+    from rsrl_amd import _asmfilter
+
+    def case(before, n_between=0):
+        src = "\n".join(["k:"] + ["\t" + b for b in before] + ["\tv_mul_f32_e32 v9, v8, v8"] * n_between +
+                        ["\tv_pk_fma_f32 v[10:11], v[0:1], v[2:3], v[4:5]", "\ts_nop 0", "\tv_mul_f32_e32 v0, v10, v6"])
+        return _asmfilter.filter_asm(src)[1]
+    assert case([]) == 1 and case(["v_fma_f32 v20, v21, v22, v23", "global_store_dwordx2 v30, v[0:1], s[0:1]"]) == 1
+    for hazard in ("global_store_dwordx4 v30, v[0:3], s[0:1]", "buffer_store_dwordx3 v[0:2], v30, s[0:3], 0 offen", "flat_store_dwordx4 v[30:31], v[0:3]",
+                   "v_cmp_lt_f32_e32 vcc, v1, v2", "v_cmp_gt_f32_e64 s[2:3], v1, v2", "v_readfirstlane_b32 s4, v1", "v_exp_f32_e32 v1, v2", "v_rcp_f32_e32 v1, v2",
+                   "v_mad_u64_u32 v[12:13], s[4:5], v2, v3, v[14:15]", "v_mfma_f32_4x4x1_16b_f32 v[0:3], v4, v5, v[0:3]", "s_and_saveexec_b64 s[0:1], vcc",
+                   "s_mov_b64 exec, s[0:1]", "v_add_co_u32_e32 v1, vcc, v2, v3", "v_div_scale_f32 v1, vcc, v2, v3, v4"):
+        for n in range(_asmfilter.LOOKBACK):
+            assert case([hazard], n) == 0, (hazard, n)
+        assert case([hazard], _asmfilter.LOOKBACK) == 1, hazard             # ... and beyond the window the rule applies again
+    # an inline-asm instruction counts as a possible source too
+    src = "\n".join(["k:", "\t;;#ASMSTART", "\tv_cmp_lt_f32_e32 vcc, v1, v2", "\t;;#ASMEND", "\tv_pk_mul_f32 v[10:11], v[0:1], v[2:3]", "\ts_nop 0", "\tv_add_f32_e32 v0, v10, v6"])
+    assert _asmfilter.filter_asm(src)[1] == 0
+
+
+def test_asm_filter_scope_and_counts():
+    # the pass runs on the translation units where it pays and only under the validated compiler; the per-unit removal counts of the shipped library
+    # are pinned, so a toolchain or source change that moves them is noticed (and re-validated on the GPU) rather than shipped silently
+    import json
+    from rsrl_amd import _build
+    assert set(_build.NOP_FILTER_SOURCES) == {"train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip", "rsrl_hip.hip"}
+    assert _build.nop_filter_applies("/x/train_reg_d0b.hip") == _build.nop_filter_enabled()
+    assert not _build.nop_filter_applies("/x/train_td.hip") and not _build.nop_filter_applies("/x/train_gq.hip")
+    if _build.hipcc_version() and _build.NOP_FILTER_VALIDATED_HIPCC in _build.hipcc_version() and os.environ.get("RSRL_NOP_FILTER", "1") != "0":
+        assert _build.nop_filter_enabled()
+    counts = json.load(open(_build.NOP_COUNTS_PATH))
+    assert set(counts) == {os.path.basename(s) for s in _build.sources()}
+    for name, n in counts.items():
+        assert (n is not None) == (name in _build.NOP_FILTER_SOURCES and _build.nop_filter_enabled()), name
+    if _build.nop_filter_enabled():
+        assert {k: v for k, v in counts.items() if v is not None} == EXPECTED_NOP_COUNTS, counts
+
+
+def test_asm_filter_fails_closed_on_an_unknown_compiler(monkeypatch):
+    from rsrl_amd import _build
+    monkeypatch.setattr(_build, "_HIPCC_VERSION", "AMD clang version 23.0.0git (roc-8.0.0 1 deadbeef)")
+    monkeypatch.setattr(_build, "_warned_version", True)
+    assert not _build.nop_filter_enabled() and not _build.nop_filter_applies("/x/train_reg_d0b.hip")
+
+
+# wait states removed per translation unit in the shipped build (rsrl_amd/lib/librsrl_hip.nop_filter.json, written by _build); re-validate on the GPU
+# (tests -m gpu, scripts/ab_bits.py) before changing these
+EXPECTED_NOP_COUNTS = {"rsrl_hip.hip": 848, "train_reg_d0a.hip": 534, "train_reg_d0b.hip": 315, "train_reg_d1.hip": 20, "train_reg_d2.hip": 22}
