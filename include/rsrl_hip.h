@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 6
+#define RSRL_HIP_ABI_VERSION 7
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -164,7 +164,12 @@ typedef struct {
                                     schedule step for step.  The agent's policy follows when it IS the behaviour policy object
                                     (agent_policy = -1, as in the example).  Needs policy = RSRL_EPSILON_GREEDY, per-learner weights and a
                                     fused driver loop: the one-step agents and SARSALambda / QLambda on a register-family Fourier basis,
-                                    or any one-step agent on tile coding / a generic Fourier order. */
+                                    or any one-step agent on tile coding / a generic Fourier order.
+                                    Precision: the per-learner field is fp32 and eps * decay is rounded to fp32 once per episode, where the
+                                    reference decays an f64 field: gen_bool's threshold (eps * 2^24, truncated) can differ from the f64
+                                    schedule's by a few units after many episodes (relative 6e-8 per episode at most; ~1e-4 of a threshold of
+                                    1.7e6 after 1 000 episodes) -- bit parity of the schedule is against the oracle's f32 instantiation, the f64
+                                    oracle is matched to that tolerance (tests/test_gpu_round4.py). */
     double   epsilon_min;        /* floor of the schedule (0 = none) */
 } rsrl_hip_config;
 /* size of the ABI 3 struct: the oldest layout rsrl_hip_create accepts */
@@ -294,7 +299,9 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v
  *              A ctx with config.epsilon_decay writes file version 4: everything above, then f32 eps[N], every learner's current
  *              epsilon (the schedule's state), so that a resumed run continues the schedule.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header
- * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run resumes bit-identically. */
+ * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run's LEARNING resumes bit-identically (weights, traces,
+ * backups, epsilons, step counter -- with the env states restored through rsrl_hip_set_states / _set_actions); the evaluation-rollout draw
+ * counter of rsrl_hip_rollout_policy is not part of the file (see there). */
 int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
 int rsrl_hip_load_weights(rsrl_hip_ctx* ctx, const char* path);
 /* same weights broadcast to every learner (per-env mode) */
@@ -326,7 +333,11 @@ int64_t rsrl_hip_pending_steps(const rsrl_hip_ctx* ctx);
 
 /* Domain::rollout with the closure s -> policy.mode(s) and Some(step_limit), + n_states
  *   rsrl_domains/src/lib.rs:448-479, :340; one fresh default env per learner, the ctx's
- *   training envs are untouched.  step_limit >= 1. */
+ *   training envs are untouched.  step_limit >= 1.
+ *   step_limit == 0 (all three rollout calls): Domain::rollout(.., None), lib.rs:469-476 -- no limit, the trajectory ends at the first
+ *   Terminal observation.  A device loop needs a bound, so config.max_episode_steps (> 0, else RSRL_HIP_EINVAL) caps it at that many
+ *   transitions: outputs are sized as for step_limit = max_episode_steps + 1, and a trajectory that terminates within the cap
+ *   (terminal_out = 1) is exactly the reference's unbounded one.  (ABI 7) */
 int rsrl_hip_rollout_greedy(rsrl_hip_ctx* ctx, int64_t step_limit,
                             uint32_t* n_states_out /*[N]*/, float* total_reward_out /*[N]*/);
 /* The same rollout for learners 0..M-1 with the Trajectory itself (rsrl_domains/src/lib.rs:334-409): every output but
@@ -344,7 +355,10 @@ int rsrl_hip_rollout_trajectory(rsrl_hip_ctx* ctx, int64_t step_limit, int64_t M
  * rsrl_policy over the ctx's Q function with its own parameters (epsilon for RSRL_EPSILON_GREEDY, tau for RSRL_SOFTMAX; the ctx's
  * behaviour policy is not touched).  Outputs as rsrl_hip_rollout_trajectory (every one but n_states_out optional).  The draws
  * are a stream of their own, addressed by (number of rollout_policy calls made on the ctx so far, action selection k, global
- * learner id): a call is reproducible, successive calls are independent samples. */
+ * learner id): a call is reproducible, successive calls are independent samples.  The call counter belongs to the ctx OBJECT: it starts
+ * at 0 when the ctx is created and is neither saved by rsrl_hip_save_weights nor changed by rsrl_hip_load_weights / rsrl_hip_reset -- the n-th
+ * evaluation rollout of a process that restored a checkpoint draws what the n-th rollout of any fresh ctx draws (training draws are keyed by
+ * the checkpointed step counter; evaluation draws are not part of the learning state). */
 int rsrl_hip_rollout_policy(rsrl_hip_ctx* ctx, int policy, double epsilon, double tau, int64_t step_limit, int64_t M,
                             uint32_t* n_states_out, float* total_reward_out, float* states_out, int32_t* actions_out,
                             float* rewards_out, uint8_t* terminal_out);
@@ -384,6 +398,11 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* ctx, int world_size, uint8_t* handle_out 
 /* 1 if `device` can read and write `peer_device`'s memory directly (hipDeviceCanAccessPeer; a device can always access itself), 0 if not,
  * a negative status on error: what a host needs to choose RSRL_EXCHANGE_PEER for its ranks (every pair must say 1) */
 int rsrl_hip_can_access_peer(int device, int peer_device);
+/* Which PHYSICAL device is ordinal `device` of this process: PCI domain << 32 | bus << 16 | device (bit 63 set), the same number in every
+ * process of a node whatever HIP_VISIBLE_DEVICES it runs under.  With the host's identity it is what a multi-process launcher all-gathers to
+ * decide RSRL_EXCHANGE_AUTO the same way on every rank: the peer exchange only if all ranks share ONE host and every rank sees, and can access,
+ * every other rank's device (rsrl_amd/distributed.py: choose_exchange); RCCL otherwise.  (ABI 7) */
+int rsrl_hip_device_identity(int device, uint64_t* identity_out);
 int rsrl_hip_peer_connect(rsrl_hip_ctx* ctx, const uint8_t* handles /*[world_size][128]*/, int world_size, int rank);
 
 /* All ranks in ONE process (a single-threaded host, like the reference's Rc<RefCell> owner graph, rsrl/src/core.rs:13-15):

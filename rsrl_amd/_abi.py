@@ -88,6 +88,7 @@ SYMBOLS = {
     "rsrl_hip_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_peer_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "rsrl_hip_can_access_peer": (C.c_int, [C.c_int, C.c_int]),
+    "rsrl_hip_device_identity": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "rsrl_hip_peer_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "rsrl_hip_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "rsrl_hip_group_train": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64]),

@@ -43,6 +43,14 @@ def can_access_peer(device, peer_device):
     return rc == 1
 
 
+def device_identity(device):
+    """which PHYSICAL device ordinal `device` is (PCI domain : bus : device): the same number in every process of the node, whatever
+    HIP_VISIBLE_DEVICES each runs under"""
+    out = C.c_uint64()
+    _abi.check(_abi.lib().rsrl_hip_device_identity(int(device), C.byref(out)))
+    return int(out.value)
+
+
 def device_count():
     """visible HIP devices (raises RsrlHipError when the runtime finds none)"""
     n = _abi.lib().rsrl_hip_device_count()
@@ -309,21 +317,26 @@ class Context:
         """batch-steps accepted by train() but not enqueued yet (launch coalescing on a ctx-owned stream)"""
         return int(self._L.rsrl_hip_pending_steps(self._h))
 
+    def _rollout_rows(self, step_limit):
+        """rows of a rollout's state output: step_limit, or -- step_limit 0 / None = Domain::rollout(.., None), bounded by the ctx's
+        max_episode_steps -- max_episode_steps + 1"""
+        return int(step_limit) if step_limit else int(self.cfg.max_episode_steps) + 1
+
     def rollout_greedy(self, step_limit):
         n_states = np.empty(self.N, dtype=np.uint32)
         tot = np.empty(self.N, dtype=np.float32)
-        _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit), _p(n_states), _p(tot)))
+        _abi.check(self._L.rsrl_hip_rollout_greedy(self._h, int(step_limit or 0), _p(n_states), _p(tot)))
         return n_states, tot
 
     def rollout_trajectory(self, step_limit, M=None):
         """Domain::rollout with the Trajectory (lib.rs:334-409) of learners 0..M-1 -> dict(n_states, total_reward, states
         (step_limit, D, M), actions / rewards (step_limit - 1, M), terminal (M,)); rows past n_states are zero"""
         M = self.N if M is None else int(M)
-        L = int(step_limit)
+        L = self._rollout_rows(step_limit)
         out = dict(n_states=np.empty(M, dtype=np.uint32), total_reward=np.empty(M, dtype=np.float32),
                    states=np.zeros((L, self.D, M), dtype=np.float32), actions=np.zeros((max(L - 1, 0), M), dtype=np.int32),
                    rewards=np.zeros((max(L - 1, 0), M), dtype=np.float32), terminal=np.empty(M, dtype=np.uint8))
-        _abi.check(self._L.rsrl_hip_rollout_trajectory(self._h, L, M, _p(out["n_states"]), _p(out["total_reward"]), _p(out["states"]),
+        _abi.check(self._L.rsrl_hip_rollout_trajectory(self._h, int(step_limit or 0), M, _p(out["n_states"]), _p(out["total_reward"]), _p(out["states"]),
                                                        _p(out["actions"]) if L > 1 else None, _p(out["rewards"]) if L > 1 else None,
                                                        _p(out["terminal"])))
         return out
@@ -332,11 +345,11 @@ class Context:
         """Domain::rollout with the closure s -> policy.sample(rng, s) for ANY of the four policies over the ctx's Q function
         (lib.rs:448-479 takes any FnMut(&S) -> A) -> the same dict as rollout_trajectory"""
         M = self.N if M is None else int(M)
-        L = int(step_limit)
+        L = self._rollout_rows(step_limit)
         out = dict(n_states=np.empty(M, dtype=np.uint32), total_reward=np.empty(M, dtype=np.float32),
                    states=np.zeros((L, self.D, M), dtype=np.float32), actions=np.zeros((max(L - 1, 0), M), dtype=np.int32),
                    rewards=np.zeros((max(L - 1, 0), M), dtype=np.float32), terminal=np.empty(M, dtype=np.uint8))
-        _abi.check(self._L.rsrl_hip_rollout_policy(self._h, int(policy), float(epsilon), float(tau), L, M, _p(out["n_states"]),
+        _abi.check(self._L.rsrl_hip_rollout_policy(self._h, int(policy), float(epsilon), float(tau), int(step_limit or 0), M, _p(out["n_states"]),
                                                    _p(out["total_reward"]), _p(out["states"]), _p(out["actions"]) if L > 1 else None,
                                                    _p(out["rewards"]) if L > 1 else None, _p(out["terminal"])))
         return out

@@ -2160,7 +2160,14 @@ static int rollout_impl(rsrl_hip_ctx* c, int64_t step_limit, int64_t M, uint32_t
                         int32_t* actions_out, float* rewards_out, uint8_t* terminal_out, const RolloutPolicy& rp) {
     CHECK_CTX(c); FLUSH(c);
     if (!n_states_out) return fail(RSRL_HIP_EINVAL, "null argument");
-    if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1 (unbounded rollouts are not offered)");
+    if (step_limit == 0) {
+        // Domain::rollout(.., None) (rsrl_domains/src/lib.rs:469-476 collects until the first Terminal observation, without a limit).  A device
+        // loop needs a bound: the ctx's max_episode_steps, the same cap the driver loop truncates episodes at -- at most that many transitions,
+        // so a trajectory that terminates within the cap is exactly the reference's unbounded one
+        if (c->cfg.max_episode_steps == 0) return fail(RSRL_HIP_EINVAL, "step_limit 0 (no limit, Domain::rollout(.., None)) needs config.max_episode_steps > 0 as the bound");
+        step_limit = (int64_t)c->cfg.max_episode_steps + 1;
+    }
+    if (step_limit < 1) return fail(RSRL_HIP_EINVAL, "step_limit must be >= 1, or 0 for no limit (bounded by config.max_episode_steps)");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M, (long long)c->cfg.n_envs);
     if (is_pred(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "a prediction agent has a state-value function only: no action values to roll out with");
     if (!rp.sample && c->cfg.policy == RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "Random policy has no mode.");
@@ -2279,14 +2286,26 @@ int rsrl_hip_comm_init(rsrl_hip_ctx* c, const uint8_t* id_bytes, int world_size,
     memcpy(&id, id_bytes, sizeof(id));
     if (c->multi) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
     if (c->cfg.exchange == RSRL_EXCHANGE_PEER) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the peer exchange: use rsrl_hip_peer_export / _connect");
-    c->cfg.exchange = RSRL_EXCHANGE_RCCL;                              // (AUTO: attaching a communicator decides)
-    NCCL_TRY(ncclCommInitRank(&c->comm, world_size, id, rank));
-    c->world_size = world_size; c->rank = rank; c->multi = true;
+    // (AUTO: attaching a communicator decides -- but only once it IS attached: a failed attach leaves the ctx as configured, so that a host
+    // can still fall back to the other exchange)
+    {
+        const ncclResult_t nr = ncclCommInitRank(&c->comm, world_size, id, rank);
+        if (nr != ncclSuccess) { c->comm = nullptr; return fail(RSRL_HIP_ERCCL, "ncclCommInitRank: %s", ncclGetErrorString(nr)); }
+    }
     // warm-up: RCCL sets its connections up lazily, at the first collective -- which must not be the one inside the step graph's
     // stream capture.  dW is zero between operations, so all-reducing it leaves it zero; every rank makes this call (comm_init is
     // collective by nature).
-    NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    {
+        const ncclResult_t nr = ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream);
+        const hipError_t he = nr == ncclSuccess ? hipStreamSynchronize(c->stream) : hipSuccess;
+        if (nr != ncclSuccess || he != hipSuccess) {
+            (void)ncclCommAbort(c->comm); c->comm = nullptr; (void)hipGetLastError();
+            return nr != ncclSuccess ? fail(RSRL_HIP_ERCCL, "warm-up all-reduce: %s", ncclGetErrorString(nr))
+                                     : fail(RSRL_HIP_EHIP, "warm-up all-reduce: %s", hipGetErrorString(he));
+        }
+    }
+    c->cfg.exchange = RSRL_EXCHANGE_RCCL;
+    c->world_size = world_size; c->rank = rank; c->multi = true;
     return RSRL_HIP_OK;
 }
 
@@ -2322,7 +2341,6 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     if (c->cfg.weight_mode != RSRL_W_SHARED) return fail(RSRL_HIP_ESTATE, "per-env weights need no exchange: shard by env_offset instead");
     if (c->cfg.exchange == RSRL_EXCHANGE_RCCL) return fail(RSRL_HIP_ESTATE, "this ctx was configured for the RCCL exchange: use rsrl_hip_comm_init");
     if (c->multi || c->peer_recv) return fail(RSRL_HIP_ESTATE, "an exchange is already attached");
-    c->cfg.exchange = RSRL_EXCHANGE_PEER;                              // (AUTO: exporting a receive buffer decides)
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->peer_old_bytes = sizeof(uint2) * 2 * (size_t)world_size * c->dw_elems;
     // second region: the hop-2 buffer of the persistent kernel, [2 (parity)][world][A*F rounded up to even] granules
@@ -2331,18 +2349,37 @@ int rsrl_hip_peer_export(rsrl_hip_ctx* c, int world_size, uint8_t* handle_out) {
     // back to a plain allocation (same-device peers only need the system-scope accesses the kernels already use)
     hipError_t e = getenv("RSRL_PEER_COARSE") ? hipErrorNotSupported
                                              : hipExtMallocWithFlags((void**)&c->peer_recv, c->peer_recv_bytes, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc((void**)&c->peer_recv, c->peer_recv_bytes)); }
-    HIP_TRY(hipMemsetAsync(c->peer_recv, 0, c->peer_recv_bytes, c->stream));      // tag 0 never matches a batch-step (tags start at 1)
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->peer_world = world_size;
+    if (e != hipSuccess) { (void)hipGetLastError(); c->peer_recv = nullptr; e = hipMalloc((void**)&c->peer_recv, c->peer_recv_bytes); }
     PeerBlob b; memset(&b, 0, sizeof(b));
+    if (e == hipSuccess) e = hipMemsetAsync(c->peer_recv, 0, c->peer_recv_bytes, c->stream);      // tag 0 never matches a batch-step (tags start at 1)
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipIpcGetMemHandle(&b.h, c->peer_recv);
+    if (e != hipSuccess) {
+        // (AUTO: exporting a receive buffer decides -- but only once it HAS been exported: a failed export leaves the ctx as configured and
+        // without a receive buffer, so that a host can still attach the RCCL exchange)
+        (void)hipGetLastError();
+        if (c->peer_recv) { (void)hipFree(c->peer_recv); c->peer_recv = nullptr; }
+        c->peer_recv_bytes = 0; c->peer_old_bytes = 0;
+        return fail(e == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "exporting the receive buffer: %s", hipGetErrorString(e));
+    }
+    c->cfg.exchange = RSRL_EXCHANGE_PEER;
+    c->peer_world = world_size;
     b.magic = 0x52504552u; b.pid = (int32_t)getpid(); b.ptr = (uint64_t)(uintptr_t)c->peer_recv; b.bytes = c->peer_recv_bytes; b.world = world_size;
     b.sh_rows = c->sh_rows; b.dev_id = device_identity(c->cfg.device);
     b.budget_shared = persist_budget_shared(c);
     b.flags = persist_capable(c) ? 1u : 0u;                            // (RSRL_NO_PERSIST in this rank's environment included: it travels to the others)
-    HIP_TRY(hipIpcGetMemHandle(&b.h, c->peer_recv));
     memset(handle_out, 0, RSRL_HIP_PEER_HANDLE_BYTES);
     memcpy(handle_out, &b, sizeof(b));
+    return RSRL_HIP_OK;
+}
+/* identity of the physical device behind ordinal `device` -- PCI domain : bus : device, the same number in every process of the node whatever
+ * HIP_VISIBLE_DEVICES each of them runs under (ordinals are not) */
+int rsrl_hip_device_identity(int device, uint64_t* identity_out) {
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (!identity_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (device < 0 || device >= n) return fail(RSRL_HIP_EINVAL, "device out of range (%d devices)", n);
+    *identity_out = device_identity(device);
     return RSRL_HIP_OK;
 }
 int rsrl_hip_can_access_peer(int device, int peer_device) {

@@ -92,10 +92,47 @@ class ControlPlane:
             self._dist = None
 
 
+def host_identity():
+    """what tells two ranks they run on the SAME machine: the kernel's boot id (unique per boot, shared by every container of the host) plus
+    the hostname"""
+    import socket
+    try:
+        boot = open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        boot = ""
+    return f"{boot}:{socket.gethostname()}"
+
+
+def rank_topology(device, device_identity=None, device_count=None, can_access_peer=None):
+    """what one rank tells the others for the RSRL_EXCHANGE_AUTO decision: its host, the physical identity of its device, and which physical
+    devices it sees and can reach from its own (identity -> bool).  Ordinals mean nothing across processes (HIP_VISIBLE_DEVICES)."""
+    if device_identity is None:
+        from .context import can_access_peer, device_count, device_identity
+    n = device_count()
+    return {"host": host_identity(), "device": device_identity(device),
+            "reach": {device_identity(d): bool(can_access_peer(device, d)) for d in range(n)}}
+
+
+def choose_exchange(topologies):
+    """RSRL_EXCHANGE_AUTO, decided identically by every rank from the all-gathered rank_topology records (None = that rank could not tell):
+    the one-hop peer exchange (1) only if ALL ranks run on one host and every rank sees AND can access every other rank's physical device --
+    a rank on another node, a device hidden from a peer by HIP_VISIBLE_DEVICES, or a pair without peer access makes it RCCL (0), which
+    works on any topology."""
+    if not topologies or any(t is None for t in topologies):
+        return 0
+    if len({t["host"] for t in topologies}) != 1:
+        return 0
+    for t in topologies:
+        for o in topologies:
+            if not t["reach"].get(o["device"], False):
+                return 0
+    return 1
+
+
 def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=None, force_exchange=False, **cfg):
     """Create this rank's Context for its shard of `total_envs` environments.  In shared-weight mode with more
     than one rank the exchange of the weight delta is set up: exchange=EXCHANGE_AUTO (default) takes the one-hop peer
-    exchange whenever every rank's device reaches every other rank's memory and RCCL otherwise; EXCHANGE_PEER / _RCCL
+    exchange when all ranks share one host and every rank sees and can access every other rank's physical device (choose_exchange), RCCL otherwise; EXCHANGE_PEER / _RCCL
     force one.  force_exchange attaches it for a single rank too (a group of size 1 runs the same sequence: how the
     multi-rank path is exercised on a one-GPU box).
 
@@ -132,16 +169,16 @@ def make_sharded_context(total_envs, control, context_cls=None, unique_id_fn=Non
 
     if attach:
         exchange = cfg.get("exchange", 2)
-        if exchange == 2:                      # AUTO: the peer exchange whenever EVERY rank's device reaches every other rank's (decided by all
-            mine = False                       # ranks alike from the all-gathered devices), RCCL -- any topology -- otherwise
-            devs = control.all_gather_bytes(cfg["device"])
+        if exchange == 2:                      # AUTO: one decision from the all-gathered (host, physical device, reachable devices) of every rank
+            mine = None
             if err is None and context_cls.__name__ == "Context":
                 try:
-                    from .context import can_access_peer
-                    mine = all(can_access_peer(cfg["device"], d) for d in devs)
+                    mine = rank_topology(cfg["device"])
                 except Exception:      # noqa: BLE001
-                    mine = False
-            exchange = 1 if all(control.all_gather_bytes(bool(mine))) else 0
+                    mine = None
+            elif err is None:
+                mine = getattr(context_cls, "fake_topology", lambda d: None)(cfg["device"])
+            exchange = choose_exchange(control.all_gather_bytes(mine))
         together("creating the ctxs")
         if exchange == 1:                      # one-hop peer-write: all-gather the receive-buffer handles
             h = None

@@ -56,6 +56,28 @@ class PeerOk(FakeCtx):
 pc = make_sharded_context(64, cp, context_cls=PeerOk, weight_mode=1, exchange=1)
 out["peer_connected"] = [len(pc.connected[0]), pc.connected[1], pc.connected[0][1][0]]
 
+# EXCHANGE_AUTO is decided from (host, physical device, reachable devices) of every rank, not from local ordinals: a control plane that reports
+# two hosts -- or a device a peer cannot see -- must end up on RCCL; one host with full reach takes the peer exchange
+class TopoCtx(PeerOk):
+    topo = None
+    used = None
+    @staticmethod
+    def fake_topology(device): return TopoCtx.topo
+    def comm_init(self, uid, world, rank): TopoCtx.used = "rccl"
+    def peer_connect(self, handles, rank): TopoCtx.used = "peer"
+both = {100: True, 101: True}
+scen = {"two_hosts": {"host": "A" if cp.rank == 0 else "B", "device": 100, "reach": {100: True}},          # per-rank HIP_VISIBLE_DEVICES on 2 nodes: every rank "device 0"
+        "hidden_device": {"host": "A", "device": 100 + cp.rank, "reach": {100 + cp.rank: True}},          # one node, each rank sees only its own GPU
+        "no_peer_access": {"host": "A", "device": 100 + cp.rank, "reach": {100 + cp.rank: True, 101 - cp.rank: False}},
+        "one_rank_cannot_tell": ({"host": "A", "device": 100 + cp.rank, "reach": both} if cp.rank == 0 else None),
+        "one_host_full_reach": {"host": "A", "device": 100 + cp.rank, "reach": both},
+        "one_host_shared_device": {"host": "A", "device": 100, "reach": {100: True}}}
+out["auto"] = {}
+for name, topo in scen.items():
+    TopoCtx.topo, TopoCtx.used = topo, None
+    make_sharded_context(64, cp, context_cls=TopoCtx, weight_mode=1)
+    out["auto"][name] = TopoCtx.used
+
 # the sharding scheme, exercised with the oracle
 N, K = 24, 40
 off, cnt = shard_range(N, cp.world, cp.rank)
@@ -89,6 +111,21 @@ def test_shard_range_partitions_exactly():
         assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def test_choose_exchange_rules():
+    from rsrl_amd.distributed import choose_exchange, host_identity, rank_topology
+    t = lambda host, dev, reach: {"host": host, "device": dev, "reach": reach}       # noqa: E731
+    assert choose_exchange([t("h", 1, {1: True, 2: True}), t("h", 2, {1: True, 2: True})]) == 1
+    assert choose_exchange([t("h", 1, {1: True, 2: True}), t("g", 2, {1: True, 2: True})]) == 0      # two hosts
+    assert choose_exchange([t("h", 1, {1: True}), t("h", 2, {1: True, 2: True})]) == 0               # rank 0 does not see device 2
+    assert choose_exchange([t("h", 1, {1: True, 2: False}), t("h", 2, {1: True, 2: True})]) == 0     # ... or cannot access it
+    assert choose_exchange([t("h", 1, {1: True}), None]) == 0 and choose_exchange([]) == 0
+    assert choose_exchange([t("h", 1, {1: True})]) == 1                                              # a group of one
+    assert host_identity() == host_identity() and ":" in host_identity()
+    # rank_topology through injected device functions: 2 visible devices, the second unreachable
+    top = rank_topology(0, device_identity=lambda d: 1000 + d, device_count=lambda: 2, can_access_peer=lambda a, b: a == b)
+    assert top["device"] == 1000 and top["reach"] == {1000: True, 1001: False}
 
 
 def test_sharded_context_needs_one_env_per_rank():
@@ -133,6 +170,9 @@ def test_world2_gloo_sharding_and_control_plane(tmp_path, orc):
     for r in (0, 1):
         pass
     assert res[0]["shard"] == [0, 501, 0] and res[1]["shard"] == [501, 500, 1]
+    for r in (0, 1):                                               # the AUTO decision knows hosts and physical devices
+        assert res[r]["auto"] == {"two_hosts": "rccl", "hidden_device": "rccl", "no_peer_access": "rccl", "one_rank_cannot_tell": "rccl",
+                                  "one_host_full_reach": "peer", "one_host_shared_device": "peer"}, res[r]["auto"]
 
     # unsharded reference runs
     N, K = 24, 40

