@@ -331,6 +331,7 @@ def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=1310
             "value": envs_per_gpu * cp.world * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
             "exchange_world_size": comm_world, "exchange_kind": {0: "rccl", 1: "peer"}.get(comm_kind, "none"),
             "per_rank_env_steps_per_s": [envs_per_gpu * steps / max(1e-12, float(x)) for x in cp.all_gather_bytes(dt_own)],
+            "per_rank_kernel_us_per_batch_step": [float(x) for x in cp.all_gather_bytes(ms * 1e3 / max(1, steps))],
             "kernel": kn, "kernel_us_per_batch_step": ms * 1e3 / max(1, n_l),
             "roofline": leg_roofline(kn, envs_per_gpu * steps / max(1e-12, ms * 1e-3), envs_per_gpu,
                                      ms * 1e-3 if kn == "k_shared_persist" else ms * 1e-3 / max(1, n_l), 1 if kn == "k_shared_persist" else n_l, 32,
@@ -550,6 +551,16 @@ def main():
     order = sorted(range(len(regions)), key=lambda j: regions[j][0])
     dt = regions[order[len(order) // 2]][0]                    # the MEDIAN region
     own_rates = cp.all_gather_bytes(args.envs * args.steps * repeats / regions[order[len(order) // 2]][1])
+    # per rank, so that the first real multi-GPU run localises a slow rank: its own median region, its kernel time per batch-step by HIP events
+    # on its own stream, its device and which physical device that is
+    try:
+        dev_id = "%x" % rsrl_amd.device_identity(device)
+    except Exception:      # noqa: BLE001
+        dev_id = None
+    per_rank = cp.all_gather_bytes({"rank": rank, "local_rank": local_rank, "device": device, "device_identity": dev_id,
+                                    "kernel_us_per_batch_step": kernel_ms * 1e3 / max(1, args.steps * repeats * len(regions)),
+                                    "kernel_launches": launches, "regions_s": [r[1] for r in regions],
+                                    "env_steps_per_s": args.envs * args.steps * repeats / regions[order[len(order) // 2]][1]})
     # the same K-step driver call WITHOUT launch coalescing (one launch per call): what a single train(K) costs
     no_coalesce = None
     if not args.no_nocoalesce_leg and args.steps_per_launch != 1:
@@ -633,7 +644,7 @@ def main():
             "timed_region_s": dt, "regions_s": [r[0] for r in regions],
             "spread": (max(r[0] for r in regions) - min(r[0] for r in regions)) / dt,
             "timing": f"median of {len(regions)} regions, each {repeats} back-to-back calls of {args.steps} batch-steps between one barrier + synchronize pair",
-            "ranks_seen": world, "per_rank_env_steps_per_s": [float(x) for x in own_rates],
+            "ranks_seen": world, "per_rank_env_steps_per_s": [float(x) for x in own_rates], "per_rank": per_rank,
             "config": {"workload": f"{args.envs} vectorised MountainCar envs per GPU, QLearning + Fourier(5), "
                                    "eps-greedy(0.1), gamma 0.9, SGD(0.001), per-env W, 1xMI355X per rank "
                                    "(BASELINE.json configs[1])",

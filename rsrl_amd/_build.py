@@ -219,5 +219,20 @@ def build_pk_forward(force=False):
     return PK_FORWARD_BIN
 
 
+RCCL_STUB_SRC = os.path.join(os.path.dirname(HERE), "tests", "stubs", "rccl_stub.cpp")
+RCCL_STUB_LIB = os.path.join(os.path.dirname(RCCL_STUB_SRC), "librccl_stub.so")
+
+
+def build_rccl_stub(force=False):
+    """tests/stubs/librccl_stub.so: the TEST DOUBLE of the RCCL entry points (tests/test_gpu_rccl_stub.py LD_PRELOADs it to run the N > 1 RCCL
+    path on one device).  Host-only C++; built in-tree so that it travels to the GPU box.  Never loaded by the product."""
+    if not force and os.path.exists(RCCL_STUB_LIB) and os.path.getmtime(RCCL_STUB_LIB) >= os.path.getmtime(RCCL_STUB_SRC):
+        return RCCL_STUB_LIB
+    rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc())))
+    subprocess.check_call(["g++", "-shared", "-fPIC", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), RCCL_STUB_SRC,
+                           "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", RCCL_STUB_LIB])
+    return RCCL_STUB_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -2509,7 +2509,10 @@ int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         devs[(size_t)i] = ctxs[i]->cfg.device;
         for (int j = 0; j < i; ++j)
-            if (devs[(size_t)j] == devs[(size_t)i]) return fail(RSRL_HIP_EINVAL, "RCCL needs one device per rank: ctxs %d and %d share device %d (use RSRL_EXCHANGE_PEER)", j, i, devs[(size_t)i]);
+            // (RSRL_RCCL_ALLOW_SHARED_DEVICE=1: for a collectives library that admits ranks sharing a device -- the test double of
+            // tests/stubs/rccl_stub.cpp, which exercises this path on a one-GPU box; real RCCL would refuse in ncclCommInitAll)
+            if (devs[(size_t)j] == devs[(size_t)i] && !getenv("RSRL_RCCL_ALLOW_SHARED_DEVICE"))
+                return fail(RSRL_HIP_EINVAL, "RCCL needs one device per rank: ctxs %d and %d share device %d (use RSRL_EXCHANGE_PEER)", j, i, devs[(size_t)i]);
     }
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
     NCCL_TRY(ncclCommInitAll(comms.data(), n, devs.data()));

@@ -77,8 +77,9 @@ import os, sys, json, threading
 import numpy as np
 sys.path.insert(0, os.environ["RSRL_ROOT"])
 import rsrl_amd as ra
-G, N = 4, 4096
+G, N = int(os.environ["RSRL_G"]), int(os.environ["RSRL_N"])
 C4 = json.loads(os.environ["RSRL_KW"])
+from rsrl_amd.distributed import shard_range
 def _run(c, steps):
     c.reset()
     for k in steps:
@@ -86,7 +87,7 @@ def _run(c, steps):
     c.sync()
     return c.get_weights(), c.states, c.actions
 kw = dict(C4, lr=0.001 / N, exchange=ra.EXCHANGE_PEER)
-ctxs = [ra.Context(n_envs=N // G, env_offset=r * (N // G), **kw) for r in range(G)]
+ctxs = [ra.Context(n_envs=cnt, env_offset=off, **kw) for off, cnt in (shard_range(N, G, r) for r in range(G))]
 handles = [c.peer_export(G) for c in ctxs]
 for r, c in enumerate(ctxs):
     c.peer_connect(handles, r)
@@ -112,13 +113,16 @@ os._exit(0)
 '''
 
 
-def test_g_ranks_as_g_streams_on_one_device(ra, tmp_path):
-    # 4 ctxs = 4 ranks on ONE device in one process, one host thread each, peer-write exchange through same-process pointers.
+@pytest.mark.parametrize("G,N", [(4, 4096), (8, 4096), (8, 4000), (8, 8 * 512 + 77)])
+def test_g_ranks_as_g_streams_on_one_device(ra, tmp_path, G, N):
+    # G ctxs = G ranks on ONE device in one process, one host thread each, peer-write exchange through same-process pointers: the real world
+    # size of a node (8: hop-2 fans out to 8 receive buffers), shards that are not whole 512-learner blocks (4000 / 8 = 500) and a ragged split
+    # (4173 = 5 x 522 + 3 x 521).
     # A rank's waiting kernel must not sit in front of a peer's kernels in the same hardware queue, so the process gets more
     # hardware queues than ranks (GPU_MAX_HW_QUEUES, read by the HIP runtime at start-up: hence the subprocess).
     script = tmp_path / "gstreams.py"
     script.write_text(G_STREAMS)
-    env = dict(os.environ, RSRL_ROOT=ROOT, RSRL_KW=json.dumps(C4), GPU_MAX_HW_QUEUES="8")
+    env = dict(os.environ, RSRL_ROOT=ROOT, RSRL_KW=json.dumps(C4), GPU_MAX_HW_QUEUES=str(2 * G), RSRL_G=str(G), RSRL_N=str(N))
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
@@ -203,10 +207,11 @@ def test_two_processes_one_gpu_peer_exchange_over_hipipc(ra, tmp_path):
             p.kill()
             so, se = p.communicate()
         outs.append((p.returncode, so, se[-2000:]))
-    if any("timed out" in o[2] for o in outs):
+    if any("timed out" in o[2] for o in outs) and os.environ.get("RSRL_ALLOW_TIMESLICE_SKIP") == "1":
         # kernels of different PROCESSES did not run at the same time on this box's single GPU (exclusive time slicing): a
         # rank's bounded wait cannot overlap the peer's push.  That is a property of sharing ONE device, not of the exchange
         # (one process per GPU is the deployment); the in-process G-streams test above covers the exchange itself.
+        # An explicit opt-in only: by default a time-out FAILS below, so a regression cannot turn green by skipping.
         pytest.skip("processes are time-sliced exclusively on this GPU: " + repr([o[2][-200:] for o in outs]))
     for rc, so, se in outs:
         assert rc == 0, (so, se)
