@@ -393,6 +393,214 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// bf16 weights, TWO waves per SIMD (round 5): the weights stay PACKED in the registers
+// ---------------------------------------------------------------------------------------
+// k_train_wave keeps W as fp32 values: 192 VGPRs per lane, 411-432 registers with everything else, ONE wave per SIMD -- and > 80 % of its
+// ~1 720 issue slots per env-step are the learner's scalar work (RK4, two softmaxes, Philox, rounding) done 64-wide for one learner with nothing
+// to hide behind.  bf16 weights are bf16-representable by construction (every update is rounded), so the registers can hold them as they lie in
+// memory: two per dword, A x 32 = 96 VGPRs.  A pair is opened with two integer instructions where it is used (v_lshlrev_b32 16 / v_and_b32
+// 0xffff0000: exact) and closed with one v_perm_b32 after its update; the arithmetic between is the fp32 arithmetic of k_train_wave in the
+// same order -- every bit of W, Q, delta and the trajectory is unchanged (tests/test_gpu_bitwise.py, test_gpu_fullsize.py: still bitwise
+// against the oracle).  What that buys: <= 256 registers, so a SECOND wave is resident on every SIMD to issue into the first one's dependency
+// stalls -- and, so that eight waves fit a CU's 160 KiB of LDS, only phi(s) lives there (16 KiB per wave instead of 32): the update pass rebuilds each
+// chunk of phi(s') from 16 kept values (WaveFourierPk::Tail) and writes it over the chunk of phi(s) it has just consumed.
+struct WavePk {
+    // shift count and mask of open(), each pass's own OPAQUE scalars (an empty asm statement defines them): written as literals, the compiler
+    // recognises the pair opened in the projection pass as the one the update pass opens again and KEEPS the 192 opened halves alive between
+    // the two -- in scratch memory -- instead of spending the two integer instructions again
+    uint32_t sh, mask;
+    __device__ __forceinline__ WavePk() : sh(16u), mask(0xffff0000u) { asm volatile("" : "+s"(sh), "+s"(mask)); }
+    __device__ __forceinline__ f2 open(uint32_t w) const { return f2{__builtin_bit_cast(float, w << sh), __builtin_bit_cast(float, w & mask)}; }
+    // both halves already bf16-representable (low 16 bits zero): bytes 3:2 of each
+    // (scalar arguments on purpose: with an f2 argument, `bit_cast<uint32_t>(x.y)` of a vector assembled element by element came out of ROCm 7.2's
+    // clang as the LOW element -- v_perm_b32 v, lo, lo -- the same mis-extraction scripts/ubench/pk_forward.hip ran into with an f2 asm output)
+    __device__ static __forceinline__ uint32_t close(float lo, float hi) {
+        return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x07060302u);
+    }
+};
+
+template <int DOMAIN>
+struct WaveFourierPk : WaveFourier<DOMAIN> {
+    using Base = WaveFourier<DOMAIN>;
+    using typename Base::Stream;
+    static constexpr int D = Base::D, A = Base::A, F = Base::F;
+    // What of phi(s') survives from the projection to the update: per chunk j the complex product E0[j] * E1[c1] * E2[c2] of this lane (16 values) and
+    // the wave-uniform dimension-3 harmonics (scalar registers).  The chunk's 8 features are ONE more packed multiply + fma each from there
+    // (the tail of stream_chunk): the update pass recomputes them -- 8 packed instructions per chunk, bit for bit what the projection pass fed into
+    // the dot products -- instead of holding 64 feature values in registers (which spilled) or in a second LDS buffer (which does not fit eight waves).
+    struct Tail { float re[8], im[8]; f2 c3[4], s3[4]; };
+    __device__ static __forceinline__ void chunk_head(const Stream& st, int j, float& re_out, float& im_out) {
+        float re = st.c0[j], im = st.s0[j];
+        float nre = fmaf(-im, st.e1i, re * st.e1r), nim = fmaf(re, st.e1i, im * st.e1r);
+        re = nre; im = nim;
+        nre = fmaf(-im, st.e2i, re * st.e2r); nim = fmaf(re, st.e2i, im * st.e2r);
+        re_out = nre; im_out = nim;
+    }
+    __device__ static __forceinline__ void chunk_tail(const Tail& tl, int j, f2 (&phi)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) phi[p] = __builtin_elementwise_fma(splat2(-tl.im[j]), tl.s3[p], splat2(tl.re[j]) * tl.c3[p]);
+    }
+    // Q(s, b) for every action (wave-uniform) -- the sums of stream_project_q, term for term -- and the Tail of phi(s)
+    __device__ static __forceinline__ void project_q(const float (&s)[D], int lane, const uint32_t (&wp)[A][8][4], float (&q)[A], Tail& tl) {
+        Stream st;
+        Base::stream_begin(s, lane, st);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { tl.c3[p] = st.c3[p]; tl.s3[p] = st.s3[p]; }
+        f2 acc[A][2];
+        const WavePk pk;
+#pragma unroll
+        for (int b = 0; b < A; ++b) { acc[b][0] = splat2(0.0f); acc[b][1] = splat2(0.0f); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            chunk_head(st, j, tl.re[j], tl.im[j]);
+            f2 phi[4];
+            chunk_tail(tl, j, phi);
+#pragma unroll
+            for (int b = 0; b < A; ++b)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[b][p & 1] = __builtin_elementwise_fma(phi[p], pk.open(wp[b][j][p]), acc[b][p & 1]);
+            // a chunk is self-contained (24 opened halves, 12 packed fmas): the scheduler may not pull the next chunks' unpacking up in front of
+            // it -- hoisted, the opened pairs of several chunks are live at once
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = wave_sum_uniform((acc[b][0].x + acc[b][0].y) + (acc[b][1].x + acc[b][1].y));
+    }
+    // W[:,a] += scale * phi(s) (phi(s) read from the wave's LDS buffer P, chunk by chunk, each chunk then OVERWRITTEN with phi(s') -- next step's
+    // phi(s)), every updated weight rounded stochastically; returns Q(s',a) with the updated column (stream_update_q<bf16_t>, term for term)
+    __device__ static __forceinline__ float update_q(uint32_t (&wa)[8][4], float* __restrict__ P, const Tail& tn, float scale, const U4& rnd) {
+        f2 acc[2] = {splat2(0.0f), splat2(0.0f)};
+        const WavePk pk;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f2 ps[4], pn[4];
+            Base::lds_get(P, j, ps);
+            chunk_tail(tn, j, pn);
+            Base::lds_put(P, j, pn);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const f2 u = __builtin_elementwise_fma(splat2(scale), ps[p], pk.open(wa[j][p]));
+                const float x0 = round_bf16_sr(u.x, sr_bits(rnd, j * 8 + 2 * p));
+                const float x1 = round_bf16_sr(u.y, sr_bits(rnd, j * 8 + 2 * p + 1));
+                wa[j][p] = WavePk::close(x0, x1);
+                acc[p & 1] = __builtin_elementwise_fma(pn[p], f2{x0, x1}, acc[p & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return wave_sum_uniform((acc[0].x + acc[0].y) + (acc[1].x + acc[1].y));
+    }
+    __device__ static __forceinline__ void put_all(float* __restrict__ P, const Tail& tl) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f2 phi[4];
+            chunk_tail(tl, j, phi);
+            Base::lds_put(P, j, phi);
+        }
+    }
+};
+
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* __restrict__ Wbase, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
+    using WF = WaveFourierPk<DOMAIN>;
+    using Dom = Domain<DOMAIN>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t N = c.n_envs;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < N) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        bf16_t* Wi = Wbase + i * (int64_t)(A * F);
+        float s[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+        int a = __builtin_amdgcn_readfirstlane(c.action[i]);
+        uint32_t ep = c.ep_step[i];
+        uint32_t wp[A][8][4];                                                        // the lane's 8 x 8 weights of every action, two per register
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Wi) + (int64_t)b * F + j * 512 + lane * 8);
+                wp[b][j][0] = v.x; wp[b][j][1] = v.y; wp[b][j][2] = v.z; wp[b][j][3] = v.w;
+            }
+        // this wave's feature buffer in LDS, [chunk][lane][8]: phi of the CURRENT state; only this wave touches it (no barriers)
+        __shared__ __attribute__((aligned(16))) float sh_phi[kBlock / 64][8 * 64 * 8];
+        float* const P = &sh_phi[threadIdx.x >> 6][lane * 8];
+        float q_s[A];
+        {
+            typename WF::Tail t0;
+            WF::project_q(s, lane, wp, q_s, t0);
+            WF::put_all(P, t0);
+        }
+        float facc_abs = 0.0f, facc_r = 0.0f;
+        for (int k = 0; k < n_steps; ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) ns[d] = s[d];
+            float r;
+            bool term;
+            if constexpr (DOMAIN == 2) term = Dom::step_uniform(ns, a, r, lane);      // wave-uniform state: trigonometry across lanes
+            else term = Dom::step(ns, a, r);
+            ep += 1;
+            const bool trunc = !term && cap > 0 && ep >= cap;
+            if (term) Dom::reset(ns);
+            float q_n[A];
+            typename WF::Tail tn;
+            WF::project_q(ns, lane, wp, q_n, tn);
+            U4 xin = U4{0, 0, 0, 0};
+            if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+            float e;
+            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e, lane);
+            const float scale = c.alg.lr * e;
+            const U4 rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
+            float qa = 0.0f;
+            static_for<0, A>([&](auto Bb) {
+                constexpr int b = Bb;
+                if (a == b) qa = WF::update_q(wp[b], P, tn, scale, rnd);                // Q(s',a) with the UPDATED column; LDS now holds phi(s')
+            });
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            int na = policy_sample<A>(c.pol, q_n, x, lane);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                WF::project_q(ns, lane, wp, q_n, tn);
+                WF::put_all(P, tn);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(c.pol, q_n, xr, lane);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+            a = __builtin_amdgcn_readfirstlane(na);
+        }
+#pragma unroll
+        for (int b = 0; b < A; ++b)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(Wi) + (int64_t)b * F + j * 512 + lane * 8) = make_uint4(wp[b][j][0], wp[b][j][1], wp[b][j][2], wp[b][j][3]);
+        if (lane == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+            c.action[i] = a;
+            c.ep_step[i] = ep;
+            sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+        } else {
+            n_ep = 0; n_trunc = 0; sum_len = 0;                      // the wave's statistics are counted once (lane 0)
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
 // trait-granular kernels, one wave per item
 // ---------------------------------------------------------------------------------------
 template <int DOMAIN, class WT>

@@ -2058,11 +2058,17 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             c->kernel_name = "k_train_lambda";
             KCHECK();
         } else if (is_wave(c->cfg)) {
+            // bf16 weights: the packed-register kernel, two waves per SIMD (kernels_wave.hpp; RSRL_WAVE_PK=0 keeps the fp32-register one: A/B, same bits)
+            static const bool wave_pk = !(getenv("RSRL_WAVE_PK") && getenv("RSRL_WAVE_PK")[0] == '0');
+            const bool pk = wave_pk && c->cfg.weight_dtype == RSRL_W_BF16;
             for_wave(c, [&](auto tag) {
                 using T = decltype(tag); using WT = typename T::wt;
+                if constexpr (WaveIO<WT>::kBf16) {
+                    if (pk) { hipLaunchKernelGGL((k_train_wave_pk<T::domain>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats); return; }
+                }
                 hipLaunchKernelGGL((k_train_wave<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
             });
-            c->kernel_name = "k_train_wave";
+            c->kernel_name = pk ? "k_train_wave_pk" : "k_train_wave";
             KCHECK();
         } else if (stream_k1) {
             TRY(enqueue_k1_step(c, k, d_stats, c->t, nullptr));

@@ -32,15 +32,17 @@ __device__ __forceinline__ float rnd(uint32_t& s) { s = mix(s + 0x9e3779b9u); re
 #define G0 ""
 #define G1 "s_nop 0\n\t"
 #define G2 "s_nop 4\n\t"
-#define IN : [a] "v"(a), [b] "v"(b), [c] "v"(c), [k] "v"(k), [kk] "v"(kk), [px] "v"(poison.x), [py] "v"(poison.y) : "v20", "v21"
+#define IN : [a] "v"(a), [b] "v"(b), [c] "v"(c), [k] "v"(k), [kk] "v"(kk), [px] "v"(poison.x), [py] "v"(poison.y) : "v20", "v21", "v22", "v23"
+// (the packed consumer writes the fixed pair v[22:23], copied out as two scalars after a long wait: element extraction from a 64-bit vector asm
+// output was seen to read the low half twice)
 #define VARIANT(P, G)                                                                             \
     asm volatile(POISON P G "v_add_f32 %[r], v20, %[k]" : [r] "=&v"(r0) IN);                       \
-    asm volatile(POISON P G "v_pk_mul_f32 %[r], v[20:21], %[kk]" : [r] "=&v"(r2) IN);              \
+    asm volatile(POISON P G "v_pk_mul_f32 v[22:23], v[20:21], %[kk]\n\ts_nop 4\n\tv_mov_b32 %[rx], v22\n\tv_mov_b32 %[ry], v23" : [rx] "=&v"(r2x), [ry] "=&v"(r2y) IN); \
     asm volatile(POISON P G "v_fma_f32 %[r], v21, %[k], v20" : [r] "=&v"(r1) IN);
 
 template <int PROD, int GAP>
 __device__ __forceinline__ void one(f2 a, f2 b, f2 c, float k, f2 poison, uint32_t (&out)[4]) {
-    float r0, r1; f2 r2; const f2 kk{k, k};
+    float r0, r1, r2x, r2y; const f2 kk{k, k};
     if constexpr (PROD == 0 && GAP == 0) { VARIANT(P_FMA, G0) }
     if constexpr (PROD == 0 && GAP == 1) { VARIANT(P_FMA, G1) }
     if constexpr (PROD == 0 && GAP == 2) { VARIANT(P_FMA, G2) }
@@ -51,8 +53,8 @@ __device__ __forceinline__ void one(f2 a, f2 b, f2 c, float k, f2 poison, uint32
     if constexpr (PROD == 2 && GAP == 1) { VARIANT(P_ADD, G1) }
     if constexpr (PROD == 2 && GAP == 2) { VARIANT(P_ADD, G2) }
     out[0] = __builtin_bit_cast(uint32_t, r0);
-    out[1] = __builtin_bit_cast(uint32_t, r2.x);
-    out[2] = __builtin_bit_cast(uint32_t, r2.y);
+    out[1] = __builtin_bit_cast(uint32_t, r2x);
+    out[2] = __builtin_bit_cast(uint32_t, r2y);
     out[3] = __builtin_bit_cast(uint32_t, r1);
 }
 

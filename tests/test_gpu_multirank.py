@@ -126,9 +126,13 @@ def test_g_ranks_as_g_streams_on_one_device(ra, tmp_path, G, N):
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
-    # same mini-batch rule and -- the shards being whole 512-learner blocks, the ranks exchanging exact 64-bit sums -- the same
-    # bits as the unsharded run
-    assert d["absw"] > 0 and d["err_w"] == 0.0 and d["same"] == 1.0, d
+    # same mini-batch rule.  A 512-learner block sums its learners' terms in fp32 (fixed order) before the exact 64-bit fixed-point sums across
+    # blocks and ranks take over: shards that are whole blocks keep every block's membership, hence the same bits as the unsharded run; other
+    # splits regroup the learners into different blocks and agree to the rounding of those block sums
+    if N % (G * 512) == 0:
+        assert d["absw"] > 0 and d["err_w"] == 0.0 and d["same"] == 1.0, d
+    else:
+        assert d["absw"] > 0 and 0 < d["err_w"] <= 1e-6 and d["same"] >= 0.99, d       # measured 1.5e-7 (relative to max(1, |W|))
 
 
 def test_missing_peer_times_out_instead_of_hanging(ra):

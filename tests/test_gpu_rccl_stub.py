@@ -7,7 +7,8 @@ order, and records every call -- lets G = 8 ranks run end to end and lets the te
 * single-thread group (rsrl_hip_group_train): per batch-step ONE ncclGroupStart / ncclGroupEnd pair holding exactly one in-place all-reduce per
   rank (ncclInt64 table for the dense basis, ncclFloat delta for tile coding), nothing un-grouped after the warm-up;
 * one thread per rank (comm_init + rsrl_hip_train): un-grouped all-reduces, one per rank and batch-step, that rendezvous;
-* both: every replica of W identical, and -- the sums being exact 64-bit integers -- identical to the unsharded run bit for bit (dense basis).
+* both: every replica of W identical, and -- shards of whole 512-learner blocks, the sums across ranks exact 64-bit integers -- identical to the
+  unsharded run bit for bit (dense basis).
 What stays hardware-only: RCCL's own ring / xGMI transport."""
 import json
 import os
@@ -105,8 +106,10 @@ def test_single_thread_group_of_8_ranks_groups_every_all_reduce(tmp_path, kind, 
     d = _run(tmp_path, G, "group", kind, ragged)
     assert d["info"] == [[G, r, 0] for r in range(G)]                  # what the communicator itself reports: world 8, rank r, RCCL
     assert d["replicas_equal"] and d["absw"] > 0
-    if kind == "dense":
-        assert d["err_w"] == 0.0 and d["states_same"] == 1.0, d       # exact 64-bit sums: sharded == unsharded, ragged shards included
+    if kind == "dense" and not ragged:
+        assert d["err_w"] == 0.0 and d["states_same"] == 1.0, d       # whole 512-learner blocks per rank + exact 64-bit sums across ranks: sharded == unsharded
+    elif kind == "dense":
+        assert d["err_w"] <= 1e-6 * max(1.0, d["absw"]) and d["states_same"] >= 0.99, d   # other splits regroup the fp32 block sums (test_gpu_multirank)
     else:
         assert d["err_w"] <= 2e-6 * max(1.0, d["absw"]) and d["states_same"] >= 0.99, d   # float delta: the summation order over ranks differs
     # ---- the protocol: per batch-step one group with one in-place all-reduce per rank, ranks 0..G-1, and nothing outside a group
