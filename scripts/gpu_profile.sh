@@ -42,7 +42,7 @@ done
 (cd $R && python -c "
 import json
 from rsrl_amd import _kdigest, _build
-print(json.dumps(_kdigest.kernel_digests(_build.LIB_PATH, ['k_train_reg', 'k_step_reg_lm', 'k_step_reg_q4', 'k_shared_persist', 'k_shared_step', 'k_shared_ca', 'k_tile_scatter', 'k_apply_rep', 'k_train_wave'])))" > $O/kernel_digests.json)
+print(json.dumps(_kdigest.kernel_digests(_build.LIB_PATH, ['k_train_reg', 'k_step_reg_lm', 'k_step_reg_q4', 'k_shared_persist', 'k_shared_step', 'k_shared_ca', 'k_tile_scatter', 'k_apply_rep', 'k_train_wave', 'k_train_wave_pk'])))" > $O/kernel_digests.json)
 find $O -name "*_agent_info.csv" -delete
 # rocprofv3 nests its output (<dir>/<host>/<pid>_...csv): flatten
 for d in $(find $O -mindepth 1 -maxdepth 2 -type d -name "kt*" -o -mindepth 1 -maxdepth 2 -type d -name "p[0-9]"); do find $d -mindepth 2 -name "*.csv" -exec mv {} $d/ \; 2>/dev/null; done

@@ -7,7 +7,7 @@
     persist    configs[3], one GPU's share: 131 072 MountainCar, ONE shared Fourier(5) approximator                         k_shared_persist
     perstep    the same, one launch per batch-step (RSRL_NO_PERSIST=1: the path of RCCL-attached ctxs)                      k_shared_step
     tile       configs[2]: 262 144 CartPole, SARSA, 8 x 8^4 tiles, one shared table                                         k_shared_ca, k_tile_scatter, k_apply_rep
-    wave       configs[4], one GPU's share: 32 768 Acrobot, ExpectedSARSA, Fourier(7), Softmax, bf16 W                      k_train_wave
+    wave       configs[4], one GPU's share: 32 768 Acrobot, ExpectedSARSA, Fourier(7), Softmax, bf16 W                      k_train_wave_pk
 
 Prints one JSON line: leg, kernel, learners, steps of the measured call, launches, HIP-event microseconds per batch-step."""
 import json

@@ -27,7 +27,7 @@ G, P = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
 # leg -> kernels of interest (substring of the kernel name, dominant first)
 LEG_KERNELS = {
     "fused": ["k_train_reg"], "stream": ["k_step_reg_lm"], "stream1m": ["k_step_reg_q4"], "persist": ["k_shared_persist"], "perstep": ["k_shared_step"],
-    "tile": ["k_shared_ca", "k_tile_scatter", "k_apply_rep"], "wave": ["k_train_wave"],
+    "tile": ["k_shared_ca", "k_tile_scatter", "k_apply_rep"], "wave": ["k_train_wave_pk"],
 }
 # static counts of the executed path of k_train_reg's steady-state loop (scripts/isa_stats.py on train_reg_d0b.hip): v_pk_fma_f32 314 per
 # pair of steps; v_pk_mul_f32 42 + v_pk_add_f32 4; v_cndmask_b32 30 (after the assembly post-pass of rsrl_amd/_asmfilter.py: 719 instructions per
@@ -146,7 +146,7 @@ def main():
                 rec["kernel_us_kernel_trace"], rec["kernel_trace_calls"] = ka
             raw[f"{leg}:{sub}"] = rec
             learners = info.get("learners", 0)
-            spd = info.get("steps_per_dispatch", 1) if sub in ("k_train_reg", "k_shared_persist", "k_train_wave") else 1
+            spd = info.get("steps_per_dispatch", 1) if sub in ("k_train_reg", "k_shared_persist", "k_train_wave", "k_train_wave_pk") else 1
             env_steps = float(learners) * spd                       # env-steps one dispatch of this kernel covers
             if "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
                 fetch, write = 2.0 * rec["FETCH_SIZE"] * 1024.0, rec["WRITE_SIZE"] * 1024.0
@@ -154,7 +154,7 @@ def main():
                                 "traffic_bytes_per_launch": fetch + write, "bytes_per_env_step": (fetch + write) / env_steps if env_steps else None,
                                 # what the bytes of a launch follow: its number of batch-steps (every step streams / exchanges), or nothing but
                                 # the launch itself (W in + out once, whatever the depth)
-                                "scales": "per_launch" if sub in ("k_train_reg", "k_train_wave") else "per_step",
+                                "scales": "per_launch" if sub in ("k_train_reg", "k_train_wave", "k_train_wave_pk") else "per_step",
                                 "source": f"profiles/{tag}_pmc_raw.json [{leg}:{sub}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 gfx950 correction, KiB units)"}
             if "SQ_INSTS_VALU" in rec and env_steps:
                 per = lambda k: rec.get(k, 0.0) / env_steps             # noqa: E731   wave-instructions (or counter units) per env-step
