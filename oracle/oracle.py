@@ -499,7 +499,7 @@ class Run:
         k_train_wave."""
         st = Stats()
         if self._f("orc_run_train_wave")(self._h, int(n_steps), C.byref(st), int(bool(bf16))) != 0:
-            raise ValueError("train_wave: one-step control agents, Fourier order 7 on CartPole / Acrobot, per-env weights, f32 only")
+            raise ValueError("train_wave: one-step control agents (f32 / bf16), lambda agents, GreedyGQ, TD, TDLambda (f32); Fourier order 7 on CartPole / Acrobot, per-env weights")
         return st.as_dict()
 
     def train_shared_dev(self, n_steps):

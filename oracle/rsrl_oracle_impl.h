@@ -1211,21 +1211,24 @@ static R FN(wave_dot)(const R* phi, const R* W, int A, int a) {
 }
 int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
-    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), d, j, l, v;
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), d, j, l, v, AW = ag->n_actions;     /* AW: columns of the weight matrix */
     int64_t N = run->n_envs, i, k;
     R *phi_s, *phi_n, *tmp;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
     if (FN(eps_sched)(ag)) return -1;
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
-          (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z))) return -1;
+          (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z) || (ag->algo == ORC_GREEDY_GQ && !w_bf16 && run->Z) ||
+          (ag->algo == ORC_TD && !w_bf16) || (ag->algo == ORC_TD_LAMBDA && !w_bf16 && run->Z))) return -1;
+    if (ORC_IS_PRED(ag->algo)) AW = 1;
     phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
     for (i = 0; i < N; i++) {
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
         R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
         int a = run->action[i]; uint32_t ep = run->ep_step[i];
         FN(wave_project)(b, s, phi_s);
-        for (j = 0; j < A; j++) q_s[j] = FN(wave_dot)(phi_s, W, A, j);
+        for (j = 0; j < A; j++) q_s[j] = q_n[j] = (R)0.0;
+        for (j = 0; j < AW; j++) q_s[j] = FN(wave_dot)(phi_s, W, AW, j);
         for (k = 0; k < n_steps; k++) {
             const uint64_t t = run->t + (uint64_t)k;
             R r, delta, e, scale; int term, trunc, na; uint32_t x[4], xin[4] = { 0, 0, 0, 0 };
@@ -1235,7 +1238,47 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
             trunc = !term && ag->max_episode_steps > 0 && ep >= ag->max_episode_steps;
             if (term) FN(orc_domain_reset)(ag->domain, ns);
             FN(wave_project)(b, ns, phi_n);
-            for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+            for (j = 0; j < AW; j++) q_n[j] = FN(wave_dot)(phi_n, W, AW, j);
+            if (ag->algo == ORC_GREEDY_GQ) {
+                /* GreedyGQ on the wave family (rsrl_amd/csrc/kernels_wave_aux.hpp): greedy_gq.rs:73-141 with every dot product in the wave order */
+                R* V = run->Z + (size_t)i * F * A; R m, td_est, sc1, sc2, sc3; int na_star;
+                const R qsa = q_s[a];
+                td_est = FN(wave_dot)(phi_s, V, A, a);
+                na_star = FN(orc_find_max)(q_n, A, &m);
+                delta = term ? (r - qsa) : (r + (R)ag->gamma * m - qsa);
+                sc1 = (R)ag->lr * delta; sc2 = (R)ag->lr * (-(R)ag->gamma * td_est); sc3 = (R)ag->lr_td * (delta - td_est);
+                for (l = 0; l < 64; l++)
+                    for (j = 0; j < 8; j++)
+                        for (v = 0; v < 8; v++) {
+                            const size_t row = FN(wave_row)(l, j, v); const int e_ = (l * 8 + j) * 8 + v;
+                            W[row * A + a] = FN(fma_)(sc1, phi_s[e_], W[row * A + a]);
+                            if (!term) W[row * A + na_star] = FN(fma_)(sc2, phi_n[e_], W[row * A + na_star]);
+                            V[row * A + a] = FN(fma_)(sc3, phi_s[e_], V[row * A + a]);
+                        }
+                for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+                goto sampled_target;
+            }
+            if (ORC_IS_PRED(ag->algo)) {
+                /* TD / TDLambda on the wave family: td.rs:31-59, td_lambda.rs:41-78; one weight column, V(s) in the wave order */
+                R* Z = run->Z ? run->Z + (size_t)i * F : NULL; R rate = (R)ag->gamma * (R)ag->lambda;
+                if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+                delta = term ? (r - q_s[0]) : (r + (R)ag->gamma * q_n[0] - q_s[0]);
+                for (l = 0; l < 64; l++)
+                    for (j = 0; j < 8; j++)
+                        for (v = 0; v < 8; v++) {
+                            const size_t row = FN(wave_row)(l, j, v); const int e_ = (l * 8 + j) * 8 + v;
+                            if (ag->algo == ORC_TD_LAMBDA) {
+                                R z = FN(fma_)(rate, Z[row], phi_s[e_]);
+                                if (ag->trace == ORC_TRACE_SATURATE) { z = (z < (R)1.0) ? z : (R)1.0; z = (z > (R)-1.0) ? z : (R)-1.0; }
+                                W[row] = FN(fma_)(delta, z, W[row]);
+                                Z[row] = term ? (R)0.0 : z;
+                            } else {
+                                W[row] = FN(fma_)((R)ag->lr * delta, phi_s[e_], W[row]);
+                            }
+                        }
+                q_n[0] = FN(wave_dot)(phi_n, W, 1, 0);
+                goto sampled_target;
+            }
             if (ORC_IS_LAMBDA(ag->algo)) {
                 R* Z = run->Z + (size_t)i * F * A; R rate, m; int c, na_in;
                 const R qsa = q_s[a];
@@ -1294,7 +1337,7 @@ sampled_target:
                 acc.episodes += 1; acc.episodes_truncated += 1; acc.sum_episode_steps += ep; ep = 0;
                 FN(orc_domain_reset)(ag->domain, ns);
                 FN(wave_project)(b, ns, phi_n);
-                for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
+                for (j = 0; j < AW; j++) q_n[j] = FN(wave_dot)(phi_n, W, AW, j);
                 orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_RESET, x);
                 na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
             }

@@ -1,0 +1,239 @@
+// kernels_wave_aux.hpp -- the agents with a SECOND per-learner matrix, and the prediction agents, on the WAVE family (Fourier order 7 on a 4-D
+// state space, F = 4096, one wavefront per learner, f32 weights; round 5 -- the reference's agents are generic over the approximator):
+//   GreedyGQ::handle   rsrl/src/control/td/greedy_gq.rs:73-141      fa_q = W, fa_td = V (the ctx's auxiliary matrix), both f32[N][A][F]
+//   TD::handle         rsrl/src/prediction/td/td.rs:31-59           one weight column w, f32[N][1][F]
+//   TDLambda::handle   rsrl/src/prediction/td/td_lambda.rs:41-78    + the trace z (auxiliary matrix, f32[N][1][F]); rules traces.rs:188-240
+//
+// Like the eligibility-trace agents of this family (kernels_wave_lambda.hpp) these cannot keep their matrices on the chip -- W + V are 96 KiB per
+// learner -- so a learner-step is a memory sweep, 16 B per lane, coalesced, in the family's layout (internal index k = j*512 + lane*8 + v):
+//   GreedyGQ   Q(s',.) with the pre-update W and td_est = <phi(s), V[:,a]>  (W once, one column of V), then ONE sweep over the columns of W that
+//              move (a: += lr*delta*phi(s); argmax of Q(s',.), non-terminal: += lr*(-gamma*td_est)*phi(s'), in that order when they coincide) and
+//              over V[:,a] (+= lr_td*(delta - td_est)*phi(s)); Q(s',.) with the UPDATED W -- what the behaviour policy samples from and the next
+//              step's Q(s,.) -- falls out of the sweep.  Columns that do not move are read once more for that dot product only.
+//   TD         V(s') with the pre-update w, w += lr*td*phi(s), V(s') with the updated w out of the same sweep.
+//   TDLambda   z = rule(rate*z + phi(s)) (rate 0 after a terminal transition: the trace was reset), w += td * z, V(s') with the updated w.
+// Element by element the operations are those of the register-family kernels (kernels_gq.hpp, kernels_td.hpp); every dot product runs over (j, v)
+// in WaveFourier::dot()'s order: bit-identical to the oracle's wave-order loop (orc_run_train_wave).
+#pragma once
+
+#include "kernels_wave.hpp"
+#include "kernels_gq.hpp"
+#include "kernels_td.hpp"
+
+namespace rsrl {
+
+enum : int { WAUX_GQ = 0, WAUX_TD = 1, WAUX_TDL = 2 };
+
+struct WaveAuxParams {
+    int mode;          // WAUX_*
+    float* aux;        // GreedyGQ: V [N][A][F]; TDLambda: z [N][1][F]; TD: unused
+    float lr_td;       // GreedyGQ: SGD rate of fa_td
+    float rate;        // TDLambda: gamma*lambda (Dutch: * (1 - alpha))
+    int trace;         // TDLambda: TRACE_*
+};
+
+// <phi, column> with the column streamed from memory, dot()'s order (4 interleaved chains over (j, v), then the wave total)
+template <int DOMAIN>
+__device__ __forceinline__ float wave_col_dot(const float* __restrict__ col, int lane, const float (&phi)[8][8]) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float w8[8];
+        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, w8);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi[j][v], w8[v], acc[v & 3]);
+    }
+    return wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
+// from == nullptr: the driver loop, n_steps batch-steps of the wave's learner.  Otherwise Handler::handle on ONE caller-supplied transition per
+// learner (Mn of them; the prediction agents ignore `act`).
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap, float* __restrict__ Wbase, uint64_t t0, int n_steps,
+                                                     DevStats* __restrict__ stats, const float* __restrict__ from, const int32_t* __restrict__ act,
+                                                     const float* __restrict__ rew, const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                     int64_t Mn, float* __restrict__ td_out) {
+    using WF = WaveFourier<DOMAIN>;
+    using Dom = Domain<DOMAIN>;
+    using IO = WaveIO<float>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t N = c.n_envs;
+    const bool driver = from == nullptr;
+    const bool gq = ap.mode == WAUX_GQ;
+    const int Aw = gq ? A : 1;                                                         // columns of the weight matrix
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < (driver ? N : Mn)) {
+        PolicyParams pol = c.pol;
+        if (!gq) pol.kind = POL_RANDOM;                                                // prediction: the only policy that needs no Q
+        const float gamma = c.alg.gamma, lr = c.alg.lr;
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        const uint32_t cap = c.max_episode_steps;
+        float* __restrict__ Wi = Wbase + i * (int64_t)Aw * F;
+        float* __restrict__ Xi = ap.aux ? ap.aux + i * (int64_t)Aw * F : nullptr;
+        float s[D];
+        int a = 0; uint32_t ep = 0;
+        if (driver) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+            a = __builtin_amdgcn_readfirstlane(c.action[i]); ep = c.ep_step[i];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = from[(int64_t)d * Mn + i];
+            if (gq) a = clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i]));
+        }
+        float phi_s[8][8], q_s[A];
+#pragma unroll
+        for (int b = 0; b < A; ++b) q_s[b] = 0.0f;
+        WF::project(s, lane, phi_s);
+#pragma unroll
+        for (int b = 0; b < A; ++b) if (b < Aw) q_s[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_s);       // GQ: Q(s,.); prediction: q_s[0] = V(s)
+        float facc_abs = 0.0f, facc_r = 0.0f;
+        bool cut = false;                                                              // TDLambda: the previous transition was terminal
+        for (int k = 0; k < (driver ? n_steps : 1); ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D], r;
+            bool term, trunc = false;
+            if (driver) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = s[d];
+                term = Dom::step(ns, a, r);
+                ep += 1;
+                trunc = !term && cap > 0 && ep >= cap;
+                if (term) Dom::reset(ns);
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = to[(int64_t)d * Mn + i];
+                r = rew[i]; term = termf[i] != 0;
+            }
+            float phi_n[8][8], q_n[A];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = 0.0f;
+            WF::project(ns, lane, phi_n);
+#pragma unroll
+            for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_n);   // PRE-update weights
+            float delta;
+            if (gq) {
+                const float qsa = select_a<A>(q_s, a);
+                const float td_est = wave_col_dot<DOMAIN>(Xi + (int64_t)a * F, lane, phi_s);
+                float qmax;
+                const int na_star = __builtin_amdgcn_readfirstlane(find_max<A>(q_n, qmax));
+                delta = term ? (r - qsa) : (r + gamma * qmax - qsa);
+                const float sc1 = lr * delta, sc2 = lr * (-gamma * td_est), sc3 = ap.lr_td * (delta - td_est);
+#pragma unroll
+                for (int b = 0; b < A; ++b) {
+                    const bool hit1 = a == b, hit2 = !term && na_star == b;            // wave-uniform
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t off = (int64_t)b * F + j * 512 + lane * 8;
+                        float w8[8];
+                        IO::load8(Wi, off, w8);
+                        if (hit1) {
+#pragma unroll
+                            for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc1, phi_s[j][v], w8[v]);
+                            float v8[8];
+                            IO::load8(Xi, off, v8);
+#pragma unroll
+                            for (int v = 0; v < 8; ++v) v8[v] = fmaf(sc3, phi_s[j][v], v8[v]);
+                            IO::store8(Xi, off, v8);
+                        }
+                        if (hit2) {
+#pragma unroll
+                            for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc2, phi_n[j][v], w8[v]);
+                        }
+                        if (hit1 || hit2) IO::store8(Wi, off, w8);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi_n[j][v], w8[v], acc[v & 3]);
+                    }
+                    q_n[b] = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+                }
+            } else {
+                delta = term ? (r - q_s[0]) : (r + gamma * q_n[0] - q_s[0]);
+                const bool lam = ap.mode == WAUX_TDL;
+                const float rate_eff = cut ? 0.0f : ap.rate;
+                const float sc = lr * delta;
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t off = (int64_t)j * 512 + lane * 8;
+                    float w8[8], z8[8];
+                    IO::load8(Wi, off, w8);
+                    if (lam) {
+                        IO::load8(Xi, off, z8);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            float zz = fmaf(rate_eff, z8[v], 1.0f * phi_s[j][v]);      // WBuf::decay_add with the indicator 1
+                            if (ap.trace == TRACE_SATURATE) zz = __builtin_amdgcn_fmed3f(zz, -1.0f, 1.0f);
+                            w8[v] = fmaf(delta, zz, w8[v]);                            // ScaledGradientUpdate{alpha: td_error}: no learning rate
+                            z8[v] = term ? 0.0f : zz;                                  // trace.reset() after a terminal transition
+                        }
+                        IO::store8(Xi, off, z8);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc, phi_s[j][v], w8[v]);
+                    }
+                    IO::store8(Wi, off, w8);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi_n[j][v], w8[v], acc[v & 3]);
+                }
+                q_n[0] = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+                cut = term;
+            }
+            if (!driver) { if (lane == 0 && td_out) td_out[i] = delta; break; }
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            int na = policy_sample<A>(pol, q_n, x);
+            facc_abs += fabsf(delta); facc_r += r;
+            if (term) { n_ep += 1; sum_len += ep; ep = 0; }
+            if (trunc) {                                                               // step cap: new episode (a trace is NOT reset)
+                n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                WF::project(ns, lane, phi_n);
+#pragma unroll
+                for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_n);
+                const U4 xr = draw(c.seed, gid, t, BLK_RESET);
+                na = policy_sample<A>(pol, q_n, xr);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) phi_s[j][v] = phi_n[j][v];
+            a = __builtin_amdgcn_readfirstlane(na);
+        }
+        if (driver && lane == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+            c.action[i] = a;
+            c.ep_step[i] = ep;
+            sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+        } else {
+            n_ep = 0; n_trunc = 0; sum_len = 0;
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// V(s) of a prediction agent for M caller-supplied states (Function<(S,)> of the ScalarLFA), one wave per state
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock) void k_wave_v_evaluate(const float* __restrict__ Wbase, const float* __restrict__ states, int64_t Mn, float* __restrict__ out) {
+    using WF = WaveFourier<DOMAIN>;
+    constexpr int D = WF::D, F = WF::F;
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (i >= Mn) return;
+    float s[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * Mn + i];
+    float phi[8][8];
+    WF::project(s, lane, phi);
+    const float v = wave_col_dot<DOMAIN>(Wbase + i * (int64_t)F, lane, phi);
+    if (lane == 0) out[i] = v;
+}
+
+}  // namespace rsrl

@@ -27,6 +27,7 @@
 #include "kernels_qsigma.hpp"
 #include "kernels_persist.hpp"
 #include "kernels_wave_lambda.hpp"
+#include "kernels_wave_aux.hpp"
 
 using namespace rsrl;
 
@@ -457,6 +458,22 @@ static TdParams make_td(const rsrl_hip_ctx* c) {
     return tp;
 }
 
+// GreedyGQ / TD / TDLambda on the order-7 wave family (kernels_wave_aux.hpp)
+static inline bool is_wave_aux_algo(int algo) { return algo == RSRL_GREEDY_GQ || is_pred(algo); }
+static WaveAuxParams make_wave_aux(const rsrl_hip_ctx* c) {
+    WaveAuxParams ap{};
+    ap.mode = c->cfg.algo == RSRL_GREEDY_GQ ? WAUX_GQ : (c->cfg.algo == RSRL_TD ? WAUX_TD : WAUX_TDL);
+    ap.aux = c->Z; ap.lr_td = (float)c->cfg.lr_td;
+    const TdParams tp = make_td(c);
+    ap.rate = tp.rate; ap.trace = tp.trace;
+    return ap;
+}
+template <class... Args>
+static void launch_wave_aux(const rsrl_hip_ctx* c, dim3 grid, Args... args) {
+    if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_aux<1>), grid, dim3(kBlock), 0, c->stream, args...);
+    else hipLaunchKernelGGL((k_wave_aux<2>), grid, dim3(kBlock), 0, c->stream, args...);
+}
+
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 // resolution of the fixed-point delta tables of shared tile coding: 2^(floor(log2 |lr|) - 28), the same bits the kernel derives
 static inline float tile_lsb(float lr) {
@@ -733,9 +750,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     if (is_pred(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;
-        if (!tile_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
-            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights (any Fourier order but 7 on CartPole / Acrobot, "
-                                         "or tile coding)");
+        if (!tile_ok && (cfg->basis != RSRL_FOURIER || cfg->weight_mode != RSRL_W_PER_ENV || (is_wave(*cfg) && cfg->weight_dtype != RSRL_W_F32)))
+            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a Fourier basis (f32 on the order-7 wave family) "
+                                         "or on tile coding");
         if (cfg->policy != RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "prediction agents have no Q function: the behaviour policy must be RSRL_RANDOM");
         if (cfg->algo == RSRL_TD_LAMBDA) {
             if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
@@ -743,8 +760,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         }
     }
     if (cfg->algo == RSRL_GREEDY_GQ) {
-        if (is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV)
-            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights (any Fourier order but 7 on CartPole / Acrobot, or tile coding)");
+        if (cfg->weight_mode != RSRL_W_PER_ENV || (is_wave(*cfg) && cfg->weight_dtype != RSRL_W_F32))
+            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights (f32 on the order-7 wave family)");
         if (!(cfg->lr_td >= 0.0)) return fail(RSRL_HIP_EINVAL, "lr_td must be >= 0");
     }
     if (is_lambda(cfg->algo)) {
@@ -1086,7 +1103,10 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     const uint64_t call = c->api_calls;
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
-    if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && c->cfg.basis == RSRL_TILE_CODING) {
+    if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && is_wave(c->cfg)) {
+        if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_v_evaluate<1>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, (const float*)c->W, d_states, M_, of.dev);
+        else hipLaunchKernelGGL((k_wave_v_evaluate<2>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, (const float*)c->W, d_states, M_, of.dev);
+    } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, false, 0, c->stream, k, g, make_td(c), 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M_,
                             of.dev, d_states)) return NO_MODEL(c);
     } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && is_generic_fourier(c->cfg)) {
@@ -1176,7 +1196,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
+    if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
+        launch_wave_aux(c, dim3(wave_grid_for(M)), k, make_wave_aux(c), (float*)c->W, c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+    } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, M, c->stream, k, g, make_td(c), c->t, 1, nullptr, d_from, d_rew,
                             d_to, d_term, M, otd.dev, nullptr)) return NO_MODEL(c);
     } else if (is_pred(c->cfg.algo) && is_generic_fourier(c->cfg)) {
@@ -1246,7 +1268,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using WT = typename decltype(tag)::wt;
-            hipLaunchKernelGGL((k_wave_weights_get<WT>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const WT*)c->W + env_index * (int64_t)n, c->F, c->A, ow.dev);
+            hipLaunchKernelGGL((k_wave_weights_get<WT>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const WT*)c->W + env_index * (int64_t)n, c->F, c->Aw, ow.dev);
         });
     } else
     hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, (shared ? 0 : env_index) * c->w_ls, c->F, c->Aw, ow.dev);
@@ -1266,8 +1288,8 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using WT = typename decltype(tag)::wt;
-            const int64_t groups = (int64_t)c->A * (c->F / 8);
-            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, env_index, (int64_t)1, c->F, c->A, d_w);
+            const int64_t groups = (int64_t)c->Aw * (c->F / 8);
+            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, env_index, (int64_t)1, c->F, c->Aw, d_w);
         });
     } else
     hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, (shared ? 0 : env_index) * c->w_ls, c->F, c->Aw, d_w);
@@ -1284,7 +1306,7 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
     if (out) {
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
-        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_get<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->Z + env_index * (int64_t)n, c->F, c->A, oz.dev);
+        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_get<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, (const float*)c->Z + env_index * (int64_t)n, c->F, c->Aw, oz.dev);
         else hipLaunchKernelGGL(k_weights_get, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
@@ -1292,7 +1314,7 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
     } else {
         const float* d_z;
         TRY(stage_in(c, 0, in, (size_t)n, &d_z));
-        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_set<float>), dim3((unsigned)(((int64_t)c->A * (c->F / 8) + 255) / 256)), dim3(256), 0, c->stream, c->Z, env_index, (int64_t)1, c->F, c->A, d_z);
+        if (is_wave(c->cfg)) hipLaunchKernelGGL((k_wave_weights_set<float>), dim3((unsigned)(((int64_t)c->Aw * (c->F / 8) + 255) / 256)), dim3(256), 0, c->stream, c->Z, env_index, (int64_t)1, c->F, c->Aw, d_z);
         else hipLaunchKernelGGL(k_weights_set, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->Z, c->cfg.basis == RSRL_TILE_CODING, c->w_stride, env_index, c->F, c->Aw, d_z);
         KCHECK();
         if (!is_device_ptr(in)) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1514,8 +1536,8 @@ int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     if (is_wave(c->cfg)) {
         for_wave(c, [&](auto tag) {
             using WT = typename decltype(tag)::wt;
-            const int64_t groups = c->cfg.n_envs * (int64_t)c->A * (c->F / 8);
-            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, (int64_t)0, c->cfg.n_envs, c->F, c->A, d_w);
+            const int64_t groups = c->cfg.n_envs * (int64_t)c->Aw * (c->F / 8);
+            hipLaunchKernelGGL((k_wave_weights_set<WT>), dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, c->stream, (WT*)c->W, (int64_t)0, c->cfg.n_envs, c->F, c->Aw, d_w);
         });
     } else
     hipLaunchKernelGGL(k_weights_set_all, dim3(grid_for(c->cfg.n_envs), gy), dim3(kBlock), 0, c->stream, c->W, c->cfg.basis == RSRL_TILE_CODING, c->cfg.n_envs, c->cfg.basis == RSRL_TILE_CODING ? c->cfg.n_envs : c->w_stride, c->w_ls,
@@ -2011,6 +2033,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         if (shared) {
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
             c->kernel_name = fourier ? "k_shared_step" : "k_shared_ca";
+        } else if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
+            launch_wave_aux(c, dim3(wave_grid_for(k.n_envs)), k, make_wave_aux(c), (float*)c->W, c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr,
+                            (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
+            c->kernel_name = "k_wave_aux";
+            KCHECK();
         } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
             if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, k.n_envs, c->stream, k, g, make_td(c), c->t, chunk, d_stats,
                                 nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr)) return NO_MODEL(c);

@@ -92,6 +92,11 @@ CONFIGS = {
                K_free=0, cap=100, bf16=True, kw=dict(domain=2, order=7, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0)),
     "c5s": dict(what="configs[4] in small at a stable step size: lr 2.5e-4 (lr |phi|^2 ~ 0.5)", M=8, K=200, K_free=2000,
                 cap=100, bf16=True, kw=dict(domain=2, order=7, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.00025, alpha=1.0)),
+    # the agents widened onto the order-7 wave family in round 5 (kernels_wave_aux.hpp), teacher-forced against f64 like the configurations above
+    "w7_gq": dict(what="GreedyGQ on Acrobot Fourier(7), eps-greedy: W and fa_td's V", M=6, K=200, K_free=1000, cap=100,
+                  kw=dict(domain=2, order=7, algo=6, policy=1, epsilon=0.1, gamma=0.99, lr=0.0002, lr_td=0.001)),
+    "w7_td": dict(what="TD (state values) on CartPole Fourier(7), Random behaviour", M=6, K=200, K_free=1000, cap=100,
+                  kw=dict(domain=1, order=7, algo=7, policy=3, gamma=0.99, lr=0.0002)),
 }
 
 
@@ -132,7 +137,10 @@ def teacher_forced(name, M=None, K=None, seed=11):
     W64 = np.array(run.weights)
     wmax = float(np.abs(W64).max())
     probe = np.ascontiguousarray(t["to"].T, dtype=np.float32)
-    q64 = np.stack([orc.q_evaluate(ag, W64 if shared else W64[i], t["to"][i], "f64") for i in range(M)], axis=1)
+    if ag.algo in (orc.TD, orc.TD_LAMBDA):
+        q64 = np.array([[orc.v_evaluate(ag, W64[i], t["to"][i], "f64") for i in range(M)]])
+    else:
+        q64 = np.stack([orc.q_evaluate(ag, W64 if shared else W64[i], t["to"][i], "f64") for i in range(M)], axis=1)
     out = {"what": cfg["what"], "learners": M, "steps": K, "max_abs_w_f64": wmax}
     res = {}
     for k, c in ctxs.items():

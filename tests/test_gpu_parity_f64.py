@@ -37,10 +37,12 @@ F32_BOUNDS = {
     "c4": (6e-6, 3e-6, 1e-6, 4e-6),        # measured 1.9e-6, 9.7e-7, 2.6e-7, 1.2e-6   (1 000 steps, 512 learners on one W)
     "c5": (1e-4, 6e-6, 5e-7, 2e-5),        # measured 3.2e-5, 2.2e-6, 1.5e-7, 5.9e-6   (200 steps, lr 1e-3: past SGD's stability limit, errors feed back)
     "c5s": (1e-5, 1.5e-6, 3e-8, 4e-6),     # measured 2.5e-6, 3.5e-7, 6.0e-9, 1.1e-6   (200 steps, lr 2.5e-4)
+    "w7_gq": (6e-6, 2e-6, 2e-8, 4e-6),     # measured 1.9e-6, 6.7e-7, 6.1e-9, 1.4e-6   (GreedyGQ on the order-7 wave family, 200 steps)
+    "w7_td": (2e-6, 2e-6, 4e-9, 1e-6),     # measured 5.1e-7, 6.1e-7, 1.1e-9, 3.0e-7   (TD on the order-7 wave family, 200 steps)
 }
 
 
-@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c5s"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c4", "c5", "c5s", "w7_gq", "w7_td"])
 def test_teacher_forced_vs_f64(mp, name):
     r = mp.teacher_forced(name)
     b = F32_BOUNDS[name]

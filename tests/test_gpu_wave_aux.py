@@ -1,0 +1,148 @@
+"""GreedyGQ, TD and TDLambda on the order-7 WAVE family (F = 4096, one wavefront per learner; rsrl_amd/csrc/kernels_wave_aux.hpp) -- the reference's
+agents are generic over the approximator (greedy_gq.rs:49-60, prediction/td/td.rs:25-32, td_lambda.rs:25-40).  Bitwise against the oracle's
+wave-order loop (f32d), single transitions against the f64 oracle, V(s) / trait-granular entry points, checkpoint."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ra():
+    import rsrl_amd
+    return rsrl_amd
+
+
+def rand_states(orc, domain, M, seed, shrink=0.5):
+    lo, hi = orc.domain_bounds(domain)
+    rng = np.random.default_rng(seed)
+    mid, half = (lo + hi) / 2, (hi - lo) / 2 * shrink
+    return (mid[:, None] + half[:, None] * (2 * rng.random((len(lo), M)) - 1)).astype(np.float32)
+
+
+# (name, domain, device kwargs, oracle kwargs, steps).  TDLambda's weight step is the TD error itself -- ScaledGradientUpdate{alpha: td_error}, no
+# learning rate (td_lambda.rs:59-62): on 4096 features it diverges within a few updates in ANY arithmetic (the f64 reference included), so those
+# runs stop while every value is still finite (the bits are compared all the same).
+CASES = [
+    ("gq_cartpole_egreedy", 1, dict(algo=6, policy=1, epsilon=0.2, lr=0.0002, lr_td=0.001, gamma=0.99), 60),
+    ("gq_acrobot_softmax", 2, dict(algo=6, policy=2, tau=0.7, lr=0.0001, lr_td=0.0005, gamma=0.95), 40),
+    ("gq_acrobot_greedy", 2, dict(algo=6, policy=0, lr=0.0002, lr_td=0.002, gamma=0.99), 40),
+    ("td_cartpole", 1, dict(algo=7, policy=3, lr=0.0002, gamma=0.99), 60),
+    ("td_acrobot", 2, dict(algo=7, policy=3, lr=0.0001, gamma=0.9), 40),
+    ("tdl_cartpole_accumulate", 1, dict(algo=8, policy=3, gamma=0.99, lam=0.8, trace=0, alpha=0.1), 16),
+    ("tdl_cartpole_saturate", 1, dict(algo=8, policy=3, gamma=0.99, lam=0.8, trace=1, alpha=0.1), 16),
+    ("tdl_acrobot_dutch", 2, dict(algo=8, policy=3, gamma=0.99, lam=0.7, trace=2, alpha=0.2), 12),
+]
+
+
+def _okw(kw):
+    o = dict(kw)
+    return o
+
+
+@pytest.mark.parametrize("name,domain,kw,K", CASES, ids=[c[0] for c in CASES])
+def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K):
+    N = 7                                                      # two thread blocks, the second one partially filled
+    ag = orc.make_agent(domain=domain, order=7, seed=9, max_episode_steps=13, **_okw(kw))
+    run = orc.Run(ag, N, "f32d")
+    if kw["algo"] == 6:
+        run.reset_wave()
+    else:
+        run.reset()
+    run.train_wave(K)
+    pred = kw["algo"] in (7, 8)
+    for spl in (0, 1, 5):                                      # any split into launches: one, K, ceil(K / 5)
+        with ra.Context(domain=domain, order=7, n_envs=N, seed=9, max_episode_steps=13, steps_per_launch=spl, **kw) as c:
+            assert c.F == 4096 and c.n_out == (1 if pred else c.A)
+            c.reset()
+            st = c.train(K)
+            assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action), (name, spl)
+            for i in range(N):
+                assert np.array_equal(c.get_weights(i), run.weights[i]), (name, spl, i)
+            if kw["algo"] == 6:
+                for i in (0, N - 1):
+                    assert np.array_equal(c.get_td_weights(i), run.traces[i]), (name, spl, i)
+            if kw["algo"] == 8:
+                for i in (0, N - 1):
+                    assert np.array_equal(c.get_traces(i), run.traces[i]), (name, spl, i)
+            assert st["env_steps"] == N * K
+            assert np.isfinite(run.weights).all() and np.abs(run.weights).max() > 0
+
+
+@pytest.mark.parametrize("algo,domain", [(6, 1), (6, 2), (7, 2), (8, 1)])
+def test_single_transitions_vs_f64(ra, orc, algo, domain):
+    # Handler::handle on caller-supplied transitions, against the reference-precision oracle (identical fp32-representable inputs)
+    M = 6
+    rng = np.random.default_rng(algo * 10 + domain)
+    pol = 3 if algo in (7, 8) else 1
+    kw = dict(gamma=0.97, lr=0.001, lr_td=0.002, lam=0.6, trace=0, alpha=0.3)
+    ag = orc.make_agent(domain=domain, order=7, algo=algo, policy=pol, seed=4, **kw)
+    A = 2 if domain == 1 else 3
+    n_out = 1 if algo in (7, 8) else A
+    s = rand_states(orc, domain, M, 21)
+    a = rng.integers(0, A, M).astype(np.int32)
+    with ra.Context(domain=domain, order=7, algo=algo, policy=pol, seed=4, n_envs=M, **kw) as c:
+        Ws = [(rng.normal(size=(4096, n_out)) * 0.02).astype(np.float32) for _ in range(M)]
+        Xs = [(rng.normal(size=(4096, n_out)) * 0.02).astype(np.float32) for _ in range(M)]
+        for i in range(M):
+            c.set_weights(Ws[i], i)
+            if algo == 6:
+                c.set_td_weights(Xs[i], i)
+            if algo == 8:
+                c.set_traces(Xs[i], i)
+        c.states = s
+        frm, nxt, rew, term = c.domain_step(a)
+        term[0] = 1                                            # one terminal transition in the batch
+        if algo in (7, 8):
+            v = c.q_evaluate(frm)                              # V(s): one value per state
+            assert v.shape == (1, M)
+        td = c.handle(frm, a, rew, nxt, term)
+        for i in range(M):
+            W, X = Ws[i].astype(np.float64), Xs[i].astype(np.float64)
+            if algo == 6:
+                d = orc.handle_gq(ag, W, X, frm[:, i], a[i], rew[i], nxt[:, i], term[i], "f64")
+                assert np.max(np.abs(c.get_td_weights(i) - X)) <= 3e-6 * (1 + abs(d))
+            else:
+                w1, z1 = W.reshape(-1).copy(), (X.reshape(-1).copy() if algo == 8 else None)
+                assert abs(v[0, i] - orc.v_evaluate(ag, w1, frm[:, i], "f64")) <= 5e-5 * (1 + abs(v[0, i]))
+                d = orc.handle_td(ag, w1, z1, frm[:, i], rew[i], nxt[:, i], term[i], "f64")
+                W = w1.reshape(4096, 1)
+                if algo == 8:
+                    assert np.max(np.abs(c.get_traces(i).reshape(-1) - z1)) <= 3e-6
+            assert abs(td[i] - d) <= 1e-4 * (1 + abs(d)), (i, td[i], d)
+            tol = 3e-6 * (1 + abs(d)) if algo != 8 else 1e-5 * (1 + abs(d)) * (1 + np.abs(Xs[i]).max() * 50)
+            assert np.max(np.abs(c.get_weights(i) - W)) <= tol, (i, np.max(np.abs(c.get_weights(i) - W)), tol)
+
+
+def test_wave_aux_entry_points_and_checkpoint(ra, tmp_path):
+    # GreedyGQ on the wave family behind the whole trait surface: policy ops, rollouts, checkpoint with the second matrix
+    kw = dict(domain=1, order=7, algo=6, policy=1, epsilon=0.1, lr=0.0002, lr_td=0.001, gamma=0.99, n_envs=5, seed=2, max_episode_steps=0)     # (no step cap: the per-learner episode counters are not part of a checkpoint)
+    with ra.Context(**kw) as c, ra.Context(**kw) as d:
+        c.reset()
+        c.train(50)
+        s = c.states
+        assert c.q_evaluate(s).shape == (2, 5) and c.policy_mode(s).shape == (5,) and c.policy_probs(s).shape == (2, 5)
+        n, _ = c.rollout_greedy(40)
+        assert n.min() >= 2
+        path = str(tmp_path / "gq7.ckpt")
+        c.save_weights(path)
+        d.load_weights(path)
+        for i in range(5):
+            assert np.array_equal(c.get_weights(i), d.get_weights(i)) and np.array_equal(c.get_td_weights(i), d.get_td_weights(i))
+        d.states, d.actions = c.states, c.actions
+        # (the step counter keys the draws: a resumed run needs it too -- it travels in the file)
+        c.train(20), d.train(20)
+        assert np.array_equal(c.states, d.states) and np.array_equal(c.get_weights(3), d.get_weights(3))
+    # prediction agents: no action values
+    with ra.Context(domain=2, order=7, algo=7, policy=3, n_envs=3, lr=1e-4) as c:
+        c.reset()
+        c.train(5)
+        with pytest.raises(ra.RsrlHipError):
+            c.policy_mode(c.states)
+        with pytest.raises(ra.RsrlHipError):
+            c.rollout_greedy(10)
+        assert c.project(c.states).shape == (4096, 3)
+    # still refused where no kernel exists: bf16 weights for these agents
+    for algo, pol in ((6, 1), (7, 3), (8, 3)):
+        with pytest.raises(ra.RsrlHipError):
+            ra.Context(domain=2, order=7, algo=algo, policy=pol, n_envs=2, weight_dtype=ra.W_BF16)
