@@ -64,7 +64,11 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  * the eligibility-trace agents {SARSALambda, QLambda}
  *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights; register-family Fourier bases, the order-7 Fourier bases of
  *   the 4-D domains with f32 weights (W and the trace streamed from memory every step), or tile coding with one dense trace
- *   table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12)
+ *   table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12;
+ *   round 5: weight_mode = RSRL_W_SHARED on tile coding -- ONE shared table, every learner its own SPARSE trace as params/sparse.rs:13-97
+ *   offers: a list of at most 512 (entry, value) pairs, the entry with the smallest |value| making room once it is full; the table moves by the
+ *   synchronous mini-batch rule W += sum_i alpha * residual_i * z_i in exact 64-bit fixed point.  Stepped by rsrl_hip_train only;
+ *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists are not part of a checkpoint)
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights: register-family Fourier bases, the generic Fourier orders, tile coding, and (round 5)

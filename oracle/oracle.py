@@ -134,6 +134,9 @@ def _declare(L):
         g("orc_run_set_epsilon").argtypes = [C.c_void_p, C.c_double]
         g("orc_run_reset").argtypes = [C.c_void_p]
         g("orc_run_train").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_train_sparse_lambda").restype = C.c_int
+        g("orc_run_train_sparse_lambda").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
+        g("orc_run_sparse_trace").argtypes = [C.c_void_p, C.c_int64, Rp]
         g("orc_run_teacher").argtypes = [C.c_void_p, C.POINTER(Stats), Rp, C.POINTER(C.c_int32), Rp, Rp, C.POINTER(C.c_uint8), Rp]
         g("orc_run_eps").restype = Rp
         g("orc_run_eps").argtypes = [C.c_void_p]
@@ -462,6 +465,21 @@ class Run:
         st = Stats()
         self._f("orc_run_train")(self._h, int(n_steps), C.byref(st))
         return st.as_dict()
+
+    def train_sparse_lambda(self, n_steps):
+        """SARSALambda / QLambda over ONE shared tile-coded table with a sparse trace per learner (the device's rule and order,
+        rsrl_amd/csrc/kernels_sparse_lambda.hpp): float precisions are bit-identical to the HIP path, "f64" is the same rule in the reference's
+        precision."""
+        st = Stats()
+        if self._f("orc_run_train_sparse_lambda")(self._h, int(n_steps), C.byref(st)) != 0:
+            raise ValueError("train_sparse_lambda: SARSALambda / QLambda, tile coding, shared weights")
+        return st.as_dict()
+
+    def sparse_trace(self, i):
+        """learner i's sparse trace as the dense (F, A) matrix it stands for"""
+        out = np.zeros((self.F, self.A), dtype=self._dt)
+        self._f("orc_run_sparse_trace")(self._h, int(i), _ptr(out, self._ct))
+        return out
 
     def teacher_step(self):
         """ONE batch-step of train() as a teacher: successor states rounded to fp32, the handled transitions returned ->

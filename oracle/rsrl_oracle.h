@@ -135,6 +135,8 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     R*    orc_run_traces_##S(void* h);                                                                  \
     R*    orc_run_eps_##S(void* h);                                                                     \
     void  orc_run_train_##S(void* h, int64_t n_steps, orc_stats* st);                                   \
+    int   orc_run_train_sparse_lambda_##S(void* h, int64_t n_steps, orc_stats* st);                   \
+    void  orc_run_sparse_trace_##S(void* h, int64_t i, R* out);                                         \
     void  orc_run_teacher_##S(void* h, orc_stats* st, R* from, int32_t* act, R* rew, R* to, uint8_t* term, R* td); \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
                                  void (*dw_hook)(R* dW, int n, void* user), void* user);                \

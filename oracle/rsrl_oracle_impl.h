@@ -778,6 +778,8 @@ typedef struct {
     /* teacher forcing (orc_run_teacher): when round32 is set every successor state is rounded to fp32 before anything uses it, so the
      * transitions this run handles are fp32-representable and can be replayed, value for value, through the device's
      * Handler::handle; tape_* (may be NULL) receive the batch-step's transitions as the agent saw them */
+    /* SARSALambda / QLambda over ONE shared tile table: every learner's sparse trace (orc_run_train_sparse_lambda) */
+    uint32_t* sp_keys; R* sp_vals; int* sp_len;
     int round32;
     R* tape_from; int32_t* tape_act; R* tape_rew; R* tape_to; uint8_t* tape_term; R* tape_td;
 } FN(orc_run);
@@ -838,7 +840,8 @@ void* FN(orc_run_create)(const orc_agent* ag, int64_t n_envs) {
 }
 void FN(orc_run_destroy)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h;
-    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run->eps); free(run->qs); free(run);
+    free(run->state); free(run->action); free(run->ep_step); free(run->W); free(run->Z); free(run->qc); free(run->eps); free(run->qs);
+    free(run->sp_keys); free(run->sp_vals); free(run->sp_len); free(run);
 }
 R* FN(orc_run_state)(void* h) { return ((FN(orc_run)*)h)->state; }
 int32_t* FN(orc_run_action)(void* h) { return ((FN(orc_run)*)h)->action; }
@@ -1353,6 +1356,128 @@ sampled_target:
     if (st) *st = acc;
     return 0;
 }
+/* SARSALambda / QLambda over ONE SHARED tile-coded table with a SPARSE trace per learner -- the reference's Trace<B, R> is generic over its
+ * buffer (rsrl/src/traces.rs:5-12) and ships a sparse one (rsrl/src/params/sparse.rs:13-97) -- restating rsrl_amd/csrc/kernels_sparse_lambda.hpp
+ * operation for operation (float instantiations: bit-identical to the HIP path; R = double: the same rule in the reference's precision with a
+ * plain sum over the learners):
+ *   batch-step = the synchronous mini-batch rule of the shared-weight modes: every learner's residual (sarsa_lambda.rs:53-98,
+ *   q_lambda.rs:56-99) and trace update against W_t; W_{t+1} = W_t + sum_i (alpha * residual_i) * z_i; a terminal transition empties z_i; then
+ *   every learner samples from W_{t+1} and finished episodes restart.
+ *   the list: ORC_SPARSE_CAP = 512 (key = tile index * A + action, value) entries per learner.  Per step: (1) every entry
+ *   v <- rule(fma(rate, v, hit ? 1 : 0)) with hit = its key is one of the T new keys; (2) new keys not in the list, in tiling order: appended, or --
+ *   list full -- written over the entry with the smallest |v| (ties: lowest slot), value rule(fma(rate, 0, 1)); (3) terms (alpha*residual) * v
+ *   into the sum (float: 64-bit fixed point, lsb = 2^(floor(log2 alpha) - 28), clamped to +-2^42 -- exact and order-independent).
+ * Returns -1 for any other configuration. */
+#define ORC_SPARSE_CAP 512
+int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
+    FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
+    int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), T = b->n_tilings, d, tt, c, e;
+    int64_t N = run->n_envs, i, k;
+    const int fixed = sizeof(R) == 4, sarsa = ag->algo == ORC_SARSA_LAMBDA;
+    const R alpha = (R)ag->alpha;
+    double rate_d = ag->gamma * ag->lambda; R rate, fresh;
+    R* ns_all; uint8_t* flag_all; R* dW; int64_t* qacc; float lsb_f = 1.0f, inv_lsb_f = 1.0f;
+    orc_agent tgt = *ag;
+    orc_stats acc; memset(&acc, 0, sizeof(acc));
+    if (!ORC_IS_LAMBDA(ag->algo) || b->kind != ORC_TILE || !ag->shared_w || FN(eps_sched)(ag)) return -1;
+    if (ag->trace == ORC_TRACE_DUTCH) rate_d *= (1.0 - ag->alpha);
+    rate = (R)rate_d;                                                         /* (the device's make_lambda: the product in double, rounded once) */
+    tgt.algo = sarsa ? ORC_SARSA : ORC_QLEARNING;                             /* the TD target formula */
+    if (!run->sp_keys) {
+        run->sp_keys = (uint32_t*)calloc((size_t)N * ORC_SPARSE_CAP, sizeof(uint32_t));
+        run->sp_vals = (R*)calloc((size_t)N * ORC_SPARSE_CAP, sizeof(R));
+        run->sp_len = (int*)calloc((size_t)N, sizeof(int));
+    }
+    fresh = FN(fma_)(rate, (R)0.0, (R)1.0);
+    if (ag->trace == ORC_TRACE_SATURATE) { fresh = (fresh < (R)1.0) ? fresh : (R)1.0; fresh = (fresh > (R)-1.0) ? fresh : (R)-1.0; }
+    if (fixed) {
+        const float af = (float)ag->alpha; uint32_t u, eb, ex, v;
+        memcpy(&u, &af, 4); eb = (u >> 23) & 0xffu; ex = (eb < 30u ? 30u : eb) - 28u;
+        v = ex << 23; memcpy(&lsb_f, &v, 4); v = (254u - ex) << 23; memcpy(&inv_lsb_f, &v, 4);
+    }
+    ns_all = (R*)malloc(sizeof(R) * (size_t)N * D); flag_all = (uint8_t*)malloc((size_t)N);
+    dW = (R*)malloc(sizeof(R) * (size_t)F * A); qacc = (int64_t*)malloc(sizeof(int64_t) * (size_t)F * A);
+    for (k = 0; k < n_steps; k++, run->t++) {
+        memset(dW, 0, sizeof(R) * (size_t)F * A); memset(qacc, 0, sizeof(int64_t) * (size_t)F * A);
+        for (i = 0; i < N; i++) {
+            R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
+            uint32_t* K = run->sp_keys + (size_t)i * ORC_SPARSE_CAP; R* V = run->sp_vals + (size_t)i * ORC_SPARSE_CAP; int len = run->sp_len[i];
+            R r, delta, e_, scale, q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS]; int a = run->action[i], term, trunc, is[ORC_MAX_TILINGS], in[ORC_MAX_TILINGS];
+            uint32_t nk[ORC_MAX_TILINGS], xin[4] = { 0, 0, 0, 0 }; int found[ORC_MAX_TILINGS]; float sf[8];
+            memcpy(ns, s, sizeof(R) * D);
+            term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+            run->ep_step[i] += 1;
+            trunc = !term && ag->max_episode_steps > 0 && run->ep_step[i] >= ag->max_episode_steps;
+            flag_all[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+            for (d = 0; d < D; d++) sf[d] = (float)s[d];
+            orc_tile_indices(b, sf, is);
+            for (d = 0; d < D; d++) sf[d] = (float)ns[d];
+            orc_tile_indices(b, sf, in);
+            for (c = 0; c < A; c++) { q_s[c] = (R)0.0; q_n[c] = (R)0.0; }
+            for (tt = 0; tt < T; tt++) for (c = 0; c < A; c++) { q_s[c] = q_s[c] + run->W[(size_t)is[tt] * A + c]; q_n[c] = q_n[c] + run->W[(size_t)in[tt] * A + c]; }
+            if (!sarsa && a != FN(orc_argmax_first)(q_s, A)) len = 0;                    /* Watkins's cut (q_lambda.rs:62-66) */
+            for (tt = 0; tt < T; tt++) { nk[tt] = (uint32_t)is[tt] * (uint32_t)A + (uint32_t)a; found[tt] = 0; }
+            for (e = 0; e < len; e++) {
+                int hit = 0; R v;
+                for (tt = 0; tt < T; tt++) if (K[e] == nk[tt]) { hit = 1; found[tt] = 1; }
+                v = FN(fma_)(rate, V[e], hit ? (R)1.0 : (R)0.0);
+                if (ag->trace == ORC_TRACE_SATURATE) { v = (v < (R)1.0) ? v : (R)1.0; v = (v > (R)-1.0) ? v : (R)-1.0; }
+                V[e] = v;
+            }
+            for (tt = 0; tt < T; tt++) {
+                int slot;
+                if (found[tt]) continue;
+                if (len < ORC_SPARSE_CAP) slot = len++;
+                else {
+                    R best = V[0] < 0 ? -V[0] : V[0]; slot = 0;
+                    for (e = 1; e < ORC_SPARSE_CAP; e++) { const R m = V[e] < 0 ? -V[e] : V[e]; if (m < best) { best = m; slot = e; } }
+                }
+                K[slot] = nk[tt]; V[slot] = fresh;
+            }
+            if (sarsa) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xin);
+            delta = FN(td_from_q)(&tgt, q_s, a, q_n, r, term, xin, &e_);
+            scale = alpha * delta;
+            for (e = 0; e < len; e++) {
+                const R term_ = scale * V[e];
+                if (fixed) {
+                    float sc = (float)term_ * inv_lsb_f;
+                    sc = sc < -4.398046511104e12f ? -4.398046511104e12f : (sc > 4.398046511104e12f ? 4.398046511104e12f : sc);
+                    qacc[K[e]] += (int64_t)rintf(sc);
+                } else dW[K[e]] += term_;
+            }
+            if (term) len = 0;                                                           /* trace.reset() */
+            run->sp_len[i] = len;
+            acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
+        }
+        { int j; for (j = 0; j < F * A; j++) run->W[j] += fixed ? (R)((float)qacc[j] * lsb_f) : dW[j]; }
+        for (i = 0; i < N; i++) {
+            R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
+            R q[ORC_MAX_ACTIONS]; uint32_t x[4]; int idx[ORC_MAX_TILINGS]; float sf[8];
+            if (flag_all[i]) {
+                acc.episodes += 1; if (flag_all[i] & 2) acc.episodes_truncated += 1;
+                acc.sum_episode_steps += run->ep_step[i]; run->ep_step[i] = 0;
+                FN(orc_domain_reset)(ag->domain, ns);
+            }
+            for (d = 0; d < D; d++) sf[d] = (float)ns[d];
+            orc_tile_indices(b, sf, idx);
+            for (c = 0; c < A; c++) q[c] = (R)0.0;
+            for (tt = 0; tt < T; tt++) for (c = 0; c < A; c++) q[c] = q[c] + run->W[(size_t)idx[tt] * A + c];
+            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_STEP, x);
+            run->action[i] = FN(orc_policy_sample)(ag->policy, q, A, ag->eps_thr, (R)ag->tau, x);
+            memcpy(s, ns, sizeof(R) * D);
+        }
+    }
+    free(ns_all); free(flag_all); free(dW); free(qacc);
+    if (st) *st = acc;
+    return 0;
+}
+/* learner i's sparse trace as the dense (F, A) matrix it stands for; `out` holds F*A zeros on entry */
+void FN(orc_run_sparse_trace)(void* h, int64_t i, R* out) {
+    FN(orc_run)* run = (FN(orc_run)*)h; int e;
+    if (!run->sp_keys) return;
+    for (e = 0; e < run->sp_len[i]; e++) out[run->sp_keys[(size_t)i * ORC_SPARSE_CAP + e]] = run->sp_vals[(size_t)i * ORC_SPARSE_CAP + e];
+}
+
 /* the wave family's initial policy.sample (k_wave_reset): Q(s0,.) in the wave order */
 void FN(orc_run_reset_wave)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;

@@ -128,7 +128,7 @@ struct TileModel {
     using Dom = Domain<DOMAIN>;
     static constexpr int D = Dom::D, A = Dom::A;
     static constexpr bool kDense = false, kSparse = true;
-    static constexpr int kT = T;
+    static constexpr int kT = T, kDomain = DOMAIN;
     struct Feat { int idx[T]; };
     __host__ __device__ static constexpr int F_or_1() { return 1; }
     __device__ static __forceinline__ void q_all_lds(const float*, const Feat&, float (&)[A]) {}

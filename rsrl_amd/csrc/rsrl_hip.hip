@@ -28,6 +28,7 @@
 #include "kernels_persist.hpp"
 #include "kernels_wave_lambda.hpp"
 #include "kernels_wave_aux.hpp"
+#include "kernels_sparse_lambda.hpp"
 
 using namespace rsrl;
 
@@ -344,6 +345,8 @@ struct rsrl_hip_ctx {
     float* qcache = nullptr;         // [A][N]: Q(s,.) carried between train launches (register family)
     float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
     float* eps = nullptr;            // [N] per-learner EpsilonGreedy.epsilon (config.epsilon_decay != 1), else null
+    // lambda agents over ONE shared tile table: every learner's sparse trace + the step's mailbox (kernels_sparse_lambda.hpp)
+    uint32_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr; float* sp_ns = nullptr;
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
@@ -458,6 +461,10 @@ static TdParams make_td(const rsrl_hip_ctx* c) {
     return tp;
 }
 
+// SARSALambda / QLambda over one shared tile-coded table: per-learner SPARSE traces (kernels_sparse_lambda.hpp)
+static inline bool is_sparse_lambda(const rsrl_hip_config& cfg) {
+    return is_lambda(cfg.algo) && cfg.basis == RSRL_TILE_CODING && cfg.weight_mode == RSRL_W_SHARED;
+}
 // GreedyGQ / TD / TDLambda on the order-7 wave family (kernels_wave_aux.hpp)
 static inline bool is_wave_aux_algo(int algo) { return algo == RSRL_GREEDY_GQ || is_pred(algo); }
 static WaveAuxParams make_wave_aux(const rsrl_hip_ctx* c) {
@@ -681,6 +688,10 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->Z) (void)hipFree(c->Z);
     if (c->eps) (void)hipFree(c->eps);
     if (c->flags) (void)hipFree(c->flags);
+    if (c->sp_keys) (void)hipFree(c->sp_keys);
+    if (c->sp_vals) (void)hipFree(c->sp_vals);
+    if (c->sp_len) (void)hipFree(c->sp_len);
+    if (c->sp_ns) (void)hipFree(c->sp_ns);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->comm) (void)ncclCommDestroy(c->comm);
@@ -767,10 +778,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (is_lambda(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;     // dense per-learner trace tables
         const bool wave_ok = cfg->basis == RSRL_FOURIER && is_wave(*cfg) && cfg->weight_mode == RSRL_W_PER_ENV && cfg->weight_dtype == RSRL_W_F32;
-        if (!tile_ok && !wave_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
+        // ... or sparse per-learner traces over ONE shared table (traces.rs:5-12 over params/sparse.rs; round 5)
+        const bool sparse_ok = is_sparse_lambda(*cfg) && (cfg->n_tilings == 4 || cfg->n_tilings == 8 || cfg->n_tilings == 16);
+        if (!tile_ok && !wave_ok && !sparse_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
             return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
                                          "(MountainCar orders 1-5, CartPole/Acrobot order 1), on the order-7 wave family with f32 weights, "
-                                         "or on tile coding");
+                                         "or on tile coding (per-learner tables, or one shared table with sparse per-learner traces)");
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
     }
@@ -839,7 +852,14 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         hipLaunchKernelGGL(k_fill_f32, dim3(grid_for(N)), dim3(kBlock), 0, c->stream, c->eps, N, (float)cfg->epsilon);
         KCHECK();
     }
-    if (has_aux(cfg->algo)) {
+    if (is_sparse_lambda(*cfg)) {
+        HIP_TRY(hipMalloc((void**)&c->sp_keys, sizeof(uint32_t) * (size_t)kSparseCap * (size_t)N));
+        HIP_TRY(hipMalloc((void**)&c->sp_vals, sizeof(float) * (size_t)kSparseCap * (size_t)N));
+        HIP_TRY(hipMalloc((void**)&c->sp_len, sizeof(uint32_t) * (size_t)N));
+        HIP_TRY(hipMalloc((void**)&c->sp_ns, sizeof(float) * c->D * (size_t)N));
+        HIP_TRY(hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)N, c->stream));        // Trace::zeros: empty lists
+        if (wave_grid_for(N) > c->n_stat_slots) c->n_stat_slots = wave_grid_for(N);
+    } else if (has_aux(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
         HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
     }
@@ -1196,6 +1216,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
+    if (is_sparse_lambda(c->cfg))
+        return fail(RSRL_HIP_ESTATE, "SARSALambda / QLambda over a shared tile table keep one sparse trace per LEARNER of the ctx: they are stepped by rsrl_hip_train "
+                                     "(caller-supplied transitions have no learner to attach a trace to)");
     if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
         launch_wave_aux(c, dim3(wave_grid_for(M)), k, make_wave_aux(c), (float*)c->W, c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
     } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
@@ -1299,6 +1322,21 @@ int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
 }
 static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in) {
     CHECK_CTX(c); FLUSH(c);
+    if (c->sp_keys) {
+        // a learner's SPARSE trace over the shared table, shown as the dense (F, A) matrix it stands for; the list itself is not settable
+        if (!out) return fail(RSRL_HIP_ESTATE, "the sparse traces of a shared-table lambda agent cannot be set from a dense matrix");
+        if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        const int n = c->F * c->Aw;
+        OutBuf<float> oz;
+        TRY(stage_out(c, 0, out, (size_t)n, &oz));
+        HIP_TRY(hipMemsetAsync(oz.dev, 0, sizeof(float) * (size_t)n, c->stream));
+        hipLaunchKernelGGL(k_sparse_trace_get, dim3(kSparseCap / 256), dim3(256), 0, c->stream, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, env_index, oz.dev);
+        KCHECK();
+        bool sync = false; TRY(flush_out(c, &oz, &sync));
+        if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+        return RSRL_HIP_OK;
+    }
     if (!c->Z) return fail(RSRL_HIP_ESTATE, "this agent has no auxiliary matrix (eligibility trace / fa_td weights)");
     if (env_index < 0 || env_index >= c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1358,7 +1396,7 @@ struct Ckpt {
     bool has_eps;                                 // (not a header field: the file version says it)
 };
 // 1 = eligibility traces, 2 = fa_td weights (both: a second matrix of W's shape), 3 = QSigma's per-learner n-step backups
-int aux_kind_of(const rsrl_hip_ctx* c) { return c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1)); }
+int aux_kind_of(const rsrl_hip_ctx* c) { return c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1)); }     // (sparse shared-table traces: Z is null -> 0, the lists are not part of a checkpoint)
 size_t qs_floats(const rsrl_hip_ctx* c) { return (size_t)(c->D + 5) * (size_t)c->cfg.n_steps * (size_t)c->cfg.n_envs; }
 Ckpt ckpt_of(const rsrl_hip_ctx* c) {
     Ckpt h{};
@@ -1966,12 +2004,63 @@ static int persist_launch(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, 
     return RSRL_HIP_OK;
 }
 
+// SARSALambda / QLambda over one shared tile table (kernels_sparse_lambda.hpp): per batch-step phase A (one wave per learner: residual against W_t,
+// sparse trace update, the learner's terms into the fixed-point table), the table -> W (the same finalize -> [exchange] -> apply as rsrl_hip_handle),
+// phase C (sample from W_{t+1}, restarts).  Plain launches: correctness first.
+static int train_sparse_lambda(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
+    const SparseTrace st{c->sp_keys, c->sp_vals, c->sp_len};
+    const SparseMail mail{c->sp_ns, c->flags};
+    const LambdaParams lp = make_lambda(c);
+    const int n = (int)c->dw_elems;
+    const int64_t N = k.n_envs;
+    for (int64_t j = 0; j < n_steps; ++j) {
+        TRY(timing_begin(c));
+        if (!for_model(c, [&](auto tag) {
+                using M = typename decltype(tag)::type;
+                if constexpr (M::kSparse)
+                    hipLaunchKernelGGL((k_sparse_lambda_step<M::kDomain, M::kT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, g, lp, st, mail, c->h_fx, c->t, d_stats);
+            })) return NO_MODEL(c);
+        KCHECK();
+        hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.alpha));
+        KCHECK();
+        TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
+        if (c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
+        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+        KCHECK();
+        for_model(c, [&](auto tag) {
+            using M = typename decltype(tag)::type;
+            if constexpr (M::kSparse)
+                hipLaunchKernelGGL((k_sparse_lambda_sample<M::kDomain, M::kT>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, mail, c->t, d_stats);
+        });
+        KCHECK();
+        TRY(timing_end(c, 1));
+        c->t += 1;
+    }
+    c->kernel_name = "k_sparse_lambda_step";
+    return RSRL_HIP_OK;
+}
+
 static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
     Common k = make_common(c);
     const BasisGeom g = make_geom(c);
+    if (is_sparse_lambda(c->cfg)) {
+        TRY(train_sparse_lambda(c, k, g, n_steps, d_stats));
+        if (stats_out) {
+            HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            memset(stats_out, 0, sizeof(*stats_out));
+            stats_out->env_steps = (uint64_t)n_steps * (uint64_t)c->cfg.n_envs;
+            for (size_t b = 0; b < c->n_stat_slots; ++b) {
+                stats_out->episodes += c->h_stats[b].episodes; stats_out->episodes_truncated += c->h_stats[b].episodes_truncated;
+                stats_out->sum_episode_steps += c->h_stats[b].sum_episode_steps;
+                stats_out->sum_abs_td_error += c->h_stats[b].sum_abs_td_error; stats_out->sum_reward += c->h_stats[b].sum_reward;
+            }
+        }
+        return RSRL_HIP_OK;
+    }
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : fuse_depth(c);

@@ -47,3 +47,48 @@ def test_teacher_step_shared_minibatch_rule(orc):
             dW += Wi - W
         W += dW
     assert np.allclose(W, run.weights, rtol=0, atol=1e-15) and np.abs(W).max() > 0
+
+
+def test_sparse_trace_rule_is_the_dense_rule_while_nothing_is_evicted(orc):
+    # the sparse-trace mini-batch loop (f64) against a dense numpy restatement of SURVEY A.7 with eligibility traces: identical while no list is full
+    N, K, T, B, A = 5, 40, 4, 5, 2
+    kw = dict(domain=1, basis=orc.TILE, n_tilings=T, tiles_per_dim=B, algo=orc.SARSA_LAMBDA, policy=orc.EGREEDY, epsilon=0.2, shared_w=True, seed=11,
+              gamma=0.97, lam=0.8, trace=orc.TRACE_ACCUMULATE, alpha=0.01, max_episode_steps=25)
+    ag = orc.make_agent(**kw)
+    run = orc.Run(ag, N, "f64")
+    run.reset()
+    F = run.F
+    W = np.zeros((F, A)); Z = np.zeros((N, F, A))
+    s = run.state.copy(); a = run.action.copy(); ep = np.zeros(N, int)
+    rate = 0.97 * 0.8
+    for k in range(K):
+        dW = np.zeros_like(W); nss = []; flags = []
+        for i in range(N):
+            ns, r, term = orc.domain_step(1, s[i], a[i], "f64")
+            ep[i] += 1
+            idx, idn = orc.tile_indices(ag, s[i]), orc.tile_indices(ag, ns)
+            qs, qn = W[idx].sum(0), W[idn].sum(0)
+            Z[i] *= rate
+            Z[i][idx, a[i]] += 1.0
+            if term:
+                delta = r - qs[a[i]]
+            else:
+                na = orc.policy_sample(orc.EGREEDY, qn, orc.draw(11, i, k, orc.BLK_INNER), eps=0.2)
+                delta = r + 0.97 * qn[na] - qs[a[i]]
+            dW += 0.01 * delta * Z[i]
+            if term:
+                Z[i][:] = 0
+            nss.append(ns); flags.append(term or ep[i] >= 25)
+        W += dW
+        for i in range(N):
+            ns = nss[i]
+            if flags[i]:
+                ns = orc.domain_reset(1, "f64"); ep[i] = 0
+            q = W[orc.tile_indices(ag, ns)].sum(0)
+            a[i] = orc.policy_sample(orc.EGREEDY, q, orc.draw(11, i, k, orc.BLK_STEP), eps=0.2)
+            s[i] = ns
+    run.train_sparse_lambda(K)
+    assert np.allclose(run.weights, W, rtol=0, atol=1e-14) and np.abs(W).max() > 0
+    assert np.array_equal(run.action, a) and np.allclose(run.state, s, atol=1e-14)
+    for i in range(N):
+        assert np.allclose(run.sparse_trace(i), Z[i], rtol=0, atol=1e-15)
