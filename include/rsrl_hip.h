@@ -84,7 +84,8 @@ typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL
                /* QSigma, the n-step Q(sigma) agent (control/td/q_sigma.rs:80-202; config.sigma, config.n_steps, alpha, gamma, and the
                 * agent's own policy).  The reference panics at its first full backup -- Backup::propagate reads entries[n_steps]
                 * (q_sigma.rs:52-53 vs :113-114) -- so the library implements it with that one dead out-of-bounds read removed
-                * (rsrl_amd/csrc/kernels_qsigma.hpp).  Per-learner weights, register-family Fourier bases. */
+                * (rsrl_amd/csrc/kernels_qsigma.hpp).  Per-learner f32 weights on every basis: register-family and generic Fourier orders, tile
+                * coding, and (round 5) the order-7 wave family (one wavefront per learner, kernels_wave_aux.hpp k_wave_qsigma). */
                RSRL_Q_SIGMA = 9 } rsrl_algo;
 /* rsrl::traces::{Accumulate, Saturate (Trace::replacing), Dutch}      traces.rs:188-240 */
 typedef enum { RSRL_TRACE_ACCUMULATE = 0, RSRL_TRACE_SATURATE = 1, RSRL_TRACE_DUTCH = 2 } rsrl_trace;

@@ -337,9 +337,22 @@ static void FN(dot_columns)(const R* phi, const R* W, int A, int F, R* q) {
     }
 }
 /* Function<(S,)>::evaluate -> Q(s,.) = W^T phi      fa/linear.rs:303-311 */
+/* Wave-order switch (set by orc_run_train_wave around an agent's handle, e.g. QSigma's): Q(s,.) and the column update of an order-7 Fourier
+ * basis on a 4-D domain go through the wave family's projection and summation order (wave_project / wave_dot below), so that agents written
+ * against orc_q_evaluate / orc_q_update_index are bit-comparable with the device's one-wavefront-per-learner kernels. */
+static int FN(g_wave_order) = 0;
+static void FN(wave_project)(const orc_basis* b, const R* s, R* phi);
+static R FN(wave_dot)(const R* phi, const R* W, int A, int a);
+static inline size_t FN(wave_row)(int l, int j, int v);
+static int FN(use_wave_order)(const orc_basis* b) { return FN(g_wave_order) && b->kind == ORC_FOURIER && b->order == 7 && b->dim == 4; }
 void FN(orc_q_evaluate)(const orc_basis* b, const R* W, int A, const R* s, R* q) {
     int F = orc_basis_nfeat(b), a;
-    if (b->kind == ORC_FOURIER) {
+    if (FN(use_wave_order)(b)) {
+        R* phi = (R*)malloc(sizeof(R) * 4096);
+        FN(wave_project)(b, s, phi);
+        for (a = 0; a < A; a++) q[a] = FN(wave_dot)(phi, W, A, a);
+        free(phi);
+    } else if (b->kind == ORC_FOURIER) {
         R* phi = (R*)malloc(sizeof(R) * (size_t)F);             /* reference allocs a feature array per call */
         FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
         FN(dot_columns)(phi, W, A, F, q);
@@ -372,7 +385,15 @@ int FN(orc_find_max)(const R* q, int A, R* val) {
 void FN(orc_q_update_index)(const orc_basis* b, R* W, int A, const R* s, int a, R lr, R error) {
     int F = orc_basis_nfeat(b), f;
     R scale = lr * error;
-    if (b->kind == ORC_FOURIER) {
+    if (FN(use_wave_order)(b)) {
+        R* phi = (R*)malloc(sizeof(R) * 4096); int l, j, v;
+        FN(wave_project)(b, s, phi);
+        for (l = 0; l < 64; l++) for (j = 0; j < 8; j++) for (v = 0; v < 8; v++) {
+            const size_t at = FN(wave_row)(l, j, v) * A + a;
+            W[at] = FN(fma_)(scale, phi[(l * 8 + j) * 8 + v], W[at]);
+        }
+        free(phi);
+    } else if (b->kind == ORC_FOURIER) {
         R* phi = (R*)malloc(sizeof(R) * (size_t)F);
         FN(orc_fourier_project)(b->order, b->dim, FN(basis_lo)(b), FN(basis_hi)(b), s, phi);
         for (f = 0; f < F; f++) W[(size_t)f * A + a] = FN(fma_)(scale, phi[f], W[(size_t)f * A + a]);
@@ -1222,12 +1243,12 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
           (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z) || (ag->algo == ORC_GREEDY_GQ && !w_bf16 && run->Z) ||
-          (ag->algo == ORC_TD && !w_bf16) || (ag->algo == ORC_TD_LAMBDA && !w_bf16 && run->Z))) return -1;
+          (ag->algo == ORC_TD && !w_bf16) || (ag->algo == ORC_TD_LAMBDA && !w_bf16 && run->Z) || (ag->algo == ORC_Q_SIGMA && !w_bf16 && run->qs))) return -1;
     if (ORC_IS_PRED(ag->algo)) AW = 1;
     phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
     for (i = 0; i < N; i++) {
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
-        R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8];
+        R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8], ns_pre[8];
         int a = run->action[i]; uint32_t ep = run->ep_step[i];
         FN(wave_project)(b, s, phi_s);
         for (j = 0; j < A; j++) q_s[j] = q_n[j] = (R)0.0;
@@ -1237,11 +1258,22 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
             R r, delta, e, scale; int term, trunc, na; uint32_t x[4], xin[4] = { 0, 0, 0, 0 };
             for (d = 0; d < D; d++) ns[d] = s[d];
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);
+            for (d = 0; d < D; d++) ns_pre[d] = ns[d];
             ep += 1;
             trunc = !term && ag->max_episode_steps > 0 && ep >= ag->max_episode_steps;
             if (term) FN(orc_domain_reset)(ag->domain, ns);
             FN(wave_project)(b, ns, phi_n);
             for (j = 0; j < AW; j++) q_n[j] = FN(wave_dot)(phi_n, W, AW, j);
+            if (ag->algo == ORC_Q_SIGMA) {
+                /* QSigma on the wave family (kernels_wave_aux.hpp k_wave_qsigma): q_sigma.rs:138-201 through the wave-order switch; the n-step
+                 * backup, the anchor's update and the residual are orc_handle_qsigma's */
+                orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+                FN(g_wave_order) = 1;
+                delta = FN(orc_handle_qsigma)(ag, W, &run->qs[i], s, a, r, ns_pre, term, xin);
+                FN(g_wave_order) = 0;
+                for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);          /* (phi_n is phi of the restart state after a terminal step) */
+                goto sampled_target;
+            }
             if (ag->algo == ORC_GREEDY_GQ) {
                 /* GreedyGQ on the wave family (rsrl_amd/csrc/kernels_wave_aux.hpp): greedy_gq.rs:73-141 with every dot product in the wave order */
                 R* V = run->Z + (size_t)i * F * A; R m, td_est, sc1, sc2, sc3; int na_star;

@@ -19,6 +19,7 @@
 #include "kernels_wave.hpp"
 #include "kernels_gq.hpp"
 #include "kernels_td.hpp"
+#include "kernels_qsigma.hpp"
 
 namespace rsrl {
 
@@ -214,6 +215,107 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
             sum_abs = (double)facc_abs; sum_r = (double)facc_r;
         } else {
             n_ep = 0; n_trunc = 0; sum_len = 0;
+        }
+    }
+    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
+}
+
+// ---------------------------------------------------------------------------------------
+// QSigma on the wave family: the Model interface qsigma_handle<M> is written against (kernels_qsigma.hpp), one WAVE per learner
+// ---------------------------------------------------------------------------------------
+// The n-step backup, its propagation and every decision are wave-uniform scalar work (all lanes alike, the ring in memory as on the other
+// families); what the 64 lanes share is the approximator: features = the lane's 64 of the 4096, Q = lane partials + the wave total in dot()'s
+// order, the anchor's column update = one coalesced sweep of that column.
+template <int DOMAIN>
+struct WaveModel {
+    using WF = WaveFourier<DOMAIN>;
+    using Dom = Domain<DOMAIN>;
+    static constexpr int D = WF::D, A = WF::A, F = WF::F;
+    struct Feat { float phi[8][8]; };
+    __device__ static __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
+    __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom&, Feat& f) { WF::project(s, lane(), f.phi); }
+    __device__ static __forceinline__ float q_index(const Common& c, int64_t i, const BasisGeom&, const Feat& f, int a) {
+        return wave_col_dot<DOMAIN>(c.W + (i * A + __builtin_amdgcn_readfirstlane(a)) * (int64_t)F, lane(), f.phi);
+    }
+    __device__ static __forceinline__ void q_all(const Common& c, int64_t i, const BasisGeom&, const Feat& f, float (&q)[A]) {
+#pragma unroll
+        for (int b = 0; b < A; ++b) q[b] = wave_col_dot<DOMAIN>(c.W + (i * A + b) * (int64_t)F, lane(), f.phi);
+    }
+    __device__ static __forceinline__ void update(const Common& c, int64_t i, const BasisGeom&, const Feat& f, int a, float scale) {
+        float* __restrict__ col = c.W + (i * A + __builtin_amdgcn_readfirstlane(a)) * (int64_t)F;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float w8[8];
+            WaveIO<float>::load8(col, (int64_t)j * 512 + lane() * 8, w8);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) w8[v] = fmaf(scale, f.phi[j][v], w8[v]);
+            WaveIO<float>::store8(col, (int64_t)j * 512 + lane() * 8, w8);
+        }
+    }
+};
+
+// from == nullptr: the driver loop (k_train_qsigma's, one wave per learner); otherwise Handler::handle on Mn caller-supplied transitions
+template <int DOMAIN>
+__global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, uint64_t t0, int n_steps, DevStats* __restrict__ stats,
+                                                        const float* __restrict__ from, const int32_t* __restrict__ act, const float* __restrict__ rew,
+                                                        const float* __restrict__ to, const uint8_t* __restrict__ termf, int64_t Mn, float* __restrict__ td_out) {
+    using M = WaveModel<DOMAIN>;
+    using Dom = Domain<DOMAIN>;
+    constexpr int D = M::D, A = M::A;
+    const BasisGeom g{M::F, kWaveOrder};
+    const int64_t N = c.n_envs;
+    const bool driver = from == nullptr;
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
+    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
+    double sum_abs = 0.0, sum_r = 0.0;
+    if (i < (driver ? N : Mn)) {
+        const uint32_t gid = (uint32_t)(c.env_offset + i);
+        if (!driver) {
+            float s[D], ns[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
+            const U4 xin = draw(c.seed, gid, t0, BLK_INNER);
+            const float res = qsigma_handle<M>(c, qp, g, i, N, s, clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i])), rew[i], ns, termf[i] != 0, xin);
+            if (td_out && M::lane() == 0) td_out[i] = res;
+        } else {
+            const uint32_t cap = c.max_episode_steps;
+            float s[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
+            int a = __builtin_amdgcn_readfirstlane(c.action[i]);
+            uint32_t ep = c.ep_step[i];
+            float facc_abs = 0.0f, facc_r = 0.0f;
+            for (int k = 0; k < n_steps; ++k) {
+                const uint64_t t = t0 + (uint64_t)k;
+                float ns[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) ns[d] = s[d];
+                float r;
+                const bool term = Dom::step(ns, a, r);
+                ep += 1;
+                const bool trunc = !term && cap > 0 && ep >= cap;
+                const U4 xin = draw(c.seed, gid, t, BLK_INNER);
+                const float res = qsigma_handle<M>(c, qp, g, i, N, s, a, r, ns, term, xin);
+                if (term || trunc) {
+                    n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; ep = 0;
+                    Dom::reset(ns);
+                }
+                typename M::Feat fn; float q_n[A];
+                M::features(ns, g, fn);
+                M::q_all(c, i, g, fn, q_n);                                        // the UPDATED weights at s' (or at s0 after the episode ended)
+                const U4 x = draw(c.seed, gid, t, BLK_STEP);
+                a = __builtin_amdgcn_readfirstlane(policy_sample<A>(c.pol, q_n, x));
+                facc_abs += fabsf(res); facc_r += r;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s[d] = ns[d];
+            }
+            if (M::lane() == 0) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
+                c.action[i] = a;
+                c.ep_step[i] = ep;
+                sum_abs = (double)facc_abs; sum_r = (double)facc_r;
+            } else { n_ep = 0; n_trunc = 0; sum_len = 0; }
         }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);

@@ -721,8 +721,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->algo < 0 || cfg->algo > RSRL_Q_SIGMA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->algo == RSRL_Q_SIGMA) {
         // any basis but the order-7 wave family: register-family Fourier, the generic Fourier orders, tile coding (per-learner tables)
-        if (cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32 || (cfg->basis == RSRL_FOURIER && cfg->order == kWaveOrder && cfg->domain != RSRL_MOUNTAIN_CAR))
-            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights (any Fourier order but 7 on CartPole / Acrobot, or tile coding)");
+        if (cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32)
+            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights");
         if (!(cfg->sigma >= 0.0 && cfg->sigma <= 1.0)) return fail(RSRL_HIP_EINVAL, "sigma must be in [0, 1]");
         if (cfg->n_steps < 1 || cfg->n_steps > 32) return fail(RSRL_HIP_EINVAL, "n_steps must be in [1, 32]");
     }
@@ -838,7 +838,6 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
     if (cfg->algo == RSRL_Q_SIGMA) {
-        if (is_wave(*cfg)) return fail(RSRL_HIP_EINVAL, "QSigma is not available on the order-7 wave family");
         const size_t nf = (size_t)(c->D + 5) * (size_t)cfg->n_steps * (size_t)N;
         HIP_TRY(hipMalloc((void**)&c->qs_buf, sizeof(float) * nf));
         HIP_TRY(hipMalloc((void**)&c->qs_head, sizeof(uint32_t) * (size_t)N));
@@ -1230,6 +1229,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     } else if (is_pred(c->cfg.algo)) {
         if (!launch_handle_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_td(c),
                               d_from, d_rew, d_to, d_term, M, otd.dev)) return NO_MODEL(c);
+    } else if (c->cfg.algo == RSRL_Q_SIGMA && is_wave(c->cfg)) {
+        if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_qsigma<1>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_qs(c), c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+        else hipLaunchKernelGGL((k_wave_qsigma<2>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_qs(c), c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
     } else if (c->cfg.algo == RSRL_Q_SIGMA) {
         const bool reg = c->cfg.basis == RSRL_FOURIER && !is_generic_fourier(c->cfg);
         if (!(reg ? launch_qsigma(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_qs(c), g, c->t, 0, nullptr,
@@ -2141,6 +2143,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (!launch_train_td(c->cfg.domain, c->cfg.order, c->cfg.algo == RSRL_TD_LAMBDA, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k,
                                  make_td(c), c->t, chunk, d_stats)) return NO_MODEL(c);
             c->kernel_name = "k_train_td";
+            KCHECK();
+        } else if (c->cfg.algo == RSRL_Q_SIGMA && is_wave(c->cfg)) {
+            if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_qsigma<1>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_qs(c), c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
+            else hipLaunchKernelGGL((k_wave_qsigma<2>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_qs(c), c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
+            c->kernel_name = "k_wave_qsigma";
             KCHECK();
         } else if (c->cfg.algo == RSRL_Q_SIGMA) {
             const bool reg = fourier && !is_generic_fourier(c->cfg);

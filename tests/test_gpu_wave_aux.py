@@ -32,6 +32,10 @@ CASES = [
     ("tdl_cartpole_accumulate", 1, dict(algo=8, policy=3, gamma=0.99, lam=0.8, trace=0, alpha=0.1), 16),
     ("tdl_cartpole_saturate", 1, dict(algo=8, policy=3, gamma=0.99, lam=0.8, trace=1, alpha=0.1), 16),
     ("tdl_acrobot_dutch", 2, dict(algo=8, policy=3, gamma=0.99, lam=0.7, trace=2, alpha=0.2), 12),
+    # QSigma (q_sigma.rs:80-202): the n-step backup ring in memory, one wave per learner
+    ("qsigma_cartpole_n3_half", 1, dict(algo=9, policy=1, epsilon=0.2, lr=0.0002, alpha=0.5, gamma=0.99, sigma=0.5, n_steps=3), 60),
+    ("qsigma_acrobot_n1_sarsa", 2, dict(algo=9, policy=1, epsilon=0.1, lr=0.0001, alpha=1.0, gamma=0.95, sigma=1.0, n_steps=1), 40),
+    ("qsigma_cartpole_n4", 1, dict(algo=9, policy=1, epsilon=0.3, lr=0.0002, alpha=0.5, gamma=0.99, sigma=0.3, n_steps=4), 60),      # (sigma = 0 with n > 1 learns nothing from a terminal-only reward: the terminal entry has pi = 0, q_sigma.rs:142-153)
 ]
 
 
@@ -45,7 +49,7 @@ def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K)
     N = 7                                                      # two thread blocks, the second one partially filled
     ag = orc.make_agent(domain=domain, order=7, seed=9, max_episode_steps=13, **_okw(kw))
     run = orc.Run(ag, N, "f32d")
-    if kw["algo"] == 6:
+    if kw["algo"] in (6, 9):
         run.reset_wave()
     else:
         run.reset()
@@ -67,6 +71,32 @@ def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K)
                     assert np.array_equal(c.get_traces(i), run.traces[i]), (name, spl, i)
             assert st["env_steps"] == N * K
             assert np.isfinite(run.weights).all() and np.abs(run.weights).max() > 0
+
+
+def test_qsigma_single_transitions_vs_f64(ra, orc):
+    # three handle calls per learner through a 2-step backup: the second and third update the anchor
+    M, n = 5, 2
+    rng = np.random.default_rng(5)
+    kw = dict(gamma=0.97, lr=0.001, alpha=0.5, sigma=0.5, n_steps=n, epsilon=0.2)
+    ag = orc.make_agent(domain=1, order=7, algo=9, policy=1, seed=4, **kw)
+    with ra.Context(domain=1, order=7, algo=9, policy=1, seed=4, n_envs=M, **kw) as c:
+        Ws = [(rng.normal(size=(4096, 2)) * 0.02).astype(np.float32) for _ in range(M)]
+        for i in range(M):
+            c.set_weights(Ws[i], i)
+        W64 = [w.astype(np.float64) for w in Ws]
+        bks = [orc.QSigmaBackup(n, "f64") for _ in range(M)]
+        s = rand_states(orc, 1, M, 33, shrink=0.3)
+        c.states = s
+        for k in range(3):
+            a = rng.integers(0, 2, M).astype(np.int32)
+            frm, nxt, rew, term = c.domain_step(a)
+            td = c.handle(frm, a, rew, nxt, term)
+            for i in range(M):
+                d = bks[i].handle(ag, W64[i], frm[:, i], a[i], rew[i], nxt[:, i], term[i], orc.draw(4, i, k, orc.BLK_INNER))
+                assert abs(td[i] - d) <= 1e-4 * (1 + abs(d)), (k, i, td[i], d)
+        for i in range(M):
+            assert np.max(np.abs(c.get_weights(i) - W64[i])) <= 5e-6
+            assert not np.array_equal(c.get_weights(i), Ws[i])      # the anchor did move
 
 
 @pytest.mark.parametrize("algo,domain", [(6, 1), (6, 2), (7, 2), (8, 1)])
