@@ -108,7 +108,8 @@ def main():
         r = d["roofline"]
         return (f"* {what}: value {d['value']:.4g} env-steps/s, `{r['kernel']}` {r['avg_launch_ms'] * 1e3:.2f} us per launch by HIP events "
                 f"({r['launches']} launches of {d['config']['steps_per_launch']:.1f} batch-steps = {r['avg_launch_ms'] * 1e3 / d['config']['steps_per_launch']:.4f} us per batch-step), "
-                f"roofline.frac {r['frac']:.3f}")
+                f"roofline.frac " + (f"{r['frac']:.3f}" if r.get('frac') is not None else
+                                     f"withheld (this run preceded the stamping of the profile it would be computed from; from the stale constants: {r.get('from_stale_profile', {}).get('frac')})"))
     md = [f"# rocprofv3 --kernel-trace --stats of the bench command ({tag}, 1 x MI355X)", "",
           "## `python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's invocation)", "",
           line(plain, "plain run"), line(prof, "the same command under rocprofv3 (`--no-cpu-baseline`, legs off)"), "",

@@ -90,5 +90,6 @@ def test_lambda_tile_checkpoint_and_errors(ra, tmp_path):
         b.states, b.actions = s, act
         b.train(20, want_stats=False)
         assert np.array_equal(b.get_weights(5), ref[0]) and np.array_equal(b.get_traces(5), ref[1]) and np.array_equal(b.states, ref[2])
-    with pytest.raises(ra.RsrlHipError):                               # one trace table per learner: not with a shared approximator
-        ra.Context(**dict(kw, weight_mode=ra.W_SHARED))
+    with ra.Context(**dict(kw, weight_mode=ra.W_SHARED)) as sh:        # a shared table takes SPARSE per-learner traces instead (round 5,
+        with pytest.raises(ra.RsrlHipError):                           # tests/test_gpu_sparse_lambda.py); those cannot be set from a dense matrix
+            sh.set_traces(np.zeros((sh.F, sh.A), np.float32), 0)

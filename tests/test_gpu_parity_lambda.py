@@ -93,8 +93,8 @@ def test_lambda_error_paths(ra):
         ra.Context(algo=3, weight_mode=ra.W_SHARED, n_envs=4)
     with ra.Context(algo=4, basis=ra.TILE_CODING, domain=1, n_envs=4):     # tile coding: built in round 3 (tests/test_gpu_lambda_tile.py)
         pass
-    with pytest.raises(ra.RsrlHipError):                                    # ... with per-learner tables only
-        ra.Context(algo=4, basis=ra.TILE_CODING, domain=1, n_envs=4, weight_mode=ra.W_SHARED)
+    with ra.Context(algo=4, basis=ra.TILE_CODING, domain=1, n_envs=4, weight_mode=ra.W_SHARED):     # one shared table, sparse per-learner traces: round 5
+        pass                                                                                        # (tests/test_gpu_sparse_lambda.py)
     with ra.Context(algo=3, domain=2, order=7, n_envs=4):                   # the order-7 wave family: built in round 3 (tests/test_gpu_wave_lambda.py)
         pass
     with pytest.raises(ra.RsrlHipError):                                    # ... with f32 tables only
