@@ -67,8 +67,10 @@ def test_domain_step_matches_oracle(ra, orc, domain, steps):
             assert np.array_equal(frm, cur)
             for i in range(0, N, 5):
                 es, er, et = orc.domain_step(domain, cur[:, i], a[i], "f32")
-                # Acrobot: dt = 0.2 with |theta'| up to 9*pi amplifies sincos ulps through the 4 RK4 stages
-                t32, t64 = (2e-5, 4e-4) if domain == 2 else (2e-6, 1e-5)
+                # Acrobot: dt = 0.2 with |theta'| up to 9*pi amplifies sincos ulps through the 4 RK4 stages.  Measured worst case over ALL 512
+                # learners x 30 steps of this very loop: 1.85e-5 against the f32 oracle, 3.7e-5 against f64 (relative to 1 + |x|; reached at
+                # theta1' = -4 pi, theta2' = -6.0): asserted at ~2x that (round 4 asserted 4e-4 against f64)
+                t32, t64 = (4e-5, 8e-5) if domain == 2 else (2e-6, 1e-5)
                 assert np.allclose(nxt[:, i], es, rtol=t32, atol=t32), (k, i, nxt[:, i], es)
                 es64, er64, et64 = orc.domain_step(domain, cur[:, i], a[i], "f64")
                 assert np.allclose(nxt[:, i], es64, rtol=t64, atol=t64)
