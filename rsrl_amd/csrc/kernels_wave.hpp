@@ -89,29 +89,58 @@ struct WaveFourier {
     static constexpr int D = Dom::D, A = Dom::A, N1 = kWaveN1, F = 4096;
     static_assert(D == 4, "the wave family is laid out for 4-D state spaces");
 
+    // ---- the per-dimension harmonic tables, SPREAD OVER THE LANES (round 5).  The tables are the register family's -- per dimension one
+    // sincospi01 of the scaled state and the angle-addition chain cos/sin(n x) from (n-1) x, FourierTables::build -- but here the state is the
+    // wave's, so 64 lanes building all 4 x 8 entries each would do the same work 64 times (it was ~230 issue slots of the wave-step, the packed
+    // pair tables included).  Instead lane l builds ONE entry: dimension d = (l >> 3) & 3, harmonic n = l & 7, by running its own dimension's
+    // chain and keeping step n -- the very operations of FourierTables::build on that entry, hence the same bits -- and the entries travel:
+    // dimension 0 / 3 (indexed by the chunk j / the element v: wave-uniform) by v_readlane, dimension 1 / 2 (indexed by the lane's own c1 / c2)
+    // by one ds_bpermute each.
+    struct Harm { float c, s; };
+    __device__ static __forceinline__ Harm harmonic_of_lane(const float (&sv)[D], int lane) {
+        const int d = (lane >> 3) & 3, n = lane & 7;
+        float sc[D];
+        static_for<0, D>([&](auto Dd) {
+            constexpr int dd = Dd;
+            constexpr float lo = (float)Dom::lo_d(dd), hi = (float)Dom::hi_d(dd);
+            constexpr float inv = 1.0f / (hi - lo);                          // as FourierTables::build
+            sc[dd] = (sv[dd] - lo) * inv;
+        });
+        const float x = d == 0 ? sc[0] : (d == 1 ? sc[1] : (d == 2 ? sc[2] : sc[3]));
+        float s1, c1;
+        sincospi01(x, s1, c1);
+        float pc = c1, ps = s1;                                              // harmonic 1
+        Harm h{n == 0 ? 1.0f : c1, n == 0 ? 0.0f : s1};
+#pragma unroll
+        for (int m = 2; m < N1; ++m) {
+            const float nc = fmaf(-ps, s1, pc * c1), nsn = fmaf(pc, s1, ps * c1);
+            pc = nc; ps = nsn;
+            h.c = (n == m) ? pc : h.c; h.s = (n == m) ? ps : h.s;
+        }
+        return h;
+    }
+    __device__ static __forceinline__ float from_lane(float v, int src) { return __shfl(v, src, 64); }
+    __device__ static __forceinline__ float uni_lane(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
     // phi[j][v] = cos(pi * (j*s~0 + c1*s~1 + c2*s~2 + v*s~3)), evaluated exactly like the register family
     // (per dimension one sincospi + the angle-addition chain, then the complex product over dimensions in
     // dimension order) -- the same op order as the f32 oracle.
     __device__ static __forceinline__ void project(const float (&s)[D], int lane, float (&phi)[8][8]) {
-        FourierTables<DOMAIN, kWaveOrder> tb;
-        tb.build(s);
+        const Harm h = harmonic_of_lane(s, lane);
         const int c1 = lane >> 3, c2 = lane & 7;
-        float e1r = tb.ct[1][0], e1i = tb.st[1][0], e2r = tb.ct[2][0], e2i = tb.st[2][0];
+        const float e1r = from_lane(h.c, 8 + c1), e1i = from_lane(h.s, 8 + c1), e2r = from_lane(h.c, 16 + c2), e2i = from_lane(h.s, 16 + c2);
+        float c3[8], s3[8];
 #pragma unroll
-        for (int c = 1; c < N1; ++c) {
-            e1r = (c1 == c) ? tb.ct[1][c] : e1r; e1i = (c1 == c) ? tb.st[1][c] : e1i;
-            e2r = (c2 == c) ? tb.ct[2][c] : e2r; e2i = (c2 == c) ? tb.st[2][c] : e2i;
-        }
+        for (int v = 0; v < 8; ++v) { c3[v] = uni_lane(h.c, 24 + v); s3[v] = uni_lane(h.s, 24 + v); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             // ((E0[j] * E1[c1]) * E2[c2]) * E3[v], real part
-            float re = tb.ct[0][j], im = tb.st[0][j];
+            float re = uni_lane(h.c, j), im = uni_lane(h.s, j);
             float nre = fmaf(-im, e1i, re * e1r), nim = fmaf(re, e1i, im * e1r);
             re = nre; im = nim;
             nre = fmaf(-im, e2i, re * e2r); nim = fmaf(re, e2i, im * e2r);
             re = nre; im = nim;
 #pragma unroll
-            for (int v = 0; v < 8; ++v) phi[j][v] = fmaf(-im, tb.st[3][v], re * tb.ct[3][v]);
+            for (int v = 0; v < 8; ++v) phi[j][v] = fmaf(-im, s3[v], re * c3[v]);
         }
     }
     // per-lane partial of <phi, w_b> (4 interleaved chains), then the wave total (uniform)
@@ -150,26 +179,17 @@ struct WaveFourier {
         f2 c3[4], s3[4];                 // dimension-3 harmonics, pairs (v, v+1)
     };
     __device__ static __forceinline__ void stream_begin(const float (&s)[D], int lane, Stream& st) {
-        PairTab tb;
-        tb.build(s);
+        const Harm h = harmonic_of_lane(s, lane);
         const int c1 = lane >> 3, c2 = lane & 7;
-        st.e1r = tb.c(1, 0); st.e1i = tb.s(1, 0); st.e2r = tb.c(2, 0); st.e2i = tb.s(2, 0);
+        st.e1r = from_lane(h.c, 8 + c1); st.e1i = from_lane(h.s, 8 + c1); st.e2r = from_lane(h.c, 16 + c2); st.e2i = from_lane(h.s, 16 + c2);
+        // dimension 0 / 3 are indexed by the chunk / the element, the same in every lane: held as wave-uniform scalars they cost no vector
+        // registers next to W (32 values that otherwise push the loop past its register budget)
 #pragma unroll
-        for (int c = 1; c < N1; ++c) {
-            const float a1r = tb.c(1, c), a1i = tb.s(1, c), a2r = tb.c(2, c), a2i = tb.s(2, c);
-            st.e1r = (c1 == c) ? a1r : st.e1r; st.e1i = (c1 == c) ? a1i : st.e1i;
-            st.e2r = (c2 == c) ? a2r : st.e2r; st.e2i = (c2 == c) ? a2i : st.e2i;
-        }
-        // the state is the wave's (one learner per wave), so the dimension-0 / dimension-3 harmonics are the same bits in every lane:
-        // held as wave-uniform scalars they cost no vector registers next to the 192 of W (32 values that otherwise push the loop
-        // past the 256 architectural VGPRs and into AGPR copies around every use)
-        auto uni = [](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { st.c0[j] = uni(tb.c(0, j)); st.s0[j] = uni(tb.s(0, j)); }
+        for (int j = 0; j < 8; ++j) { st.c0[j] = uni_lane(h.c, j); st.s0[j] = uni_lane(h.s, j); }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            st.c3[p] = f2{uni(tb.c(3, 2 * p)), uni(tb.c(3, 2 * p + 1))};
-            st.s3[p] = f2{uni(tb.s(3, 2 * p)), uni(tb.s(3, 2 * p + 1))};
+            st.c3[p] = f2{uni_lane(h.c, 24 + 2 * p), uni_lane(h.c, 24 + 2 * p + 1)};
+            st.s3[p] = f2{uni_lane(h.s, 24 + 2 * p), uni_lane(h.s, 24 + 2 * p + 1)};
         }
     }
     __device__ static __forceinline__ void stream_chunk(const Stream& st, int j, f2 (&phi)[4]) {
