@@ -558,6 +558,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
         float facc_abs = 0.0f, facc_r = 0.0f;
         for (int k = 0; k < n_steps; ++k) {
             const uint64_t t = t0 + (uint64_t)k;
+            // the step's Philox blocks depend on nothing but (learner, t): drawn FIRST, their integer work sits in the same basic block as the
+            // transition's long dependent chain and fills its stalls
+            const U4 rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             float ns[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) ns[d] = s[d];
@@ -576,7 +580,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             float e;
             const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e, lane);
             const float scale = c.alg.lr * e;
-            const U4 rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
             float qa = 0.0f;
             static_for<0, A>([&](auto Bb) {
                 constexpr int b = Bb;
@@ -584,7 +587,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             });
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
-            const U4 x = draw(c.seed, gid, t, BLK_STEP);
             int na = policy_sample<A>(c.pol, q_n, x, lane);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }

@@ -4,6 +4,7 @@
 // fold is done at all.   build: hipcc --offload-arch=gfx950 -O3 -o grid_barrier grid_barrier.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 
@@ -83,9 +84,13 @@ int run(const char* name, int nb) {
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     printf("%s, %d CUs\n", p.name, p.multiProcessorCount);
+    if (argc > 1) {      // `grid_barrier 512 ...`: the barrier alone at the given block counts (512 blocks x 512 threads = C3's 262 144 resident learners)
+        for (int a = 1; a < argc; ++a) if (run<0>("barrier only", atoi(argv[a]))) return 1;
+        return 0;
+    }
     for (int nb : {64, 256}) {
         if (run<0>("barrier only", nb)) return 1;
         if (run<1>("fences + plain rows + fold", nb)) return 1;
