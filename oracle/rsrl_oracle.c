@@ -31,6 +31,13 @@
  *     - crate rand = "0.7" streams: replaced by Philox4x32-10 (pinned against
  *       the Random123 known-answer vectors); parity on stochastic paths is
  *       distributional, exact on deterministic sub-paths.
+ *   ROUND 5 (rsrl_oracle_impl.h): orc_run_teacher (one batch-step as a teacher:
+ *     fp32-rounded successor states + the handled transitions, for the
+ *     teacher-forced f64 comparisons of every BASELINE configuration);
+ *     orc_run_train_wave also in the wave order for GreedyGQ / TD / TDLambda /
+ *     QSigma; orc_run_train_sparse_lambda (traces.rs:5-12 over params/sparse.rs:
+ *     eligibility traces over one shared tile table, sparse per learner, checked
+ *     against a dense numpy restatement in tests/test_oracle_round5.py).
  * ============================================================================
  */
 #include <math.h>
