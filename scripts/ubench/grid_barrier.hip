@@ -62,6 +62,54 @@ __global__ __launch_bounds__(BLOCK) void k(float* rows /*[2][AF][nb]*/, unsigned
     if (threadIdx.x < AF && blockIdx.x == 0) out[threadIdx.x] = sh_w[threadIdx.x];
 }
 
+// The guide's "barrier-xcd": blocks arrive on the counter of their group (g = blockIdx % 8: the XCD under the observed placement -- speed only, the
+// protocol does not depend on it), the group's LAST arriver goes to the top counter, waits for all groups and releases its group's generation word.
+// Counters are monotonic (no reset); one 128-byte line per word.
+struct XcdBar { unsigned w[(8 + 1 + 8) * 32]; };
+__device__ __forceinline__ unsigned* xb_cnt(XcdBar* b, int g) { return &b->w[g * 32]; }
+__device__ __forceinline__ unsigned* xb_top(XcdBar* b) { return &b->w[8 * 32]; }
+__device__ __forceinline__ unsigned* xb_gen(XcdBar* b, int g) { return &b->w[(9 + g) * 32]; }
+__global__ __launch_bounds__(BLOCK) void k_xcd(XcdBar* bar, unsigned* err, int iters) {
+    const int nb = gridDim.x, g = blockIdx.x & 7;
+    const unsigned members = (unsigned)((nb - g + 7) / 8), groups = (unsigned)(nb < 8 ? nb : 8);
+    __shared__ int ok;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            bool fine = true;
+            const unsigned old = __hip_atomic_fetch_add(xb_cnt(bar, g), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (old + 1 == members * (unsigned)(it + 1)) {
+                __hip_atomic_fetch_add(xb_top(bar), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                fine = wait_count(xb_top(bar), groups * (unsigned)(it + 1), err);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(xb_gen(bar, g), (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                fine = wait_count(xb_gen(bar, g), (unsigned)(it + 1), err);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            ok = fine ? 1 : 0;
+        }
+        __syncthreads();
+        if (!ok) return;
+    }
+}
+int run_xcd(int nb) {
+    XcdBar* bar; unsigned* err;
+    CHECK(hipMalloc(&bar, sizeof(XcdBar))); CHECK(hipMalloc(&err, 4));
+    for (int iters : {100, 2000}) {
+        CHECK(hipMemset(bar, 0, sizeof(XcdBar))); CHECK(hipMemset(err, 0, 4));
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_xcd, dim3(nb), dim3(BLOCK), 0, 0, bar, err, iters);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned h_err; CHECK(hipMemcpy(&h_err, err, 4, hipMemcpyDeviceToHost));
+        printf("%-34s blocks %3d iters %4d: %8.3f ms  = %6.2f us per step   err %u\n", "barrier only, XCD-hierarchical", nb, iters, ms, ms * 1e3 / iters, h_err);
+    }
+    hipFree(bar); hipFree(err);
+    return 0;
+}
+
 template <int MODE>
 int run(const char* name, int nb) {
     float *rows, *out; unsigned *ctr, *err;
@@ -88,7 +136,7 @@ int main(int argc, char** argv) {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     printf("%s, %d CUs\n", p.name, p.multiProcessorCount);
     if (argc > 1) {      // `grid_barrier 512 ...`: the barrier alone at the given block counts (512 blocks x 512 threads = C3's 262 144 resident learners)
-        for (int a = 1; a < argc; ++a) if (run<0>("barrier only", atoi(argv[a]))) return 1;
+        for (int a = 1; a < argc; ++a) if (run<0>("barrier only", atoi(argv[a])) || run_xcd(atoi(argv[a]))) return 1;
         return 0;
     }
     for (int nb : {64, 256}) {
