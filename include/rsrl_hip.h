@@ -288,13 +288,13 @@ int rsrl_hip_set_traces(rsrl_hip_ctx* ctx, int64_t env_index, const float* z /*[
 int rsrl_hip_get_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, float* v /*[F][A]*/);
 int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v /*[F][A]*/);
 /* Checkpoint of the approximator(s) (the reference's only persistence story is the optional serde
- * derive on the agents, rsrl/Cargo.toml:26).  File format version 2 (3 for files that carry QSigma's backups), little-endian,
+ * derive on the agents, rsrl/Cargo.toml:26).  File format version 2 (3 for files that carry QSigma's backups, 5 for sparse traces), little-endian,
  * serialised field by field (no padding):
  *   offset  0  char magic[8] = "RSRLHIPW"
- *           8  u32  version = 2 (3 iff aux_kind = 3)
+ *           8  u32  version = 2 (3 iff aux_kind = 3, 5 iff aux_kind = 4, 4 with the epsilon schedule)
  *          12  i32  domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A (weight columns),
  *                   algo, weight_dtype, aux_kind (0 none, 1 eligibility traces, 2 GreedyGQ's fa_td weights,
- *                   3 QSigma's n-step backups)                                                                  [11 x i32]
+ *                   3 QSigma's n-step backups, 4 sparse traces over a shared table)                             [11 x i32]
  *          56  i64  n_learners (1 in shared mode)
  *          64  u64  step_count
  *          72  n_learners x f32[F][A] weights in the reference's row-major (F, A) order (Parameterised::weights,
@@ -303,6 +303,9 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v
  *              if aux_kind is 3 (file version 3): u32 head[N], u32 len[N], f32 entries[D + 5][n_steps][N] -- every learner's
  *              Backup ring {s, a, q, residual, pi, mu} (q_sigma.rs:30-63), so that a QSigma run with n_steps > 1 resumes
  *              bit-identically too.  Files of version 2 (no aux_kind 3) are still read.
+ *              if aux_kind is 4 (file version 5; SARSALambda / QLambda over ONE shared tile-coded table): u32 len[N], then for every learner
+ *              in turn u32 key[len] (= feature index * A + action) and f32 value[len] -- its sparse trace (params/sparse.rs:13-97), in slot
+ *              order, so that the run resumes bit-identically (the slot order decides which entry a full list overwrites).
  *              A ctx with config.epsilon_decay writes file version 4: everything above, then f32 eps[N], every learner's current
  *              epsilon (the schedule's state), so that a resumed run continues the schedule.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header

@@ -1391,14 +1391,17 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) 
 namespace {
 constexpr uint32_t kCkptVersion = 3;          // files carrying aux_kind 3 (QSigma's n-step backups); every other file is still written as version 2
 constexpr uint32_t kCkptVersionEps = 4;       // ... or as version 4 when the ctx runs the per-learner epsilon schedule: f32 eps[N] follows the payload
+constexpr uint32_t kCkptVersionSparse = 5;    // files carrying aux_kind 4 (the sparse per-learner traces over a shared table)
+constexpr int64_t kSparseChunk = 4096;        // learners per staging chunk of the sparse lists
 constexpr size_t kCkptHeaderBytes = 72;
 struct Ckpt {
     int32_t domain, basis, order, n_tilings, tiles_per_dim, weight_mode, F, A, algo, weight_dtype, aux_kind;
     int64_t n_learners; uint64_t step_count;
     bool has_eps;                                 // (not a header field: the file version says it)
 };
-// 1 = eligibility traces, 2 = fa_td weights (both: a second matrix of W's shape), 3 = QSigma's per-learner n-step backups
-int aux_kind_of(const rsrl_hip_ctx* c) { return c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1)); }     // (sparse shared-table traces: Z is null -> 0, the lists are not part of a checkpoint)
+// 1 = eligibility traces, 2 = fa_td weights (both: a second matrix of W's shape), 3 = QSigma's per-learner n-step backups,
+// 4 = every learner's sparse trace over the shared table (the lists, compact)
+int aux_kind_of(const rsrl_hip_ctx* c) { return c->sp_keys ? 4 : (c->qs_buf ? 3 : (!c->Z ? 0 : (c->cfg.algo == RSRL_GREEDY_GQ ? 2 : 1))); }
 size_t qs_floats(const rsrl_hip_ctx* c) { return (size_t)(c->D + 5) * (size_t)c->cfg.n_steps * (size_t)c->cfg.n_envs; }
 Ckpt ckpt_of(const rsrl_hip_ctx* c) {
     Ckpt h{};
@@ -1416,7 +1419,7 @@ uint64_t get64(const uint8_t*& p) { uint64_t v = 0; for (int i = 0; i < 8; ++i) 
 void ckpt_encode(const Ckpt& h, uint8_t (&buf)[kCkptHeaderBytes]) {
     uint8_t* p = buf;
     memcpy(p, "RSRLHIPW", 8); p += 8;
-    put32(p, h.has_eps ? kCkptVersionEps : (h.aux_kind == 3 ? kCkptVersion : 2u));
+    put32(p, h.has_eps ? kCkptVersionEps : (h.aux_kind == 4 ? kCkptVersionSparse : (h.aux_kind == 3 ? kCkptVersion : 2u)));
     const int32_t f[11] = {h.domain, h.basis, h.order, h.n_tilings, h.tiles_per_dim, h.weight_mode, h.F, h.A, h.algo, h.weight_dtype, h.aux_kind};
     for (int32_t v : f) put32(p, (uint32_t)v);
     put64(p, (uint64_t)h.n_learners); put64(p, h.step_count);
@@ -1459,6 +1462,28 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
         if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the QSigma backups: %s", hipGetErrorString(e));
         else if (fwrite(hl.data(), 4, 2 * N, f) != 2 * N || fwrite(buf.data(), 4, nf, f) != nf) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
     }
+    if (rc == RSRL_HIP_OK && h.aux_kind == 4) {                        // sparse traces: u32 len[N], then per learner its len keys and len values
+        const int64_t N = c->cfg.n_envs;
+        std::vector<uint32_t> len((size_t)N), keys((size_t)(kSparseChunk * kSparseCap));
+        std::vector<float> vals((size_t)(kSparseChunk * kSparseCap));
+        hipError_t e = hipMemcpyAsync(len.data(), c->sp_len, 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the sparse traces: %s", hipGetErrorString(e));
+        else if (fwrite(len.data(), 4, (size_t)N, f) != (size_t)N) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+        for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
+            const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
+            e = hipMemcpyAsync(keys.data(), c->sp_keys + i0 * kSparseCap, 4 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(vals.data(), c->sp_vals + i0 * kSparseCap, 4 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) { rc = fail(RSRL_HIP_EHIP, "reading the sparse traces: %s", hipGetErrorString(e)); break; }
+            for (int64_t i = 0; rc == RSRL_HIP_OK && i < n; ++i) {
+                const size_t l = len[(size_t)(i0 + i)];
+                if (l > (size_t)kSparseCap) rc = fail(RSRL_HIP_ESTATE, "learner %lld's sparse trace has %zu entries", (long long)(i0 + i), l);
+                else if (fwrite(keys.data() + i * kSparseCap, 4, l, f) != l || fwrite(vals.data() + i * kSparseCap, 4, l, f) != l)
+                    rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+            }
+        }
+    }
     if (rc == RSRL_HIP_OK && h.has_eps) {                              // the schedule's state: every learner's current epsilon
         std::vector<float> e((size_t)c->cfg.n_envs);
         rc = rsrl_hip_get_epsilons(c, e.data());
@@ -1477,11 +1502,13 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     Ckpt h{}; uint32_t version = 0; uint8_t hdr[kCkptHeaderBytes];
     int rc = RSRL_HIP_OK;
     if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || !ckpt_decode(hdr, &h, &version)) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
-    else if (version != kCkptVersion && version != 2u && version != kCkptVersionEps)
-        rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2, %u and %u", path, version, kCkptVersion, kCkptVersionEps);
+    else if (version != kCkptVersion && version != 2u && version != kCkptVersionEps && version != kCkptVersionSparse)
+        rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2, %u, %u and %u", path, version, kCkptVersion, kCkptVersionEps,
+                  kCkptVersionSparse);
     // a QSigma file written before the backups travelled (version 2, aux_kind 0) is still read: the weights are loaded and the run
     // resumes from EMPTY n-step backups, as after a terminal transition (q_sigma.rs:154)
-    const bool old_qsigma = rc == RSRL_HIP_OK && want.aux_kind == 3 && h.aux_kind == 0 && version == 2u;
+    // (the same for a sparse-trace file of ABI 7's first build, version 2 / aux_kind 0: the run resumes from EMPTY lists, Trace::zeros)
+    const bool old_qsigma = rc == RSRL_HIP_OK && (want.aux_kind == 3 || want.aux_kind == 4) && h.aux_kind == 0 && version == 2u;
     if (rc == RSRL_HIP_OK &&
         (h.domain != want.domain || h.basis != want.basis || h.order != want.order || h.n_tilings != want.n_tilings ||
          h.tiles_per_dim != want.tiles_per_dim || h.weight_mode != want.weight_mode || h.F != want.F || h.A != want.A ||
@@ -1490,11 +1517,23 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration%s", path,
                   h.has_eps != want.has_eps ? " (the per-learner epsilon schedule, config.epsilon_decay, is part of it)" : "");
     const size_t per = (size_t)c->F * c->Aw;
+    std::vector<uint32_t> sp_len_in;
     if (rc == RSRL_HIP_OK) {                                             // a truncated file is refused before anything is touched
-        const long long expect = (long long)kCkptHeaderBytes + (long long)((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1) * h.n_learners * (long long)per * 4 +
-                                 (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0) +
-                                 (h.has_eps ? (long long)c->cfg.n_envs * 4 : 0);
-        if (fseek(f, 0, SEEK_END) != 0 || ftell(f) != expect || fseek(f, (long)kCkptHeaderBytes, SEEK_SET) != 0)
+        long long expect = (long long)kCkptHeaderBytes + (long long)((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1) * h.n_learners * (long long)per * 4 +
+                           (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0) +
+                           (h.has_eps ? (long long)c->cfg.n_envs * 4 : 0);
+        if (h.aux_kind == 4) {                                           // the lists are compact: their lengths say how long the file is
+            const size_t N = (size_t)c->cfg.n_envs;
+            sp_len_in.resize(N);
+            if (fseek(f, (long)(kCkptHeaderBytes + h.n_learners * (long long)per * 4), SEEK_SET) != 0 || fread(sp_len_in.data(), 4, N, f) != N)
+                rc = fail(RSRL_HIP_EINVAL, "%s is truncated (the sparse traces' lengths)", path);
+            expect += 4 * (long long)N;
+            for (size_t i = 0; rc == RSRL_HIP_OK && i < N; ++i) {
+                if (sp_len_in[i] > (uint32_t)kSparseCap) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt sparse trace of learner %zu (%u entries)", path, i, sp_len_in[i]);
+                expect += 8 * (long long)sp_len_in[i];
+            }
+        }
+        if (rc == RSRL_HIP_OK && (fseek(f, 0, SEEK_END) != 0 || ftell(f) != expect || fseek(f, (long)kCkptHeaderBytes, SEEK_SET) != 0))
             rc = fail(RSRL_HIP_EINVAL, "%s is truncated or has trailing bytes (expected %lld bytes)", path, expect);
     }
     if (rc != RSRL_HIP_OK) { fclose(f); return rc; }
@@ -1518,6 +1557,31 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
             if (fread(w.data(), sizeof(float), per, f) != per) { rc = fail(RSRL_HIP_EINVAL, "%s: read error", path); break; }
             rc = pass == 0 ? rsrl_hip_set_weights(c, i, w.data()) : traces_rw(c, i, nullptr, w.data());
         }
+    uint32_t* spk_new = nullptr; float* spv_new = nullptr;              // sparse traces: shadow lists, switched in at the end like W
+    if (rc == RSRL_HIP_OK && h.aux_kind == 4) {
+        const int64_t N = c->cfg.n_envs;
+        hipError_t e2 = hipMalloc((void**)&spk_new, 4 * (size_t)kSparseCap * (size_t)N);
+        if (e2 == hipSuccess) e2 = hipMalloc((void**)&spv_new, 4 * (size_t)kSparseCap * (size_t)N);
+        if (e2 != hipSuccess) rc = fail(e2 == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "staging buffers for the sparse traces: %s", hipGetErrorString(e2));
+        std::vector<uint32_t> keys((size_t)(kSparseChunk * kSparseCap));
+        std::vector<float> vals((size_t)(kSparseChunk * kSparseCap));
+        if (rc == RSRL_HIP_OK && fseek(f, 4 * (long)N, SEEK_CUR) != 0) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);      // (the lengths: read above)
+        const uint32_t n_keys = (uint32_t)c->F * (uint32_t)c->Aw;
+        for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
+            const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
+            for (int64_t i = 0; rc == RSRL_HIP_OK && i < n; ++i) {
+                const size_t l = sp_len_in[(size_t)(i0 + i)];
+                if (fread(keys.data() + i * kSparseCap, 4, l, f) != l || fread(vals.data() + i * kSparseCap, 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
+                for (size_t k = 0; rc == RSRL_HIP_OK && k < l; ++k)
+                    if (keys[(size_t)(i * kSparseCap) + k] >= n_keys) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt sparse trace of learner %lld (key out of range)", path, (long long)(i0 + i));
+            }
+            if (rc != RSRL_HIP_OK) break;
+            e2 = hipMemcpyAsync(spk_new + i0 * kSparseCap, keys.data(), 4 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(spv_new + i0 * kSparseCap, vals.data(), 4 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);                 // (the staging vectors are reused by the next chunk)
+            if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the sparse traces: %s", hipGetErrorString(e2));
+        }
+    }
     std::vector<uint32_t> hl; std::vector<float> ring;
     if (rc == RSRL_HIP_OK && h.aux_kind == 3) {                        // read first, install only when everything has been read
         const size_t N = (size_t)c->cfg.n_envs, nf = qs_floats(c);
@@ -1535,7 +1599,10 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     }
     fclose(f);
     (void)hipStreamSynchronize(c->stream);
-    if (rc == RSRL_HIP_OK && old_qsigma) {                             // old file: no backups in it -> empty ones
+    if (rc == RSRL_HIP_OK && old_qsigma && c->sp_len) {                // old file: no lists in it -> empty ones
+        hipError_t e2 = hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
+        if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "clearing the sparse traces: %s", hipGetErrorString(e2));
+    } else if (rc == RSRL_HIP_OK && old_qsigma) {                      // old file: no backups in it -> empty ones
         hipError_t e2 = hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
         if (e2 == hipSuccess) e2 = hipMemsetAsync(c->qs_head, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
         if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "clearing the QSigma backups: %s", hipGetErrorString(e2));
@@ -1553,13 +1620,21 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
         if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the QSigma backups: %s", hipGetErrorString(e2));
     }
+    if (rc == RSRL_HIP_OK && h.aux_kind == 4) {                        // the last step that can fail: the lengths
+        hipError_t e2 = hipMemcpyAsync(c->sp_len, sp_len_in.data(), 4 * sp_len_in.size(), hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the sparse traces: %s", hipGetErrorString(e2));
+    }
     if (rc == RSRL_HIP_OK) {
         (void)hipFree(W_old); if (Z_old) (void)hipFree(Z_old);
+        if (spk_new) { (void)hipFree(c->sp_keys); (void)hipFree(c->sp_vals); c->sp_keys = spk_new; c->sp_vals = spv_new; }
         c->t = h.step_count; c->q_valid = false;
     } else {
         std::string keep = g_last_error;
         c->W = W_old; c->Z = Z_old;
         (void)hipFree(W_new); if (Z_new) (void)hipFree(Z_new);
+        if (spk_new) (void)hipFree(spk_new);
+        if (spv_new) (void)hipFree(spv_new);
         g_last_error = keep;
     }
     return rc;

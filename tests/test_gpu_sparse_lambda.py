@@ -65,6 +65,52 @@ def test_sparse_traces_bitwise_and_f64(ra, orc, name, N, K, kw):
         assert max(int((run.sparse_trace(i) != 0).sum()) for i in range(N)) == 512
 
 
+def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
+    # file version 5 / aux kind 4: every learner's list in slot order -- with lists that are FULL (the slot order decides which entry the next new
+    # key overwrites), so the resumed run is the straight one bit for bit
+    kw = dict(domain=0, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.3, gamma=0.99, lam=0.97, trace=2, max_episode_steps=0,
+              weight_mode=ra.W_SHARED, seed=7, alpha=0.1 / 8 / 64, n_envs=64)
+    path = str(tmp_path / "sparse.rsrlw")
+    with ra.Context(**kw) as a, ra.Context(**kw) as b:
+        a.reset()
+        a.train(700)
+        assert max(int((a.get_traces(i) != 0).sum()) for i in range(64)) == 512          # full lists at the checkpoint
+        a.save_weights(path)
+        s, act = a.states.copy(), a.actions.copy()
+        a.train(200)
+        b.reset()
+        b.train(13)                                                                      # (other lists, to be replaced)
+        b.load_weights(path)
+        b.states, b.actions = s, act
+        b.train(200)
+        assert b.step_count == a.step_count == 900
+        assert np.array_equal(a.get_weights(), b.get_weights())
+        assert np.array_equal(a.states, b.states) and np.array_equal(a.actions, b.actions)
+        for i in (0, 31, 63):
+            assert np.array_equal(a.get_traces(i), b.get_traces(i)), i
+        # a damaged file leaves the ctx as it was: one byte short; a length beyond the cap
+        raw = open(path, "rb").read()
+        w_before, z_before = b.get_weights(), b.get_traces(5)
+        cut = str(tmp_path / "cut.rsrlw")
+        open(cut, "wb").write(raw[:-1])
+        with pytest.raises(ra.RsrlHipError):
+            b.load_weights(cut)
+        off = 72 + b.F * b.A * 4                                                         # header, the one shared table, then u32 len[N]
+        bad = bytearray(raw); bad[off:off + 4] = (513).to_bytes(4, "little")
+        open(cut, "wb").write(bytes(bad))
+        with pytest.raises(ra.RsrlHipError):
+            b.load_weights(cut)
+        key0 = off + 4 * 64                                                              # learner 0's first key
+        bad = bytearray(raw); bad[key0:key0 + 4] = (b.F * b.A).to_bytes(4, "little")
+        open(cut, "wb").write(bytes(bad))
+        with pytest.raises(ra.RsrlHipError):
+            b.load_weights(cut)
+        assert np.array_equal(b.get_weights(), w_before) and np.array_equal(b.get_traces(5), z_before)
+    with ra.Context(**dict(kw, lam=0.5, n_envs=32)) as other:                            # another learner count: refused
+        with pytest.raises(ra.RsrlHipError):
+            other.load_weights(path)
+
+
 def test_sparse_lambda_is_refused_where_it_does_not_exist(ra):
     with pytest.raises(ra.RsrlHipError):                            # a shared DENSE basis has no sparse gradient
         ra.Context(domain=0, order=3, algo=3, policy=1, weight_mode=ra.W_SHARED, n_envs=8)
