@@ -86,7 +86,8 @@ def _run(c, steps):
         c.train(k, want_stats=False)
     c.sync()
     return c.get_weights(), c.states, c.actions
-kw = dict(C4, lr=0.001 / N, exchange=ra.EXCHANGE_PEER)
+kw = dict(C4, exchange=ra.EXCHANGE_PEER)
+kw.setdefault("lr", 0.001 / N)
 ctxs = [ra.Context(n_envs=cnt, env_offset=off, **kw) for off, cnt in (shard_range(N, G, r) for r in range(G))]
 handles = [c.peer_export(G) for c in ctxs]
 for r, c in enumerate(ctxs):
@@ -133,6 +134,23 @@ def test_g_ranks_as_g_streams_on_one_device(ra, tmp_path, G, N):
         assert d["absw"] > 0 and d["err_w"] == 0.0 and d["same"] == 1.0, d
     else:
         assert d["absw"] > 0 and 0 < d["err_w"] <= 1e-6 and d["same"] >= 0.99, d       # measured 1.5e-7 (relative to max(1, |W|))
+
+
+@pytest.mark.parametrize("kind", ["tile", "sparse_lambda"])
+def test_g_ranks_shared_tile_table(ra, tmp_path, kind):
+    # the same four in-process ranks over ONE shared tile-coded table: ExpectedSARSA (C3's agent), and SARSA(lambda) with sparse per-learner traces
+    # (round 5).  Every rank sums its learners' terms exactly (64-bit fixed point), converts once, and the ranks' float deltas are added in rank order:
+    # replicas identical; against the unsharded run the G-term float sum regroups -- equal to its rounding.
+    G, N = 4, 2048
+    kw = dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, policy=1, epsilon=0.1, gamma=0.99, weight_mode=1, seed=0, max_episode_steps=200)
+    kw.update(dict(algo=1, lr=0.1 / 8 / N) if kind == "tile" else dict(algo=3, alpha=0.1 / 8 / N, lam=0.9, trace=0))
+    script = tmp_path / "gstreams.py"
+    script.write_text(G_STREAMS)
+    env = dict(os.environ, RSRL_ROOT=ROOT, RSRL_KW=json.dumps(kw), GPU_MAX_HW_QUEUES=str(2 * G), RSRL_G=str(G), RSRL_N=str(N))
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "RESULT " in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert d["absw"] > 1e-3 and d["err_w"] <= 2e-9 and d["same"] == 1.0, d          # measured 1.2e-10 / 2.3e-10 absolute at |W| = 1.5e-3
 
 
 def test_missing_peer_times_out_instead_of_hanging(ra):
