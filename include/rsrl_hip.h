@@ -68,7 +68,7 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  *   round 5: weight_mode = RSRL_W_SHARED on tile coding -- ONE shared table, every learner its own SPARSE trace as params/sparse.rs:13-97
  *   offers: a list of at most 512 (entry, value) pairs, the entry with the smallest |value| making room once it is full; the table moves by the
  *   synchronous mini-batch rule W += sum_i alpha * residual_i * z_i in exact 64-bit fixed point.  Stepped by rsrl_hip_train only;
- *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists are not part of a checkpoint)
+ *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists travel with a checkpoint, file version 5)
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights: register-family Fourier bases, the generic Fourier orders, tile coding, and (round 5)
