@@ -605,8 +605,9 @@ def main():
             dict(domain=rsrl_amd.ACROBOT, order=7, algo=rsrl_amd.EXPECTED_SARSA, policy=rsrl_amd.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,
                  n_envs=32768, weight_dtype=rsrl_amd.W_BF16, max_episode_steps=1000, env_offset=rank * 32768, device=device), 512, 64, 32816,
             "SURVEY 8(d): 32 816 B/env-step if W (24 KiB bf16 per learner) were streamed every step; k_train_wave_pk keeps W PACKED in registers (two "
-            "bf16 per VGPR, 96 of them) for the whole launch, so the figure is an equivalent, not moved bytes: two waves per SIMD, the vector ALU "
-            "92 % busy (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, profiles/r05_pmc_raw.json): VALU-issue bound"), 180)
+            "bf16 per VGPR, 96 of them) for the whole launch, so the figure is an equivalent, not moved bytes: two waves per SIMD, 4.4 cycles per "
+            "VALU instruction against the measured 2.5 (fast class) / 4.9 (slow class: packed, shifts, bfe, perm, readlane ...) of "
+            "profiles/r05_ubench_valu_pair.txt: VALU-issue bound (DESIGN 4.6)"), 180)
     # shared-W legs: `shared_w` = what a user gets (exchange AUTO: the one-hop peer exchange whenever every rank's device reaches every
     # other's, and then the persistent kernel); `shared_w_rccl` = the any-topology fallback asked for explicitly
     shared = shared_rccl = None

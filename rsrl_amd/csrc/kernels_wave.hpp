@@ -429,7 +429,9 @@ struct WavePk {
     // recognises the pair opened in the projection pass as the one the update pass opens again and KEEPS the 192 opened halves alive between
     // the two -- in scratch memory -- instead of spending the two integer instructions again
     uint32_t sh, mask;
-    __device__ __forceinline__ WavePk() : sh(16u), mask(0xffff0000u) { asm volatile("" : "+s"(sh), "+s"(mask)); }
+    // (the mask lives in a VECTOR register: on gfx950 a VALU instruction with a scalar-register operand issues at the slow rate -- v_and_b32 v, s, v
+    // 4.9 cycles against 2.5 with two waves per SIMD, profiles/r05_ubench_valu_pair.txt; the shift is a slow instruction either way)
+    __device__ __forceinline__ WavePk() : sh(16u), mask(0xffff0000u) { asm volatile("" : "+s"(sh), "+v"(mask)); }
     __device__ __forceinline__ f2 open(uint32_t w) const { return f2{__builtin_bit_cast(float, w << sh), __builtin_bit_cast(float, w & mask)}; }
     // both halves already bf16-representable (low 16 bits zero): bytes 3:2 of each
     // (scalar arguments on purpose: with an f2 argument, `bit_cast<uint32_t>(x.y)` of a vector assembled element by element came out of ROCm 7.2's
