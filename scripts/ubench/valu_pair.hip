@@ -11,7 +11,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
-constexpr int ITER = 2000;
+constexpr int ITER = 2000;      // (the 1024-instruction bodies run ITER / 4 iterations)
 
 // one iteration = BODY (64 instructions); registers: destinations v[16..31], sources v[8..15], s[20..23]
 #define R4(x) x x x x
@@ -119,6 +119,12 @@ constexpr int ITER = 2000;
 #define FOUR(d) "v_fma_f32 v16, v16, v9, v10\n v_fma_f32 v17, v17, v9, v10\n v_fma_f32 v18, v18, v9, v10\n v_fma_f32 v19, v19, v9, v10\n"
 
 KERNEL(k_fma, R4(SEQ16(FMA)))
+KERNEL(k_fma_256, R16(SEQ16(FMA)))
+KERNEL(k_fma_1024, R16(R4(SEQ16(FMA))))
+KERNEL(k_pk_1024, R16(R8(SEQ8PK(PK))))
+KERNEL(k_bfe_1024, R16(R4(SEQ16(BFE))))
+KERNEL(k_mix_1024, R16(R4(ALT16(FMA, BFE))) )
+KERNEL(k_chain_1024, R16(R4(SEQ16(CHAIN))))
 KERNEL(k_fma_sgpr, R4(SEQ16(FMAS)))
 KERNEL(k_fmac, R4(SEQ16(FMAC)))
 KERNEL(k_add_mul, R4(ALT16(ADDF, MULF)))
@@ -194,7 +200,10 @@ int main() {
     float* d_out; unsigned long long* d_clk;
     CHECK(hipMalloc(&d_out, sizeof(float) * 256 * 256 * 8)); CHECK(hipMalloc(&d_clk, 16));
     const Case cases[] = {
-        {"v_fma_f32 x16 indep", k_fma, 64}, {"v_fma_f32 sgpr operand", k_fma_sgpr, 64}, {"v_fmac_f32", k_fmac, 64},
+        {"v_fma_f32 x16 indep", k_fma, 64}, {"v_fma_f32 x16, 256 per iteration", k_fma_256, 256}, {"v_fma_f32 x16, 1024 per iteration", k_fma_1024, 1024},
+        {"v_pk_fma_f32, 1024 per iteration", k_pk_1024, 1024}, {"v_bfe_u32, 1024 per iteration", k_bfe_1024, 1024}, {"fma / bfe, 1024 per iteration", k_mix_1024, 1024},
+        {"1 chain, 1024 per iteration", k_chain_1024, 1024},
+        {"v_fma_f32 sgpr operand", k_fma_sgpr, 64}, {"v_fmac_f32", k_fmac, 64},
         {"v_add_f32 / v_mul_f32", k_add_mul, 64}, {"v_max_f32", k_max, 64}, {"v_and_b32", k_and, 64}, {"v_and_b32 literal", k_and_lit, 64},
         {"v_lshlrev / v_and (open a pair)", k_shl_and, 64}, {"v_add_u32", k_addu, 64}, {"v_xor_b32", k_xor, 64}, {"v_bfe_u32", k_bfe, 64},
         {"v_perm_b32", k_perm, 64}, {"v_mov_b32", k_mov, 64}, {"v_cndmask_b32", k_cnd, 64}, {"v_mul_lo_u32", k_mullo, 64}, {"v_mul_hi_u32", k_mulhi, 64},
@@ -224,14 +233,15 @@ int main() {
             hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, d_out, 10, d_clk);
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0));
-            hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, d_out, ITER, d_clk);
+            const int iters = c.per_iter >= 1024 ? ITER / 4 : ITER;
+            hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(256), 0, 0, d_out, iters, d_clk);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             unsigned long long h_clk[2]; CHECK(hipMemcpy(h_clk, d_clk, 16, hipMemcpyDeviceToHost));
             // wave 0's own clocks: s_memtime ticks / (s_memrealtime ticks at 100 MHz) = the rate s_memtime counts at during the run (MHz)
             mhz[n_mhz++] = h_clk[1] ? 100.0 * (double)h_clk[0] / (double)h_clk[1] : 0.0;
-            printf(" %8.2f", ms * 1e6 / ((double)ITER * c.per_iter * wps) * 2.4);
+            printf(" %8.2f", ms * 1e6 / ((double)iters * c.per_iter * wps) * 2.4);
             CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
         }
         printf("   s_memtime MHz %.0f %.0f %.0f %.0f\n", mhz[0], mhz[1], mhz[2], mhz[3]);
