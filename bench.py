@@ -413,6 +413,10 @@ def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
     ub = {"pk": 4.47, "mad_u64": 4.96, "cndmask": 4.13, "other": 2.46}
     ub_cyc = sum(mix[k] * ub[k] for k in ub)
     ub_peak = N_SIMD * 64 * CLOCK_HZ / ub_cyc
+    # one wave per SIMD (65 536 learners / 1 024 SIMDs): a lone wave issues one VALU instruction per 4.1-4.5 cycles whatever its class and pays ~120
+    # cycles per taken branch (scripts/ubench/valu_pair.hip: 1 024- against 64-instruction loop bodies); the fused loop takes one branch per two steps
+    lone_cyc = n_valu * 4.2 + 60.0
+    lone_peak = N_SIMD * 64 * CLOCK_HZ / lone_cyc
     tf = flop * per_gpu_steps_per_s / 1e12
     useful = mix.get("useful_flop_per_env_step", flop - 4.0 * mix.get("pk_fma_masked_zero", 36.0))
     return {"bound": "valu", "achieved": tf, "peak": FP32_VECTOR_PEAK / 1e12, "unit": "TFLOP/s", "frac": flop * per_gpu_steps_per_s / FP32_VECTOR_PEAK,
@@ -426,6 +430,10 @@ def valu_roofline(kname, per_gpu_steps_per_s, steps_per_wave_cycles=None):
             "ubench_ceiling": {"peak_env_steps_per_s": ub_peak, "frac": per_gpu_steps_per_s / ub_peak,
                                "what": "NOT a published peak: the same mix at this machine's measured saturated issue costs (8 waves/SIMD: packed 4.47, "
                                        "mad_u64 4.96, cndmask 4.13, other 2.46 cycles; profiles/r01_ubench_valu_issue.txt)"},
+            "lone_wave_ceiling": {"peak_env_steps_per_s": lone_peak, "frac": per_gpu_steps_per_s / lone_peak, "cycles_per_env_step": lone_cyc,
+                                  "what": "NOT a published peak: ONE wave per SIMD is all 65 536 learners give 1 024 SIMDs, and a lone wave issues one VALU "
+                                          "instruction per 4.1-4.5 cycles (4.2 used) whatever its class + ~120 cycles per taken branch, one per two steps "
+                                          "(profiles/r05_ubench_valu_pair.txt): at this size the kernel's time is its instruction COUNT"},
             "source": "profiles/isa_mix.json (rocprofv3 SQ_INSTS_VALU_* class counters per env-step) x HIP-event kernel rate of this run"}
 
 
