@@ -171,15 +171,22 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Round 5: once the weights no longer fit the 256 MiB Infinity Cache the column goes back as whole 128-BYTE LINES instead (two lines = four
+    // store instructions per quad instead of three sectors): the bare pattern takes 126 us against 135 at 1 M learners but 25.4 against 23.7 at
+    // 262 144, where the stores end in the cache (profiles/r03_ubench_stream_pattern.txt) -- so the width follows the working set.
     if (i < N) {
-        static_assert((LPW * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
-        constexpr int NSEC = (48 + F * 4 + 63) / 64;
-        const int sec = ((q * AF + a * F) * 4) & ~63;
+        static_assert((LPW * AF * 4) % 128 == 0, "no sector or line is shared between two waves' images");
+        const bool lines = N * (int64_t)(AF * 4) > ((int64_t)256 << 20);              // (wave-uniform: a kernel argument)
+        constexpr int NSEC = (48 + F * 4 + 63) / 64, NLINE2 = 2 * ((112 + F * 4 + 127) / 128);
+        const int sec = ((q * AF + a * F) * 4) & (lines ? ~127 : ~63);
+        const int n_st = lines ? NLINE2 : NSEC;
 #pragma unroll
-        for (int p = 0; p < NSEC; ++p) {
-            const int off = sec + 64 * p + 16 * b;
-            const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + off);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, RSRL_Q4_AUX_ST);
+        for (int p = 0; p < (NLINE2 > NSEC ? NLINE2 : NSEC); ++p) {
+            if (p < n_st) {
+                const int off = sec + 64 * p + 16 * b;
+                const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + off);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, RSRL_Q4_AUX_ST);
+            }
         }
     }
 #endif

@@ -155,3 +155,26 @@ def test_c5_full_size_sampled_learners_bitwise_vs_oracle(ra, orc):
             assert np.array_equal(S[:, off:off + M].T, r.state) and np.array_equal(A[off:off + M], r.action), off
             for i in (0, M - 1):
                 assert np.array_equal(c.get_weights(off + i), r.weights[i]), (off, i)
+
+
+def test_streaming_kernel_beyond_the_infinity_cache_bitwise_vs_fused(ra):
+    # k_step_reg_q4 writes the touched column back as whole 128-byte lines once the weights exceed 256 MiB (64-byte sectors below):
+    # 700 003 learners x 432 B = 302 MB, a last wave of three learners -- against the fused loop (weights in registers), bit for bit
+    N = 700003
+    kw = dict(C2, n_envs=N)
+    ref = None
+    for spl in (8, 1):
+        with ra.Context(steps_per_launch=spl, **kw) as c:
+            c.reset()
+            c.timing_enable(True)
+            st = c.train(8)
+            assert st["env_steps"] == N * 8
+            got = (c.checksum(), c.get_weights(0).copy(), c.get_weights(N // 2 + 5).copy(), c.get_weights(N - 1).copy(), c.states.copy())
+            if spl == 1:
+                assert c.timing_read()[2] == "k_step_reg_q4", c.timing_read()
+        if ref is None:
+            ref = got
+        else:
+            assert got[0] == ref[0]
+            assert all(np.array_equal(a, b) for a, b in zip(got[1:], ref[1:]))
+    assert np.abs(ref[1]).max() > 0
