@@ -62,7 +62,8 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
 /* rsrl::control::td::{QLearning, SARSA, ExpectedSARSA}
  *   q_learning.rs:35-71, sarsa.rs:35-75, expected_sarsa.rs:22-66
  * the eligibility-trace agents {SARSALambda, QLambda}
- *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights; register-family Fourier bases, the order-7 Fourier bases of
+ *   sarsa_lambda.rs:37-98, q_lambda.rs:37-99 (per-learner weights; register-family Fourier bases, every other Fourier order (round 5: W and
+ *   the trace in memory, one thread per learner, rsrl_amd/csrc/kernels_lambda_mem.hpp), the order-7 Fourier bases of
  *   the 4-D domains with f32 weights (W and the trace streamed from memory every step), or tile coding with one dense trace
  *   table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12;
  *   round 5: weight_mode = RSRL_W_SHARED on tile coding -- ONE shared table, every learner its own SPARSE trace as params/sparse.rs:13-97

@@ -180,6 +180,16 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     ag->apol_same = 1; ag->eps_decay = 1.0; ag->eps_min = 0.0;
 }
 
+/* The trace's decay Trace::new(gamma * lambda) (sarsa_lambda.rs:47-52; Dutch: x (1 - alpha), traces.rs:233-239): the agents' parameters are f64 in
+ * the reference's API, so the product is taken in f64 and rounded ONCE to the instantiation's type -- the same value the device's host side
+ * hands its kernels (rsrl_hip.hip make_lambda / make_td).  (Until round 5 the f32 instantiations multiplied the two ROUNDED factors; for most pairs
+ * that is the same float, for (0.9, 0.9) it is not: found by tests/fuzz_parity.py.) */
+static double orc_trace_rate(const orc_agent* ag) {
+    double rate = ag->gamma * ag->lambda;
+    if (ag->trace == ORC_TRACE_DUTCH) rate *= (1.0 - ag->alpha);
+    return rate;
+}
+
 /* ------------------------------------------------------------------ */
 /* instantiate the type-generic body: f64 (reference precision), f32   */
 /* ------------------------------------------------------------------ */

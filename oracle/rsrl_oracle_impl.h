@@ -589,8 +589,7 @@ R FN(orc_handle_lambda)(const orc_agent* ag, R* W, R* Z, const R* s, int a, R r,
         orc_tile_indices(b, sf, idx);
         for (t = 0; t < b->n_tilings; t++) phi[idx[t]] = (R)1.0;
     }
-    rate = (R)ag->gamma * (R)ag->lambda;
-    if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+    rate = (R)orc_trace_rate(ag);
     for (f = 0; f < F; f++)
         for (c = 0; c < A; c++) {
             R g = (c == a) ? phi[f] : (R)0.0;
@@ -682,8 +681,7 @@ R FN(orc_handle_td)(const orc_agent* ag, R* w, R* z, const R* s, R r, const R* n
         for (t = 0; t < b->n_tilings; t++) phi[idx[t]] = (R)1.0;
     }
     if (ag->algo == ORC_TD_LAMBDA) {
-        rate = (R)ag->gamma * (R)ag->lambda;
-        if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+        rate = (R)orc_trace_rate(ag);
         for (f = 0; f < F; f++) {
             R v = FN(fma_)(rate, z[f], phi[f]);
             if (ag->trace == ORC_TRACE_SATURATE) { v = (v < (R)1.0) ? v : (R)1.0; v = (v > (R)-1.0) ? v : (R)-1.0; }
@@ -1295,8 +1293,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
             }
             if (ORC_IS_PRED(ag->algo)) {
                 /* TD / TDLambda on the wave family: td.rs:31-59, td_lambda.rs:41-78; one weight column, V(s) in the wave order */
-                R* Z = run->Z ? run->Z + (size_t)i * F : NULL; R rate = (R)ag->gamma * (R)ag->lambda;
-                if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+                R* Z = run->Z ? run->Z + (size_t)i * F : NULL; R rate = (R)orc_trace_rate(ag);
                 delta = term ? (r - q_s[0]) : (r + (R)ag->gamma * q_n[0] - q_s[0]);
                 for (l = 0; l < 64; l++)
                     for (j = 0; j < 8; j++)
@@ -1318,8 +1315,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                 R* Z = run->Z + (size_t)i * F * A; R rate, m; int c, na_in;
                 const R qsa = q_s[a];
                 const int cut = ag->algo == ORC_Q_LAMBDA && a != FN(orc_argmax_first)(q_s, A);
-                rate = (R)ag->gamma * (R)ag->lambda;
-                if (ag->trace == ORC_TRACE_DUTCH) rate = rate * ((R)1.0 - (R)ag->alpha);
+                rate = (R)orc_trace_rate(ag);
                 if (cut) memset(Z, 0, sizeof(R) * (size_t)F * A);
                 if (term) delta = r - qsa;
                 else if (ag->algo == ORC_SARSA_LAMBDA) {

@@ -64,6 +64,9 @@ namespace rsrl {
 bool launch_gq_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const GqParams& gp, const BasisGeom& g, uint64_t t,
                      int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                      int64_t Mn, float* td_out);
+bool launch_lambda_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const LambdaParams& lp, const BasisGeom& g,
+                         uint64_t t, int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to,
+                         const uint8_t* termf, int64_t Mn, float* td_out);
 bool launch_td_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const TdParams& tp, const BasisGeom& g, bool lambda,
                      uint64_t t, int chunk, DevStats* stats, const float* from, const float* rew, const float* to, const uint8_t* termf, int64_t Mn,
                      float* out, const float* states);

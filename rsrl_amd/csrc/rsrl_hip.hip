@@ -780,9 +780,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         const bool wave_ok = cfg->basis == RSRL_FOURIER && is_wave(*cfg) && cfg->weight_mode == RSRL_W_PER_ENV && cfg->weight_dtype == RSRL_W_F32;
         // ... or sparse per-learner traces over ONE shared table (traces.rs:5-12 over params/sparse.rs; round 5)
         const bool sparse_ok = is_sparse_lambda(*cfg) && (cfg->n_tilings == 4 || cfg->n_tilings == 8 || cfg->n_tilings == 16);
-        if (!tile_ok && !wave_ok && !sparse_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || is_generic_fourier(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
-            return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a register-family Fourier basis "
-                                         "(MountainCar orders 1-5, CartPole/Acrobot order 1), on the order-7 wave family with f32 weights, "
+        if (!tile_ok && !wave_ok && !sparse_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
+            return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a Fourier basis (f32 on the order-7 wave family) "
                                          "or on tile coding (per-learner tables, or one shared table with sparse per-learner traces)");
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
@@ -1250,6 +1249,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     } else if (is_lambda(c->cfg.algo) && is_wave(c->cfg)) {
         if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
         else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+    } else if (is_lambda(c->cfg.algo) && is_generic_fourier(c->cfg)) {
+        if (!launch_lambda_model(c->cfg, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c), g, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
+                                 M, otd.dev)) return NO_MODEL(c);
     } else if (is_lambda(c->cfg.algo)) {
         if (!launch_handle_lambda(c->cfg.domain, c->cfg.order, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c),
                                   d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev)) return NO_MODEL(c);
@@ -2249,6 +2251,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
             else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
             c->kernel_name = "k_wave_lambda";
+            KCHECK();
+        } else if (is_lambda(c->cfg.algo) && is_generic_fourier(c->cfg)) {
+            if (!launch_lambda_model(c->cfg, dim3(grid_for(k.n_envs)), dim3(kBlock), c->stream, k, make_lambda(c), g, c->t, chunk, d_stats, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr, 0, nullptr)) return NO_MODEL(c);
+            c->kernel_name = "k_train_lambda_mem";
             KCHECK();
         } else if (is_lambda(c->cfg.algo)) {
             if (!launch_train_lambda(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, dim3(grid_for(k.n_envs)), dim3(kBlock),

@@ -1,6 +1,7 @@
 // fused eligibility-trace driver loops (SARSA(lambda), Q(lambda)) for the register family
 #include "launch.hpp"
 #include "kernels_lambda.hpp"
+#include "kernels_lambda_mem.hpp"
 namespace rsrl {
 
 #define RSRL_LAMBDA_CASE(DM, OR, AL, PO)                                                                      \
@@ -27,6 +28,21 @@ bool launch_handle_lambda(int domain, int order, dim3 grid, dim3 block, hipStrea
                           const float* from, const int32_t* act, const float* rew, const float* to, const uint8_t* termf,
                           int64_t Mn, uint64_t t, float* td_out) {
     RSRL_HL_CASE(0, 1) RSRL_HL_CASE(0, 2) RSRL_HL_CASE(0, 3) RSRL_HL_CASE(0, 4) RSRL_HL_CASE(0, 5) RSRL_HL_CASE(1, 1) RSRL_HL_CASE(2, 1)
+    return false;
+}
+// SARSALambda / QLambda on the generic Fourier orders (kernels_lambda_mem.hpp): from != nullptr -> handle, else the driver loop
+bool launch_lambda_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipStream_t st, const Common& k, const LambdaParams& lp, const BasisGeom& g,
+                         uint64_t t, int chunk, DevStats* stats, const float* from, const int32_t* act, const float* rew, const float* to,
+                         const uint8_t* termf, int64_t Mn, float* td_out) {
+#define RSRL_LM_CASE(DM)                                                                                                             \
+    if (cfg.domain == DM) {                                                                                                          \
+        using M = FourierGenericModel<DM>;                                                                                           \
+        if (from) hipLaunchKernelGGL((k_handle_lambda_mem<M>), grid, block, 0, st, k, lp, g, from, act, rew, to, termf, Mn, t, td_out); \
+        else hipLaunchKernelGGL((k_train_lambda_mem<M>), grid, block, 0, st, k, lp, g, t, chunk, stats);                             \
+        return true;                                                                                                                 \
+    }
+    if (cfg.basis != RSRL_FOURIER || cfg.order < 1 || cfg.order > 7) return false;
+    RSRL_LM_CASE(0) RSRL_LM_CASE(1) RSRL_LM_CASE(2)
     return false;
 }
 }  // namespace rsrl

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Differential campaign: RANDOM configurations of the whole supported space, the HIP path (through the C ABI) against the oracle's
+device-order instantiation ("f32d"), bit for bit -- states, actions, every learner's weights and auxiliary matrix -- over a short run cut
+into random train() calls.  The fixed test-suite pins chosen configurations; this samples the combinations nobody chose
+(domain x basis x order x agent x policy x weight mode x dtype x fuse depth x episode cap x learner count x env offset).
+
+    python tests/fuzz_parity.py [n_cases=200] [seed=0]          (GPU box; test infrastructure: imports oracle/)
+
+Prints one line per case and a JSON summary; exit code 1 if any accepted configuration differs from the oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rsrl_amd as ra  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+ONE_STEP = (ra.QLEARNING, ra.SARSA, ra.EXPECTED_SARSA, ra.PAL)
+LAMBDA = (ra.SARSA_LAMBDA, ra.Q_LAMBDA)
+PRED = (ra.TD, ra.TD_LAMBDA)
+NAMES = {0: "QLearning", 1: "SARSA", 2: "ExpectedSARSA", 3: "SARSALambda", 4: "QLambda", 5: "PAL", 6: "GreedyGQ", 7: "TD", 8: "TDLambda", 9: "QSigma"}
+N_DIM = {0: 2, 1: 4, 2: 4}
+
+
+def sample(rng):
+    """-> (family, device kwargs, oracle kwargs, oracle method name, method kwargs)"""
+    domain = int(rng.integers(0, 3))
+    family = rng.choice(["reg", "reg", "generic", "tile", "tile", "wave", "shared_dense", "shared_tile", "sparse_lambda"])
+    kw = dict(domain=domain, seed=int(rng.integers(0, 1 << 20)), gamma=float(rng.choice([0.9, 0.99, 1.0])),
+              max_episode_steps=int(rng.choice([0, 25, 200])), env_offset=int(rng.choice([0, 0, 64, 1000003])))
+    n = int(rng.choice([1, 3, 63, 64, 65, 130, 257]))
+    method, mkw = "train", {}
+    if family in ("reg", "shared_dense"):
+        kw.update(basis=ra.FOURIER, order=int(rng.integers(1, 6)) if domain == 0 else 1)
+    elif family == "generic":
+        kw.update(basis=ra.FOURIER, order=int(rng.choice([6, 7])) if domain == 0 else int(rng.choice([2, 3, 4])))
+    elif family == "wave":
+        if domain == 0:
+            domain = kw["domain"] = int(rng.integers(1, 3))
+        kw.update(basis=ra.FOURIER, order=7)
+        n = int(rng.choice([1, 3, 4, 5, 9, 16]))
+    else:
+        kw.update(basis=ra.TILE_CODING, n_tilings=int(rng.choice([4, 8, 16])), tiles_per_dim=int(rng.choice([4, 6, 8])))
+    feats = (kw.get("order", 0) + 1) ** N_DIM[domain] if kw["basis"] == ra.FOURIER else kw["n_tilings"]
+    step = float(rng.choice([0.02, 0.2])) / feats                 # lr |phi|^2 well below 1
+    # ---- the agent
+    if family == "shared_dense" or family == "shared_tile":
+        algo = int(rng.choice(ONE_STEP[:3]))
+    elif family == "sparse_lambda":
+        algo = int(rng.choice(LAMBDA))
+    else:
+        algo = int(rng.integers(0, 10))
+    kw["algo"] = algo
+    kw["policy"] = ra.RANDOM if algo in PRED else int(rng.choice([ra.GREEDY, ra.EPSILON_GREEDY, ra.EPSILON_GREEDY, ra.SOFTMAX]))
+    kw["epsilon"] = float(rng.choice([0.05, 0.3]))
+    kw["tau"] = float(rng.choice([0.5, 1.0, 5.0]))
+    kw["lr"] = step
+    kw["alpha"] = float(rng.choice([0.5, 1.0])) if algo in (ra.EXPECTED_SARSA, ra.PAL) else step
+    if algo in LAMBDA + (ra.TD_LAMBDA,):
+        kw.update(lam=float(rng.choice([0.0, 0.5, 0.9])), trace=int(rng.integers(0, 3)))
+    if algo == ra.GREEDY_GQ:
+        kw["lr_td"] = step * float(rng.choice([0.1, 1.0]))
+    if algo == ra.Q_SIGMA:
+        kw.update(sigma=float(rng.choice([0.0, 0.5, 1.0])), n_steps=int(rng.choice([1, 2, 5])), alpha=float(rng.choice([0.3, 1.0])) * step * feats)
+    if algo in (ra.SARSA, ra.EXPECTED_SARSA, ra.SARSA_LAMBDA) and rng.random() < 0.3:     # the agent's own policy object
+        kw.update(agent_policy=int(rng.choice([ra.GREEDY, ra.EPSILON_GREEDY, ra.SOFTMAX])), agent_epsilon=0.2, agent_tau=2.0)
+    dev = dict(kw, n_envs=n)
+    if family in ("tile", "generic", "wave") or (family == "reg" and algo not in ONE_STEP):
+        dev["steps_per_launch"] = int(rng.choice([0, 0, 1, 5]))
+    # ---- which loop of the oracle restates the kernel family's evaluation order
+    if family == "reg" and algo in ONE_STEP:
+        method = "train_dev"
+        dev["steps_per_launch"] = int(rng.choice([0, 0, 1, 7]))
+        if algo != ra.PAL and kw["policy"] == ra.EPSILON_GREEDY and dev["steps_per_launch"] != 1 and rng.random() < 0.25:
+            kw.update(epsilon_decay=0.97, epsilon_min=0.01)
+            dev.update(epsilon_decay=0.97, epsilon_min=0.01)
+    elif family == "wave":
+        method = "train_wave"
+        if algo in ONE_STEP[:3] and rng.random() < 0.5:
+            dev["weight_dtype"] = ra.W_BF16
+            mkw["bf16"] = True
+    elif family == "shared_dense":
+        method = "train_shared_dev"
+        dev["weight_mode"] = ra.W_SHARED
+        n = dev["n_envs"] = int(rng.choice([64, 512, 600, 1024, 1500]))
+        dev["lr"] = kw["lr"] = step / n
+    elif family == "shared_tile":
+        dev["weight_mode"] = ra.W_SHARED
+        n = dev["n_envs"] = int(rng.choice([64, 300, 1024, 2000]))
+        dev["lr"] = kw["lr"] = step / n
+    elif family == "sparse_lambda":
+        method = "train_sparse_lambda"
+        dev["weight_mode"] = ra.W_SHARED
+        n = dev["n_envs"] = int(rng.choice([5, 64, 300]))
+        dev["alpha"] = kw["alpha"] = step / n
+    okw = {k: v for k, v in kw.items() if k not in ("basis",)}
+    okw["basis"] = orc.TILE if kw["basis"] == ra.TILE_CODING else orc.FOURIER
+    okw["shared_w"] = dev.get("weight_mode", ra.W_PER_ENV) == ra.W_SHARED
+    if okw["max_episode_steps"] == 0:
+        okw["max_episode_steps"] = 0
+    return family, dev, okw, method, mkw
+
+
+def run_case(rng, idx):
+    family, dev, okw, method, mkw = sample(rng)
+    n = dev["n_envs"]
+    total = int(rng.choice([40, 90, 150])) if family != "wave" else int(rng.choice([8, 20, 60]))
+    cuts = sorted(set(int(x) for x in rng.integers(1, total, size=int(rng.integers(0, 3)))))
+    calls = [b - a for a, b in zip([0] + cuts, cuts + [total])]
+    tag = f"{idx:4d} {family:13s} {NAMES[dev['algo']]:13s} dom {dev['domain']} N {n:5d} K {total:3d} calls {calls}"
+    try:
+        ctx = ra.Context(**dev)
+    except ra.RsrlHipError as e:
+        return "refused", tag + f"  REFUSED: {str(e)[:90]}", dev
+    with ctx as c:
+        ag = orc.make_agent(**okw)
+        run = orc.Run(ag, n, "f32d")
+        try:
+            (run.reset_wave if method == "train_wave" else run.reset)()
+            c.reset()
+            for k in calls:
+                getattr(run, method)(k, **mkw)
+                c.train(k, want_stats=bool(rng.integers(0, 2)))
+        except ValueError as e:                                   # the oracle has no loop for it
+            return "no_oracle", tag + f"  NO ORACLE LOOP: {str(e)[:80]}", dev
+        bad = []
+        if not np.array_equal(c.states.T, run.state, equal_nan=True):
+            bad.append("states")
+        if not np.array_equal(c.actions, run.action):
+            bad.append("actions")
+        shared = dev.get("weight_mode", ra.W_PER_ENV) == ra.W_SHARED
+        ow = run.weights
+        if shared:
+            if not np.array_equal(c.get_weights(), ow.reshape(c.get_weights().shape), equal_nan=True):
+                bad.append("weights")
+        else:
+            for i in sorted(set([0, n // 2, n - 1])):
+                if not np.array_equal(c.get_weights(i), ow[i].reshape(c.get_weights(i).shape), equal_nan=True):
+                    bad.append(f"weights[{i}]")
+        if family == "sparse_lambda":
+            for i in sorted(set([0, n - 1])):
+                if not np.array_equal(c.get_traces(i), run.sparse_trace(i)):
+                    bad.append(f"sparse trace[{i}]")
+        elif dev["algo"] in LAMBDA + (ra.TD_LAMBDA, ra.GREEDY_GQ):
+            get = c.get_td_weights if dev["algo"] == ra.GREEDY_GQ else c.get_traces
+            for i in sorted(set([0, n - 1])):
+                if not np.array_equal(get(i), run.traces[i].reshape(get(i).shape), equal_nan=True):
+                    bad.append(f"aux[{i}]")
+        finite = bool(np.all(np.isfinite(ow)))
+        moved = bool(np.nanmax(np.abs(ow)) > 0) if ow.size else False
+    if bad:
+        return "MISMATCH", tag + f"  MISMATCH {bad}", dev
+    return "ok", tag + f"  ok{'' if finite else ' (non-finite, NaN for NaN)'}{'' if moved else ' (weights did not move)'}", dev
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    counts, failures = {}, []
+    for idx in range(n_cases):
+        try:
+            status, line, dev = run_case(rng, idx)
+        except Exception as e:      # noqa: BLE001
+            status, line, dev = "ERROR", f"{idx:4d} ERROR {type(e).__name__}: {str(e)[:200]}", None
+        counts[status] = counts.get(status, 0) + 1
+        print(line, flush=True)
+        if status in ("MISMATCH", "ERROR"):
+            failures.append({"case": idx, "line": line, "config": dev})
+    print("SUMMARY " + json.dumps({"cases": n_cases, "seed": seed, "counts": counts, "failures": failures}, default=str), flush=True)
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

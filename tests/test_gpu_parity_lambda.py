@@ -104,3 +104,47 @@ def test_lambda_error_paths(ra):
     with ra.Context(n_envs=4) as c:
         with pytest.raises(ra.RsrlHipError):
             c.get_traces(0)
+
+
+# ---- SARSALambda / QLambda on the Fourier orders without a register-family kernel (round 5, rsrl_amd/csrc/kernels_lambda_mem.hpp): the reference's
+# agents are generic over the approximator (sarsa_lambda.rs:37-52, q_lambda.rs:37-54).  Found missing by tests/fuzz_parity.py.
+@pytest.mark.parametrize("domain,order,algo,trace,policy", [(0, 6, 3, 0, 1), (0, 7, 4, 2, 2), (1, 2, 3, 1, 1), (2, 3, 4, 0, 0), (1, 4, 3, 2, 2)])
+def test_lambda_generic_fourier_orders_bitwise(ra, orc, domain, order, algo, trace, policy):
+    N, K = 96, 120
+    F = (order + 1) ** (2 if domain == 0 else 4)
+    kw = dict(domain=domain, order=order, algo=algo, policy=policy, trace=trace, gamma=0.9, lam=0.9, alpha=0.3 / F, epsilon=0.2, tau=1.0, seed=21,
+              max_episode_steps=40)
+    ag = orc.make_agent(**kw)
+    run = orc.Run(ag, N, "f32d")
+    run.reset()
+    ost = run.train(K)
+    r64 = orc.Run(ag, N, "f64")
+    r64.reset()
+    r64.train(K)
+    with ra.Context(n_envs=N, steps_per_launch=7, **kw) as c:
+        assert c.F == F
+        c.reset()
+        st = [c.train(k) for k in (50, 1, K - 51)]                       # any split into launches (7 steps each)
+        assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
+        for i in (0, 47, N - 1):
+            assert np.array_equal(c.get_weights(i), run.weights[i]), i
+            assert np.array_equal(c.get_traces(i), run.traces[i]), i
+        assert sum(s["episodes"] for s in st) == ost["episodes"] > 0
+        assert np.abs(run.weights).max() > 0 and np.abs(run.traces).max() > 0
+        # the reference's precision: learners whose trajectory has not parted from the f64 run (an argmax decided by an fp32 rounding parts them)
+        same = np.all(np.abs(c.states.T - r64.state) <= 1e-4 * (1 + np.abs(r64.state)), axis=1) & (c.actions == r64.action)
+        assert same.mean() >= 0.8, same.mean()
+        for i in np.flatnonzero(same)[:8]:
+            assert np.max(np.abs(c.get_weights(i) - r64.weights[i])) <= 2e-5 * (1 + np.abs(r64.weights[i]).max())
+        # Handler::handle on caller-supplied transitions: the same operations
+        a0 = c.actions
+        frm, nxt, rew, term = c.domain_step(a0)
+        Wb = [c.get_weights(i).copy() for i in range(4)]
+        Zb = [c.get_traces(i).copy() for i in range(4)]
+        t_h = c.step_count                                                # the counter that keys the agent's own draw of this handle
+        td = c.handle(frm, a0, rew, nxt, term)
+        for i in range(4):
+            W, Z = Wb[i].copy(), Zb[i].copy()
+            d = orc.handle_lambda(ag, W, Z, frm[:, i], a0[i], rew[i], nxt[:, i], term[i], orc.draw(21, i, t_h, orc.BLK_INNER), "f32d")
+            assert td[i] == np.float32(d), (i, td[i], d)
+            assert np.array_equal(c.get_weights(i), W) and np.array_equal(c.get_traces(i), Z), i
