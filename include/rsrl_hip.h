@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 7
+#define RSRL_HIP_ABI_VERSION 8
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -226,6 +226,20 @@ int rsrl_hip_get_states(rsrl_hip_ctx* ctx, float* states /*[D][N]*/);
 int rsrl_hip_set_states(rsrl_hip_ctx* ctx, const float* states /*[D][N]*/);
 int rsrl_hip_get_actions(rsrl_hip_ctx* ctx, int32_t* actions /*[N]*/);
 int rsrl_hip_set_actions(rsrl_hip_ctx* ctx, const int32_t* actions /*[N]*/);
+/* (ABI 8) The rest of a learner's state between two driver calls, so that a run can be carried into another ctx EXACTLY (with the checkpoint of
+ * rsrl_hip_save_weights, the states and the actions above):
+ *   - the steps every learner's current episode has taken (what the driver loop's `for j in 0..step_limit` counter would hold,
+ *     rsrl/src/lib.rs:82-88 as the examples drive it): without it a resumed run counts its step cap from zero;
+ *   - the register-family loops (one-step agents on MountainCar Fourier 1-5, CartPole / Acrobot Fourier 1) CARRY Q(s,.) of the current state from
+ *     launch to launch as the fused loop left it (the pre-update value plus the rank-1 term of the last update).  rsrl_hip_set_states / _set_weights /
+ *     _load_weights drop it and the next launch evaluates Q(s,.) from the weights: equal in exact arithmetic, not always in the last bit -- enough to
+ *     part a Softmax / ExpectedSARSA run from the uninterrupted one.  get: *valid = 1 and q filled while something is carried, 0 (q untouched)
+ *     otherwise -- always 0 for the families that evaluate Q from the weights every step; set (AFTER the states and weights are in place): the next
+ *     launch continues from it.  EINVAL for a ctx whose kernels carry nothing. */
+int rsrl_hip_get_episode_steps(rsrl_hip_ctx* ctx, uint32_t* steps /*[N]*/);
+int rsrl_hip_set_episode_steps(rsrl_hip_ctx* ctx, const uint32_t* steps /*[N]*/);
+int rsrl_hip_get_q_carry(rsrl_hip_ctx* ctx, float* q /*[A][N]*/, int32_t* valid);
+int rsrl_hip_set_q_carry(rsrl_hip_ctx* ctx, const float* q /*[A][N]*/);
 
 /* Domain::transition                                rsrl_domains/src/lib.rs:436-446
  * Steps every env of the ctx with `actions` (NULL: the ctx's pending actions).  Outputs are
@@ -311,7 +325,8 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v
  *              epsilon (the schedule's state), so that a resumed run continues the schedule.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header
  * implies, and stages the data: a failing load leaves the ctx's weights untouched.  A loaded run's LEARNING resumes bit-identically (weights, traces,
- * backups, epsilons, step counter -- with the env states restored through rsrl_hip_set_states / _set_actions); the evaluation-rollout draw
+ * backups, epsilons, step counter -- with the env states restored through rsrl_hip_set_states / _set_actions, the episodes' step counts through
+ * rsrl_hip_set_episode_steps and, for the register-family loops, the carried Q(s,.) through rsrl_hip_set_q_carry: ABI 8); the evaluation-rollout draw
  * counter of rsrl_hip_rollout_policy is not part of the file (see there). */
 int rsrl_hip_save_weights(rsrl_hip_ctx* ctx, const char* path);
 int rsrl_hip_load_weights(rsrl_hip_ctx* ctx, const char* path);

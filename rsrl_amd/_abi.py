@@ -52,6 +52,10 @@ SYMBOLS = {
     "rsrl_hip_set_states": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_get_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_set_actions": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsrl_hip_get_episode_steps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsrl_hip_set_episode_steps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rsrl_hip_get_q_carry": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]),
+    "rsrl_hip_set_q_carry": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_domain_step": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     "rsrl_hip_domain_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rsrl_hip_q_evaluate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

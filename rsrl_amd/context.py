@@ -164,6 +164,29 @@ class Context:
     def actions(self, v):
         _abi.check(self._L.rsrl_hip_set_actions(self._h, _p(_in(v, np.int32, (self.N,)))))
 
+    @property
+    def episode_steps(self):
+        """steps every learner's current episode has taken (ABI 8)"""
+        out = np.empty(self.N, dtype=np.uint32)
+        _abi.check(self._L.rsrl_hip_get_episode_steps(self._h, _p(out)))
+        return out
+
+    @episode_steps.setter
+    def episode_steps(self, v):
+        _abi.check(self._L.rsrl_hip_set_episode_steps(self._h, _p(_in(v, np.uint32, (self.N,)))))
+
+    @property
+    def q_carry(self):
+        """Q(s,.) as the register-family loops carry it from launch to launch, (A, N) -- None while nothing is carried (ABI 8)"""
+        out = np.empty((self.A, self.N), dtype=np.float32)
+        valid = C.c_int32(0)
+        _abi.check(self._L.rsrl_hip_get_q_carry(self._h, _p(out), C.byref(valid)))
+        return out if valid.value else None
+
+    @q_carry.setter
+    def q_carry(self, v):
+        _abi.check(self._L.rsrl_hip_set_q_carry(self._h, _p(_in(v, np.float32, (self.A, self.N)))))
+
     def domain_step(self, actions=None):
         """Domain::transition for every env -> (from, next, reward, terminal)"""
         frm = np.empty((self.D, self.N), dtype=np.float32)

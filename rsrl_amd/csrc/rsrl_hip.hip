@@ -1055,6 +1055,45 @@ int rsrl_hip_set_actions(rsrl_hip_ctx* c, const int32_t* actions) {
     return RSRL_HIP_OK;
 }
 
+// ---- ABI 8: the learners' state between two driver calls that is neither weights nor env state (include/rsrl_hip.h)
+static bool carries_q(const rsrl_hip_ctx* c) {          // the kernels that read Common::qcache: the register family's one-step loops
+    const int al = c->cfg.algo;
+    return c->cfg.basis == RSRL_FOURIER && !is_wave(c->cfg) && !is_generic_fourier(c->cfg) && c->cfg.weight_mode == RSRL_W_PER_ENV &&
+           (al == RSRL_QLEARNING || al == RSRL_SARSA || al == RSRL_EXPECTED_SARSA || al == RSRL_PAL);
+}
+int rsrl_hip_get_episode_steps(rsrl_hip_ctx* c, uint32_t* steps) {
+    CHECK_CTX(c); FLUSH(c); if (!steps) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(steps, c->ep_step, sizeof(uint32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return peer_check(c);
+}
+int rsrl_hip_set_episode_steps(rsrl_hip_ctx* c, const uint32_t* steps) {
+    CHECK_CTX(c); FLUSH(c); if (!steps) return fail(RSRL_HIP_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->ep_step, steps, sizeof(uint32_t) * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_get_q_carry(rsrl_hip_ctx* c, float* q, int32_t* valid) {
+    CHECK_CTX(c); FLUSH(c); if (!q || !valid) return fail(RSRL_HIP_EINVAL, "null argument");
+    *valid = (carries_q(c) && c->q_valid) ? 1 : 0;
+    if (!*valid) return RSRL_HIP_OK;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(q, c->qcache, sizeof(float) * (size_t)c->A * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
+int rsrl_hip_set_q_carry(rsrl_hip_ctx* c, const float* q) {
+    CHECK_CTX(c); FLUSH(c); if (!q) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (!carries_q(c)) return fail(RSRL_HIP_EINVAL, "this ctx's kernels evaluate Q(s,.) from the weights every step: there is nothing carried to restore");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(c->qcache, q, sizeof(float) * (size_t)c->A * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->q_valid = true;
+    return RSRL_HIP_OK;
+}
+
 int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_states, float* next_states,
                          float* rewards, uint8_t* terminal) {
     CHECK_CTX(c); FLUSH(c);

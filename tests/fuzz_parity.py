@@ -150,9 +150,73 @@ def run_case(rng, idx):
                     bad.append(f"aux[{i}]")
         finite = bool(np.all(np.isfinite(ow)))
         moved = bool(np.nanmax(np.abs(ow)) > 0) if ow.size else False
+        extra = ""
+        # ---- a checkpoint in the middle of the run: a second ctx that loads it continues like the first, bit for bit (weights, traces / fa_td / backups /
+        # lists / epsilons, step counter travel in the file; states, actions, the episodes' step counts and -- register-family loops -- the carried
+        # Q(s,.) through the setters of ABI 8)
+        if not bad and rng.random() < 0.5:
+            import tempfile
+            more = int(rng.choice([5, 23]))
+            with tempfile.TemporaryDirectory() as td, ra.Context(**dev) as c2:
+                path = os.path.join(td, "w.rsrlw")
+                c.save_weights(path)
+                st0, ac0, ep0, qc0 = c.states.copy(), c.actions.copy(), c.episode_steps, c.q_carry
+                c2.reset()
+                c2.train(3, want_stats=False)                      # (something to overwrite)
+                c2.load_weights(path)
+                c2.states, c2.actions, c2.episode_steps = st0, ac0, ep0
+                if qc0 is not None:
+                    c2.q_carry = qc0
+                c.train(more, want_stats=False)
+                c2.train(more, want_stats=False)
+                same = np.array_equal(c.states, c2.states, equal_nan=True) and np.array_equal(c.actions, c2.actions) and c.step_count == c2.step_count
+                for i in ([0] if shared else sorted(set([0, n - 1]))):
+                    same = same and np.array_equal(c.get_weights(i), c2.get_weights(i), equal_nan=True)
+                    if family == "sparse_lambda" or dev["algo"] in LAMBDA + (ra.TD_LAMBDA,):
+                        same = same and np.array_equal(c.get_traces(n - 1), c2.get_traces(n - 1), equal_nan=True)
+                    if dev["algo"] == ra.GREEDY_GQ:
+                        same = same and np.array_equal(c.get_td_weights(i), c2.get_td_weights(i), equal_nan=True)
+                if not same:
+                    bad.append("checkpoint resume")
+                extra += " +ckpt"
+        # ---- Handler::handle on caller-supplied transitions, where the oracle's handle_* restates the kernel (the reference-order families)
+        if not bad and not shared and finite and family in ("tile", "generic") and dev["algo"] in LAMBDA + PRED + (ra.GREEDY_GQ,) + ONE_STEP[:3] \
+                and dev.get("agent_policy") is None and rng.random() < 0.5:
+            m = min(n, 4)
+            a0 = c.actions
+            frm, nxt, rew, term = c.domain_step(a0)
+            t_h = c.step_count
+            W0 = [c.get_weights(i).copy() for i in range(m)]
+            aux = None
+            if dev["algo"] in LAMBDA + (ra.TD_LAMBDA,):
+                aux = [c.get_traces(i).copy() for i in range(m)]
+            elif dev["algo"] == ra.GREEDY_GQ:
+                aux = [c.get_td_weights(i).copy() for i in range(m)]
+            tdv = c.handle(frm, a0, rew, nxt, term)
+            for i in range(m):
+                W = W0[i].copy()
+                x = orc.draw(dev["seed"], dev["env_offset"] + i, t_h, orc.BLK_INNER)
+                if dev["algo"] in LAMBDA:
+                    Z = aux[i].copy()
+                    d = orc.handle_lambda(ag, W, Z, frm[:, i], a0[i], rew[i], nxt[:, i], term[i], x, "f32d")
+                    okh = np.array_equal(c.get_traces(i), Z, equal_nan=True)
+                elif dev["algo"] in PRED:
+                    Z = aux[i].copy() if aux else None
+                    d = orc.handle_td(ag, W, Z, frm[:, i], rew[i], nxt[:, i], term[i], "f32d")
+                    okh = aux is None or np.array_equal(c.get_traces(i), Z, equal_nan=True)
+                elif dev["algo"] == ra.GREEDY_GQ:
+                    V = aux[i].copy()
+                    d = orc.handle_gq(ag, W, V, frm[:, i], a0[i], rew[i], nxt[:, i], term[i], "f32d")
+                    okh = np.array_equal(c.get_td_weights(i), V, equal_nan=True)
+                else:
+                    d = orc.handle(ag, W, frm[:, i], a0[i], rew[i], nxt[:, i], term[i], x, "f32d")
+                    okh = True
+                if not (okh and np.array_equal(c.get_weights(i), W, equal_nan=True) and (np.float32(d) == tdv[i] or (np.isnan(d) and np.isnan(tdv[i])))):
+                    bad.append(f"handle[{i}]")
+            extra += " +handle"
     if bad:
         return "MISMATCH", tag + f"  MISMATCH {bad}", dev
-    return "ok", tag + f"  ok{'' if finite else ' (non-finite, NaN for NaN)'}{'' if moved else ' (weights did not move)'}", dev
+    return "ok", tag + f"  ok{extra}{'' if finite else ' (non-finite, NaN for NaN)'}{'' if moved else ' (weights did not move)'}", dev
 
 
 def main():

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(abi):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rsrl_hip.h but not exported"
     assert sorted(abi.SYMBOLS) == names, "python binding table and header drifted apart"
-    assert L.rsrl_hip_abi_version() == 7
+    assert L.rsrl_hip_abi_version() == 8
 
 
 def test_config_struct_layout_and_defaults(abi):

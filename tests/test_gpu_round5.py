@@ -88,3 +88,41 @@ def test_failed_attach_leaves_auto_undecided(ra):
         c.reset()
         c.train(8)
         assert np.isfinite(c.get_weights()).all()
+
+
+def test_exact_resume_needs_the_episode_counters_and_the_carried_q(tmp_path):
+    # ABI 8 (found by tests/fuzz_parity.py): the register-family loops carry Q(s,.) from launch to launch as the fused loop left it (the pre-update value
+    # plus the rank-1 term); set_states / load_weights drop it and the next launch evaluates Q(s,.) from the weights -- equal in exact arithmetic, not in
+    # the last bit, which a Softmax / ExpectedSARSA run notices.  With the checkpoint, the states, the actions, rsrl_hip_set_episode_steps and
+    # rsrl_hip_set_q_carry a second ctx continues the first one's run bit for bit -- step cap included.
+    import numpy as np
+    import rsrl_amd as ra
+    kw = dict(domain=1, order=1, algo=ra.EXPECTED_SARSA, policy=ra.SOFTMAX, tau=1.0, gamma=0.99, lr=0.0125, alpha=0.5, n_envs=65, seed=187902,
+              max_episode_steps=37)
+    path = str(tmp_path / "w.rsrlw")
+    with ra.Context(**kw) as a, ra.Context(**kw) as b, ra.Context(**kw) as plain:
+        a.reset()
+        a.train(150)
+        assert a.episode_steps.max() > 0
+        q = a.q_carry
+        assert q is not None and q.shape == (2, 65)
+        a.save_weights(path)
+        s, act, ep = a.states, a.actions, a.episode_steps
+        for c in (b, plain):
+            c.reset(); c.train(3)
+            c.load_weights(path)
+            c.states, c.actions = s, act
+            assert c.q_carry is None                              # dropped by the setters
+        b.episode_steps = ep
+        b.q_carry = q
+        a.train(400); b.train(400); plain.train(400)
+        assert np.array_equal(a.states, b.states) and np.array_equal(a.actions, b.actions) and np.array_equal(a.episode_steps, b.episode_steps)
+        for i in (0, 33, 64):
+            assert np.array_equal(a.get_weights(i), b.get_weights(i)), i
+        # without the two: another run (the caps fall elsewhere), close in its weights where the trajectories have not parted
+        assert not np.array_equal(a.states, plain.states)
+    with ra.Context(domain=1, basis=ra.TILE_CODING, n_envs=8) as t:  # a family that evaluates Q from the weights every step carries nothing
+        t.reset(); t.train(5)
+        assert t.q_carry is None and t.episode_steps.shape == (8,)
+        with pytest.raises(ra.RsrlHipError):
+            t.q_carry = np.zeros((2, 8), np.float32)
