@@ -880,6 +880,9 @@ void FN(orc_run_reset)(void* h) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
     int D = ag->basis.dim, A = ag->n_actions; int64_t i;
     run->q_valid = 0;
+    /* QSigma: fresh episodes start from an EMPTY n-step backup, as after a terminal transition (q_sigma.rs:154) -- what rsrl_hip_reset does: entries of
+     * the abandoned trajectories must not enter the first anchor updates of the new ones (found unrestated by tests/fuzz_parity.py, round 5) */
+    if (run->qs) for (i = 0; i < run->n_envs; i++) run->qs[i].len = 0;
     for (i = 0; i < run->n_envs; i++) {
         R q[ORC_MAX_ACTIONS]; uint32_t x[4];
         R* s = run->state + (size_t)i * D;
@@ -1512,6 +1515,7 @@ void FN(orc_run_reset_wave)(void* h) {
     int D = ag->basis.dim, A = ag->n_actions, j; int64_t i;
     R* phi = (R*)malloc(sizeof(R) * 4096);
     run->q_valid = 0;
+    if (run->qs) for (i = 0; i < run->n_envs; i++) run->qs[i].len = 0;         /* (as orc_run_reset) */
     for (i = 0; i < run->n_envs; i++) {
         R q[ORC_MAX_ACTIONS]; uint32_t x[4];
         R* s = run->state + (size_t)i * D;

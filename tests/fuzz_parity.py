@@ -169,6 +169,7 @@ def run_case(rng, idx):
                     c2.q_carry = qc0
                 c.train(more, want_stats=False)
                 c2.train(more, want_stats=False)
+                getattr(run, method)(more, **mkw)                  # (the oracle keeps pace: later legs compare against it again)
                 same = np.array_equal(c.states, c2.states, equal_nan=True) and np.array_equal(c.actions, c2.actions) and c.step_count == c2.step_count
                 for i in ([0] if shared else sorted(set([0, n - 1]))):
                     same = same and np.array_equal(c.get_weights(i), c2.get_weights(i), equal_nan=True)
@@ -179,6 +180,54 @@ def run_case(rng, idx):
                 if not same:
                     bad.append("checkpoint resume")
                 extra += " +ckpt"
+        # ---- set_weights / get_weights: every layout (rows of learners, tile tables, the wave family's lane order, bf16 storage) gives back what went in
+        if not bad and rng.random() < 0.3:
+            i = int(rng.integers(0, 1 if shared else n))
+            w_in = (rng.normal(size=c.get_weights(0).shape) * 0.3).astype(np.float32)
+            if dev.get("weight_dtype", ra.W_F32) == ra.W_BF16:
+                w_in = (w_in.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)      # bf16-representable: stored exactly
+            keep = c.get_weights(i).copy()
+            other = c.get_weights((i + 1) % n).copy() if (not shared and n > 1) else None
+            c.set_weights(w_in, i)
+            if not np.array_equal(c.get_weights(i), w_in):
+                bad.append("set/get weights")
+            if other is not None and not np.array_equal(c.get_weights((i + 1) % n), other, equal_nan=True):
+                bad.append("set_weights touched a neighbour")
+            c.set_weights(keep, i)
+            extra += " +setget"
+        # ---- Domain::default() + the first action in the middle of a run: reset() on both sides, then on
+        if not bad and family != "sparse_lambda" and rng.random() < 0.25:
+            more = int(rng.choice([4, 19]))
+            (run.reset_wave if method == "train_wave" else run.reset)()
+            c.reset()
+            getattr(run, method)(more, **mkw)
+            c.train(more, want_stats=False)
+            if not (np.array_equal(c.states.T, run.state, equal_nan=True) and np.array_equal(c.actions, run.action)):
+                bad.append("after reset: states / actions")
+            ow = run.weights
+            w0 = c.get_weights(0)
+            if not np.array_equal(w0, (ow if shared else ow[0]).reshape(w0.shape), equal_nan=True):
+                bad.append("after reset: weights")
+            extra += " +reset"
+        # ---- sharding by global env id: two ctxs with env offsets reproduce the one (per-learner weights: no communication)
+        if not bad and not shared and n >= 3 and rng.random() < 0.3:
+            n1 = int(rng.integers(1, n))
+            parts = []
+            for off, cnt in ((0, n1), (n1, n - n1)):
+                with ra.Context(**dict(dev, n_envs=cnt, env_offset=dev["env_offset"] + off)) as cs:
+                    cs.reset()
+                    cs.train(17, want_stats=False)
+                    parts.append((cs.states.copy(), cs.actions.copy(), cs.get_weights(0).copy(), cs.get_weights(cnt - 1).copy()))
+            with ra.Context(**dev) as cf:
+                cf.reset()
+                cf.train(17, want_stats=False)
+                okp = np.array_equal(np.concatenate([parts[0][0], parts[1][0]], axis=1), cf.states, equal_nan=True) and \
+                    np.array_equal(np.concatenate([parts[0][1], parts[1][1]]), cf.actions) and \
+                    np.array_equal(parts[0][2], cf.get_weights(0), equal_nan=True) and np.array_equal(parts[0][3], cf.get_weights(n1 - 1), equal_nan=True) and \
+                    np.array_equal(parts[1][2], cf.get_weights(n1), equal_nan=True) and np.array_equal(parts[1][3], cf.get_weights(n - 1), equal_nan=True)
+            if not okp:
+                bad.append("sharded != unsharded")
+            extra += " +shard"
         # ---- Handler::handle on caller-supplied transitions, where the oracle's handle_* restates the kernel (the reference-order families)
         if not bad and not shared and finite and family in ("tile", "generic") and dev["algo"] in LAMBDA + PRED + (ra.GREEDY_GQ,) + ONE_STEP[:3] \
                 and dev.get("agent_policy") is None and rng.random() < 0.5:
