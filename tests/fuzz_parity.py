@@ -28,8 +28,8 @@ def sample(rng):
     """-> (family, device kwargs, oracle kwargs, oracle method name, method kwargs)"""
     domain = int(rng.integers(0, 3))
     family = rng.choice(["reg", "reg", "generic", "tile", "tile", "wave", "shared_dense", "shared_tile", "sparse_lambda"])
-    kw = dict(domain=domain, seed=int(rng.integers(0, 1 << 20)), gamma=float(rng.choice([0.9, 0.99, 1.0])),
-              max_episode_steps=int(rng.choice([0, 25, 200])), env_offset=int(rng.choice([0, 0, 64, 1000003])))
+    kw = dict(domain=domain, seed=int(rng.integers(0, 1 << 20)), gamma=float(rng.choice([0.0, 0.9, 0.9, 0.99, 1.0])),
+              max_episode_steps=int(rng.choice([0, 1, 25, 25, 200])), env_offset=int(rng.choice([0, 0, 64, 1000003])))
     n = int(rng.choice([1, 3, 63, 64, 65, 130, 257]))
     method, mkw = "train", {}
     if family in ("reg", "shared_dense"):
@@ -54,12 +54,12 @@ def sample(rng):
         algo = int(rng.integers(0, 10))
     kw["algo"] = algo
     kw["policy"] = ra.RANDOM if algo in PRED else int(rng.choice([ra.GREEDY, ra.EPSILON_GREEDY, ra.EPSILON_GREEDY, ra.SOFTMAX]))
-    kw["epsilon"] = float(rng.choice([0.05, 0.3]))
-    kw["tau"] = float(rng.choice([0.5, 1.0, 5.0]))
+    kw["epsilon"] = float(rng.choice([0.0, 0.05, 0.3, 0.3, 1.0]))
+    kw["tau"] = float(rng.choice([0.05, 0.5, 1.0, 5.0]))
     kw["lr"] = step
     kw["alpha"] = float(rng.choice([0.5, 1.0])) if algo in (ra.EXPECTED_SARSA, ra.PAL) else step
     if algo in LAMBDA + (ra.TD_LAMBDA,):
-        kw.update(lam=float(rng.choice([0.0, 0.5, 0.9])), trace=int(rng.integers(0, 3)))
+        kw.update(lam=float(rng.choice([0.0, 0.5, 0.9, 0.9, 1.0])), trace=int(rng.integers(0, 3)))
     if algo == ra.GREEDY_GQ:
         kw["lr_td"] = step * float(rng.choice([0.1, 1.0]))
     if algo == ra.Q_SIGMA:
@@ -76,6 +76,10 @@ def sample(rng):
         if algo != ra.PAL and kw["policy"] == ra.EPSILON_GREEDY and dev["steps_per_launch"] != 1 and rng.random() < 0.25:
             kw.update(epsilon_decay=0.97, epsilon_min=0.01)
             dev.update(epsilon_decay=0.97, epsilon_min=0.01)
+    elif family in ("reg", "tile", "generic") and kw["policy"] == ra.EPSILON_GREEDY and dev.get("steps_per_launch", 0) != 1 and rng.random() < 0.25 and \
+            ((family == "reg" and algo in LAMBDA) or (family != "reg" and algo in ONE_STEP)):
+        kw.update(epsilon_decay=0.97, epsilon_min=0.01)           # the drivers' per-episode schedule (examples/sarsa_lambda.rs:68)
+        dev.update(epsilon_decay=0.97, epsilon_min=0.01)
     elif family == "wave":
         method = "train_wave"
         if algo in ONE_STEP[:3] and rng.random() < 0.5:
@@ -109,6 +113,8 @@ def run_case(rng, idx):
     total = int(rng.choice([40, 90, 150])) if family != "wave" else int(rng.choice([8, 20, 60]))
     cuts = sorted(set(int(x) for x in rng.integers(1, total, size=int(rng.integers(0, 3)))))
     calls = [b - a for a, b in zip([0] + cuts, cuts + [total])]
+    if rng.random() < 0.1:
+        calls.insert(int(rng.integers(0, len(calls) + 1)), 0)     # a call of zero batch-steps changes nothing
     tag = f"{idx:4d} {family:13s} {NAMES[dev['algo']]:13s} dom {dev['domain']} N {n:5d} K {total:3d} calls {calls}"
     try:
         ctx = ra.Context(**dev)
@@ -121,7 +127,8 @@ def run_case(rng, idx):
             (run.reset_wave if method == "train_wave" else run.reset)()
             c.reset()
             for k in calls:
-                getattr(run, method)(k, **mkw)
+                if k:
+                    getattr(run, method)(k, **mkw)
                 c.train(k, want_stats=bool(rng.integers(0, 2)))
         except ValueError as e:                                   # the oracle has no loop for it
             return "no_oracle", tag + f"  NO ORACLE LOOP: {str(e)[:80]}", dev
@@ -180,6 +187,14 @@ def run_case(rng, idx):
                 if not same:
                     bad.append("checkpoint resume")
                 extra += " +ckpt"
+        # ---- Domain::rollout under the greedy policy from the learned weights (lib.rs:334-409): episode lengths as the oracle's, learner for learner
+        if not bad and not shared and finite and dev["algo"] not in PRED and family in ("reg", "tile", "generic") and rng.random() < 0.2:
+            lim = int(rng.choice([30, 120]))
+            n_d, _ = c.rollout_greedy(lim)
+            n_o, _ = run.rollout_greedy(lim)
+            if not np.array_equal(n_d, n_o):
+                bad.append(f"rollout_greedy ({int((n_d != n_o).sum())} of {n} learners)")
+            extra += " +rollout"
         # ---- set_weights / get_weights: every layout (rows of learners, tile tables, the wave family's lane order, bf16 storage) gives back what went in
         if not bad and rng.random() < 0.3:
             i = int(rng.integers(0, 1 if shared else n))
@@ -230,7 +245,7 @@ def run_case(rng, idx):
             extra += " +shard"
         # ---- Handler::handle on caller-supplied transitions, where the oracle's handle_* restates the kernel (the reference-order families)
         if not bad and not shared and finite and family in ("tile", "generic") and dev["algo"] in LAMBDA + PRED + (ra.GREEDY_GQ,) + ONE_STEP[:3] \
-                and dev.get("agent_policy") is None and rng.random() < 0.5:
+                and dev.get("agent_policy") is None and "epsilon_decay" not in dev and rng.random() < 0.5:     # (orc.handle_* take the agent's epsilon, not a learner's)
             m = min(n, 4)
             a0 = c.actions
             frm, nxt, rew, term = c.domain_step(a0)
