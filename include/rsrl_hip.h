@@ -224,6 +224,8 @@ int rsrl_hip_reset(rsrl_hip_ctx* ctx);
 /* Domain::emit (state part)                         rsrl_domains/src/lib.rs:430 */
 int rsrl_hip_get_states(rsrl_hip_ctx* ctx, float* states /*[D][N]*/);
 int rsrl_hip_set_states(rsrl_hip_ctx* ctx, const float* states /*[D][N]*/);
+/*   (set_states: a HOST array must hold finite values within 1000 widths of each dimension's bounds, else EINVAL -- the reference's wrap! macro,
+ *    rsrl_domains/src/macros.rs:14-24, loops without end on an infinite angle; a DEVICE array is clamped into that range instead) */
 int rsrl_hip_get_actions(rsrl_hip_ctx* ctx, int32_t* actions /*[N]*/);
 int rsrl_hip_set_actions(rsrl_hip_ctx* ctx, const int32_t* actions /*[N]*/);
 /* (ABI 8) The rest of a learner's state between two driver calls, so that a run can be carried into another ctx EXACTLY (with the checkpoint of

@@ -303,6 +303,9 @@ static int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     g_last_error = buf;
+    // the HIP runtime keeps the last failure of ANY call of this thread until somebody asks for it: asked for here, so that a failure this library has
+    // already reported (or chose to ignore on a clean-up path) is not found again by the next launch check (KCHECK) of a healthy ctx
+    (void)hipGetLastError();
     return code;
 }
 #define HIP_TRY(expr)                                                                              \
@@ -587,6 +590,33 @@ static int check_host_actions(const int32_t* a, size_t n, int A) {
         if (a[i] < 0 || a[i] >= A) return fail(RSRL_HIP_EINVAL, "action[%zu] = %d is outside [0, %d)", i, a[i], A);
     return RSRL_HIP_OK;
 }
+// caller-supplied STATES: the reference's wrap! (rsrl_domains/src/macros.rs:14-24) brings an angle home by repeated +-2 pi -- a loop that does not end
+// for an infinite value and practically not for a huge one (Acrobot; on the device that is a hung GPU).  A HOST array is validated (EINVAL: every
+// component finite and within 1000 widths of its dimension's bounds); a DEVICE array cannot be inspected from here and is clamped into that range
+// by k_clamp_states (NaN stays NaN: comparisons with it are false, nothing loops).
+static void state_limits(const rsrl_hip_ctx* c, float* lo, float* hi);
+static int check_host_states(const rsrl_hip_ctx* c, const float* s, size_t n_cols) {
+    if (!s || is_device_ptr(s)) return RSRL_HIP_OK;
+    float lo[8], hi[8];
+    state_limits(c, lo, hi);
+    for (int d = 0; d < c->D; ++d)
+        for (size_t i = 0; i < n_cols; ++i) {
+            const float x = s[(size_t)d * n_cols + i];
+            if (!(x >= lo[d] && x <= hi[d]))
+                return fail(RSRL_HIP_EINVAL, "state[%d][%zu] = %g is not a finite value within 1000 widths of the dimension's bounds [%g, %g]", d, i, (double)x,
+                            (double)lo[d], (double)hi[d]);
+        }
+    return RSRL_HIP_OK;
+}
+struct StateLimits { float lo[8], hi[8]; };
+__global__ void k_clamp_states(float* __restrict__ s, int64_t n, int D, StateLimits lim) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int d = 0; d < D; ++d) {
+        const float x = s[(int64_t)d * n + i];
+        s[(int64_t)d * n + i] = x > lim.hi[d] ? lim.hi[d] : (x < lim.lo[d] ? lim.lo[d] : x);
+    }
+}
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define KCHECK() HIP_TRY(hipGetLastError())
 
@@ -658,7 +688,9 @@ int rsrl_hip_config_init(rsrl_hip_config* cfg) {
 
 int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (!c) return RSRL_HIP_OK;
-    (void)hipSetDevice(c->cfg.device);
+    // (a ctx whose creation failed on its device ordinal is torn down through here too: the failure of this call must not stay behind as the thread's
+    //  last HIP error -- tests/fuzz_abi.py found it reported by the next ctx's first launch check)
+    if (hipSetDevice(c->cfg.device) != hipSuccess) (void)hipGetLastError();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& s : c->scratch) if (s.p) (void)hipFree(s.p);
@@ -703,6 +735,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->px_B && c->px_B_owned) (void)hipFree(c->px_B);
     if (c->d_px_Bptrs) (void)hipFree(c->d_px_Bptrs);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    (void)hipGetLastError();                     // (whatever a release above may have failed with is not the next ctx's business)
     delete c;
     return RSRL_HIP_OK;
 }
@@ -970,6 +1003,12 @@ int rsrl_hip_state_bounds(const rsrl_hip_ctx* c, double* lo, double* hi) {
     return RSRL_HIP_OK;
 }
 
+static void state_limits(const rsrl_hip_ctx* c, float* lo, float* hi) {
+    double l[8], h[8];
+    (void)rsrl_hip_state_bounds(c, l, h);
+    for (int d = 0; d < c->D; ++d) { const double w = 1000.0 * (h[d] - l[d]); lo[d] = (float)(l[d] - w); hi[d] = (float)(h[d] + w); }
+}
+
 int rsrl_hip_set_epsilon(rsrl_hip_ctx* c, double eps) {
     CHECK_CTX(c); FLUSH(c);
     if (!(eps >= 0.0 && eps <= 1.0)) return fail(RSRL_HIP_EINVAL, "epsilon must be in [0,1]");   // gen_bool panics otherwise
@@ -1031,9 +1070,16 @@ int rsrl_hip_get_states(rsrl_hip_ctx* c, float* states) {
 }
 int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
     CHECK_CTX(c); FLUSH(c);
-    c->q_valid = false; if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
+    TRY(check_host_states(c, states, (size_t)c->cfg.n_envs));
+    c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
+    if (is_device_ptr(states)) {
+        StateLimits lim; state_limits(c, lim.lo, lim.hi);
+        hipLaunchKernelGGL(k_clamp_states, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->state, c->cfg.n_envs, c->D, lim);
+        KCHECK();
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }

@@ -20,3 +20,32 @@ def test_random_configurations_bitwise_against_the_oracle():
     d = json.loads(line[0][8:])
     assert p.returncode == 0 and not d["failures"], d["failures"][:3]
     assert d["counts"].get("ok", 0) >= 240 and d["counts"].get("refused", 0) == 0, d["counts"]      # every sampled configuration exists
+
+
+def test_adversarial_configurations_and_arguments_return_errors():
+    # tests/fuzz_abi.py: out-of-range, non-finite and contradictory config fields; null pointers, learner indices and batch sizes out of range,
+    # non-finite states, actions outside the action set -- every entry point returns, and a healthy ctx created afterwards trains to the same checksum.
+    # (Round 5 findings: a ctx refused for its device ordinal left HIP's sticky last error behind for the next ctx's first launch check; an infinite or
+    # huge Acrobot angle handed to set_states would have spun in the reference's wrap! loop on the device.)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_abi.py"), "400", "5"], capture_output=True, text=True, timeout=600)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SUMMARY ")]
+    assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(line[0][8:])
+    assert not d["failures"] and d["created"] >= 80 and d["refused"] >= 150, d
+
+
+def test_set_states_refuses_what_would_spin_in_wrap():
+    import numpy as np
+    import rsrl_amd as ra
+    with ra.Context(domain=ra.ACROBOT, order=1, n_envs=8, policy=1) as c:
+        c.reset()
+        s = c.states
+        for bad in (np.inf, -np.inf, np.nan, 1e30, -1e9):
+            t = s.copy(); t[0, 3] = bad
+            with pytest.raises(ra.RsrlHipError):
+                c.states = t
+        assert np.array_equal(c.states, s)                       # refused: untouched
+        t = s.copy(); t[0, 3] = 100.0                             # far outside [-pi, pi], but a few wraps away: accepted as the reference would
+        c.states = t
+        c.train(3)
+        assert np.all(np.abs(c.states[0]) <= np.float32(np.pi))
