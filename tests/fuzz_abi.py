@@ -79,6 +79,20 @@ def poke(L, h, rng, log):
         r = np.full(M, rng.choice([np.nan, 1.0]), dtype=np.float32); t = np.full(M, 7, dtype=np.uint8); out = np.zeros(M, dtype=np.float32)
         return L.rsrl_hip_handle(h, p(s), p(a), p(r), p(s), p(t), M, p(out))
     calls.append(handle_bad)
+    def eval_bad():                                    # the query entry points on non-finite / huge states
+        M = int(rng.choice([1, 5, N]))
+        s = np.full((D, M), rng.choice([np.nan, np.inf, -np.inf, 1e30, -3e38]), dtype=np.float32)
+        out = np.zeros((max(A, O) + 1) * M + 64, dtype=np.float32); iout = np.zeros(64 * M + 64, dtype=np.int32)
+        rcs = [L.rsrl_hip_q_evaluate(h, p(s), M, p(out)), L.rsrl_hip_q_find_max(h, p(s), M, p(iout), p(out)), L.rsrl_hip_policy_mode(h, p(s), M, p(iout))]
+        if hasattr(L, "rsrl_hip_tile_indices"):
+            rcs.append(L.rsrl_hip_tile_indices(h, p(s), M, p(iout)))
+        L.rsrl_hip_sync(h)
+        return rcs
+    calls.append(eval_bad)
+    def rollout_bad():
+        n_st = np.zeros(N, dtype=np.uint32); tot = np.zeros(N, dtype=np.float32)
+        return [L.rsrl_hip_rollout_greedy(h, int(v), p(n_st), p(tot)) for v in (-1, 1, 2, 30)]
+    calls.append(rollout_bad)
     order = rng.permutation(len(calls))[: int(rng.integers(3, 12))]
     for j in order:
         rc = calls[int(j)]()
