@@ -49,3 +49,15 @@ def test_set_states_refuses_what_would_spin_in_wrap():
         c.states = t
         c.train(3)
         assert np.all(np.abs(c.states[0]) <= np.float32(np.pi))
+
+
+def test_random_configurations_against_the_f64_oracle_teacher_forced():
+    # tests/fuzz_f64.py: the reference's precision.  Random configurations of every family and agent, the f64 run drives the trajectory, the device learns
+    # from the identical transitions through Handler::handle.  Bounds asserted there: per-step TD error 2e-4 (relative to 1 + |td|), final weights 1e-4
+    # (relative to max(1, |W|)), Q at the final states 2e-4; measured over 3 278 cases: 2.0e-4 / 1.4e-5 / 1.6e-4 worst (generic Fourier orders), shared
+    # weights 1e-6.  Agents with a discrete decision inside handle (GreedyGQ's argmax, ...) may be tipped by a rounding: reported, not failed.
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_f64.py"), "300", "77"], capture_output=True, text=True, timeout=600)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SUMMARY ")]
+    assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-2000:])
+    d = json.loads(line[0][8:])
+    assert not d["over"] and d["counts"].get("ok", 0) >= 220 and d["counts"].get("tipped", 0) <= 5, d["counts"]
