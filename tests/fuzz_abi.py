@@ -93,6 +93,24 @@ def poke(L, h, rng, log):
         n_st = np.zeros(N, dtype=np.uint32); tot = np.zeros(N, dtype=np.float32)
         return [L.rsrl_hip_rollout_greedy(h, int(v), p(n_st), p(tot)) for v in (-1, 1, 2, 30)]
     calls.append(rollout_bad)
+    def ranks_bad():                                   # the multi-rank entry points: null lists, duplicates, counts and ranks out of range, garbage handles
+        hbuf = (C.c_uint8 * (128 * 4))(*[int(x) for x in rng.integers(0, 256, 512)])
+        two = (C.c_void_p * 2)(h, h); nul = (C.c_void_p * 2)(h, None)
+        ws, rk, ex = C.c_int(0), C.c_int(0), C.c_int(0); ident = C.c_uint64(0)
+        rcs = [L.rsrl_hip_peer_export(h, int(v), None) for v in (-1, 0, 1)]
+        rcs += [L.rsrl_hip_peer_export(h, int(v), hbuf) for v in (-1, 0, 100000)]
+        rcs += [L.rsrl_hip_peer_connect(h, None, 2, 0), L.rsrl_hip_peer_connect(h, hbuf, 2, 5), L.rsrl_hip_peer_connect(h, hbuf, 0, 0),
+                L.rsrl_hip_peer_connect(h, hbuf, 2, int(rng.integers(0, 2)))]
+        rcs += [L.rsrl_hip_comm_init(h, None, 1, 0), L.rsrl_hip_comm_init(h, hbuf, 0, 0), L.rsrl_hip_comm_init(h, hbuf, 2, 7), L.rsrl_hip_comm_init(h, hbuf, -1, -1)]
+        rcs += [L.rsrl_hip_group_create(None, 2), L.rsrl_hip_group_create(two, 0), L.rsrl_hip_group_create(two, -3), L.rsrl_hip_group_create(two, 2),
+                L.rsrl_hip_group_create(nul, 2), L.rsrl_hip_group_train(None, 1, 3), L.rsrl_hip_group_train(two, 2, 2), L.rsrl_hip_group_train(nul, 2, 2),
+                L.rsrl_hip_group_train(two, 1, -4)]
+        rcs += [L.rsrl_hip_can_access_peer(-1, 0), L.rsrl_hip_can_access_peer(0, 99), L.rsrl_hip_device_identity(99, C.byref(ident)), L.rsrl_hip_device_identity(0, None),
+                L.rsrl_hip_comm_info(h, None, None, None), L.rsrl_hip_comm_info(h, C.byref(ws), C.byref(rk), C.byref(ex)), L.rsrl_hip_comm_unique_id(None)]
+        rcs.append(L.rsrl_hip_train(h, 2, None))
+        L.rsrl_hip_sync(h)
+        return rcs
+    calls.append(ranks_bad)
     order = rng.permutation(len(calls))[: int(rng.integers(3, 12))]
     for j in order:
         rc = calls[int(j)]()
@@ -133,6 +151,8 @@ def main():
         feats = (max(1, min(8, cfg.order)) + 1) ** (2 if cfg.domain == 0 else 4) if cfg.basis == 0 else max(1, min(16, cfg.n_tilings)) * max(1, min(64, cfg.tiles_per_dim)) ** (2 if cfg.domain == 0 else 4)
         if 0 < cfg.n_envs <= 10 ** 7 and cfg.weight_mode == 0 and feats * 3 * 4 * 2 * cfg.n_envs > 2e9:
             cfg.n_envs = max(1, int(2e9 / (feats * 24)))
+        if cfg.peer_timeout_ms == 0 or cfg.peer_timeout_ms > 300:
+            cfg.peer_timeout_ms = 200                               # (a rank whose peers never show up gives up after 0.2 s instead of the default 4 s)
         h = C.c_void_p()
         rc = L.rsrl_hip_create(C.byref(cfg), C.byref(h))
         log = []
