@@ -175,12 +175,13 @@ __global__ __launch_bounds__(256) void k_peer_push(const float* __restrict__ dW,
                                                    uint64_t t, const uint64_t* __restrict__ t_dev, int64_t xdelta) {
     if (t_dev) t += *t_dev;
     const uint64_t xs = t + (uint64_t)xdelta;          // exchange sequence number: parity and tag (see Common::xdelta)
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint64_t g = (uint64_t)__float_as_uint(dW[j]) | ((uint64_t)(uint32_t)(xs + 1) << 32);
-    const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
-    for (int r = 0; r < world; ++r)
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a grid-stride loop: the grid is capped where several ranks share one device, peer_grid() below)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const uint64_t g = (uint64_t)__float_as_uint(dW[j]) | ((uint64_t)(uint32_t)(xs + 1) << 32);
+        const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
+        for (int r = 0; r < world; ++r)
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 // sum over ranks (ascending) of slot [parity][r][j], each polled until its tag says "exchange xs".  The spin is bounded by the
 // wall clock (100 MHz; `timeout` ticks): a missing peer sets *err instead of hanging the GPU, and the sum is POISONED (NaN) --
@@ -205,9 +206,8 @@ __device__ __forceinline__ float peer_sum(const uint2* __restrict__ recv, int n,
 __global__ __launch_bounds__(256) void k_peer_reduce(float* __restrict__ dW, int n, const uint2* __restrict__ recv, int world, uint64_t t,
                                                      const uint64_t* __restrict__ t_dev, int64_t xdelta, uint32_t* __restrict__ err, uint64_t timeout) {
     if (t_dev) t += *t_dev;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    dW[j] = peer_sum(recv, n, world, j, t + (uint64_t)xdelta, err, timeout);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        dW[j] = peer_sum(recv, n, world, j, t + (uint64_t)xdelta, err, timeout);
 }
 // multi-rank mode: the fold as a kernel of its own (the copies of batch-step t's fixed-point delta table -> one float per
 // output), feeding the exchange
@@ -233,14 +233,16 @@ __global__ __launch_bounds__(256) void k_tab_exchange_apply(const long long* __r
                                                             const uint64_t* __restrict__ t_dev, int64_t xdelta, uint32_t* __restrict__ err, uint64_t timeout) {
     if (t_dev) t += *t_dev;
     const uint64_t xs = t + (uint64_t)xdelta;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const float tot = tab_total(tab, n, j, lr, t);
-    const uint64_t mine = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(xs + 1) << 32);
-    const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
-    for (int r = 0; r < world; ++r)
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    W[j] += peer_sum(recv, n, world, j, xs, err, timeout);
+    // every element is pushed BEFORE the first wait (two grid-stride loops: the grid may be capped, peer_grid() below)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const float tot = tab_total(tab, n, j, lr, t);
+        const uint64_t mine = (uint64_t)__float_as_uint(tot) | ((uint64_t)(uint32_t)(xs + 1) << 32);
+        const size_t slot = ((size_t)(xs & 1) * world + rank) * (size_t)n + j;
+        for (int r = 0; r < world; ++r)
+            __hip_atomic_store(reinterpret_cast<uint64_t*>(peers[r] + slot), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+        W[j] += peer_sum(recv, n, world, j, xs, err, timeout);
 }
 __global__ void k_fill_f32(float* __restrict__ p, int64_t n, float v) { const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_set_dyn(DynParams* __restrict__ d, DynParams v) { *d = v; }
@@ -401,6 +403,7 @@ struct rsrl_hip_ctx {
     // ---- co-residency of the persistent kernel (every block of the grid -- and of every peer rank -- must be resident at once)
     int persist_occ = -1;                      // blocks of k_shared_persist one CU admits (occupancy query; -1 = not asked yet, 0 = none)
     bool group_persist = false;                // PEER group: the COLLECTIVE decision of rsrl_hip_peer_connect (every rank takes the same path)
+    int peer_share = 1;                        // ranks of this ctx's group on ITS device, itself included (rsrl_hip_peer_connect); caps the exchange grids
     bool coop_allowed = true;                  // no rank of this ctx's group shares (process, device) with it: a cooperative launch cannot queue behind a peer's
     bool coop_validated = false;               // one cooperative launch of this ctx's persistent grid has been accepted by the runtime
     bool persist_refused = false;              // ... or refused (single rank: the per-step path takes over for good)
@@ -630,12 +633,23 @@ __global__ void k_clamp_states(float* __restrict__ s, int64_t n, int D, StateLim
 // synchronisation, capturable into the step graph.  A communicator of size 1 runs the same sequence (that is how the
 // multi-rank path is exercised on a one-GPU box).  At 432 B (MountainCar Fourier(5)) this is latency-bound, not link-bound.
 //   t / t_dev: the batch-step this exchange belongs to (PEER: slot parity and granule tag); t_dev != nullptr inside a graph.
+// Grid of the peer-exchange kernels (grid-stride loops over the n outputs).  A rank that has its device to itself takes one block per 256 outputs, as
+// before.  Ranks that SHARE a device (oversubscribed tests, several ranks per GPU) wait -- bounded -- for each other's pushes while occupying compute
+// units: eight ranks x 768 waiting blocks (a 16 x 8^4 x 3 tile table) fill the device and the rank they wait for never gets a unit (found by
+// tests/fuzz_ranks.py as an exchange time-out).  So the group's waiting blocks together may take at most HALF of the device's resident blocks.
+static unsigned peer_grid(const rsrl_hip_ctx* c, int n) {
+    const unsigned full = (unsigned)((n + 255) / 256);
+    if (c->peer_share <= 1) return full;
+    const unsigned resident = (unsigned)(c->n_cu > 0 ? c->n_cu : 256) * 8u;            // 256-thread blocks per device at full occupancy
+    const unsigned cap = std::max(1u, resident / 2u / (unsigned)c->peer_share);
+    return std::min(full, cap);
+}
 static int exchange_dw(rsrl_hip_ctx* c, uint64_t t, const uint64_t* t_dev, int64_t xdelta) {
     if (!c->multi) return RSRL_HIP_OK;
     const int n = (int)c->dw_elems;
     if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {
-        hipLaunchKernelGGL(k_peer_push, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->d_peer_ptrs, c->world_size, c->rank, t, t_dev, xdelta);
-        hipLaunchKernelGGL(k_peer_reduce, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->dW, n, c->peer_recv, c->world_size, t, t_dev, xdelta, c->d_peer_err,
+        hipLaunchKernelGGL(k_peer_push, dim3(peer_grid(c, n)), dim3(256), 0, c->stream, c->dW, n, c->d_peer_ptrs, c->world_size, c->rank, t, t_dev, xdelta);
+        hipLaunchKernelGGL(k_peer_reduce, dim3(peer_grid(c, n)), dim3(256), 0, c->stream, c->dW, n, c->peer_recv, c->world_size, t, t_dev, xdelta, c->d_peer_err,
                            c->peer_timeout);
         KCHECK();
         return RSRL_HIP_OK;
@@ -1825,7 +1839,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         // multi-rank: the delta table of this batch-step -> exchange; the sum reaches the weights in the exchange kernel (peer) or
         // in the next launch's prologue (RCCL: table -> dW -> all-reduce, folded as floats)
         if (c->cfg.exchange == RSRL_EXCHANGE_PEER) {                              // fused: delta -> every rank's slot; slots -> W
-            hipLaunchKernelGGL(k_tab_exchange_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->sh_tab, n, k.alg.lr, c->d_peer_ptrs, c->peer_recv, c->W,
+            hipLaunchKernelGGL(k_tab_exchange_apply, dim3(peer_grid(c, n)), dim3(256), 0, c->stream, c->sh_tab, n, k.alg.lr, c->d_peer_ptrs, c->peer_recv, c->W,
                                c->world_size, c->rank, t, t_dev, k.xdelta, c->d_peer_err, c->peer_timeout);
             KCHECK();
             return RSRL_HIP_OK;
@@ -2756,6 +2770,8 @@ int rsrl_hip_peer_connect(rsrl_hip_ctx* c, const uint8_t* handles, int world_siz
         for (int r = 0; r < world_size; ++r)
             if (r != rank && bl[(size_t)r].pid == bl[(size_t)rank].pid && bl[(size_t)r].dev_id == bl[(size_t)rank].dev_id) c->coop_allowed = false;
         c->coop_validated = false; c->persist_refused = false;
+        c->peer_share = 0;
+        for (int r = 0; r < world_size; ++r) if (bl[(size_t)r].dev_id == bl[(size_t)rank].dev_id) c->peer_share += 1;
     }
     c->world_size = world_size; c->rank = rank; c->multi = true;
     return RSRL_HIP_OK;

@@ -61,3 +61,16 @@ def test_random_configurations_against_the_f64_oracle_teacher_forced():
     assert p.returncode == 0 and line, (p.stdout[-2000:], p.stderr[-2000:])
     d = json.loads(line[0][8:])
     assert not d["over"] and d["counts"].get("ok", 0) >= 220 and d["counts"].get("tipped", 0) <= 5, d["counts"]
+
+
+def test_random_rank_groups_on_one_device():
+    # tests/fuzz_ranks.py: G = 2 / 3 / 4 / 8 in-process ranks over one shared approximator (dense basis, tile coding, sparse-trace lambda agents),
+    # random learner counts (ragged shards) and step splits: replicas identical, the group equal to the unsharded run (bit for bit where every shard is
+    # whole blocks).  (Round 5 finding: eight ranks sharing the device and waiting on a 786 KB delta filled it with waiting blocks -- the exchange
+    # kernels' grids are capped now where ranks share a device.)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_ranks.py"), "40", "9"], capture_output=True, text=True, timeout=900, env=env)
+    line = [l for l in p.stdout.splitlines() if l.startswith("SUMMARY ")]
+    assert p.returncode == 0 and line, (p.stdout[-3000:], p.stderr[-2000:])
+    d = json.loads(line[0][8:])
+    assert not d["failures"] and d["counts"].get("ok", 0) >= 36, d["counts"]
