@@ -30,7 +30,7 @@ def sample(rng):
     family = rng.choice(["reg", "reg", "generic", "tile", "tile", "wave", "shared_dense", "shared_tile", "sparse_lambda"])
     kw = dict(domain=domain, seed=int(rng.integers(0, 1 << 20)), gamma=float(rng.choice([0.0, 0.9, 0.9, 0.99, 1.0])),
               max_episode_steps=int(rng.choice([0, 1, 25, 25, 200])), env_offset=int(rng.choice([0, 0, 64, 1000003])))
-    n = int(rng.choice([1, 3, 63, 64, 65, 130, 257]))
+    n = int(rng.choice([1, 3, 63, 64, 65, 130, 257, 257, 1000, 2049]))
     method, mkw = "train", {}
     if family in ("reg", "shared_dense"):
         kw.update(basis=ra.FOURIER, order=int(rng.integers(1, 6)) if domain == 0 else 1)
@@ -126,13 +126,22 @@ def run_case(rng, idx):
         try:
             (run.reset_wave if method == "train_wave" else run.reset)()
             c.reset()
+            stat_bad = None
             for k in calls:
-                if k:
-                    getattr(run, method)(k, **mkw)
-                c.train(k, want_stats=bool(rng.integers(0, 2)))
+                ost = getattr(run, method)(k, **mkw) if k else None
+                dst = c.train(k, want_stats=bool(rng.integers(0, 2)))
+                # the call's statistics: counters exact, the f64 sums of fp32 terms to their summation order
+                if ost and dst and stat_bad is None:
+                    for key in ("env_steps", "episodes", "episodes_truncated", "sum_episode_steps"):
+                        if int(ost[key]) != int(dst[key]):
+                            stat_bad = f"stats.{key}: device {dst[key]} oracle {ost[key]}"
+                    for key in ("sum_abs_td_error", "sum_reward"):
+                        a_, b_ = float(dst[key]), float(ost[key])
+                        if np.isfinite(a_) and np.isfinite(b_) and abs(a_ - b_) > 2e-4 * (1 + abs(b_)):
+                            stat_bad = stat_bad or f"stats.{key}: device {a_} oracle {b_}"
         except ValueError as e:                                   # the oracle has no loop for it
             return "no_oracle", tag + f"  NO ORACLE LOOP: {str(e)[:80]}", dev
-        bad = []
+        bad = [stat_bad] if stat_bad else []
         if not np.array_equal(c.states.T, run.state, equal_nan=True):
             bad.append("states")
         if not np.array_equal(c.actions, run.action):
