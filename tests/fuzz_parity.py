@@ -204,6 +204,14 @@ def run_case(rng, idx):
             if not np.array_equal(n_d, n_o):
                 bad.append(f"rollout_greedy ({int((n_d != n_o).sum())} of {n} learners)")
             extra += " +rollout"
+            # ... and under any of the four policies (lib.rs:448-479 takes any closure), twice: the second call draws from the next stream
+            pol = int(rng.integers(0, 4))
+            for call in range(2):
+                rd = c.rollout_policy(pol, lim, epsilon=0.25, tau=0.7)
+                n_o, _, a_o = run.rollout_policy(pol, lim, epsilon=0.25, tau=0.7, call=call)
+                if not (np.array_equal(rd["n_states"], n_o) and np.array_equal(rd["actions"], a_o)):
+                    bad.append(f"rollout_policy {pol} call {call} ({int((rd['n_states'] != n_o).sum())} of {n} learners)")
+                    break
         # ---- set_weights / get_weights: every layout (rows of learners, tile tables, the wave family's lane order, bf16 storage) gives back what went in
         if not bad and rng.random() < 0.3:
             i = int(rng.integers(0, 1 if shared else n))
