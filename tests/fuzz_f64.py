@@ -80,6 +80,8 @@ def run_case(rng, idx):
     rec = {"family": family, "algo": fp.NAMES[dev["algo"]], "bf16": dev.get("weight_dtype", 0) == ra.W_BF16, "td": td_rel, "w": dw / max(1.0, wmax),
            "w_rel_maxw": dw / max(wmax, 1e-30), "q": q_rel, "wmax": wmax, "config": dev}
     b = BOUNDS_BF16 if rec["bf16"] else BOUNDS
+    if dev["algo"] == ra.TD_LAMBDA:      # steps by the TD error itself (no learning rate): every rounding is amplified by ~|phi|^2 per step even while
+        b = {k: 5 * v for k, v in b.items()}      # the run stays bounded -- 4.3e-4 in Q seen in 9 000 cases
     over = [k for k in ("td", "w", "q") if rec[k] > b[k]]
     status = "over" if over else "ok"
     # A DISCRETE decision inside handle that a rounding tipped -- GreedyGQ's argmax of Q(s',.) (greedy_gq.rs:98), Q(lambda)'s "was the action greedy"
