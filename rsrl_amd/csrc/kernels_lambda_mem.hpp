@@ -29,14 +29,33 @@ __device__ __forceinline__ float lambda_handle_mem(const Common& c, const Lambda
     float e;
     const float delta = td_error<A>(alg, c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
     const float scale = lp.alpha * delta;
-    for (int f = 0; f < g.F; ++f) {
-        const float ph = M::phi_at(g, fs, f);
+    // the sweep, EIGHT features at a time: every load of the group is issued before the first store (W and Z are distinct allocations, which the
+    // compiler cannot know: written one entry at a time each iteration waits out a full memory round trip -- 622 -> 557 us per batch-step at 16 384 CartPole
+    // learners of order 3: the three Q evaluations with their per-feature index arithmetic are the rest; a generic fallback, not a tuned kernel.
+    // The values and their order per entry are the same)
+    float* __restrict__ const Wp = c.W;
+    float* __restrict__ const Zp = lp.Z;
+    constexpr int G = 8;
+    for (int f0 = 0; f0 < g.F; f0 += G) {
+        float zv[G][A], wv[G][A], ph[G];
 #pragma unroll
-        for (int b = 0; b < A; ++b) {
-            const int64_t j = M::widx(c, i, g, b, f);
-            const float zz = trace_merge(lp.trace, rate_eff, lp.Z[j], (a == b) ? ph : 0.0f);
-            c.W[j] = fmaf(scale, zz, c.W[j]);
-            lp.Z[j] = term ? 0.0f : zz;
+        for (int u = 0; u < G; ++u) {
+            const int f = f0 + u < g.F ? f0 + u : g.F - 1;          // (the tail repeats the last feature's loads; nothing of it is stored)
+            ph[u] = M::phi_at(g, fs, f);
+#pragma unroll
+            for (int b = 0; b < A; ++b) { const int64_t j = M::widx(c, i, g, b, f); zv[u][b] = Zp[j]; wv[u][b] = Wp[j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            if (f0 + u < g.F) {
+#pragma unroll
+                for (int b = 0; b < A; ++b) {
+                    const int64_t j = M::widx(c, i, g, b, f0 + u);
+                    const float zz = trace_merge(lp.trace, rate_eff, zv[u][b], (a == b) ? ph[u] : 0.0f);
+                    Wp[j] = fmaf(scale, zz, wv[u][b]);
+                    Zp[j] = term ? 0.0f : zz;
+                }
+            }
         }
     }
     return delta;
