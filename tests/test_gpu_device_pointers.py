@@ -1,0 +1,88 @@
+"""Array arguments may be HOST or DEVICE pointers (include/rsrl_hip.h, conventions): device pointers are used in place and the call is asynchronous on the
+ctx's stream.  Every entry point that takes arrays, with torch device tensors, against the same call with host arrays on a twin ctx -- bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "reg": dict(domain=0, order=5, algo=0, policy=1, epsilon=0.2, gamma=0.9, lr=0.001, n_envs=96, seed=3, max_episode_steps=60),
+    "tile_shared": dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=1, policy=1, epsilon=0.1, gamma=0.99, lr=0.1 / 8 / 96, weight_mode=1, n_envs=96, seed=3,
+                        max_episode_steps=60),
+    "wave_bf16": dict(domain=2, order=7, algo=2, policy=2, tau=1.0, gamma=0.99, lr=2.5e-4, alpha=1.0, weight_dtype=1, n_envs=8, seed=3, max_episode_steps=60),
+    "generic_tdl": dict(domain=1, order=2, algo=8, policy=3, gamma=0.9, lam=0.5, trace=1, n_envs=96, seed=3, max_episode_steps=60),
+    "lambda_tile": dict(domain=0, basis=1, n_tilings=4, tiles_per_dim=8, algo=3, policy=1, epsilon=0.2, gamma=0.99, alpha=0.02, lam=0.8, n_envs=16, seed=3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_pointer_arguments_equal_host_arguments(name):
+    import torch
+    import rsrl_amd as ra
+    kw = CASES[name]
+    dev = torch.device("cuda:0")
+    with ra.Context(**kw) as h, ra.Context(**kw) as d:
+        L = d._L
+        N, D, A, F, O = d.N, d.D, d.A, d.F, d.n_out
+        ptr = lambda t: C.c_void_p(t.data_ptr())       # noqa: E731
+        ok = lambda rc: ra._abi.check(rc)               # noqa: E731
+        for c in (h, d):
+            c.reset()
+            c.train(25, want_stats=False)
+        # get_states / get_actions / episode steps into device memory
+        ds = torch.empty((D, N), dtype=torch.float32, device=dev); da = torch.empty(N, dtype=torch.int32, device=dev)
+        de = torch.empty(N, dtype=torch.int32, device=dev)
+        ok(L.rsrl_hip_get_states(d._h, ptr(ds))); ok(L.rsrl_hip_get_actions(d._h, ptr(da))); ok(L.rsrl_hip_get_episode_steps(d._h, ptr(de)))
+        d.sync()
+        assert np.array_equal(ds.cpu().numpy(), h.states) and np.array_equal(da.cpu().numpy(), h.actions)
+        assert np.array_equal(de.cpu().numpy().view(np.uint32), h.episode_steps)
+        # q_evaluate / policy_mode on device states, device outputs
+        dq = torch.empty((O, N), dtype=torch.float32, device=dev)
+        ok(L.rsrl_hip_q_evaluate(d._h, ptr(ds), N, ptr(dq)))
+        d.sync()
+        assert np.array_equal(dq.cpu().numpy(), h.q_evaluate(h.states), equal_nan=True)
+        if kw["algo"] not in (7, 8):
+            dm = torch.empty(N, dtype=torch.int32, device=dev)
+            ok(L.rsrl_hip_policy_mode(d._h, ptr(ds), N, ptr(dm)))
+            d.sync()
+            assert np.array_equal(dm.cpu().numpy(), h.policy_mode(h.states))
+        # domain_step with device outputs, then handle with device inputs (sparse / shared-trace agents aside, every agent has a handle)
+        frm_h, nxt_h, rew_h, term_h = h.domain_step(h.actions)
+        dfrm = torch.empty((D, N), dtype=torch.float32, device=dev); dnxt = torch.empty_like(dfrm)
+        drew = torch.empty(N, dtype=torch.float32, device=dev); dterm = torch.empty(N, dtype=torch.uint8, device=dev)
+        ok(L.rsrl_hip_domain_step(d._h, ptr(da), ptr(dfrm), ptr(dnxt), ptr(drew), ptr(dterm)))
+        d.sync()
+        assert np.array_equal(dnxt.cpu().numpy(), nxt_h) and np.array_equal(drew.cpu().numpy(), rew_h) and np.array_equal(dterm.cpu().numpy(), term_h)
+        td_h = h.handle(frm_h, h.actions, rew_h, nxt_h, term_h)
+        dtd = torch.empty(N, dtype=torch.float32, device=dev)
+        ok(L.rsrl_hip_handle(d._h, ptr(dfrm), ptr(da), ptr(drew), ptr(dnxt), ptr(dterm), N, ptr(dtd)))
+        d.sync()
+        assert np.array_equal(dtd.cpu().numpy(), td_h, equal_nan=True)
+        # get_weights / set_weights through device memory: learner 0 (or the shared approximator)
+        dw = torch.empty((F, O), dtype=torch.float32, device=dev)
+        ok(L.rsrl_hip_get_weights(d._h, 0, ptr(dw)))
+        d.sync()
+        assert np.array_equal(dw.cpu().numpy(), h.get_weights(0))
+        w2 = (dw * 0.5).contiguous()
+        ok(L.rsrl_hip_set_weights(d._h, 0, ptr(w2)))
+        h.set_weights(w2.cpu().numpy(), 0)
+        assert np.array_equal(d.get_weights(0), h.get_weights(0))
+        # set_states / set_actions from device memory: out-of-range values are CLAMPED (a host array would be refused)
+        bad_s = ds.clone(); bad_s[0, 0] = float("inf"); bad_a = da.clone(); bad_a[0] = 77
+        ok(L.rsrl_hip_set_states(d._h, ptr(bad_s))); ok(L.rsrl_hip_set_actions(d._h, ptr(bad_a)))
+        d.sync()
+        assert np.isfinite(d.states).all() and 0 <= d.actions[0] < A
+        ok(L.rsrl_hip_set_states(d._h, ptr(dnxt))); ok(L.rsrl_hip_set_actions(d._h, ptr(da)))
+        h.states, h.actions = nxt_h, h.actions
+        for c in (h, d):
+            c.train(20, want_stats=False)
+        assert np.array_equal(d.states, h.states) and np.array_equal(d.get_weights(0), h.get_weights(0), equal_nan=True)
+        # greedy rollout with device outputs
+        if kw["algo"] not in (7, 8):
+            dn = torch.empty(N, dtype=torch.int32, device=dev); dt = torch.empty(N, dtype=torch.float32, device=dev)
+            ok(L.rsrl_hip_rollout_greedy(d._h, 40, ptr(dn), ptr(dt)))
+            d.sync()
+            n_h, t_h = h.rollout_greedy(40)
+            assert np.array_equal(dn.cpu().numpy().view(np.uint32), n_h) and np.array_equal(dt.cpu().numpy(), t_h)
