@@ -111,6 +111,12 @@ def run_case(rng, idx):
     family, dev, okw, method, mkw = sample(rng)
     n = dev["n_envs"]
     total = int(rng.choice([40, 90, 150])) if family != "wave" else int(rng.choice([8, 20, 60]))
+    if os.environ.get("FUZZ_LONG"):      # long horizons: across the default fuse depth (4 096), many graph replays, thousands of episodes
+        total *= 10 if family == "wave" else 60
+        if n > 130 and family not in ("shared_dense", "shared_tile"):
+            n = dev["n_envs"] = 130
+        elif n > 600:
+            n = dev["n_envs"] = 600
     cuts = sorted(set(int(x) for x in rng.integers(1, total, size=int(rng.integers(0, 3)))))
     calls = [b - a for a, b in zip([0] + cuts, cuts + [total])]
     if rng.random() < 0.1:
