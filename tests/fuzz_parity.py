@@ -47,7 +47,7 @@ def sample(rng):
     step = float(rng.choice([0.02, 0.2])) / feats                 # lr |phi|^2 well below 1
     # ---- the agent
     if family == "shared_dense" or family == "shared_tile":
-        algo = int(rng.choice(ONE_STEP[:3]))
+        algo = int(rng.choice(ONE_STEP))
     elif family == "sparse_lambda":
         algo = int(rng.choice(LAMBDA))
     else:
