@@ -212,3 +212,13 @@ def test_asm_filter_fails_closed_on_an_unknown_compiler(monkeypatch):
 # wait states removed per translation unit in the shipped build (rsrl_amd/lib/librsrl_hip.nop_filter.json, written by _build); re-validate on the GPU
 # (tests -m gpu, scripts/ab_bits.py) before changing these
 EXPECTED_NOP_COUNTS = {"rsrl_hip.hip": 950, "train_reg_d0a.hip": 528, "train_reg_d0b.hip": 315, "train_reg_d1.hip": 20, "train_reg_d2.hip": 21}
+
+
+def test_campaign_scripts_compile():
+    # tests/fuzz_*.py run on the GPU box only; here: they parse
+    import glob
+    import py_compile
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_*.py")))
+    assert len(files) >= 4
+    for f in files:
+        py_compile.compile(f, doraise=True)
