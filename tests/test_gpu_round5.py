@@ -126,3 +126,48 @@ def test_exact_resume_needs_the_episode_counters_and_the_carried_q(tmp_path):
         assert t.q_carry is None and t.episode_steps.shape == (8,)
         with pytest.raises(ra.RsrlHipError):
             t.q_carry = np.zeros((2, 8), np.float32)
+
+
+def test_distinct_ctxs_from_distinct_threads():
+    # "a ctx is NOT thread-safe; distinct ctxs may be used from distinct threads" (include/rsrl_hip.h): eight threads, each creating, training,
+    # querying and destroying its own ctxs of different kernel families at the same time -- every result equal to the same work done alone, and
+    # every thread sees its OWN last error
+    import threading
+    import rsrl_amd as ra
+    jobs = [
+        dict(domain=0, order=5, algo=0, policy=1, n_envs=256, seed=1, max_episode_steps=50),
+        dict(domain=1, basis=ra.TILE_CODING, algo=1, policy=1, n_envs=128, seed=2, max_episode_steps=50),
+        dict(domain=2, order=7, algo=2, policy=2, n_envs=4, seed=3, weight_dtype=ra.W_BF16, lr=2.5e-4),
+        dict(domain=1, order=1, algo=3, policy=1, n_envs=64, seed=4, lam=0.8, alpha=0.01),
+        dict(domain=0, order=3, algo=0, policy=1, n_envs=1024, seed=5, weight_mode=ra.W_SHARED, lr=1e-6),
+        dict(domain=1, order=2, algo=8, policy=3, n_envs=64, seed=6, lam=0.3),
+        dict(domain=0, basis=ra.TILE_CODING, algo=3, policy=1, n_envs=64, seed=7, weight_mode=ra.W_SHARED, alpha=1e-4, lam=0.9),
+        dict(domain=2, order=1, algo=9, policy=1, n_envs=64, seed=8, sigma=0.5, n_steps=3, alpha=0.1),
+    ]
+
+    def work(kw):
+        out = []
+        for _ in range(3):
+            with ra.Context(**kw) as c:
+                c.reset()
+                c.train(60, want_stats=False)
+                out.append(c.checksum())
+            try:
+                ra.Context(**dict(kw, order=99, basis=0))
+            except ra.RsrlHipError as e:
+                assert "order" in str(e).lower(), str(e)                  # this thread's own message, not a neighbour's
+        assert out[0] == out[1] == out[2]
+        return out[0]
+    alone = [work(kw) for kw in jobs]
+    got, errs = [None] * len(jobs), []
+
+    def run(k):
+        try:
+            got[k] = work(jobs[k])
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=run, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert not errs, errs
+    assert got == alone
