@@ -306,7 +306,53 @@ def run_case(rng, idx):
     return "ok", tag + f"  ok{extra}{'' if finite else ' (non-finite, NaN for NaN)'}{'' if moved else ' (weights did not move)'}", dev
 
 
+def run_big(rng, idx):
+    """The kernels only large learner counts select (four lanes per learner from 131 072 learners, 128-byte line stores beyond the Infinity Cache, two
+    waves per SIMD in the fused loop): per-learner weights make every learner independent and the draws are keyed by the GLOBAL env id, so the oracle
+    replays SLICES of the batch (env_offset) and each must match the full-size device run bit for bit."""
+    domain = int(rng.integers(0, 3))
+    kw = dict(domain=domain, order=int(rng.integers(1, 6)) if domain == 0 else 1, algo=int(rng.choice(ONE_STEP)), policy=int(rng.choice([0, 1, 1, 2])),
+              epsilon=0.2, tau=1.0, gamma=float(rng.choice([0.9, 0.99])), alpha=float(rng.choice([0.5, 1.0])), seed=int(rng.integers(0, 1 << 20)),
+              max_episode_steps=int(rng.choice([0, 7, 200])))
+    feats = (kw["order"] + 1) ** N_DIM[domain]
+    kw["lr"] = 0.1 / feats
+    n = int(rng.choice([131072, 131072 + 77, 200003, 262144, 700003]))
+    spl = int(rng.choice([1, 1, 0, 5]))
+    K = int(rng.choice([5, 12]))
+    tag = f"{idx:4d} big           {NAMES[kw['algo']]:13s} dom {domain} N {n:6d} K {K:3d} spl {spl}"
+    with ra.Context(n_envs=n, steps_per_launch=spl, **kw) as c:
+        c.reset()
+        c.train(K // 2, want_stats=False)
+        c.train(K - K // 2, want_stats=False)
+        S, Aact = c.states, c.actions
+        bad = []
+        for off in sorted(set([0, int(rng.integers(0, n - 70)), n - 64])):
+            ag = orc.make_agent(env_offset=off, **kw)
+            run = orc.Run(ag, 64, "f32d")
+            run.reset()
+            run.train_dev(K // 2)
+            run.train_dev(K - K // 2)
+            if not (np.array_equal(S[:, off:off + 64].T, run.state) and np.array_equal(Aact[off:off + 64], run.action)):
+                bad.append(f"states / actions of learners {off}..")
+            for j in (0, 63):
+                if not np.array_equal(c.get_weights(off + j), run.weights[j]):
+                    bad.append(f"weights[{off + j}]")
+    return ("MISMATCH" if bad else "ok"), tag + (f"  MISMATCH {bad}" if bad else "  ok"), dict(kw, n_envs=n, steps_per_launch=spl)
+
+
 def main():
+    if os.environ.get("FUZZ_BIG"):
+        n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+        rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+        counts, failures = {}, []
+        for idx in range(n_cases):
+            status, line, dev = run_big(rng, idx)
+            counts[status] = counts.get(status, 0) + 1
+            print(line, flush=True)
+            if status != "ok":
+                failures.append({"case": idx, "line": line, "config": dev})
+        print("SUMMARY " + json.dumps({"cases": n_cases, "counts": counts, "failures": failures}, default=str), flush=True)
+        sys.exit(1 if failures else 0)
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(seed)
