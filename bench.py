@@ -181,25 +181,41 @@ def cpu_baseline(seconds=9.0, seconds_optimised=5.0):
                       f"{dt_o:.1f} s (optimised), oracle/rsrl_oracle.c, gcc -O2"}
 
 
-def greedy_rollout_check(ctx, sample=256, limit=500):
-    """north_star: "the 1-GPU greedy rollout length matching the CPU reference".  The device's greedy rollout
-    (Domain::rollout with policy.mode, lib.rs:448-479) over ALL learners, and -- for the first `sample` learners -- the f64
-    CPU oracle's rollout from the very same weights, side by side."""
+def greedy_rollout_check(ctx, sample=256, limit=1000):
+    """north_star: "the 1-GPU greedy rollout length matching the CPU reference".  The device's greedy rollout (Domain::rollout with
+    policy.mode, lib.rs:448-479) over ALL learners; then the f64 CPU oracle's rollout from the very same weights for `sample` learners
+    whose device rollout ENDED before the limit (a rollout that runs into the limit on both sides says nothing) -- fewer than `sample`
+    terminated: the rest of the sample are the first learners that did not.  min_argmax_margin: the smallest gap between the best and
+    the second best action value over every action selection of the compared f64 rollouts (the comparison is meaningful
+    where it is above fp32 resolution, ~1e-7 of |Q|)."""
     import numpy as np
     from oracle import oracle as orc
     n_dev, _ = ctx.rollout_greedy(limit)
     m = min(sample, ctx.N)
+    ended = np.flatnonzero(n_dev < limit)
+    pick = ended[:m]
+    if len(pick) < m:
+        pick = np.concatenate([pick, np.flatnonzero(n_dev >= limit)[:m - len(pick)]])
     ag = orc.make_agent(policy=orc.EGREEDY, epsilon=0.1, seed=0, gamma=0.9, lr=0.001, max_episode_steps=1000)
-    run = orc.Run(ag, m, "f64")
-    for i in range(m):
-        run.weights[i] = ctx.get_weights(i).astype(np.float64)
-    n_cpu, _ = run.rollout_greedy(limit)
+    run = orc.Run(ag, len(pick), "f64")
+    for j, i in enumerate(pick):
+        run.weights[j] = ctx.get_weights(int(i)).astype(np.float64)
+    n_cpu, _, margin = run.rollout_greedy_margin(limit)
     run.close()
-    return {"limit": limit, "device_mean_n_states_all_learners": float(n_dev.mean()), "sample_learners": m,
-            "device_mean_n_states": float(n_dev[:m].mean()), "cpu_reference_mean_n_states": float(n_cpu.mean()),
-            "identical_n_states_frac": float((n_dev[:m] == n_cpu).mean()),
-            "note": "CPU = f64 oracle (oracle/rsrl_oracle.c orc_run_rollout_greedy) from the same weights; a learner can "
-                    "differ only where an argmax margin is below fp32 resolution"}
+    same = n_dev[pick] == n_cpu
+    term = n_dev[pick] < limit
+    return {"limit": limit, "all_learners": int(ctx.N), "terminated_frac_all_learners": float((n_dev < limit).mean()),
+            "device_mean_n_states_all_learners": float(n_dev.mean()),
+            "compared": int(len(pick)), "terminated_frac": float(term.mean()),
+            "device_mean_n_states": float(n_dev[pick].mean()), "cpu_reference_mean_n_states": float(n_cpu.mean()),
+            "identical_n_states_frac": float(same.mean()),
+            "identical_n_states_frac_of_terminated": float(same[term].mean()) if term.any() else None,
+            "min_argmax_margin": float(margin.min()), "median_min_argmax_margin": float(np.median(margin)),
+            "min_argmax_margin_of_identical": float(margin[same].min()) if same.any() else None,
+            "max_min_margin_of_differing": float(margin[~same].max()) if (~same).any() else None,
+            "note": "CPU = f64 oracle (oracle/rsrl_oracle.c orc_run_rollout_greedy_margin) from the same weights; a learner can differ only "
+                    "where an argmax margin is below fp32 resolution (max_min_margin_of_differing says how small the margin of the "
+                    "differing learners was)"}
 
 
 def parity_sample(m=2048):

@@ -170,6 +170,8 @@ def _declare(L):
         g("orc_run_train_hook").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats), C.c_void_p, C.c_void_p]
         g("orc_run_rollout_greedy").restype = C.c_int
         g("orc_run_rollout_greedy").argtypes = [C.c_void_p, C.c_int64, u32p, Rp]
+        g("orc_run_rollout_greedy_margin").restype = C.c_int
+        g("orc_run_rollout_greedy_margin").argtypes = [C.c_void_p, C.c_int64, u32p, Rp, Rp]
         g("orc_run_rollout_policy").restype = C.c_int
         g("orc_run_rollout_policy").argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int64, u32p, Rp, C.POINTER(C.c_int32)]
 
@@ -571,3 +573,14 @@ class Run:
         if rc != 0:
             raise ValueError("rollout_greedy: invalid step_limit or policy has no mode")
         return n_states, tot
+
+    def rollout_greedy_margin(self, step_limit):
+        """rollout_greedy + every learner's smallest argmax margin (largest minus second largest action value) over its action selections"""
+        n_states = np.zeros(self.n, dtype=np.uint32)
+        tot = np.zeros(self.n, dtype=self._dt)
+        mm = np.zeros(self.n, dtype=self._dt)
+        rc = self._f("orc_run_rollout_greedy_margin")(self._h, int(step_limit), n_states.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      _ptr(tot, self._ct), _ptr(mm, self._ct))
+        if rc != 0:
+            raise ValueError("rollout_greedy_margin: invalid step_limit or policy has no mode")
+        return n_states, tot, mm

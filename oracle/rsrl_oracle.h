@@ -141,6 +141,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
                                  void (*dw_hook)(R* dW, int n, void* user), void* user);                \
     int   orc_run_rollout_greedy_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward); \
+    int   orc_run_rollout_greedy_margin_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward, R* min_margin); \
     int   orc_run_rollout_policy_##S(void* h, int policy, double eps, double tau, uint64_t call, int64_t step_limit, uint32_t* n_states, R* total_reward, int32_t* actions);
 
 ORC_DECLARE(double, f64)

@@ -1627,16 +1627,28 @@ int FN(orc_run_train_shared_dev)(void* h, int64_t n_steps, orc_stats* st) {
 
 /* Domain::rollout with pi = policy.mode, Some(limit)   rsrl_domains/src/lib.rs:448-479; n_states lib.rs:340
  * One fresh default env per learner i, evaluated with learner i's weights. */
-int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward) {
+/* the gap between the largest and the second largest action value: how far this action selection is from flipping under a rounding */
+static R FN(argmax_margin)(const R* q, int A) {
+    R best = q[0], second = (R)0.0; int a, have = 0;
+    for (a = 1; a < A; a++) {
+        if (q[a] > best) { second = best; best = q[a]; have = 1; }
+        else if (!have || q[a] > second) { second = q[a]; have = 1; }
+    }
+    return have ? best - second : (R)0.0;
+}
+/* min_margin (optional, [N]): the smallest argmax margin over the learner's action selections (the greedy-rollout comparison
+ * is meaningful where it is above fp32 resolution) */
+int FN(orc_run_rollout_greedy_margin)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward, R* min_margin) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag;
     int A = ag->n_actions; int64_t i;
     if (step_limit < 1 || ag->policy == ORC_RANDOM || ORC_IS_PRED(ag->algo)) return -1;
     for (i = 0; i < run->n_envs; i++) {
-        R s[8], q[ORC_MAX_ACTIONS], r, tot = 0; int a, term; int64_t steps = 0;
+        R s[8], q[ORC_MAX_ACTIONS], r, tot = 0, mm, m; int a, term; int64_t steps = 0;
         const R* W = FN(run_W)(run, i);
         FN(orc_domain_reset)(ag->domain, s);
         /* first step happens eagerly, before take(limit-1)  (lib.rs:457-459) */
         FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+        mm = FN(argmax_margin)(q, A);
         a = FN(orc_policy_mode)(ag->policy, q, A, (R)ag->tau);
         term = FN(orc_domain_step)(ag->domain, s, a, &r);
         while (steps < step_limit - 1) {
@@ -1644,13 +1656,18 @@ int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, 
             if (term) break;                                            /* successors stops after Terminal */
             if (steps >= step_limit - 1) break;
             FN(orc_q_evaluate)(&ag->basis, W, A, s, q);
+            m = FN(argmax_margin)(q, A); if (m < mm) mm = m;
             a = FN(orc_policy_mode)(ag->policy, q, A, (R)ag->tau);
             term = FN(orc_domain_step)(ag->domain, s, a, &r);
         }
         n_states[i] = (uint32_t)(steps + 1);
         if (total_reward) total_reward[i] = tot;
+        if (min_margin) min_margin[i] = mm;
     }
     return 0;
+}
+int FN(orc_run_rollout_greedy)(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward) {
+    return FN(orc_run_rollout_greedy_margin)(h, step_limit, n_states, total_reward, (R*)0);
 }
 
 /* Domain::rollout with ANY policy as the closure: pi = |s| policy.sample(rng, s)     rsrl_domains/src/lib.rs:448-479 takes any FnMut(&S) -> A

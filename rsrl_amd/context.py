@@ -255,7 +255,13 @@ class Context:
                                            _p(_in(terminal, np.uint8, (M,))), M, _p(td)))
         return td
 
-    def policy_sample(self, states):
+    def policy_sample(self, states=None):
+        """Policy::sample.  states = None: the ctx's OWN envs (env.emit().state()) -- the driver loop's behaviour sample of the current batch-step
+        (what rsrl_hip_train draws); the actions also become the ctx's pending ones"""
+        if states is None:
+            out = np.empty(self.N, dtype=np.int32)
+            _abi.check(self._L.rsrl_hip_policy_sample(self._h, None, self.N, _p(out)))
+            return out
         states, M = self._batch(states)
         out = np.empty(M, dtype=np.int32)
         _abi.check(self._L.rsrl_hip_policy_sample(self._h, _p(states), M, _p(out)))

@@ -681,9 +681,10 @@ __global__ __launch_bounds__(kBlock) void k_wave_qop(Common c, const WT* __restr
     }
     float q[A];
     WF::template q_from_mem<WT>(Wbase + i * (int64_t)(A * F), lane, phi, q);
-    if (lane != 0 && op != QOP_SAMPLE) return;
-    if (op == QOP_SAMPLE) {                 // (the softmax path may spread its exponentials over lanes: every lane evaluates)
-        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+    const bool is_sample = op == QOP_SAMPLE || op == QOP_SAMPLE_STEP || op == QOP_SAMPLE_INIT;
+    if (lane != 0 && !is_sample) return;
+    if (is_sample) {                        // (the softmax path may spread its exponentials over lanes: every lane evaluates)
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, op == QOP_SAMPLE ? BLK_API : (op == QOP_SAMPLE_STEP ? BLK_STEP : BLK_INIT));
         const int a = policy_sample<A>(c.pol, q, x);
         if (lane == 0) iout[i] = a;
         return;

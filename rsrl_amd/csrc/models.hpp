@@ -420,7 +420,9 @@ __global__ __launch_bounds__(kBlock) void k_reset(Common c, BasisGeom g, uint64_
 enum : int { QOP_EVALUATE = 0, QOP_FIND_MAX = 1, QOP_SAMPLE = 2, QOP_MODE = 3, QOP_PROBS = 4, QOP_FEATURES = 5,
               QOP_FIND_MIN = 6,      // Enumerable::find_min                                   core.rs:86-94
               QOP_EXPECTED = 7,      // Enumerable::expected_value(ps), ps = fin f32[A][M]     core.rs:107-116
-              QOP_PROB_SA = 8 };     // Function<(S, A)> of the policy, a = iin i32[M]         greedy.rs:46-60, epsilon_greedy.rs:49-63,
+              QOP_PROB_SA = 8,
+              QOP_SAMPLE_STEP = 9,   // Policy::sample as the DRIVER LOOP draws it: `call` = the batch-step, stream BLK_STEP (rsrl_hip_policy_sample with
+              QOP_SAMPLE_INIT = 10 };  // states = NULL: the ctx's own envs) -- before the first handle: the initial sample's stream BLK_INIT     // Function<(S, A)> of the policy, a = iin i32[M]         greedy.rs:46-60, epsilon_greedy.rs:49-63,
                                      //                                                        softmax.rs:84-92 (the raw action value), random.rs:28-32
 // the tail every family's qop kernel shares: q -> the requested output of learner i
 template <int A>
@@ -436,8 +438,8 @@ __device__ __forceinline__ void qop_finish(const Common& c, int op, const float 
         float v; const int bi = op == QOP_FIND_MAX ? find_max<A>(q, v) : find_min<A>(q, v);
         if (iout) iout[i] = bi;
         if (fout) fout[i] = v;
-    } else if (op == QOP_SAMPLE) {
-        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, BLK_API);
+    } else if (op == QOP_SAMPLE || op == QOP_SAMPLE_STEP || op == QOP_SAMPLE_INIT) {
+        const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, op == QOP_SAMPLE ? BLK_API : (op == QOP_SAMPLE_STEP ? BLK_STEP : BLK_INIT));
         iout[i] = policy_sample<A>(pol, q, x);
     } else if (op == QOP_MODE) {
         iout[i] = policy_mode<A>(pol, q);

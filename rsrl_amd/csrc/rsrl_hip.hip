@@ -29,6 +29,7 @@
 #include "kernels_wave_lambda.hpp"
 #include "kernels_wave_aux.hpp"
 #include "kernels_sparse_lambda.hpp"
+#include "kernels_trait.hpp"
 
 using namespace rsrl;
 
@@ -354,6 +355,14 @@ struct rsrl_hip_ctx {
     uint32_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr; float* sp_ns = nullptr;
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
+    // ---- the trait-granular fast path (kernels_trait.hpp): register-family Fourier basis, per-learner f32 weights, learner-major layout
+    float* tq_key = nullptr;         // [D][N]: the state each learner's qcache entry belongs to (allocated iff the ctx takes the fast path)
+    bool tq_valid = false;           // qcache / tq_key hold the hand-over of rsrl_hip_handle (false: the keys are emptied before the next trait kernel)
+    // calls of the trait-granular loop accepted but not launched yet (ctx-owned stream, device pointers, the loop's own order):
+    //   stage 1 = domain_step, 2 = + handle on exactly that transition, 3 = + domain_reset with the terminal flags as its mask;
+    //   policy_sample(NULL) then launches the whole batch-step as ONE kernel; anything else launches the accepted calls one by one first
+    struct TraitPend { int stage = 0; const int32_t* act = nullptr; float* from = nullptr; float* to = nullptr; float* rew = nullptr;
+                       uint8_t* term = nullptr; float* td = nullptr; uint64_t t_handle = 0; } tp;
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
     size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
     int64_t w_stride = 0;            // stride between (action, feature) rows of W
@@ -668,7 +677,16 @@ static int peer_check(rsrl_hip_ctx* c) {
     return RSRL_HIP_OK;
 }
 
-static int flush_pending(rsrl_hip_ctx* c);      // launch the batch-steps rsrl_hip_train has accepted but not launched yet
+static int flush_pending(rsrl_hip_ctx* c);      // launch what the ctx has accepted but not launched yet (train's coalesced batch-steps, deferred trait calls)
+static int trait_flush(rsrl_hip_ctx* c);        // ... the deferred trait calls alone, one kernel per call
+static int timing_begin(rsrl_hip_ctx* c);
+static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1);
+static int trait_cache_ready(rsrl_hip_ctx* c);
+static inline bool trait_fast(const rsrl_hip_ctx* c);
+static int launch_trait_handle(rsrl_hip_ctx* c, const Common& k, const float* from, const int32_t* act, const float* rew, const float* to,
+                               const uint8_t* term, int64_t M, uint64_t t, float* td);
+static int launch_domain_step(rsrl_hip_ctx* c, const Common& k, const int32_t* d_act, float* from, float* next, float* rew, uint8_t* term);
+static int launch_domain_reset(rsrl_hip_ctx* c, const Common& k, const uint8_t* d_mask);
 #define FLUSH(c) TRY(flush_pending(c))
 
 // ------------------------------------------------------------------------------- API
@@ -705,6 +723,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     // (a ctx whose creation failed on its device ordinal is torn down through here too: the failure of this call must not stay behind as the thread's
     //  last HIP error -- tests/fuzz_abi.py found it reported by the next ctx's first launch check)
     if (hipSetDevice(c->cfg.device) != hipSuccess) (void)hipGetLastError();
+    if (c->tp.stage) (void)trait_flush(c);       // trait calls accepted but not launched: the caller's arrays are still written
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& s : c->scratch) if (s.p) (void)hipFree(s.p);
@@ -731,6 +750,7 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->d_t) (void)hipFree(c->d_t);
     if (c->d_dyn) (void)hipFree(c->d_dyn);
     if (c->qcache) (void)hipFree(c->qcache);
+    if (c->tq_key) (void)hipFree(c->tq_key);
     if (c->Z) (void)hipFree(c->Z);
     if (c->eps) (void)hipFree(c->eps);
     if (c->flags) (void)hipFree(c->flags);
@@ -883,6 +903,10 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     HIP_TRY(hipMalloc((void**)&c->W, c->w_bytes));
     HIP_TRY(hipMalloc((void**)&c->dW, sizeof(float) * c->dw_elems));
     HIP_TRY(hipMalloc((void**)&c->qcache, sizeof(float) * c->A * (size_t)N));
+    // the trait-granular fast path: learner-major per-learner f32 weights on a basis / agent kernels_trait.hpp is instantiated for, one epsilon for the ctx
+    if (c->w_ls != 1 && cfg->weight_dtype == RSRL_W_F32 && cfg->epsilon_decay == 1.0 && trait_lm_available(cfg->domain, cfg->order, cfg->algo) &&
+        !getenv("RSRL_NO_TRAIT_FAST"))
+        HIP_TRY(hipMalloc((void**)&c->tq_key, sizeof(float) * c->D * (size_t)N));
     if (cfg->algo == RSRL_Q_SIGMA) {
         const size_t nf = (size_t)(c->D + 5) * (size_t)cfg->n_steps * (size_t)N;
         HIP_TRY(hipMalloc((void**)&c->qs_buf, sizeof(float) * nf));
@@ -1159,6 +1183,15 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
     CHECK_CTX(c); FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    // the trait-granular loop on a ctx-owned stream: a transition handed over in device arrays is ACCEPTED here and launched with the calls that
+    // follow it (rsrl_hip_handle on exactly these arrays, rsrl_hip_domain_reset on the terminal flags, rsrl_hip_policy_sample of the ctx's envs) as
+    // one kernel -- or, by whatever other call comes next, as the kernel it would have been now.  Same results, same order (kernels_trait.hpp).
+    if (trait_fast(c) && c->own_stream && actions && from_states && next_states && rewards && terminal && is_device_ptr(actions) &&
+        is_device_ptr(from_states) && is_device_ptr(next_states) && is_device_ptr(rewards) && is_device_ptr(terminal) && !getenv("RSRL_NO_TRAIT_DEFER")) {
+        c->tp = rsrl_hip_ctx::TraitPend{};
+        c->tp.stage = 1; c->tp.act = actions; c->tp.from = from_states; c->tp.to = next_states; c->tp.rew = rewards; c->tp.term = terminal;
+        return RSRL_HIP_OK;
+    }
     const int64_t N = c->cfg.n_envs; const size_t DN = (size_t)c->D * N;
     const int32_t* d_act; OutBuf<float> ofrom, onext, orew; OutBuf<uint8_t> oterm;
     TRY(check_host_actions(actions, (size_t)N, c->A));
@@ -1168,13 +1201,7 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
     TRY(stage_out(c, 3, rewards, (size_t)N, &orew));
     TRY(stage_out(c, 4, terminal, (size_t)N, &oterm));
     const Common k = make_common(c);
-    const dim3 g(grid_for(N)), b(kBlock);
-    switch (c->cfg.domain) {
-    case 0: hipLaunchKernelGGL(k_domain_step<0>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
-    case 1: hipLaunchKernelGGL(k_domain_step<1>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
-    default: hipLaunchKernelGGL(k_domain_step<2>, g, b, 0, c->stream, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev); break;
-    }
-    KCHECK();
+    TRY(launch_domain_step(c, k, d_act, ofrom.dev, onext.dev, orew.dev, oterm.dev));
     bool sync = false;
     TRY(flush_out(c, &ofrom, &sync)); TRY(flush_out(c, &onext, &sync));
     TRY(flush_out(c, &orew, &sync)); TRY(flush_out(c, &oterm, &sync));
@@ -1183,26 +1210,22 @@ int rsrl_hip_domain_step(rsrl_hip_ctx* c, const int32_t* actions, float* from_st
 }
 
 int rsrl_hip_domain_reset(rsrl_hip_ctx* c, const uint8_t* mask) {
-    CHECK_CTX(c); FLUSH(c);
+    CHECK_CTX(c);
+    if (c->tp.stage == 2 && mask && mask == c->tp.term) { c->tp.stage = 3; return RSRL_HIP_OK; }      // the new episodes of the transition just handled
+    FLUSH(c);
     c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t N = c->cfg.n_envs;
     const uint8_t* d_mask;
     TRY(stage_in(c, 0, mask, (size_t)N, &d_mask));
     const Common k = make_common(c);
-    const dim3 g(grid_for(N)), b(kBlock);
-    switch (c->cfg.domain) {
-    case 0: hipLaunchKernelGGL(k_domain_reset<0>, g, b, 0, c->stream, k, d_mask); break;
-    case 1: hipLaunchKernelGGL(k_domain_reset<1>, g, b, 0, c->stream, k, d_mask); break;
-    default: hipLaunchKernelGGL(k_domain_reset<2>, g, b, 0, c->stream, k, d_mask); break;
-    }
-    KCHECK();
+    TRY(launch_domain_reset(c, k, d_mask));
     if (mask && !is_device_ptr(mask)) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 
 static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* fout, size_t fcount, int32_t* iout,
-               size_t icount = 0, const float* fin = nullptr, size_t fin_count = 0, const int32_t* iin = nullptr) {
+               size_t icount = 0, const float* fin = nullptr, size_t fin_count = 0, const int32_t* iin = nullptr, uint64_t step_t = 0) {
     CHECK_CTX(c); FLUSH(c);
     if (!states || M_ < 1 || M_ > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch (M=%lld, n_envs=%lld)", (long long)M_, (long long)c->cfg.n_envs);
     if (is_pred(c->cfg.algo) && op != QOP_EVALUATE && op != QOP_FEATURES)
@@ -1217,7 +1240,7 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     TRY(stage_in(c, 3, fin, fin_count, &d_fin));
     TRY(stage_in(c, 4, iin, (size_t)M_, &d_iin));
     const Common k = make_common(c);
-    const uint64_t call = c->api_calls;
+    const uint64_t call = (op == QOP_SAMPLE_STEP || op == QOP_SAMPLE_INIT) ? step_t : c->api_calls;      // (the driver loop's sample: addressed by the batch-step)
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
     if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && is_wave(c->cfg)) {
@@ -1266,8 +1289,72 @@ int rsrl_hip_q_evaluate(rsrl_hip_ctx* c, const float* states, int64_t M, float* 
 int rsrl_hip_q_find_max(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* idx_out, float* val_out) {
     return qop(c, QOP_FIND_MAX, states, M, val_out, (size_t)M, idx_out);
 }
+// states == NULL: policy.sample(rng, env.emit().state()) for the ctx's OWN envs (M = n_envs) -- the driver loop's behaviour sample: it draws what
+// batch-step step_count - 1 of rsrl_hip_train draws (the initial sample's stream before the first handle), and the actions also become the ctx's pending ones
+static int sample_emit(rsrl_hip_ctx* c, int64_t M, int32_t* actions_out) {
+    if (M != c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "policy_sample(states = NULL) samples for the ctx's own envs: M must be n_envs (%lld), got %lld", (long long)c->cfg.n_envs, (long long)M);
+    if (is_pred(c->cfg.algo)) return fail(RSRL_HIP_ESTATE, "a prediction agent has a state-value function only (use rsrl_hip_q_evaluate for V(s))");
+    const bool dev_out = is_device_ptr(actions_out);
+    if (c->tp.stage == 3 && dev_out) {
+        // the whole batch-step -- transition, handle, new episodes, sample -- as ONE kernel
+        const rsrl_hip_ctx::TraitPend p = c->tp;
+        c->tp.stage = 0;
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        TRY(trait_cache_ready(c));
+        const Common k = make_common(c);
+        TraitIo io{};
+        io.act = p.act; io.td_out = p.td; io.o_from = p.from; io.o_to = p.to; io.o_rew = p.rew; io.o_term = p.term; io.o_act = actions_out;
+        io.qkey = c->tq_key; io.Mn = M;
+        TRY(timing_begin(c));
+        if (!launch_trait_lm(c->cfg.domain, c->cfg.order, c->cfg.algo, c->cfg.policy, c->stream, k, io, p.t_handle)) return NO_MODEL(c);
+        KCHECK();
+        c->kernel_name = "k_trait_lm<step>";
+        return timing_end(c);
+    }
+    FLUSH(c);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const uint64_t t = c->t ? c->t - 1 : 0;
+    const uint32_t blk = c->t ? BLK_STEP : BLK_INIT;
+    if (trait_fast(c)) {
+        OutBuf<int32_t> oa;
+        TRY(stage_out(c, 2, actions_out, (size_t)M, &oa));
+        TRY(trait_cache_ready(c));
+        const Common k = make_common(c);
+        TRY(timing_begin(c));
+        if (!launch_trait_sample(c->cfg.domain, c->cfg.order, c->stream, k, nullptr, M, t, blk, c->tq_key, oa.dev)) return NO_MODEL(c);
+        KCHECK();
+        TRY(timing_end(c));
+        bool sync = false;
+        TRY(flush_out(c, &oa, &sync));
+        if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+        return RSRL_HIP_OK;
+    }
+    TRY(qop(c, c->t ? QOP_SAMPLE_STEP : QOP_SAMPLE_INIT, c->state, M, nullptr, 0, actions_out, 0, nullptr, 0, nullptr, t));
+    HIP_TRY(hipMemcpyAsync(c->action, actions_out, sizeof(int32_t) * (size_t)M, hipMemcpyDefault, c->stream));
+    if (!dev_out) HIP_TRY(hipStreamSynchronize(c->stream));
+    return RSRL_HIP_OK;
+}
 int rsrl_hip_policy_sample(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* actions_out) {
+    CHECK_CTX(c);
     if (!actions_out) return fail(RSRL_HIP_EINVAL, "null argument");
+    if (!states) return sample_emit(c, M, actions_out);
+    if (trait_fast(c) && M >= 1 && M <= c->cfg.n_envs) {
+        // the fast path's sample: a state the hand-over cache holds costs 20 B instead of the learner's 432 B of weights; same bits either way
+        FLUSH(c);
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        const float* d_states; OutBuf<int32_t> oa;
+        TRY(stage_in(c, 0, states, (size_t)c->D * M, &d_states));
+        TRY(stage_out(c, 2, actions_out, (size_t)M, &oa));
+        TRY(trait_cache_ready(c));
+        const Common k = make_common(c);
+        const uint64_t call = c->api_calls++;
+        if (!launch_trait_sample(c->cfg.domain, c->cfg.order, c->stream, k, d_states, M, call, BLK_API, c->tq_key, oa.dev)) return NO_MODEL(c);
+        KCHECK();
+        bool sync = !is_device_ptr(states);
+        TRY(flush_out(c, &oa, &sync));
+        if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+        return RSRL_HIP_OK;
+    }
     return qop(c, QOP_SAMPLE, states, M, nullptr, 0, actions_out);
 }
 int rsrl_hip_policy_mode(rsrl_hip_ctx* c, const float* states, int64_t M, int32_t* actions_out) {
@@ -1297,14 +1384,24 @@ int rsrl_hip_tile_indices(rsrl_hip_ctx* c, const float* states, int64_t M, int32
 
 int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* actions, const float* rewards,
                     const float* to_states, const uint8_t* terminal, int64_t M, float* td_error_out) {
-    CHECK_CTX(c); FLUSH(c);
+    CHECK_CTX(c);
     if (!from_states || !actions || !rewards || !to_states || !terminal) return fail(RSRL_HIP_EINVAL, "null argument");
     if (M < 1 || M > c->cfg.n_envs) return fail(RSRL_HIP_EINVAL, "bad batch size");
+    // the transition rsrl_hip_domain_step has just been handed (same arrays, every learner): accepted, launched with it (rsrl_hip_domain_step)
+    if (c->tp.stage == 1 && from_states == c->tp.from && actions == c->tp.act && rewards == c->tp.rew && to_states == c->tp.to && terminal == c->tp.term &&
+        M == c->cfg.n_envs && (!td_error_out || is_device_ptr(td_error_out))) {
+        c->tp.stage = 2; c->tp.td = td_error_out; c->tp.t_handle = c->t;
+        c->t += 1;
+        return RSRL_HIP_OK;
+    }
+    FLUSH(c);
     if (c->st_rccl_group) return fail(RSRL_HIP_ESTATE, "this ctx is a rank of a single-thread RCCL group: handle() all-reduces the mini-batch delta, and one thread "
                                                        "cannot issue that for one rank at a time -- use one thread / process per rank, or RSRL_EXCHANGE_PEER");
     HIP_TRY(hipSetDevice(c->cfg.device));
     TRY(check_host_actions(actions, (size_t)M, c->A));
     const float *d_from, *d_rew, *d_to; const int32_t* d_act; const uint8_t* d_term; OutBuf<float> otd;
+    const bool all_device = is_device_ptr(from_states) && is_device_ptr(actions) && is_device_ptr(rewards) && is_device_ptr(to_states) && is_device_ptr(terminal) &&
+                            (!td_error_out || is_device_ptr(td_error_out));
     TRY(stage_in(c, 0, from_states, (size_t)c->D * M, &d_from));
     TRY(stage_in(c, 1, actions, (size_t)M, &d_act));
     TRY(stage_in(c, 2, rewards, (size_t)M, &d_rew));
@@ -1316,7 +1413,9 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     if (is_sparse_lambda(c->cfg))
         return fail(RSRL_HIP_ESTATE, "SARSALambda / QLambda over a shared tile table keep one sparse trace per LEARNER of the ctx: they are stepped by rsrl_hip_train "
                                      "(caller-supplied transitions have no learner to attach a trace to)");
-    if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
+    if (trait_fast(c)) {
+        TRY(launch_trait_handle(c, k, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev));
+    } else if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
         launch_wave_aux(c, dim3(wave_grid_for(M)), k, make_wave_aux(c), (float*)c->W, c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
     } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, M, c->stream, k, g, make_td(c), c->t, 1, nullptr, d_from, d_rew,
@@ -1376,11 +1475,12 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         KCHECK();
     }
     c->q_valid = false;
+    if (!trait_fast(c)) c->tq_valid = false;
     c->t += 1;          // one handle call = one batch-step of learning: the agent-side draws (SARSA's inner sample,
                         // bf16 stochastic rounding) advance exactly as they do inside rsrl_hip_train
-    bool sync = true;   // inputs may be host memory staged asynchronously
+    bool sync = !all_device;   // host inputs are staged asynchronously: they must have been read when the call returns; device arrays are asynchronous
     TRY(flush_out(c, &otd, &sync));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
 
@@ -1405,7 +1505,7 @@ int rsrl_hip_get_weights(rsrl_hip_ctx* c, int64_t env_index, float* w) {
 }
 int rsrl_hip_set_weights(rsrl_hip_ctx* c, int64_t env_index, const float* w) {
     CHECK_CTX(c); FLUSH(c);
-    c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    c->q_valid = false; c->tq_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     if (!shared && (env_index < 0 || env_index >= c->cfg.n_envs)) return fail(RSRL_HIP_EINVAL, "env_index out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -1729,7 +1829,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     if (rc == RSRL_HIP_OK) {
         (void)hipFree(W_old); if (Z_old) (void)hipFree(Z_old);
         if (spk_new) { (void)hipFree(c->sp_keys); (void)hipFree(c->sp_vals); c->sp_keys = spk_new; c->sp_vals = spv_new; }
-        c->t = h.step_count; c->q_valid = false;
+        c->t = h.step_count; c->q_valid = false; c->tq_valid = false;
     } else {
         std::string keep = g_last_error;
         c->W = W_old; c->Z = Z_old;
@@ -1743,7 +1843,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
 
 int rsrl_hip_set_weights_all(rsrl_hip_ctx* c, const float* w) {
     CHECK_CTX(c); FLUSH(c);
-    c->q_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
+    c->q_valid = false; c->tq_valid = false; if (!w) return fail(RSRL_HIP_EINVAL, "null argument");
     if (c->cfg.weight_mode == RSRL_W_SHARED) return rsrl_hip_set_weights(c, 0, w);
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int n = c->F * c->Aw; const float* d_w;
@@ -1774,7 +1874,7 @@ static int timing_begin(rsrl_hip_ctx* c) {
     HIP_TRY(hipEventRecord(c->events[c->events_used].first, c->stream));
     return RSRL_HIP_OK;
 }
-static int timing_end(rsrl_hip_ctx* c, uint32_t launches = 1) {
+static int timing_end(rsrl_hip_ctx* c, uint32_t launches) {
     if (!c->timing) return RSRL_HIP_OK;
     HIP_TRY(hipEventRecord(c->events[c->events_used].second, c->stream));
     if (c->event_launches.size() <= c->events_used) c->event_launches.resize(c->events_used + 1);
@@ -2220,6 +2320,7 @@ static int train_sparse_lambda(rsrl_hip_ctx* c, const Common& k, const BasisGeom
 
 static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
+    c->tq_valid = false;                 // the weights move behind the trait path's hand-over cache
     DevStats* d_stats = stats_out ? c->d_stats : nullptr;      // statistics cost a block reduction per launch: opt-in
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
     Common k = make_common(c);
@@ -2422,8 +2523,65 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     return RSRL_HIP_OK;
 }
 
+// ---- the trait-granular loop (kernels_trait.hpp) --------------------------------------------------------------------------------------
+static inline bool trait_fast(const rsrl_hip_ctx* c) { return c->tq_key != nullptr; }
+// the hand-over cache is keyed by the state an entry belongs to; whenever the weights changed behind it (train, set / load weights) the keys are
+// emptied (NaN: never equal to a state) before the next kernel that looks at them
+static int trait_cache_ready(rsrl_hip_ctx* c) {
+    if (c->tq_valid) return RSRL_HIP_OK;
+    HIP_TRY(hipMemsetAsync(c->tq_key, 0xFF, sizeof(float) * (size_t)c->D * (size_t)c->cfg.n_envs, c->stream));
+    c->tq_valid = true;
+    return RSRL_HIP_OK;
+}
+static int launch_domain_step(rsrl_hip_ctx* c, const Common& k, const int32_t* d_act, float* from, float* next, float* rew, uint8_t* term) {
+    const dim3 g(grid_for(c->cfg.n_envs)), b(kBlock);
+    switch (c->cfg.domain) {
+    case 0: hipLaunchKernelGGL(k_domain_step<0>, g, b, 0, c->stream, k, d_act, from, next, rew, term); break;
+    case 1: hipLaunchKernelGGL(k_domain_step<1>, g, b, 0, c->stream, k, d_act, from, next, rew, term); break;
+    default: hipLaunchKernelGGL(k_domain_step<2>, g, b, 0, c->stream, k, d_act, from, next, rew, term); break;
+    }
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+static int launch_domain_reset(rsrl_hip_ctx* c, const Common& k, const uint8_t* d_mask) {
+    const dim3 g(grid_for(c->cfg.n_envs)), b(kBlock);
+    switch (c->cfg.domain) {
+    case 0: hipLaunchKernelGGL(k_domain_reset<0>, g, b, 0, c->stream, k, d_mask); break;
+    case 1: hipLaunchKernelGGL(k_domain_reset<1>, g, b, 0, c->stream, k, d_mask); break;
+    default: hipLaunchKernelGGL(k_domain_reset<2>, g, b, 0, c->stream, k, d_mask); break;
+    }
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+// Handler::handle on the fast path: one pass over the learners' weight images, the hand-over left for the sample that follows
+static int launch_trait_handle(rsrl_hip_ctx* c, const Common& k, const float* from, const int32_t* act, const float* rew, const float* to,
+                               const uint8_t* term, int64_t M, uint64_t t, float* td) {
+    TRY(trait_cache_ready(c));
+    TraitIo io{};
+    io.from = from; io.act = act; io.rew = rew; io.to = to; io.termf = term; io.td_out = td; io.qkey = c->tq_key; io.Mn = M;
+    TRY(timing_begin(c));
+    if (!launch_trait_lm(c->cfg.domain, c->cfg.order, c->cfg.algo, -1, c->stream, k, io, t)) return NO_MODEL(c);
+    KCHECK();
+    c->kernel_name = "k_trait_lm<handle>";
+    return timing_end(c);
+}
+// the deferred calls, one kernel per call, in the order they were made
+static int trait_flush(rsrl_hip_ctx* c) {
+    if (c->tp.stage == 0) return RSRL_HIP_OK;
+    const rsrl_hip_ctx::TraitPend p = c->tp;
+    c->tp.stage = 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const Common k = make_common(c);
+    TRY(launch_domain_step(c, k, p.act, p.from, p.to, p.rew, p.term));
+    if (p.stage >= 2) TRY(launch_trait_handle(c, k, p.from, p.act, p.rew, p.to, p.term, c->cfg.n_envs, p.t_handle, p.td));
+    if (p.stage >= 3) TRY(launch_domain_reset(c, k, p.term));
+    return RSRL_HIP_OK;
+}
+
 static int flush_pending(rsrl_hip_ctx* c) {
-    if (!c || c->pending == 0) return RSRL_HIP_OK;
+    if (!c) return RSRL_HIP_OK;
+    if (c->tp.stage) TRY(trait_flush(c));
+    if (c->pending == 0) return RSRL_HIP_OK;
     const int64_t n = c->pending;
     c->pending = 0;
     return train_now(c, n, nullptr);
