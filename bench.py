@@ -291,6 +291,48 @@ def streaming_leg(rsrl_amd, envs, rank, device, steps=2000, warmup=200):
         return {"error": repr(e)}
 
 
+def trait_loop_leg(envs, device, defer=True, steps=400, warmup=50):
+    """Secondary measurement: the TRAIT-GRANULAR loop a drop-in caller writes (examples/q_learning.rs:40-52) -- rsrl_hip_domain_step -> rsrl_hip_handle ->
+    rsrl_hip_domain_reset -> rsrl_hip_policy_sample(NULL), one C-ABI call per trait method, device arrays, the same workload as `value` on a ctx in the
+    learner-major layout (steps_per_launch = 1).  defer=True: a ctx-owned stream, where the library accepts the four calls and launches them as one kernel;
+    defer=False (RSRL_NO_TRAIT_DEFER=1): one kernel per call, what a caller-supplied stream gets.  frac = the loop's algorithmic bytes (679 B per env-step:
+    scripts/trait_loop.py) x env-steps/s / 8 TB/s, wall clock with one synchronize at the end (host time of the Python caller included)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("trait_loop", os.path.join(ROOT, "scripts", "trait_loop.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = os.environ.get("RSRL_NO_TRAIT_DEFER")
+    try:
+        if defer:
+            os.environ.pop("RSRL_NO_TRAIT_DEFER", None)
+        else:
+            os.environ["RSRL_NO_TRAIT_DEFER"] = "1"
+        out = mod.measure(envs, steps, warmup, device=device, steps_per_launch=1)
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
+    finally:
+        if old is None:
+            os.environ.pop("RSRL_NO_TRAIT_DEFER", None)
+        else:
+            os.environ["RSRL_NO_TRAIT_DEFER"] = old
+    out.update({"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit_roofline": "GB/s", "achieved": out["algorithmic_bytes_per_env_step"] * out["value"] / 1e9,
+                "frac": out["algorithmic_bytes_per_env_step"] * out["value"] / HBM_PEAK,
+                "launches_per_batch_step": 1 if defer else 4,
+                "what": "transition -> handle -> new episodes -> sample through the C ABI, one call per trait method, device arrays; "
+                        + ("the four calls accepted and launched as ONE kernel (ctx-owned stream)" if defer else "one kernel per call (what a caller-supplied stream gets)")})
+    return out
+
+
+def hbm_copy_measured(device, gib=1.0, reps=10):
+    """what this box's memory system delivers: a float4 device copy (rsrl_hip_measure_copy, HIP events), GB/s counting read + write -- SURVEY 8(d) asks for the
+    HBM fractions against it as well as against the published 8 TB/s (MI355X_MICROARCH.md quotes 6.29 TB/s for the same kind of copy)"""
+    import ctypes as C
+    from rsrl_amd import _abi
+    out = C.c_double()
+    _abi.check(_abi.lib().rsrl_hip_measure_copy(int(device), int(gib * 2 ** 30), int(reps), C.byref(out)))
+    return {"GBps": out.value, "bytes": int(gib * 2 ** 30), "reps": reps, "what": "float4 device-to-device copy kernel, read + write, HIP events (rsrl_amd/csrc/measure.hip)"}
+
+
 def shared_w_leg(cp, rsrl_amd, make_sharded_context, exchange, envs_per_gpu=131072, steps=320, warmup=64):
     """Secondary measurement (BASELINE.json configs[3]): 131 072 MountainCar envs per GPU, ONE shared Fourier(5)
     approximator, per-batch-step exchange of the weight delta (exchange AUTO: the one-hop peer exchange whenever every device
@@ -483,6 +525,121 @@ def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extr
         return {"workload": name, "error": repr(e)}
 
 
+def _num(x, digits=5):
+    """a number at `digits` significant digits (the compact line is for a parser and a reader, not for reproducing bits)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def _leg_summary(rec, copy_gbps=None):
+    """{value, us, bound, frac, ...}: the triple VERDICT r5 asks for per leg, from a leg's full record (whatever its shape)"""
+    if not isinstance(rec, dict):
+        return None
+    if "error" in rec or "skipped" in rec:
+        return {"error": str(rec.get("error") or rec.get("skipped"))[:160]}
+    rl = rec.get("roofline") if isinstance(rec.get("roofline"), dict) else rec
+    out = {"value": _num(rec.get("value", rec.get("env_steps_per_s_this_rank"))),
+           "us": _num(rec.get("us_per_batch_step", (rec.get("avg_launch_ms") or 0) * 1e3 or None)),
+           "kernel": rl.get("kernel") or rec.get("kernel"), "bound": rl.get("bound"), "frac": _num(rl.get("frac"))}
+    if isinstance(rl.get("hbm"), dict):
+        out["hbm_frac"] = _num(rl["hbm"].get("frac"))
+    if rl.get("bound") == "hbm" and copy_gbps and rl.get("achieved"):
+        out["frac_of_measured_copy"] = _num(rl["achieved"] / copy_gbps)
+    if "us_per_batch_step" not in rec and "calls" in rec and "avg_launch_ms" in rec:      # value_no_coalesce: a launch is a whole K-step call
+        out["us_per_launch"] = out.pop("us")
+    if "kernel_us_per_batch_step" in rec:
+        out["kernel_us"] = _num(rec["kernel_us_per_batch_step"])
+    if rl.get("profile_digest_matches") is False:
+        out["profile_digest_matches"] = False
+    return {k: v for k, v in out.items() if v is not None}
+
+
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline")
+LEG_KEYS = ("trait_loop", "trait_loop_unfused", "trait_loop_1m", "value_no_coalesce", "roofline_streaming", "roofline_streaming_hbm", "c3_shared_tiles",
+            "c5_wave_bf16", "shared_w", "shared_w_rccl")
+COMPACT_LIMIT = 6000      # bytes; the driver's parser lost the 24 KB line of round 5 (BENCH_r05.json: parsed = null) -- tests/test_bench_line_cpu.py
+
+
+def compact_line(full, detail_path="bench_detail.json"):
+    """The ONE line rank 0 prints last on stdout: the driver's contract keys, the roofline and CPU-baseline objects, one {value, us, frac} triple per
+    secondary leg -- and nothing else.  Everything (per-rank records, per-configuration parity, ceilings, digests, `what` strings) goes to the detail file
+    and to stderr."""
+    line = {k: full.get(k) for k in COMPACT_KEYS[:12]}
+    for k in ("value", "ms_per_step"):
+        line[k] = _num(line[k], 7)
+    cfg = full.get("config") or {}
+    line["config"] = {k: (_num(v) if not isinstance(v, str) else v) for k, v in cfg.items() if k in ("workload", "envs_per_gpu", "steps_per_launch", "repeats", "ranks", "parallelism")}
+    rl = full.get("roofline") or {}
+    crl = {k: _num(rl.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "useful_frac", "avg_launch_ms", "launches", "traffic", "profile_digest_matches")
+           if k in rl}
+    if isinstance(rl.get("hbm"), dict):
+        crl["hbm_frac"] = _num(rl["hbm"].get("frac"))
+    if isinstance(rl.get("issue_slots"), dict):
+        crl["issue_slots_frac"] = _num(rl["issue_slots"].get("frac"))
+    if isinstance(rl.get("lone_wave_ceiling"), dict):
+        crl["lone_wave_frac"] = _num(rl["lone_wave_ceiling"].get("frac"))
+    line["roofline"] = crl
+    copy = (full.get("hbm_copy_measured") or {}).get("GBps")
+    if copy:
+        line["hbm_copy_measured_GBps"] = _num(copy)
+        if isinstance(crl.get("hbm_frac"), float) and rl.get("hbm", {}).get("achieved"):
+            crl["hbm_frac_of_measured_copy"] = _num(rl["hbm"]["achieved"] / copy)
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "per_core": _num(cb.get("per_core")), "optimised_value": _num((cb.get("optimised") or {}).get("value")),
+                                "sample": (cb.get("sample") or "")[:200]}
+    legs = {}
+    for k in LEG_KEYS:
+        sm = _leg_summary(full.get(k), copy)
+        if sm:
+            legs[{"roofline_streaming": "streaming", "roofline_streaming_hbm": "streaming_1m"}.get(k, k)] = sm
+    line["legs"] = legs
+    gr = full.get("greedy_rollout")
+    if isinstance(gr, dict):
+        line["greedy_rollout"] = {k: _num(gr.get(k)) for k in ("limit", "compared", "terminated_frac", "identical_n_states_frac", "min_argmax_margin",
+                                                               "max_min_margin_of_differing", "error") if k in gr}
+    par = full.get("parity")
+    if isinstance(par, dict):
+        line["parity"] = {k: _num(par.get(k), 3) for k in ("phi_max_abs", "q_max_rel", "delta_max_rel", "w_update_max_abs_rel", "error") if k in par}
+    line["spread"] = _num(full.get("spread"), 3)
+    if full.get("oversubscribed"):
+        line["oversubscribed"] = full["oversubscribed"][:100]
+    line["detail"] = detail_path
+    return line
+
+
+def emit(full, detail_path=None):
+    """detail -> bench_detail.json (--detail PATH, else next to bench.py and under gpurun_out/ when that exists) and stderr; the compact line -> stdout, LAST"""
+    detail = json.dumps(full)
+    wrote = None
+    targets = [detail_path] if detail_path else [os.path.join(d, "bench_detail.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]
+    for path in targets:
+        try:
+            with open(path, "w") as f:
+                f.write(detail + "\n")
+            wrote = wrote or (path if detail_path else os.path.relpath(path, ROOT))
+        except OSError:
+            pass
+    print(detail, file=sys.stderr, flush=True)
+    text = json.dumps(compact_line(full, wrote or "stderr"), separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:           # never again a line the driver cannot parse: drop the optional objects, largest first
+        slim = compact_line(full, wrote or "stderr")
+        for k in ("parity", "greedy_rollout", "legs"):
+            slim.pop(k, None)
+            text = json.dumps(slim, separators=(",", ":"))
+            if len(text) <= COMPACT_LIMIT:
+                break
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
 def spawn_ranks(n):
     """--gpus N without a launcher: start the N ranks ourselves, one per GPU, and pass rank 0's JSON line through."""
     s = socket.socket()
@@ -510,6 +667,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shared-leg", action="store_true", help="skip the secondary shared-W (exchange) measurements")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the secondary 1-step-per-launch measurement")
+    ap.add_argument("--no-trait-leg", action="store_true", help="skip the secondary trait-granular-loop measurements")
+    ap.add_argument("--detail", default=None, help="where the full result goes (default: bench_detail.json next to bench.py and under gpurun_out/)")
     ap.add_argument("--allow-oversubscribe", action="store_true", help="let several ranks share a device (test boxes only)")
     args = ap.parse_args()
 
@@ -614,6 +773,14 @@ def main():
     # ... and at an HBM-resident size: 1 048 576 learners = 453 MB of weights (the 28 MB of 65 536 learners never leave L2 / the Infinity Cache)
     streaming_hbm = guarded(lambda: streaming_leg(rsrl_amd, 1048576, rank, device, steps=160, warmup=32), 120) \
         if (args.steps_per_launch != 1 and not args.no_streaming_leg and world <= ndev) else None
+    # the trait-granular loop (one C-ABI call per trait method): fused by the library on its own stream, one kernel per call, and at an HBM-resident size
+    trait = trait_unfused = trait_1m = copy_bw = None
+    if not args.no_trait_leg and world <= ndev:
+        trait = guarded(lambda: trait_loop_leg(args.envs, device, defer=True), 120)
+        trait_unfused = guarded(lambda: trait_loop_leg(args.envs, device, defer=False), 120)
+        trait_1m = guarded(lambda: trait_loop_leg(1048576, device, defer=True, steps=100, warmup=20), 120)
+    if rank == 0:
+        copy_bw = guarded(lambda: hbm_copy_measured(device), 60)
     c3 = c5 = None
     if not args.no_config_legs and world <= ndev:
         c3 = guarded(lambda: config_leg(
@@ -644,7 +811,7 @@ def main():
             shared_rccl = {"skipped": f"{world} ranks on {ndev} device(s): RCCL refuses ranks that share a device (shared_w, the peer exchange, runs)"}
         elif not (isinstance(shared, dict) and shared.get("error") == "timeout"):
             shared_rccl = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
-    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_rccl, c3, c5))
+    hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_rccl, c3, c5, trait, trait_unfused, trait_1m))
 
     if rank == 0:
         total_steps = args.steps * repeats
@@ -712,6 +879,18 @@ def main():
             out["roofline_streaming"] = streaming
         if streaming_hbm is not None:
             out["roofline_streaming_hbm"] = streaming_hbm
+        if trait is not None:
+            out["trait_loop"] = trait
+        if trait_unfused is not None:
+            out["trait_loop_unfused"] = trait_unfused
+        if trait_1m is not None:
+            out["trait_loop_1m"] = trait_1m
+        if copy_bw is not None:
+            out["hbm_copy_measured"] = copy_bw
+            if isinstance(copy_bw, dict) and copy_bw.get("GBps"):
+                for leg in (streaming, streaming_hbm, trait, trait_unfused, trait_1m):
+                    if isinstance(leg, dict) and leg.get("achieved"):
+                        leg["frac_of_measured_copy"] = leg["achieved"] / copy_bw["GBps"]
         if c3 is not None:
             out["c3_shared_tiles"] = c3
         if c5 is not None:
@@ -725,7 +904,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             if world > 1:
                 out["cpu_baseline"]["measured_with_ranks"] = world
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
     if hung:
         os._exit(0)          # a secondary leg is stuck in a collective: do not wait for it in the destructors
     if world > 1:

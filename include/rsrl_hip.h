@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RSRL_HIP_ABI_VERSION 8
+#define RSRL_HIP_ABI_VERSION 9
 
 typedef enum {
     RSRL_HIP_OK      = 0,
@@ -224,8 +224,9 @@ int rsrl_hip_reset(rsrl_hip_ctx* ctx);
 /* Domain::emit (state part)                         rsrl_domains/src/lib.rs:430 */
 int rsrl_hip_get_states(rsrl_hip_ctx* ctx, float* states /*[D][N]*/);
 int rsrl_hip_set_states(rsrl_hip_ctx* ctx, const float* states /*[D][N]*/);
-/*   (set_states: a HOST array must hold finite values within 1000 widths of each dimension's bounds, else EINVAL -- the reference's wrap! macro,
- *    rsrl_domains/src/macros.rs:14-24, loops without end on an infinite angle; a DEVICE array is clamped into that range instead) */
+/*   (set_states: the array must hold finite values within 1000 widths of each dimension's bounds, else EINVAL and the ctx is untouched -- the reference's
+ *    wrap! macro, rsrl_domains/src/macros.rs:14-24, loops without end on an infinite angle; a HOST array is checked on the host, a DEVICE array on the
+ *    device by the same rule (ABI 9: it used to be clamped silently, NaN passing)) */
 int rsrl_hip_get_actions(rsrl_hip_ctx* ctx, int32_t* actions /*[N]*/);
 int rsrl_hip_set_actions(rsrl_hip_ctx* ctx, const int32_t* actions /*[N]*/);
 /* (ABI 8) The rest of a learner's state between two driver calls, so that a run can be carried into another ctx EXACTLY (with the checkpoint of
@@ -243,7 +244,25 @@ int rsrl_hip_set_episode_steps(rsrl_hip_ctx* ctx, const uint32_t* steps /*[N]*/)
 int rsrl_hip_get_q_carry(rsrl_hip_ctx* ctx, float* q /*[A][N]*/, int32_t* valid);
 int rsrl_hip_set_q_carry(rsrl_hip_ctx* ctx, const float* q /*[A][N]*/);
 
-/* Domain::transition                                rsrl_domains/src/lib.rs:436-446
+/* ---- The trait-granular loop (examples/q_learning.rs:40-52), one call per trait method, every learner of the ctx:
+ *
+ *        rsrl_hip_domain_step(ctx, act, from, to, rew, term);          t  = env.transition(a)
+ *        rsrl_hip_handle(ctx, from, act, rew, to, term, n_envs, td);        agent.handle(&t)
+ *        rsrl_hip_domain_reset(ctx, term);                                  terminal -> a new episode (q_learning.rs:37, :47-51)
+ *        rsrl_hip_policy_sample(ctx, NULL, n_envs, act);               a' = policy.sample(rng, env.emit().state())
+ *
+ *   reproduces the reference's call pattern -- every action value evaluated afresh from the weights -- bit for bit against the CPU oracle's
+ *   reference-order loop (tests/test_gpu_trait_loop.py), on every basis / agent with a handle.  A ctx created with steps_per_launch = 1 on a
+ *   register-family Fourier basis (MountainCar order 1 / 3 / 5, CartPole / Acrobot order 1) with per-learner f32 weights and a one-step agent
+ *   (QLearning, SARSA, ExpectedSARSA, PAL) keeps W learner-major and serves the loop as an HBM stream (rsrl_amd/csrc/kernels_trait.hpp): handle
+ *   makes ONE pass over the learners' weights and hands Q(s',.) under the updated weights over to the sample that follows (a cache keyed by the
+ *   state itself: a hit returns the bits a fresh evaluation returns).  With DEVICE arrays on a CTX-OWNED stream such a ctx ACCEPTS the four
+ *   calls above and launches them as one kernel when they arrive in this order on the same arrays; any other call launches the accepted ones
+ *   first, one kernel each -- same results, same order; as with rsrl_hip_train's coalescing, acceptance is not completion: rsrl_hip_sync (or
+ *   any call that returns data to the host) completes them.  On a caller-supplied stream every call enqueues its own kernel before it returns.
+ *   RSRL_NO_TRAIT_DEFER=1 / RSRL_NO_TRAIT_FAST=1 in the environment switch the deferral / the fast kernels off (A/B runs).  (ABI 9)
+ *
+ * Domain::transition                                rsrl_domains/src/lib.rs:436-446
  * Steps every env of the ctx with `actions` (NULL: the ctx's pending actions).  Outputs are
  * optional (NULL to skip).  The ctx's env state becomes s'; no auto-reset. */
 int rsrl_hip_domain_step(rsrl_hip_ctx* ctx, const int32_t* actions,
@@ -271,7 +290,9 @@ int rsrl_hip_tile_indices(rsrl_hip_ctx* ctx, const float* states, int64_t M, int
  *   control/td/q_learning.rs:51-71, sarsa.rs:53-75, expected_sarsa.rs:45-66
  * td_error_out (optional) = Response.error (q_learning.rs:17-20).  Each call counts as one batch-step: it advances
  * rsrl_hip_step_count, the counter that addresses the agent-side random draws (SARSA's inner policy sample,
- * sarsa.rs:61; bf16 stochastic rounding), exactly as one step of rsrl_hip_train does. */
+ * sarsa.rs:61; bf16 stochastic rounding), exactly as one step of rsrl_hip_train does.
+ * With device arrays only the call is asynchronous on the ctx's stream (ABI 9; it used to synchronise); host arrays are staged and the call
+ * returns when they have been consumed / filled. */
 int rsrl_hip_handle(rsrl_hip_ctx* ctx, const float* from_states, const int32_t* actions,
                     const float* rewards, const float* to_states, const uint8_t* terminal,
                     int64_t M, float* td_error_out);
@@ -279,6 +300,10 @@ int rsrl_hip_handle(rsrl_hip_ctx* ctx, const float* from_states, const int32_t* 
 /* Policy::sample / Policy::mode / Function<(S,)> of the policy (action probabilities)
  *   policies/mod.rs:65-78; greedy.rs:30-44,77-83; epsilon_greedy.rs:38-45,74-82;
  *   softmax.rs:74-82,131-143; random.rs:19-48 (mode of Random: RSRL_HIP_EINVAL, random.rs:47 panics) */
+/* states == NULL (ABI 9; M must be n_envs): policy.sample(rng, env.emit().state()) for the ctx's OWN envs -- the driver loop's behaviour sample
+ *   (examples/q_learning.rs:38, :45).  It draws what batch-step rsrl_hip_step_count() - 1 of rsrl_hip_train draws (before the first handle: the initial
+ *   sample's stream, as rsrl_hip_reset), and the actions also become the ctx's pending ones.  With explicit states the draws are a stream of their own,
+ *   addressed by the number of such calls made on the ctx. */
 int rsrl_hip_policy_sample(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
 int rsrl_hip_policy_mode(rsrl_hip_ctx* ctx, const float* states, int64_t M, int32_t* actions_out);
 int rsrl_hip_policy_probs(rsrl_hip_ctx* ctx, const float* states, int64_t M, float* probs_out /*[A][M]*/);
@@ -456,6 +481,9 @@ int rsrl_hip_comm_info(rsrl_hip_ctx* ctx, int* world_size, int* rank, int* excha
  * stream.  ms_total / launches = average launch duration of the dominant kernel. */
 int rsrl_hip_timing_enable(rsrl_hip_ctx* ctx, int enable);
 int rsrl_hip_timing_read(rsrl_hip_ctx* ctx, double* ms_total, uint64_t* launches, const char** kernel_name);
+/* (ABI 9) what this box's memory system delivers: a float4 device-to-device copy of `bytes` bytes (rounded down to 16), `reps` times, by HIP events ->
+ * GB/s counting read + write.  No ctx: allocates and frees its own two buffers.  bench.py quotes every HBM fraction against it next to the published peak. */
+int rsrl_hip_measure_copy(int device, size_t bytes, int reps, double* gbps_out);
 
 #ifdef __cplusplus
 }

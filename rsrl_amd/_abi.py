@@ -100,6 +100,7 @@ SYMBOLS = {
     "rsrl_hip_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rsrl_hip_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_char_p)]),
+    "rsrl_hip_measure_copy": (C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None

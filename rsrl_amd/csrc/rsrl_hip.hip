@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <string>
@@ -306,9 +307,10 @@ static int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     g_last_error = buf;
-    // the HIP runtime keeps the last failure of ANY call of this thread until somebody asks for it: asked for here, so that a failure this library has
-    // already reported (or chose to ignore on a clean-up path) is not found again by the next launch check (KCHECK) of a healthy ctx
-    (void)hipGetLastError();
+    // the HIP runtime keeps the last failure of ANY call of this thread until somebody asks for it: asked for here WHEN THE FAILURE REPORTED IS A HIP ONE, so
+    // that it is not found again by the next launch check (KCHECK) of a healthy ctx.  A pure argument / state error (EINVAL, ESTATE) leaves it alone: a launch
+    // error not yet checked must not be lost behind an unrelated report; rsrl_hip_destroy and the clean-up paths clear it themselves.
+    if (code == RSRL_HIP_EHIP || code == RSRL_HIP_ENOMEM) (void)hipGetLastError();
     return code;
 }
 #define HIP_TRY(expr)                                                                              \
@@ -621,13 +623,17 @@ static int check_host_states(const rsrl_hip_ctx* c, const float* s, size_t n_col
     return RSRL_HIP_OK;
 }
 struct StateLimits { float lo[8], hi[8]; };
-__global__ void k_clamp_states(float* __restrict__ s, int64_t n, int D, StateLimits lim) {
+// a DEVICE array of states is validated on the device, with the host path's rule (it used to be clamped silently, and NaN passed): *bad counts the
+// components that are not finite values within the limits; the caller copies the array into the ctx only when there are none
+__global__ void k_check_states(const float* __restrict__ s, int64_t n, int D, StateLimits lim, unsigned* __restrict__ bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    unsigned cnt = 0;
     for (int d = 0; d < D; ++d) {
         const float x = s[(int64_t)d * n + i];
-        s[(int64_t)d * n + i] = x > lim.hi[d] ? lim.hi[d] : (x < lim.lo[d] ? lim.lo[d] : x);
+        cnt += (x >= lim.lo[d] && x <= lim.hi[d]) ? 0u : 1u;
     }
+    if (cnt) atomicAdd(bad, cnt);
 }
 #define TRY(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 #define KCHECK() HIP_TRY(hipGetLastError())
@@ -896,6 +902,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : (c->k1_quad ? (size_t)((N + 63) / 64) : grid_for(N));     // one statistics slot per thread block
     if ((is_lambda(cfg->algo) || is_pred(cfg->algo)) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
+    if (is_lambda(cfg->algo) && is_generic_fourier(*cfg)) c->n_stat_slots = (size_t)((N + 63) / 64);                        // k_train_lambda_mem4: 64 learners per block
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
@@ -1110,14 +1117,22 @@ int rsrl_hip_set_states(rsrl_hip_ctx* c, const float* states) {
     CHECK_CTX(c); FLUSH(c);
     if (!states) return fail(RSRL_HIP_EINVAL, "null argument");
     TRY(check_host_states(c, states, (size_t)c->cfg.n_envs));
-    c->q_valid = false;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     if (is_device_ptr(states)) {
+        // same rule as for a host array, checked where the data is; a refused array leaves the ctx untouched
         StateLimits lim; state_limits(c, lim.lo, lim.hi);
-        hipLaunchKernelGGL(k_clamp_states, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, c->state, c->cfg.n_envs, c->D, lim);
+        TRY(scratch_reserve(c, 7, sizeof(unsigned)));
+        unsigned* d_bad = (unsigned*)c->scratch[7].p;
+        unsigned bad = 0;
+        HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(k_check_states, dim3(grid_for(c->cfg.n_envs)), dim3(kBlock), 0, c->stream, states, c->cfg.n_envs, c->D, lim, d_bad);
         KCHECK();
+        HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (bad) return fail(RSRL_HIP_EINVAL, "%u component(s) of the device array of states are not finite values within 1000 widths of their dimension's bounds", bad);
     }
+    c->q_valid = false;
+    HIP_TRY(hipMemcpyAsync(c->state, states, sizeof(float) * c->D * (size_t)c->cfg.n_envs, hipMemcpyDefault, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RSRL_HIP_OK;
 }
@@ -2285,36 +2300,51 @@ static int persist_launch(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, 
 // SARSALambda / QLambda over one shared tile table (kernels_sparse_lambda.hpp): per batch-step phase A (one wave per learner: residual against W_t,
 // sparse trace update, the learner's terms into the fixed-point table), the table -> W (the same finalize -> [exchange] -> apply as rsrl_hip_handle),
 // phase C (sample from W_{t+1}, restarts).  Plain launches: correctness first.
-static int train_sparse_lambda(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
+// One batch-step of SARSALambda / QLambda over a shared tile table in two halves around the exchange of the delta (rsrl_hip_group_train's RCCL branch
+// runs the halves of all its ranks in lock-step with the all-reduces grouped between them):
+//   A: every learner's step (transition, TD error, sparse trace, fixed-point scatter of alpha * residual * z) + the table -> float delta
+//   B: W += delta (summed over the ranks by then), the behaviour policy's sample with the updated table
+static int sparse_lambda_half_a(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
     const SparseTrace st{c->sp_keys, c->sp_vals, c->sp_len};
     const SparseMail mail{c->sp_ns, c->flags};
     const LambdaParams lp = make_lambda(c);
     const int n = (int)c->dw_elems;
     const int64_t N = k.n_envs;
-    for (int64_t j = 0; j < n_steps; ++j) {
-        TRY(timing_begin(c));
-        if (!for_model(c, [&](auto tag) {
-                using M = typename decltype(tag)::type;
-                if constexpr (M::kSparse)
-                    hipLaunchKernelGGL((k_sparse_lambda_step<M::kDomain, M::kT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, g, lp, st, mail, c->h_fx, c->t, d_stats);
-            })) return NO_MODEL(c);
-        KCHECK();
-        hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.alpha));
-        KCHECK();
-        TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
-        if (c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
-        hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
-        KCHECK();
-        for_model(c, [&](auto tag) {
+    if (!for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             if constexpr (M::kSparse)
-                hipLaunchKernelGGL((k_sparse_lambda_sample<M::kDomain, M::kT>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, mail, c->t, d_stats);
-        });
-        KCHECK();
+                hipLaunchKernelGGL((k_sparse_lambda_step<M::kDomain, M::kT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, g, lp, st, mail, c->h_fx, c->t, d_stats);
+        })) return NO_MODEL(c);
+    KCHECK();
+    hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.alpha));
+    KCHECK();
+    return RSRL_HIP_OK;
+}
+static int sparse_lambda_half_b(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
+    const SparseMail mail{c->sp_ns, c->flags};
+    const int n = (int)c->dw_elems;
+    const int64_t N = k.n_envs;
+    hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+    KCHECK();
+    for_model(c, [&](auto tag) {
+        using M = typename decltype(tag)::type;
+        if constexpr (M::kSparse)
+            hipLaunchKernelGGL((k_sparse_lambda_sample<M::kDomain, M::kT>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, mail, c->t, d_stats);
+    });
+    KCHECK();
+    c->kernel_name = "k_sparse_lambda_step";
+    return RSRL_HIP_OK;
+}
+static int train_sparse_lambda(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
+    for (int64_t j = 0; j < n_steps; ++j) {
+        TRY(timing_begin(c));
+        TRY(sparse_lambda_half_a(c, k, g, d_stats));
+        TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
+        if (c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
+        TRY(sparse_lambda_half_b(c, k, g, d_stats));
         TRY(timing_end(c, 1));
         c->t += 1;
     }
-    c->kernel_name = "k_sparse_lambda_step";
     return RSRL_HIP_OK;
 }
 
@@ -2979,9 +3009,9 @@ int rsrl_hip_group_create(rsrl_hip_ctx* const* ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         devs[(size_t)i] = ctxs[i]->cfg.device;
         for (int j = 0; j < i; ++j)
-            // (RSRL_RCCL_ALLOW_SHARED_DEVICE=1: for a collectives library that admits ranks sharing a device -- the test double of
-            // tests/stubs/rccl_stub.cpp, which exercises this path on a one-GPU box; real RCCL would refuse in ncclCommInitAll)
-            if (devs[(size_t)j] == devs[(size_t)i] && !getenv("RSRL_RCCL_ALLOW_SHARED_DEVICE"))
+            // (a collectives library that admits ranks sharing a device says so by exporting `rccl_stub_allows_shared_device` -- the test double of
+            // tests/stubs/rccl_stub.cpp, LD_PRELOADed, which exercises this path on a one-GPU box; real RCCL has no such symbol and the check stands)
+            if (devs[(size_t)j] == devs[(size_t)i] && !dlsym(RTLD_DEFAULT, "rccl_stub_allows_shared_device"))
                 return fail(RSRL_HIP_EINVAL, "RCCL needs one device per rank: ctxs %d and %d share device %d (use RSRL_EXCHANGE_PEER)", j, i, devs[(size_t)i]);
     }
     std::vector<ncclComm_t> comms((size_t)n, nullptr);
@@ -3027,6 +3057,31 @@ int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps) {
         return RSRL_HIP_OK;
     }
     // RCCL: lock-step, the all-reduces of a batch-step grouped
+    if (is_sparse_lambda(ctxs[0]->cfg)) {
+        // the lambda agents over a shared tile table step their own kernels (sparse traces): their halves in lock-step, the float delta all-reduced between
+        for (int64_t j = 0; j < n_steps; ++j) {
+            for (int i = 0; i < n; ++i) {
+                rsrl_hip_ctx* c = ctxs[i];
+                HIP_TRY(hipSetDevice(c->cfg.device));
+                c->tq_valid = false; c->q_valid = false;
+                TRY(sparse_lambda_half_a(c, make_common(c), make_geom(c), nullptr));
+            }
+            NCCL_TRY(ncclGroupStart());
+            for (int i = 0; i < n; ++i) {
+                rsrl_hip_ctx* c = ctxs[i];
+                HIP_TRY(hipSetDevice(c->cfg.device));
+                NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
+            }
+            NCCL_TRY(ncclGroupEnd());
+            for (int i = 0; i < n; ++i) {
+                rsrl_hip_ctx* c = ctxs[i];
+                HIP_TRY(hipSetDevice(c->cfg.device));
+                TRY(sparse_lambda_half_b(c, make_common(c), make_geom(c), nullptr));
+                c->t += 1;
+            }
+        }
+        return RSRL_HIP_OK;
+    }
     std::vector<Common> ks((size_t)n);
     for (int i = 0; i < n; ++i) {
         rsrl_hip_ctx* c = ctxs[i];

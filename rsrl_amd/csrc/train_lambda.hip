@@ -2,6 +2,7 @@
 #include "launch.hpp"
 #include "kernels_lambda.hpp"
 #include "kernels_lambda_mem.hpp"
+#include <cstdlib>
 namespace rsrl {
 
 #define RSRL_LAMBDA_CASE(DM, OR, AL, PO)                                                                      \
@@ -38,6 +39,8 @@ bool launch_lambda_model(const rsrl_hip_config& cfg, dim3 grid, dim3 block, hipS
     if (cfg.domain == DM) {                                                                                                          \
         using M = FourierGenericModel<DM>;                                                                                           \
         if (from) hipLaunchKernelGGL((k_handle_lambda_mem<M>), grid, block, 0, st, k, lp, g, from, act, rew, to, termf, Mn, t, td_out); \
+        else if (!getenv("RSRL_LAMBDA_MEM1"))        /* four threads per learner: 64 learners per block (RSRL_LAMBDA_MEM1=1: the one-thread form, A/B) */ \
+            hipLaunchKernelGGL((k_train_lambda_mem4<M>), dim3((unsigned)((k.n_envs + 63) / 64)), dim3(256), 0, st, k, lp, g, t, chunk, stats);                \
         else hipLaunchKernelGGL((k_train_lambda_mem<M>), grid, block, 0, st, k, lp, g, t, chunk, stats);                             \
         return true;                                                                                                                 \
     }

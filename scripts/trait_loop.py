@@ -68,6 +68,18 @@ def measure(n_envs=65536, steps=400, warmup=50, device=0, steps_per_launch=0, pe
     out = {"learners": N, "steps": steps, "us_per_batch_step": dt / steps * 1e6, "value": N * steps / dt, "unit": "env-steps/s",
            "calls_per_step": len(calls), "algorithmic_bytes_per_env_step": ALG_BYTES_LOOP,
            "frac_of_8TBps": ALG_BYTES_LOOP * N * steps / dt / 8.0e12}
+    # HIP events around every launch of the trait kernels, in a run of its own (two event records per launch cost host time).  For these ~8 us kernels
+    # the interval between the two events of a launch includes its dispatch latency (~2-3 us): an upper bound of the kernel's duration, which
+    # rocprofv3's kernel trace gives exactly (profiles/r06_kernel_stats_trait.md)
+    ctx.timing_enable(True)
+    run(min(steps, 200))
+    ms, n_l, kn = ctx.timing_read()
+    ctx.timing_enable(False)
+    out["kernel"] = kn
+    out["hip_event_launches"] = n_l
+    out["hip_event_us_per_batch_step"] = ms * 1e3 / max(1, min(steps, 200))
+    out["hip_event_covers"] = ("the one fused launch per batch-step, dispatch latency included" if kn.endswith("<step>") else
+                               "handle + sample only (k_domain_step / k_domain_reset are not bracketed), dispatch latency included")
     if per_call:
         host_t = [0.0] * len(calls)
         ctx.sync()

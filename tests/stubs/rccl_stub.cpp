@@ -166,4 +166,6 @@ int rccl_stub_log(char* out, int n) {
     return len;
 }
 void rccl_stub_log_clear(void) { std::lock_guard<std::mutex> l(mu); log_text.clear(); }
+// capability probe (dlsym from rsrl_hip_group_create): this library admits ranks that share a device
+int rccl_stub_allows_shared_device(void) { return 1; }
 }

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(abi):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rsrl_hip.h but not exported"
     assert sorted(abi.SYMBOLS) == names, "python binding table and header drifted apart"
-    assert L.rsrl_hip_abi_version() == 8
+    assert L.rsrl_hip_abi_version() == 9
 
 
 def test_config_struct_layout_and_defaults(abi):
@@ -222,3 +222,30 @@ def test_campaign_scripts_compile():
     assert len(files) >= 4
     for f in files:
         py_compile.compile(f, doraise=True)
+
+
+def test_rust_binding_block_is_the_header(abi):
+    """INTEGRATION.md's `rsrl-hip-sys` block (it declared 45 of the 65 exports and claimed to mirror the header one to one): generated from the
+    header by scripts/gen_rust_sys.py, and held here to (1) the header in the tree, (2) the symbols the shared library exports -- every one declared, nothing
+    else --, (3) the arity of the ctypes binding every test drives, (4) the layout of the two structs."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("gen_rust_sys", os.path.join(ROOT, "scripts", "gen_rust_sys.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    block = gen.doc_block()
+    assert block == gen.generate(), "INTEGRATION.md's Rust block is stale: python scripts/gen_rust_sys.py --write"
+    decl = dict(gen.declared_functions(block))
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "rsrl_amd", "lib", "librsrl_hip.so")], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\b(rsrl_hip_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert sorted(decl) == exported == header_symbols()
+    for name, (_, args) in abi.SYMBOLS.items():
+        assert decl[name] == len(args), f"{name}: {decl[name]} parameters in the Rust block, {len(args)} in rsrl_amd/_abi.py"
+    # struct fields: same names, same order, same widths as the ctypes mirror of the C struct
+    width = {"u32": 4, "i32": 4, "i64": 8, "u64": 8, "f64": 8, "*mut c_void": 8}
+    for sname, ct in (("rsrl_hip_config", abi.Config), ("rsrl_hip_stats", abi.Stats)):
+        m = re.search(r"pub struct %s \{(.*?)\n\}" % sname, block, flags=re.S)
+        fields = re.findall(r"pub (\w+): ([^,]+),", m.group(1))
+        names = [{"lambda": "lam"}.get(n, n) for n, _ in fields]
+        assert names == [f[0] for f in ct._fields_], sname
+        assert [width[t.strip()] for _, t in fields] == [C.sizeof(f[1]) for f in ct._fields_], sname

@@ -69,11 +69,17 @@ def test_device_pointer_arguments_equal_host_arguments(name):
         ok(L.rsrl_hip_set_weights(d._h, 0, ptr(w2)))
         h.set_weights(w2.cpu().numpy(), 0)
         assert np.array_equal(d.get_weights(0), h.get_weights(0))
-        # set_states / set_actions from device memory: out-of-range values are CLAMPED (a host array would be refused)
-        bad_s = ds.clone(); bad_s[0, 0] = float("inf"); bad_a = da.clone(); bad_a[0] = 77
-        ok(L.rsrl_hip_set_states(d._h, ptr(bad_s))); ok(L.rsrl_hip_set_actions(d._h, ptr(bad_a)))
+        # set_states from device memory: the array is checked ON the device by the host path's rule (ABI 9; it used to be clamped silently, NaN passing) --
+        # a non-finite / far-out-of-range component refuses the call and leaves the ctx's states untouched; set_actions clamps a device array (no host copy)
+        before = d.states
+        for bad in (float("inf"), float("nan"), 1e30):
+            bad_s = ds.clone(); bad_s[0, 0] = bad
+            assert L.rsrl_hip_set_states(d._h, ptr(bad_s)) == -1 and b"device array of states" in L.rsrl_hip_last_error()
+            assert np.array_equal(d.states, before)
+        bad_a = da.clone(); bad_a[0] = 77
+        ok(L.rsrl_hip_set_actions(d._h, ptr(bad_a)))
         d.sync()
-        assert np.isfinite(d.states).all() and 0 <= d.actions[0] < A
+        assert 0 <= d.actions[0] < A
         ok(L.rsrl_hip_set_states(d._h, ptr(dnxt))); ok(L.rsrl_hip_set_actions(d._h, ptr(da)))
         h.states, h.actions = nxt_h, h.actions
         for c in (h, d):

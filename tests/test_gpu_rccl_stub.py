@@ -35,9 +35,12 @@ G, mode, kind = int(os.environ["G"]), os.environ["MODE"], os.environ["KIND"]
 N = 4000 if os.environ.get("RAGGED") else 4096                      # ragged: shards of 500 learners, not whole 512-learner blocks
 if kind == "dense":
     kw = dict(domain=0, order=5, algo=0, policy=1, epsilon=0.1, gamma=0.9, weight_mode=1, seed=0, max_episode_steps=200, lr=0.001 / N, exchange=ra.EXCHANGE_RCCL)
-else:
+elif kind == "tile":
     kw = dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=1, policy=1, epsilon=0.1, gamma=0.99, weight_mode=1, seed=0, max_episode_steps=200,
               lr=0.1 / 8 / N, exchange=ra.EXCHANGE_RCCL)
+else:                                                                 # SARSALambda / QLambda over the shared table: sparse per-learner traces (ADVICE r5)
+    kw = dict(domain=1, basis=1, n_tilings=8, tiles_per_dim=8, algo=3 if kind == "sarsa_lambda" else 4, policy=1, epsilon=0.1, gamma=0.99, weight_mode=1, seed=0,
+              max_episode_steps=200, alpha=0.1 / 8 / N, lam=0.9, trace=0, exchange=ra.EXCHANGE_RCCL)
 from rsrl_amd.distributed import shard_range
 shards = [shard_range(N, G, r) for r in range(G)]
 ctxs = [ra.Context(n_envs=cnt, env_offset=off, **kw) for off, cnt in shards]
@@ -92,7 +95,7 @@ def _run(tmp_path, G, mode, kind, ragged=False):
     script = tmp_path / "rccl_stub_run.py"
     script.write_text(SCRIPT)
     env = dict(os.environ, RSRL_ROOT=ROOT, RCCL_STUB=stub, LD_PRELOAD=stub, G=str(G), MODE=mode, KIND=kind, RSRL_NO_GRAPH="1",
-               RSRL_RCCL_ALLOW_SHARED_DEVICE="1", GPU_MAX_HW_QUEUES=str(2 * G))
+               GPU_MAX_HW_QUEUES=str(2 * G))
     if ragged:
         env["RAGGED"] = "1"
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
@@ -100,7 +103,7 @@ def _run(tmp_path, G, mode, kind, ragged=False):
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
 
 
-@pytest.mark.parametrize("kind,ragged", [("dense", False), ("dense", True), ("tile", False)])
+@pytest.mark.parametrize("kind,ragged", [("dense", False), ("dense", True), ("tile", False), ("sarsa_lambda", False), ("q_lambda", True)])
 def test_single_thread_group_of_8_ranks_groups_every_all_reduce(tmp_path, kind, ragged):
     G, steps = 8, 19
     d = _run(tmp_path, G, "group", kind, ragged)
@@ -110,8 +113,9 @@ def test_single_thread_group_of_8_ranks_groups_every_all_reduce(tmp_path, kind, 
         assert d["err_w"] == 0.0 and d["states_same"] == 1.0, d       # whole 512-learner blocks per rank + exact 64-bit sums across ranks: sharded == unsharded
     elif kind == "dense":
         assert d["err_w"] <= 1e-6 * max(1.0, d["absw"]) and d["states_same"] >= 0.99, d   # other splits regroup the fp32 block sums (test_gpu_multirank)
-    else:
-        assert d["err_w"] <= 2e-6 * max(1.0, d["absw"]) and d["states_same"] >= 0.99, d   # float delta: the summation order over ranks differs
+    else:                                                              # (the lambda agents over the shared table step their sparse-trace kernels in lock-step:
+        assert d["err_w"] <= 2e-6 * max(1.0, d["absw"]) and d["states_same"] >= 0.99, d   # the single-step kernel's TD rule would learn something else)
+        # float delta: the summation order over ranks differs
     # ---- the protocol: per batch-step one group with one in-place all-reduce per rank, ranks 0..G-1, and nothing outside a group
     log = [ln for ln in d["log"] if not ln.startswith("CommDestroy")]
     assert log.count("GroupStart") == steps and sum(ln.startswith("GroupEnd rc=0") for ln in log) == steps, log[:40]

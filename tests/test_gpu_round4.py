@@ -367,10 +367,16 @@ def test_bench_two_ranks_on_one_gpu_has_no_error_leg(tmp_path, ranks):
     # ranks = 8: the world size of a node (the largest ever exercised was 4 in-process / 2 processes): eight processes share the one
     # device, the peer group of eight decides collectively which kernels fit it, hop 2 fans out to eight hipIpc-mapped receive buffers
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--allow-oversubscribe", "--envs", "4096", "--steps", "20", "--warmup", "5",
-                        "--region-seconds", "0.2", "--regions", "3"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+                        "--region-seconds", "0.2", "--regions", "3", "--detail", str(tmp_path / "detail.json")], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=str(tmp_path))
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert p.returncode == 0 and lines, (p.stdout[-1500:], p.stderr[-3000:])
-    d = json.loads(lines[-1])
+    # the driver's line: the LAST stdout line, one compact JSON object (round 5's 24 KB line could not be parsed); the full record is the detail file
+    line = json.loads(lines[-1])
+    assert len(lines[-1]) < 8192 and line["value"] > 0 and line["n_gpus"] == 1 and "roofline" in line and "cpu_baseline" in line
+    assert line["legs"]["shared_w"]["value"] > 0 and line["detail"].endswith("detail.json")
+    d = json.load(open(tmp_path / "detail.json"))
+    assert d["value"] == pytest.approx(line["value"], rel=1e-5)
     assert d["ranks_seen"] == ranks and d["n_gpus"] == 1 and "oversubscribed" in d and d["value"] > 0
     assert [r["rank"] for r in d["per_rank"]] == list(range(ranks)) and all(r["kernel_us_per_batch_step"] > 0 and r["device"] == 0 for r in d["per_rank"])
     assert len({r["device_identity"] for r in d["per_rank"]}) == 1
