@@ -1240,7 +1240,8 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
     int64_t N = run->n_envs, i, k;
     R *phi_s, *phi_n, *tmp;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
-    if (FN(eps_sched)(ag)) return -1;
+    if (FN(eps_sched)(ag) && !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL || ORC_IS_LAMBDA(ag->algo)))
+        return -1;                   /* the schedule on the wave family: one-step agents and the lambda agents (k_train_wave / _pk <ESCHED>, k_wave_lambda) */
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
           (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z) || (ag->algo == ORC_GREEDY_GQ && !w_bf16 && run->Z) ||
@@ -1251,6 +1252,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
         R* s = run->state + (size_t)i * D; R* W = FN(run_W)(run, i);
         R q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS], ns[8], ns_pre[8];
         int a = run->action[i]; uint32_t ep = run->ep_step[i];
+        orc_agent agl = FN(agent_of)(run, i); const orc_agent* ag = &agl;          /* (shadows: learner i's own epsilon, when scheduled) */
         FN(wave_project)(b, s, phi_s);
         for (j = 0; j < A; j++) q_s[j] = q_n[j] = (R)0.0;
         for (j = 0; j < AW; j++) q_s[j] = FN(wave_dot)(phi_s, W, AW, j);
@@ -1363,6 +1365,7 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
             }
             q_n[a] = FN(wave_dot)(phi_n, W, A, a);                          /* Q(s',a) with the UPDATED column */
 sampled_target:
+            if (term || trunc) { FN(eps_episode_end)(run, i); agl = FN(agent_of)(run, i); }      /* examples/sarsa_lambda.rs:68: the episode's last handle is done */
             orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, term ? ORC_BLK_RESET : ORC_BLK_STEP, x);
             na = FN(orc_policy_sample)(ag->policy, q_n, A, ag->eps_thr, (R)ag->tau, x);
             acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;

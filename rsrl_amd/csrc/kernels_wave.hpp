@@ -316,9 +316,11 @@ enum : uint32_t { BLK_SR_BASE = 16 };   // stochastic-rounding draws: block = 16
 // ---------------------------------------------------------------------------------------
 // fused driver loop, one wave per learner (semantics identical to k_train_reg)
 // ---------------------------------------------------------------------------------------
-template <int DOMAIN, class WT>
+template <int DOMAIN, class WT, bool ESCHED = false>
 __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict__ Wbase, uint64_t t0, int n_steps,
                                                        DevStats* __restrict__ stats) {
+    // ESCHED: the per-learner epsilon schedule (Common::eps; examples/sarsa_lambda.rs:68) -- an instantiation of its own, as for k_train_reg: the
+    // learner is the wave's, so its epsilon stays wave-uniform (scalar registers) and the schedule-free loop is not one instruction longer
     using WF = WaveFourier<DOMAIN>;
     using Dom = Domain<DOMAIN>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
@@ -345,6 +347,8 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
         float q_s[A];
         WF::stream_project_q(s, lane, P0, w, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
+        PolicyParams pol = c.pol;
+        if constexpr (ESCHED) learner_eps_load(c, i, pol);
 
         auto one_step = [&](const float* __restrict__ Ps, float* __restrict__ Pn, uint64_t t) {
             float ns[D];
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e, lane);
+            const float delta = td_dispatch<A>(c.alg, (ESCHED && c.apol_same) ? pol : c.apol, q_s, a, q_n, r, term, xin, e, lane);
             const float scale = c.alg.lr * e;
             U4 rnd = U4{0, 0, 0, 0};
             if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
@@ -375,7 +379,8 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
             const U4 x = draw(c.seed, gid, t, BLK_STEP);
-            int na = policy_sample<A>(c.pol, q_n, x, lane);
+            if constexpr (ESCHED) learner_eps_step(c, term | trunc, pol);       // the episode's last handle is done: its end decays epsilon
+            int na = policy_sample<A>(pol, q_n, x, lane);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
             if (trunc) {
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
                 Dom::reset(ns);
                 WF::stream_project_q(ns, lane, Pn, w, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr, lane);
+                na = policy_sample<A>(pol, q_n, xr, lane);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_train_wave(Common c, WT* __restrict_
             for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
             c.action[i] = a;
             c.ep_step[i] = ep;
+            if constexpr (ESCHED) c.eps[i] = pol.eps;
             sum_abs = (double)facc_abs; sum_r = (double)facc_r;
         } else {
             n_ep = 0; n_trunc = 0; sum_len = 0;                      // the wave's statistics are counted once (lane 0)
@@ -524,7 +530,7 @@ struct WaveFourierPk : WaveFourier<DOMAIN> {
 #ifndef RSRL_EXP_STAGGER
 #define RSRL_EXP_STAGGER 0
 #endif
-template <int DOMAIN>
+template <int DOMAIN, bool ESCHED = false>
 __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* __restrict__ Wbase, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
     using WF = WaveFourierPk<DOMAIN>;
     using Dom = Domain<DOMAIN>;
@@ -565,6 +571,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             WF::put_all(P, t0);
         }
         float facc_abs = 0.0f, facc_r = 0.0f;
+        PolicyParams pol = c.pol;
+        if constexpr (ESCHED) learner_eps_load(c, i, pol);          // (k_train_wave: the learner's epsilon is wave-uniform)
         for (int k = 0; k < n_steps; ++k) {
             const uint64_t t = t0 + (uint64_t)k;
             // the step's Philox blocks depend on nothing but (learner, t): drawn FIRST, their integer work sits in the same basic block as the
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             U4 xin = U4{0, 0, 0, 0};
             if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
             float e;
-            const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e, lane);
+            const float delta = td_dispatch<A>(c.alg, (ESCHED && c.apol_same) ? pol : c.apol, q_s, a, q_n, r, term, xin, e, lane);
             const float scale = c.alg.lr * e;
             float qa = 0.0f;
             static_for<0, A>([&](auto Bb) {
@@ -596,7 +604,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             });
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa : q_n[b];
-            int na = policy_sample<A>(c.pol, q_n, x, lane);
+            if constexpr (ESCHED) learner_eps_step(c, term | trunc, pol);
+            int na = policy_sample<A>(pol, q_n, x, lane);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
             if (trunc) {
@@ -605,7 +614,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
                 WF::project_q(ns, lane, wp, q_n, tn);
                 WF::put_all(P, tn);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr, lane);
+                na = policy_sample<A>(pol, q_n, xr, lane);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
@@ -623,6 +632,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
             for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
             c.action[i] = a;
             c.ep_step[i] = ep;
+            if constexpr (ESCHED) c.eps[i] = pol.eps;
             sum_abs = (double)facc_abs; sum_r = (double)facc_r;
         } else {
             n_ep = 0; n_trunc = 0; sum_len = 0;                      // the wave's statistics are counted once (lane 0)
@@ -646,7 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_wave_reset(Common c, const WT* __res
     WF::project(s, lane, phi);
     WF::template q_from_mem<WT>(Wbase + i * (int64_t)(A * F), lane, phi, q);
     const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INIT);
-    const int a = policy_sample<A>(c.pol, q, x);
+    PolicyParams pol = c.pol;
+    learner_eps_load(c, i, pol);                     // per-learner epsilon, when configured (a reset is not an episode end: no decay)
+    const int a = policy_sample<A>(pol, q, x);
     if (lane == 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * c.n_envs + i] = s[d];
@@ -685,7 +697,9 @@ __global__ __launch_bounds__(kBlock) void k_wave_qop(Common c, const WT* __restr
     if (lane != 0 && !is_sample) return;
     if (is_sample) {                        // (the softmax path may spread its exponentials over lanes: every lane evaluates)
         const U4 x = draw(c.seed, (uint32_t)(c.env_offset + i), call, op == QOP_SAMPLE ? BLK_API : (op == QOP_SAMPLE_STEP ? BLK_STEP : BLK_INIT));
-        const int a = policy_sample<A>(c.pol, q, x);
+        PolicyParams pol = c.pol;
+        learner_eps_load(c, i, pol);                 // item i is evaluated with learner i's policy object (qop_finish)
+        const int a = policy_sample<A>(pol, q, x);
         if (lane == 0) iout[i] = a;
         return;
     }
@@ -717,7 +731,9 @@ __global__ __launch_bounds__(kBlock) void k_wave_handle(Common c, WT* __restrict
     U4 xin = U4{0, 0, 0, 0};
     if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_INNER);
     float e;
-    const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+    PolicyParams apol = c.apol;
+    if (c.apol_same) learner_eps_load(c, i, apol);              // the agent shares the behaviour policy object: this learner's epsilon (k_handle)
+    const float delta = td_dispatch<A>(c.alg, apol, q_s, a, q_n, r, term, xin, e);
     const float scale = c.alg.lr * e;
     U4 rnd = U4{0, 0, 0, 0};
     if constexpr (WaveIO<WT>::kBf16) rnd = draw(c.seed, (uint32_t)(c.env_offset + i), t, BLK_SR_BASE + (uint32_t)lane);

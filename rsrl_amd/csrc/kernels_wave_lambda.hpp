@@ -59,6 +59,9 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
         WF::project(s, lane, phi_s);
         WF::template q_from_mem<float>(Wi, lane, phi_s, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
+        // the per-learner epsilon schedule (Common::eps, examples/sarsa_lambda.rs:68): the learner is the wave's, its epsilon wave-uniform
+        PolicyParams pol = c.pol;
+        learner_eps_load(c, i, pol);
         for (int k = 0; k < (driver ? n_steps : 1); ++k) {
             const uint64_t t = t0 + (uint64_t)k;
             float ns[D], r;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
             U4 xin = U4{0, 0, 0, 0};
             if (sarsa) xin = draw(c.seed, gid, t, BLK_INNER);                  // the agent's own draw (sarsa_lambda.rs:78)
             float e;
-            const float delta = td_error<A>(alg, c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
+            const float delta = td_error<A>(alg, (c.eps && c.apol_same) ? pol : c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e);
             const float scale = lp.alpha * delta;
             // ---- the fused sweep: trace, weights, and Q(s', .) with the updated weights
 #pragma unroll
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
             }
             if (!driver) { if (lane == 0 && td_out) td_out[i] = delta; break; }
             const U4 x = draw(c.seed, gid, t, BLK_STEP);
-            int na = policy_sample<A>(c.pol, q_n, x);
+            if (c.eps) learner_eps_step(c, term | trunc, pol);                 // the episode's last handle is done: its end decays epsilon
+            int na = policy_sample<A>(pol, q_n, x);
             facc_abs += fabsf(delta); facc_r += r;
             if (term) { n_ep += 1; sum_len += ep; ep = 0; }
             if (trunc) {                                                       // step cap: new episode; the trace is NOT reset
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
                 WF::project(ns, lane, phi_n);
                 WF::template q_from_mem<float>(Wi, lane, phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
-                na = policy_sample<A>(c.pol, q_n, xr);
+                na = policy_sample<A>(pol, q_n, xr);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = ns[d];
@@ -138,6 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
             for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
             c.action[i] = a;
             c.ep_step[i] = ep;
+            if (c.eps) c.eps[i] = pol.eps;
             sum_abs = (double)facc_abs; sum_r = (double)facc_r;
         } else {
             n_ep = 0; n_trunc = 0; sum_len = 0;

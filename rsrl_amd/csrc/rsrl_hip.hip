@@ -865,11 +865,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         // the kernels that run the schedule: k_train_reg<.., ESCHED>, k_train_lambda, k_train_mem
         const bool reg = cfg->basis == RSRL_FOURIER && !is_wave(*cfg) && !is_generic_fourier(*cfg);
         const bool one_step = cfg->algo == RSRL_QLEARNING || cfg->algo == RSRL_SARSA || cfg->algo == RSRL_EXPECTED_SARSA || cfg->algo == RSRL_PAL;
+        // (round 6: + the order-7 wave family -- k_train_wave / k_train_wave_pk <.., ESCHED>, k_wave_lambda -- f32 and bf16)
         const bool ok = cfg->policy == RSRL_EPSILON_GREEDY && cfg->weight_mode == RSRL_W_PER_ENV && cfg->steps_per_launch != 1 &&
-                        ((reg && (one_step || is_lambda(cfg->algo))) || (!reg && !is_wave(*cfg) && one_step));
+                        (((reg || is_wave(*cfg)) && (one_step || is_lambda(cfg->algo))) || (!reg && !is_wave(*cfg) && one_step));
         if (!ok) return fail(RSRL_HIP_EINVAL, "epsilon_decay (the per-learner epsilon schedule) needs policy = EpsilonGreedy, per-learner weights, steps_per_launch != 1 and "
-                                              "a one-step agent or SARSALambda / QLambda on a register-family Fourier basis, or a one-step agent on tile coding / a "
-                                              "generic Fourier order");
+                                              "a one-step agent or SARSALambda / QLambda on a register-family or order-7 wave-family Fourier basis, or a one-step agent on "
+                                              "tile coding / a generic Fourier order");
     }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
@@ -902,7 +903,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     c->dw_elems = (size_t)c->Aw * c->F;
     c->n_stat_slots = is_wave(*cfg) ? wave_grid_for(N) : (c->k1_quad ? (size_t)((N + 63) / 64) : grid_for(N));     // one statistics slot per thread block
     if ((is_lambda(cfg->algo) || is_pred(cfg->algo)) && cfg->basis == RSRL_TILE_CODING) c->n_stat_slots = (size_t)N;      // ... and there a block is a learner
-    if (is_lambda(cfg->algo) && is_generic_fourier(*cfg)) c->n_stat_slots = (size_t)((N + 63) / 64);                        // k_train_lambda_mem4: 64 learners per block
+    if (is_lambda(cfg->algo) && is_generic_fourier(*cfg) && !is_wave(*cfg)) c->n_stat_slots = (size_t)((N + 63) / 64);     // k_train_lambda_mem4: 64 learners per block
     HIP_TRY(hipMalloc((void**)&c->state, sizeof(float) * c->D * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->action, sizeof(int32_t) * (size_t)N));
     HIP_TRY(hipMalloc((void**)&c->ep_step, sizeof(uint32_t) * (size_t)N));
@@ -2498,10 +2499,16 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             const bool pk = wave_pk && c->cfg.weight_dtype == RSRL_W_BF16;
             for_wave(c, [&](auto tag) {
                 using T = decltype(tag); using WT = typename T::wt;
+                const dim3 wg(wave_grid_for(k.n_envs)), wb(kBlock);
                 if constexpr (WaveIO<WT>::kBf16) {
-                    if (pk) { hipLaunchKernelGGL((k_train_wave_pk<T::domain>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats); return; }
+                    if (pk) {
+                        if (k.eps) hipLaunchKernelGGL((k_train_wave_pk<T::domain, true>), wg, wb, 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);      // the per-learner epsilon schedule
+                        else hipLaunchKernelGGL((k_train_wave_pk<T::domain>), wg, wb, 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
+                        return;
+                    }
                 }
-                hipLaunchKernelGGL((k_train_wave<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
+                if (k.eps) hipLaunchKernelGGL((k_train_wave<T::domain, WT, true>), wg, wb, 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
+                else hipLaunchKernelGGL((k_train_wave<T::domain, WT>), wg, wb, 0, c->stream, k, (WT*)c->W, c->t, chunk, d_stats);
             });
             c->kernel_name = pk ? "k_train_wave_pk" : "k_train_wave";
             KCHECK();

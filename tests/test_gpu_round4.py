@@ -116,7 +116,7 @@ def test_epsilon_schedule_api(ra, tmp_path):
         assert np.allclose(p.min(axis=0), e / 3, rtol=1e-6)
     for bad in (dict(epsilon_decay=0.0), dict(epsilon_decay=1.5), dict(epsilon_decay=0.9, epsilon_min=-1.0),
                 dict(epsilon_decay=0.9, policy=0), dict(epsilon_decay=0.9, weight_mode=1), dict(epsilon_decay=0.9, steps_per_launch=1, algo=0),
-                dict(epsilon_decay=0.9, algo=6, lr_td=0.01), dict(epsilon_decay=0.9, algo=0, domain=2, order=7)):
+                dict(epsilon_decay=0.9, algo=6, lr_td=0.01), dict(epsilon_decay=0.9, algo=6, lr_td=0.01, domain=2, order=7)):      # (round 6: the one-step and lambda agents run it on the wave family)
         with pytest.raises(ra.RsrlHipError):
             ra.Context(**{**dict(n_envs=8, policy=1), **bad})
 
