@@ -187,27 +187,10 @@ __device__ __forceinline__ void sincospi01_x2(f2 x, f2& sn, f2& cs) {
     quadrant_select((int)q.y, s.y, c.y, s1, c1);
     sn = f2{s0, s1}; cs = f2{c0, c1};
 }
-// {a[SA], b[SB]}: a register pair assembled from halves of two others by ONE v_pk_mov_b32 (D.lo = S0[op_sel[0]], D.hi = S1[op_sel[1]]);
-// the compiler spells the same build_vector as two v_mov_b32.  A move: the same bits.
-// MEASURED AND SWITCHED OFF (round 4): nine instructions fewer per env-step in k_train_reg (14 v_mov -> 5 v_pk_mov), and 1 % SLOWER on the
-// same box (9.38-9.43e10 against 9.48-9.53e10): a lone wave issues a packed instruction every ~5.2 cycles and a plain one every ~3.4, so
-// one packed move buys little over two plain ones, and the asm statements pin the schedule.  -DRSRL_PK_MOV=1 builds it (bitwise either way).
-#ifndef RSRL_PK_MOV
-#define RSRL_PK_MOV 0
-#endif
+// {a[SA], b[SB]}: a register pair assembled from halves of two others (two v_mov_b32; the one-instruction v_pk_mov_b32 spelling measured 1 % slower
+// in k_train_reg, round 4: scripts/ab/round6_pruned_knobs.patch)
 template <int SA, int SB>
-__device__ __forceinline__ f2 pk_pick(f2 a, f2 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && RSRL_PK_MOV
-    f2 r;
-    if constexpr (SA == 0 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,0]" : "=v"(r) : "v"(a), "v"(b));
-    else if constexpr (SA == 0 && SB == 1) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    else if constexpr (SA == 1 && SB == 0) asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(r) : "v"(a), "v"(b));
-    else asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return f2{SA ? a.y : a.x, SB ? b.y : b.x};
-#endif
-}
+__device__ __forceinline__ f2 pk_pick(f2 a, f2 b) { return f2{SA ? a.y : a.x, SB ? b.y : b.x}; }
 // sin(x), cos(x) for |x| <= 100: Cody-Waite reduction by pi/2 (two-term, fma), polynomials on [-pi/4, pi/4]
 __device__ __forceinline__ void sincos_cw(float x, float& sn, float& cs) {
     const float n = rintf(x * 0.6366197466850281f);
@@ -338,9 +321,6 @@ template <> struct Domain<1> {
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r, const Pre&) { return step(s, a, r); }
     __device__ static __forceinline__ bool step(float (&s)[D], int a, float& r) {
         constexpr float TW = (float)(kPi / 15.0);
-#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 2)          // A/B builds only: no RK4
-        s[0] += 0.001f * (float)a; s[2] += 0.0001f; r = 0.0f; return s[0] > 2.4f;
-#endif
         const float force = (a == 0) ? -10.0f : 10.0f;                 // ALL_ACTIONS (:26)
         auto grad = [force](const float (&y)[4], float (&out)[4]) {    // CartPole::grad (:52-72)
             constexpr float G = 9.8f, FOUR_THIRDS = (float)(4.0 / 3.0);
