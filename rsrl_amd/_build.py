@@ -170,7 +170,7 @@ def _compile_filtered(base, src, obj, verbose):
 
 def build(force=False, verbose=False, out=None, extra_flags=()):
     """Compile every HIP source (in parallel) and link rsrl_amd/lib/librsrl_hip.so.
-    out / extra_flags build an A/B variant (e.g. -DRSRL_RANK1_QPOST=1) next to the product library."""
+    out / extra_flags build an A/B variant (e.g. -DRSRL_DOT_SPLIT=2) next to the product library."""
     if out is not None:
         return _build_to(out, list(extra_flags), verbose)
     if not force and not is_stale():

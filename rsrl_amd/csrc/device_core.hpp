@@ -451,10 +451,7 @@ __device__ __forceinline__ uint32_t argmaxima_mask(const float (&q)[A]) {
     // iff q[0] >= -FLT_MAX (not NaN, not -inf) and the running max becomes max(q[0], -FLT_MAX) either way
     // (v_med3_f32 with +inf: fmaxf's value for every input, NaN included -- the median of three returns min3 when an operand is NaN --
     // without the canonicalising v_max_f32 x, x the compiler puts in front of fmaxf when x comes out of a bitwise select)
-#ifndef RSRL_MED3_ARGMAX
-#define RSRL_MED3_ARGMAX 1
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && RSRL_MED3_ARGMAX
+#if defined(__HIP_DEVICE_COMPILE__)
     float mx = __builtin_amdgcn_fmed3f(q[0], -FLT_MAX, __builtin_inff());
 #else
     float mx = fmaxf(q[0], -FLT_MAX);
@@ -576,10 +573,7 @@ __device__ __forceinline__ int policy_sample(const PolicyParams& pp, const float
     switch (pp.kind) {
     case POL_GREEDY: return greedy_sample<A>(q, x.z);
     case POL_EGREEDY: {
-#ifndef RSRL_EGREEDY_FUSED
-#define RSRL_EGREEDY_FUSED 1
-#endif
-        if constexpr (YZ && (RSRL_EGREEDY_FUSED != 0)) {
+        if constexpr (YZ) {
             const uint32_t m0 = argmaxima_mask<A>(q);
             const bool explore = (x.x >> 8) < pp.eps_thr;
             const uint32_t mask = (explore | (m0 == 0u)) ? ((1u << A) - 1u) : m0;

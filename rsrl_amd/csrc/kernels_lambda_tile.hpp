@@ -18,12 +18,9 @@
 
 namespace rsrl {
 
-#ifndef RSRL_LT_NT
-#define RSRL_LT_NT 3          // non-temporal loads (1) and stores (2) in the table sweep: a learner's 1 MiB comes back a whole batch-step later
-                              // (2 048 CartPole learners, env-steps/s: 0 -> 5.8-5.9e6, 1 -> 5.99e6, 2 -> 5.87e6, 3 -> 6.15-6.23e6; about one
-                              // process in four runs 15-20 % slower with byte-identical code -- where its 1 GiB of tables landed --:
-                              // scripts/gpu_exp_lt_nt.sh)
-#endif
+// The table sweep uses non-temporal loads AND stores: a learner's 1 MiB comes back a whole batch-step later (2 048 CartPole learners, env-steps/s:
+// plain 5.8-5.9e6, loads nt 5.99e6, stores nt 5.87e6, both 6.15-6.23e6; about one process in four runs 15-20 % slower with byte-identical code --
+// where its 1 GiB of tables landed).
 
 // from == nullptr: the driver loop, n_steps batch-steps of learner blockIdx.x.  Otherwise Handler::handle on ONE caller-supplied
 // transition per learner (teacher forcing), Mn learners.
@@ -102,24 +99,14 @@ __global__ __launch_bounds__(BLOCK) void k_lambda_tile(Common c, BasisGeom g, La
         }
         __syncthreads();                                        // every gather of W above precedes every store below
         for (int j = tid * 4; j < FA; j += BLOCK * 4) {
-#if RSRL_LT_NT & 1
             const f4 z4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(Zl + j));
             f4 w4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(Wl + j));
-#else
-            const f4 z4 = *reinterpret_cast<const f4*>(Zl + j);
-            f4 w4 = *reinterpret_cast<const f4*>(Wl + j);
-#endif
             f4 zz;
             zz.x = trace_merge(lp.trace, rate_eff, z4.x, 0.0f); zz.y = trace_merge(lp.trace, rate_eff, z4.y, 0.0f);
             zz.z = trace_merge(lp.trace, rate_eff, z4.z, 0.0f); zz.w = trace_merge(lp.trace, rate_eff, z4.w, 0.0f);
             w4.x = fmaf(scale, zz.x, w4.x); w4.y = fmaf(scale, zz.y, w4.y); w4.z = fmaf(scale, zz.z, w4.z); w4.w = fmaf(scale, zz.w, w4.w);
-#if RSRL_LT_NT & 2
             __builtin_nontemporal_store(w4, reinterpret_cast<f4*>(Wl + j));
             __builtin_nontemporal_store(term ? f4{0.0f, 0.0f, 0.0f, 0.0f} : zz, reinterpret_cast<f4*>(Zl + j));
-#else
-            *reinterpret_cast<f4*>(Wl + j) = w4;
-            *reinterpret_cast<f4*>(Zl + j) = term ? f4{0.0f, 0.0f, 0.0f, 0.0f} : zz;
-#endif
         }
         __syncthreads();
         if (tid < T) {

@@ -38,11 +38,6 @@
 
 #include "models.hpp"
 
-// A/B builds only (scripts/gpu_exp_persist.sh): bit 0 = no exchange (W frozen), bit 1 = no MFMA chain, bit 2 = no learner work
-#ifndef RSRL_PERSIST_ABLATE
-#define RSRL_PERSIST_ABLATE 0
-#endif
-
 namespace rsrl {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -141,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
         bool term = false, trunc = false;
         typename M::Feat fn;
         float ns[D];
-        if (member && !(RSRL_PERSIST_ABLATE & 4)) {
+        if (member) {
             float q_s[A];
             M::q_all_lds(sh_w, fs, q_s);
             if (do_c) a = policy_sample<A>(c.pol, q_s, x_c);            // ---- phase C of batch-step t-1: policy.sample with W_t
@@ -161,8 +156,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
         }
         if (!do_a) break;
         // ---- block-level sum of the learners' terms: k_shared_step's MFMA rank-1 chains, wave by wave (models.hpp)
-        if (RSRL_PERSIST_ABLATE & 2) { if (lane < F) for (int bb = 0; bb < A; ++bb) part[wave][bb * F + lane] = scale; }
-        else wave_rank1_sum<A, F>(tile[wave], lane, scale, fs.phi, member, a, part[wave]);
+        wave_rank1_sum<A, F>(tile[wave], lane, scale, fs.phi, member, a, part[wave]);
         __syncthreads();
         // ---- hop 1, publish: thread p stores the block's quantised sums of entries 2p, 2p+1 with one 16-byte sc1 store
         const uint64_t xs = xs0 + (uint64_t)j;                          // exchange sequence number: tags and parity (only ever grows)
@@ -188,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
         }
         // ---- in the shadow of the exchange (the totals need two fabric hops, ~3 us): everything of the next batch-step that depends
         //      neither on W_{t+1} nor on the next action -- the episode restart, phi(s') as the next phi(s), the draws, the statistics
-        if (member && !(RSRL_PERSIST_ABLATE & 4)) {
+        if (member) {
             const bool done = term || trunc;
             sum_abs += (double)fabsf(delta); sum_r += (double)r;
             if (done) { n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; }
@@ -201,7 +195,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_persist(Common c, BasisGeom g,
         }
         // ---- hop 1, reduce: this block owns pairs b, b + nb, ...; thread jj polls half jj & 1 of source block jj >> 1
         bool ok = true;
-        if (RSRL_PERSIST_ABLATE & 1) { __syncthreads(); continue; }
         for (int p = b; p < PAIRS; p += nb) {
             long long wv = 0;
             for (int jj = tid; jj < 2 * nb; jj += BLOCK) {

@@ -411,26 +411,6 @@ __device__ __forceinline__ float expected_value(const float (&q)[A], const float
 //  * the loop is unrolled by two with ping-pong phi buffers (no phi(s) <- phi(s') moves).
 // All A columns are written once at the end of the launch (one batch-step per launch is k_step_reg / k_step_reg_lm).
 // ---------------------------------------------------------------------------------------
-#ifndef RSRL_RANK1_QPOST
-#define RSRL_RANK1_QPOST 1
-#endif
-#ifndef RSRL_ACTION_MASKS
-#define RSRL_ACTION_MASKS 1
-#endif
-#ifndef RSRL_LOOP_ENTRY_WAIT
-#define RSRL_LOOP_ENTRY_WAIT 1
-#endif
-#ifndef RSRL_K1_STORE_ALL
-#define RSRL_K1_STORE_ALL 1
-#endif
-#ifndef RSRL_K1_LDS_DMA
-#define RSRL_K1_LDS_DMA 1          // the single-step kernels load their images with buffer_load ... lds (0: through registers + ds_write;
-                                   // k_step_reg_lm 7.91 -> 7.76 us per launch at 65 536 learners, 35.3 -> 34.3 at 262 144)
-#endif
-#ifndef RSRL_K1_SECTOR_STORE
-#define RSRL_K1_SECTOR_STORE 2     // k_step_reg_lm writes the touched column back as whole 64-byte sectors: 2 = four consecutive lanes per
-                                   // sector (default), 1 = each lane its own three sectors (A/B: slower), 0 = the 144 bytes directly
-#endif
 
 // Registers: __launch_bounds__(kBlock, 2) = at most 256 per lane, so a launch of more than 1024 waves (> 65 536 learners) runs
 // TWO waves per SIMD: a lone wave issues one VALU instruction per ~3.4 cycles (packed fma 5.2, v_mad_u64 8, v_cndmask 8.4), two
@@ -493,11 +473,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
         }
         typename Dom::Pre pre_s = Dom::pre(s);
         float facc_abs = 0.0f, facc_r = 0.0f;       // fp32 partial sums, flushed to f64 every launch
-#if RSRL_LOOP_ENTRY_WAIT
         // every load of the prologue retires HERE: otherwise the compiler, which sees the weight loads pending on the loop's entry edge
         // only, places their waits at the first uses INSIDE the loop -- ~19 s_waitcnt per pair of steps that wait for nothing
         __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
-#endif
 
         // x = this batch-step's behaviour-policy draw, xin = the agent's own (SARSA): halves of Philox blocks shared by two steps
         auto one_step = [&](const Phi& phi_s, Phi& phi_n, const U4& x, const U4& xin) {
@@ -515,13 +493,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             { float ph[F]; Bas::project(ns, ph); phi_n.set(ph); }
             w.q(phi_n, q_n);
             // ---- handle: delta with the PRE-update weights
-#if RSRL_ACTION_MASKS
             static_assert(A <= 3, "ActionMask covers three actions");
             const ActionMask am(a);
             const float qsa = A > 2 ? bitsel(am.m2, q_s.v2, bitsel(am.m1, q_s.v1, q_s.v0)) : bitsel(am.m1, q_s.v1, q_s.v0);
-#else
-            const float qsa = q_s.at(a);
-#endif
             const float q_s_all[3] = {q_s.v0, q_s.v1, q_s.v2};
             float e;
             float delta;
@@ -537,30 +511,16 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_reg(Common c, uint64_t t0, 
             const float scale = alg.lr * e;
             {
                 float sb[A];
-#if RSRL_ACTION_MASKS
 #pragma unroll
                 for (int b = 0; b < A; ++b) sb[b] = and_mask(am.of(b), scale);
-#else
-#pragma unroll
-                for (int b = 0; b < A; ++b) sb[b] = (a == b) ? scale : 0.0f;
-#endif
                 w.axpy(sb, phi_s);
             }
             // ---- policy.sample with the UPDATED weights (at s', or at s0 after a terminal transition)
-#if RSRL_RANK1_QPOST
             {   // W changed by a rank-1 term in column a only: Q_post[a] = Q_pre[a] + scale * <phi(s), phi(s')>
                 const float dot = Phi::dot(phi_s, phi_n);
-#if RSRL_ACTION_MASKS
 #pragma unroll
                 for (int b = 0; b < A; ++b) q_n[b] = bitsel(am.of(b), fmaf(scale, dot, q_n[b]), q_n[b]);
-#else
-#pragma unroll
-                for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
-#endif
             }
-#else
-            w.q(phi_n, q_n);
-#endif
             if constexpr (ESCHED) learner_eps_step(c, term | trunc, pol);        // the episode's last handle is done: its end decays epsilon
             int na = policy_sample<A, true>(pol, q_n, x);               // (x is a half block: y == z)
             facc_abs += fabsf(delta);
@@ -730,7 +690,6 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
         }
         // ---- Q(s',.) with the UPDATED weights: only column a changed
         {
-#if RSRL_RANK1_QPOST
             float dacc[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
@@ -739,9 +698,6 @@ __global__ __launch_bounds__(kBlock) void k_step_reg(Common c, uint64_t t, DevSt
             const float dot = combine_partials<P>(dacc);
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
-#else
-            q_from_reg<A, F>(wv, phi_n, q_n);
-#endif
         }
         int na = policy_sample<A>(pol, q_n, x);
         sum_abs = (double)fabsf(delta); sum_r = (double)r;
@@ -818,19 +774,11 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
     // the image: AF4 coalesced 16-B loads per lane, all in flight ...
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef int i4 __attribute__((ext_vector_type(4)));
-#if RSRL_K1_LDS_DMA
     // straight into the wave's LDS image (buffer_load_dwordx4 ... lds: wave-uniform LDS base + lane * 16): no staging registers,
     // no ds_write pass; beyond the end of W the descriptor returns zeros
 #pragma unroll
     for (int m = 0; m < AF4; ++m)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + 64 * 4 * m), 16, lane * 16, 64 * 16 * m, 0, 0);
-#else
-    f4 ld[AF4];
-#pragma unroll
-    for (int m = 0; m < AF4; ++m)
-        ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * m) * 16, 0, 0));
-#endif
-#if RSRL_K1_SECTOR_STORE == 2
     // where this lane will store in the write-back of the touched columns (see below): piece (g & 3) of sector t of learner j's
     // column -- known from the actions alone, so the lane exchange runs here, under the loads
     constexpr int NSEC = (48 + F * 4 + 63) / 64;                        // sectors a 16-byte-aligned column can touch
@@ -843,7 +791,6 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             wb_off[p] = __builtin_amdgcn_ds_bpermute(j * 4, sec) + 64 * t + 16 * (g & 3);
         }
     }
-#endif
 
     // ... and everything that needs only the state runs underneath them: the transition, both projections, the draws
     PolicyParams pol = c.pol; pol.kind = POLICY;
@@ -864,12 +811,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
     const U4 x = draw(c.seed, gid, t, BLK_STEP);
 
     // transpose through LDS: linear 16-B writes, then each lane reads its own learner's A*F weights
-#if RSRL_K1_LDS_DMA
     __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): the issuing wave's covering wait orders its ds_reads
-#else
-#pragma unroll
-    for (int m = 0; m < AF4; ++m) *reinterpret_cast<f4*>(img + (lane + 64 * m) * 4) = ld[m];
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // the image is private to this wave: no block barrier
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -909,13 +851,8 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             v.x = fmaf(scale, phi_s[4 * k], o.x); v.y = fmaf(scale, phi_s[4 * k + 1], o.y);
             v.z = fmaf(scale, phi_s[4 * k + 2], o.z); v.w = fmaf(scale, phi_s[4 * k + 3], o.w);
             vcol[4 * k] = v.x; vcol[4 * k + 1] = v.y; vcol[4 * k + 2] = v.z; vcol[4 * k + 3] = v.w;
-#if RSRL_K1_SECTOR_STORE
             *reinterpret_cast<f4*>(colp + 4 * k) = v;                     // merged into the wave's image, written back below
-#else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, 0);
-#endif
         }
-#if RSRL_K1_SECTOR_STORE
         // The touched column goes back as WHOLE 64-byte sectors: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and
         // what the memory side is slow at is a store instruction that scatters 64 separate 16-byte pieces (scripts/ubench/
         // stream_pattern.hip: read 432 + write 144 per learner, no arithmetic, 6.2 us per launch at 65 536 learners; 4.7 us with the
@@ -931,27 +868,15 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
             static_assert((64 * AF * 4) % 64 == 0, "no sector is shared between two waves' images");
-#if RSRL_K1_SECTOR_STORE == 2
             // four consecutive lanes store one sector: every store instruction writes 16 whole sectors
 #pragma unroll
             for (int p = 0; p < 4 * NSEC; ++p) {
                 const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + (wb_off[p] & 0xffff));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, wb_off[p], 0, 0);
             }
-#else
-            constexpr int NSEC = (48 + F * 4 + 63) / 64;                    // sectors a 16-byte-aligned column can touch
-            const int sec = i < N ? (((lane * AF + a * F) * 4) & ~63) : 0x40000000;       // invalid learner: out of the descriptor's range
-#pragma unroll
-            for (int p = 0; p < 4 * NSEC; ++p) {
-                const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + ((sec + 16 * p) & 0xffff));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, sec + 16 * p, 0, 0);
-            }
-#endif
         }
-#endif
         // ---- Q(s',.) with the UPDATED weights: only column a changed
         {
-#if RSRL_RANK1_QPOST
             float dacc[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) dacc[p] = 0.0f;
@@ -960,14 +885,6 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_lm(Common c, uint64_t t, De
             const float dot = combine_partials<P>(dacc);
 #pragma unroll
             for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? fmaf(scale, dot, q_n[b]) : q_n[b];
-#else
-            { float one[1][F]; float qa[1];
-#pragma unroll
-              for (int f = 0; f < F; ++f) one[0][f] = vcol[f];
-              q_from_reg<1, F>(one, phi_n, qa);
-#pragma unroll
-              for (int b = 0; b < A; ++b) q_n[b] = (a == b) ? qa[0] : q_n[b]; }
-#endif
         }
         int na = policy_sample<A>(pol, q_n, x);
         sum_abs = (double)fabsf(delta); sum_r = (double)r;

@@ -21,16 +21,8 @@
 
 namespace rsrl {
 
-#ifndef RSRL_Q4_AUX_LD
-#define RSRL_Q4_AUX_LD 0          // cache-policy bits of the image loads / column stores; A/B: 2 = nt is SLOWER at every size (loads nt
-                                  // 13.3 vs 9.8 us at 65 536 learners -- W lives in L2 / MALL between launches --, both nt 331 vs 168 at 1 M)
-#endif
-#ifndef RSRL_Q4_AUX_ST
-#define RSRL_Q4_AUX_ST 0
-#endif
-#ifndef RSRL_Q4_SECTOR_STORE
-#define RSRL_Q4_SECTOR_STORE 1
-#endif
+// (cache-policy bits of the image loads / column stores stay 0: nt is SLOWER at every size -- loads nt 13.3 vs 9.8 us at 65 536 learners, W lives in
+// L2 / MALL between launches; both nt 331 vs 168 at 1 M)
 
 template <int J>
 __device__ __forceinline__ float quad_bcast(float x) {                  // lane J of every quad, to the quad's four lanes
@@ -75,16 +67,9 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
         qc1 = c.qcache[N + il];
         if constexpr (A > 2) qc2 = c.qcache[2 * N + il];
     }
-#if RSRL_K1_LDS_DMA
 #pragma unroll
     for (int m = 0; m < NLD; ++m)         // straight into the wave's LDS image (wave-uniform LDS base + lane * 16); beyond the image: zeros into the pad
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + 64 * 4 * m), 16, lane * 16, 64 * 16 * m, 0, RSRL_Q4_AUX_LD);
-#else
-    f4 ld[NLD];
-#pragma unroll
-    for (int m = 0; m < NLD; ++m)
-        ld[m] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (lane + 64 * m) * 16, 0, RSRL_Q4_AUX_LD));
-#endif
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(img + 64 * 4 * m), 16, lane * 16, 64 * 16 * m, 0, 0);
 
     PolicyParams pol = c.pol; pol.kind = POLICY;
     AlgoParams alg = c.alg; alg.kind = ALGO;
@@ -103,13 +88,7 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
     if constexpr (ALGO == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
     const U4 x = draw(c.seed, gid, t, BLK_STEP);
 
-#if RSRL_K1_LDS_DMA
     __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): the issuing wave's covering wait orders its ds_reads
-#else
-#pragma unroll
-    for (int m = 0; m < NLD; ++m)
-        if (m + 1 < NLD || lane + 64 * m < IMG4) *reinterpret_cast<f4*>(img + (lane + 64 * m) * 4) = ld[m];
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // the image is private to this wave: no block barrier
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -153,14 +132,9 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
             v.x = fmaf(scale, phi_s[4 * k], wcol[0][4 * k]); v.y = fmaf(scale, phi_s[4 * k + 1], wcol[0][4 * k + 1]);
             v.z = fmaf(scale, phi_s[4 * k + 2], wcol[0][4 * k + 2]); v.w = fmaf(scale, phi_s[4 * k + 3], wcol[0][4 * k + 3]);
             wcol[0][4 * k] = v.x; wcol[0][4 * k + 1] = v.y; wcol[0][4 * k + 2] = v.z; wcol[0][4 * k + 3] = v.w;
-#if RSRL_Q4_SECTOR_STORE
             *reinterpret_cast<f4*>(img + q * AF + bc * F + 4 * k) = v;                   // merged into the wave's image, written back below
-#else
-            if (i < N) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, col_off + 16 * k, 0, RSRL_Q4_AUX_ST);
-#endif
         }
     }
-#if RSRL_Q4_SECTOR_STORE
     // The touched column goes back as WHOLE 64-byte sectors, one store instruction per sector with the quad's four lanes writing
     // its four 16-byte pieces: F*4 = 144 bytes at a 16-byte-aligned offset dirty three sectors, and a partially written sector is a
     // read-modify-write for the memory side (scripts/ubench/stream_pattern.hip: read 432 + write 144 per learner, no arithmetic,
@@ -185,11 +159,10 @@ __global__ __launch_bounds__(kBlock) void k_step_reg_q4(Common c, uint64_t t, De
             if (p < n_st) {
                 const int off = sec + 64 * p + 16 * b;
                 const f4 v = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(img) + off);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, RSRL_Q4_AUX_ST);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), rs, off, 0, 0);
             }
         }
     }
-#endif
     // ---- Q(s',.) with the UPDATED weights: only column a changed (rank-1 term, as k_step_reg_lm)
     {
         float dacc[P];

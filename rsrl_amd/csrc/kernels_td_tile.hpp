@@ -13,10 +13,6 @@
 
 namespace rsrl {
 
-#ifndef RSRL_TDT_NT
-#define RSRL_TDT_NT 0         // A/B: non-temporal accesses in TDLambda's table sweep
-#endif
-
 template <int DOMAIN, int T>
 __device__ __forceinline__ float v_tile(const float* __restrict__ wl, const typename TileModel<DOMAIN, T>::Feat& ft) {
     float acc = 0.0f;
@@ -90,24 +86,14 @@ __global__ __launch_bounds__(BLOCK) void k_td_tile(Common c, BasisGeom g, TdPara
         __syncthreads();                                        // every gather of w above precedes every store below
         if (lambda) {
             for (int j = tid * 4; j < F; j += BLOCK * 4) {
-#if RSRL_TDT_NT
-                const f4 z4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(zl + j));
-                f4 w4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wl + j));
-#else
                 const f4 z4 = *reinterpret_cast<const f4*>(zl + j);
                 f4 w4 = *reinterpret_cast<const f4*>(wl + j);
-#endif
                 f4 zz;
                 zz.x = trace_merge(tp.trace, tp.rate, z4.x, 0.0f); zz.y = trace_merge(tp.trace, tp.rate, z4.y, 0.0f);
                 zz.z = trace_merge(tp.trace, tp.rate, z4.z, 0.0f); zz.w = trace_merge(tp.trace, tp.rate, z4.w, 0.0f);
                 w4.x = fmaf(td, zz.x, w4.x); w4.y = fmaf(td, zz.y, w4.y); w4.z = fmaf(td, zz.z, w4.z); w4.w = fmaf(td, zz.w, w4.w);
-#if RSRL_TDT_NT
-                __builtin_nontemporal_store(w4, reinterpret_cast<f4*>(wl + j));
-                __builtin_nontemporal_store(term ? f4{0.0f, 0.0f, 0.0f, 0.0f} : zz, reinterpret_cast<f4*>(zl + j));
-#else
                 *reinterpret_cast<f4*>(wl + j) = w4;
                 *reinterpret_cast<f4*>(zl + j) = term ? f4{0.0f, 0.0f, 0.0f, 0.0f} : zz;
-#endif
             }
             __syncthreads();
         }

@@ -527,9 +527,6 @@ struct WaveFourierPk : WaveFourier<DOMAIN> {
     }
 };
 
-#ifndef RSRL_EXP_STAGGER
-#define RSRL_EXP_STAGGER 0
-#endif
 template <int DOMAIN, bool ESCHED = false>
 __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* __restrict__ Wbase, uint64_t t0, int n_steps, DevStats* __restrict__ stats) {
     using WF = WaveFourierPk<DOMAIN>;
@@ -540,10 +537,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_train_wave_pk(Common c, bf16_t* _
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
     unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
     double sum_abs = 0.0, sum_r = 0.0;
-#if RSRL_EXP_STAGGER
-    // A/B hook (off): the two waves of a SIMD start half a step apart, so that one's packed-fma passes meet the other's scalar phases
-    { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); if (hw & 1u) { for (int z = 0; z < RSRL_EXP_STAGGER; ++z) __builtin_amdgcn_s_sleep(127); } }
-#endif
     if (i < N) {
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;

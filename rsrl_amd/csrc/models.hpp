@@ -169,23 +169,6 @@ struct TileModel {
     __device__ static __forceinline__ void q_all(const Common& c, int64_t wi, const BasisGeom& g, const Feat& ft, float (&q)[A]) {
 #pragma unroll
         for (int b = 0; b < A; ++b) q[b] = 0.0f;
-#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 1)          // A/B builds only: no gathers
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int b = 0; b < A; ++b) q[b] = q[b] + (float)(ft.idx[t] + b) * 1e-6f;
-        return;
-#endif
-#if defined(RSRL_TILE_ABLATE) && (RSRL_TILE_ABLATE & 4)          // A/B builds only (timing of a folded apply): one 64-bit table entry gathered and converted per weight
-        {
-            const long long* __restrict__ tab = reinterpret_cast<const long long*>(c.qcache);
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int b = 0; b < A; ++b) q[b] = q[b] + (c.W[widx(c, wi, g, ft.idx[t], b)] + (float)tab[(int64_t)ft.idx[t] * A + b] * 1e-9f);
-            return;
-        }
-#endif
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -245,7 +228,7 @@ struct TileModel {
         for (int t = 0; t < T; ++t) iout[(int64_t)t * Mn + i] = ft.idx[t];
     }
     // Device-wide form (rsrl_hip_handle on a shared table; the driver loop when a tiling's slice does not fit LDS): the learner's
-    // term as ONE integer, added to its T entries with device atomics -- the same integers block_accumulate adds through LDS.
+    // term as ONE integer, added to its T entries with device atomics -- the same integers k_tile_scatter adds through LDS.
     __device__ static __forceinline__ void accumulate(long long* __restrict__ fx, const BasisGeom&, const Feat& ft, int a, float scale,
                                                       bool valid, float inv_lsb) {
         if (!valid) return;
@@ -253,44 +236,15 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) fx_add(&fx[ft.idx[t] * A + a], term);
     }
-    // Block-level form for the shared-W driver loop: each tiling's slice of the delta table (cells*A entries) is privatised
-    // in LDS -- an LDS atomic from every learner of the block, a sweep of the slice, then ONE device atomic per touched entry
-    // instead of one per learner.  The sweep is paid per block and tiling whatever the number of learners, so the shared-W
-    // driver runs this with 1024-learner blocks (DESIGN.md 4.3b has the measured ladder).
-    // The LDS accumulators are 64-bit FIXED-POINT integers, not floats: ds_add_f32 retires ONE LANE PER ~3 CYCLES whatever the
-    // addresses are (193 cycles per wave-instruction even for 64 conflict-free addresses, profiles/r02_ubench_lds_atomic.txt),
-    // ds_add_u64 costs 6 cycles for distinct addresses and 2 per duplicate of the most crowded one.  A term lr*e is scaled by
-    // the power of two 1/lsb (exact) and rounded to an integer: the block's sum is then EXACT and order-independent, and
-    // converting it back rounds once (in k_apply_rep).  lsb = 2^(floor(log2 lr) - 28): |e| up to 2^12 and 2^20 learners on one entry fit 63 bits;
-    // a term keeps its full 24-bit mantissa down to |e| = 2^-4 and an absolute resolution of lr * 2^-28 below that.
-    // `slice` is dynamic LDS of 2 x cells*A 64-bit words (two slices), zero on entry and left zero on exit.  All threads of the block must call.
-    // The device-wide delta table is fixed-point too (dW64: n_rep copies of cells*T*A 64-bit words): the sum over the
-    // whole batch is then EXACT whatever the order of the atomics -- the update W += fl(sum * lsb) is bitwise reproducible
-    // from run to run and restated exactly by the oracle (tests: bit-identical weights).
-    __device__ static __forceinline__ void block_accumulate(long long* __restrict__ dW64, long long* __restrict__ slice, const BasisGeom& g,
-                                                            const Feat& ft, int a, float scale, bool valid, float inv_lsb) {
-        const int S = (g.F / T) * A;                                    // entries per tiling
-        const unsigned long long term = valid ? fx_quantise(scale, inv_lsb) : 0ull;
-        // two slices in ping-pong (slice + S): tiling t+1 accumulates into one while tiling t's is swept -- one barrier per
-        // tiling instead of two
-        auto add = [&](int t, long long* sl) {
-            // (no in-wave folding of equal keys: a wave's 64 learners sit in ~46 distinct entries of a tiling with at most ~5 on
-            // one of them -- measured with the oracle on this configuration -- so ds_add_u64 costs ~6 + 2*5 cycles per wave as is)
-            if (valid) atomicAdd(reinterpret_cast<unsigned long long*>(&sl[(ft.idx[t] - t * (g.F / T)) * A + a]), term);
-        };
-        add(0, slice);
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            long long* cur = slice + (t & 1) * S;
-            if (t + 1 < T) add(t + 1, slice + ((t + 1) & 1) * S);
-            for (int j = threadIdx.x; j < S; j += blockDim.x) {
-                const long long v = cur[j];
-                if (v != 0) { atomicAdd(reinterpret_cast<unsigned long long*>(&dW64[(int64_t)t * S + j]), (unsigned long long)v); cur[j] = 0; }
-            }
-            __syncthreads();
-        }
-    }
+    // (The driver loop privatises each tiling's slice of the delta table in LDS: k_tile_scatter, rsrl_hip.hip.)  The accumulators are
+    // 64-bit FIXED-POINT integers, not floats: ds_add_f32 retires ONE LANE PER ~3 CYCLES whatever the addresses are (193 cycles per
+    // wave-instruction even for 64 conflict-free addresses, profiles/r02_ubench_lds_atomic.txt), ds_add_u64 costs 6 cycles for distinct
+    // addresses and 2 per duplicate of the most crowded one.  A term lr*e is scaled by the power of two 1/lsb (exact) and rounded to an
+    // integer: the sum is then EXACT and order-independent, and converting it back rounds once (in k_apply_rep).
+    // lsb = 2^(floor(log2 lr) - 28): |e| up to 2^12 and 2^20 learners on one entry fit 63 bits; a term keeps its full 24-bit mantissa
+    // down to |e| = 2^-4 and an absolute resolution of lr * 2^-28 below that.  The device-wide delta table is fixed-point too (dW64:
+    // n_rep copies of cells*T*A 64-bit words): the update W += fl(sum * lsb) is bitwise reproducible from run to run and restated
+    // exactly by the oracle (tests: bit-identical weights).
 };
 
 // Fourier basis of ANY order 1..7 on any domain, one thread per learner, features generated on the fly from the
@@ -642,30 +596,20 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }
 
-// k_shared_ca evaluates the transition of BOTH actions speculatively (see the kernel) for: tile coding, two actions
-template <class M> struct SpecTraits { static constexpr bool value = false; };
-template <int DOMAIN, int T> struct SpecTraits<TileModel<DOMAIN, T>> { static constexpr bool value = Domain<DOMAIN>::A == 2; };
-// MEASURED AND SWITCHED OFF (round 4, 262 144 CartPole learners): one memory round trip less, but 1 174 instead of ~810 instructions per
-// learner-step -- 23.0 -> 26.2 us per batch-step.  The step kernel is issue-bound at its four waves per SIMD, not latency-bound: the
-// speculation costs more than the round trip it hides.  Kept as an A/B build option (-DRSRL_TILE_SPECULATE=1; bitwise either way).
-#ifndef RSRL_TILE_SPECULATE
-#define RSRL_TILE_SPECULATE 0
-#endif
-template <class M> constexpr bool kSpeculate = (RSRL_TILE_SPECULATE != 0) && SpecTraits<M>::value;
-
 // shared weights, phases C(t-1) + A(t) in ONE launch.  Both read the same weights W_t: phase C finishes the previous
 // batch-step (policy.sample with the just-updated weights; finished episodes restart from Domain::default()), phase A
 // runs the transition and takes the TD error of this step against W_t and adds the learner's term lr*e*phi(s) to the
 // mini-batch delta.  phi(s) and Q(s,.) are computed once and serve both phases.  do_c = 0 on the first step of a
 // train call (the previous call already ran its phase C).  The env state becomes s'; flags[i] bit0 = terminal,
 // bit1 = truncated, consumed by the next phase C.
-//   tile coding : per-tiling slice of the delta table privatised in LDS, one device atomic per touched entry into one of
-//                 n_rep copies of the table (k_apply_rep sums them).
+//   tile coding : the learner's term and its T slice-relative entries are handed to k_tile_scatter (per-tiling slice of the delta table
+//                 privatised in LDS, one device atomic per touched entry into one of n_rep copies of the table; k_apply_rep sums them);
+//                 a slice too large for LDS (keys == nullptr): one device atomic per learner and tiling.
 //   (the register-resident dense bases have a kernel of their own, k_shared_step below, and are not launched through this one)
-template <class M, int BLOCK = kBlock>
-__global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW_base,
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uint64_t t, int do_c, float* __restrict__ dW_base,
                                                       uint8_t* __restrict__ flags,
-                                                      DevStats* __restrict__ stats, int lds_slice_floats, int n_rep, int64_t rep_stride,
+                                                      DevStats* __restrict__ stats, int n_rep, int64_t rep_stride,
                                                       const uint64_t* __restrict__ t_dev, uint16_t* __restrict__ keys = nullptr,
                                                       float* __restrict__ terms = nullptr) {
     if (t_dev) t += *t_dev;            // graph replay: the batch-step counter lives on the device, t is the node's offset
@@ -701,44 +645,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         float r = 0.0f; bool term = false;
         typename M::Feat fn;
         float q_n[A];
-        bool spec_done = false;
-        if constexpr (kSpeculate<M>) {
-            // TWO actions (CartPole) and a table in memory: the action of phase C hangs on a gather (Q(s,.) from the shared table), the
-            // transition on the action, Q(s',.) on a SECOND gather -- two dependent memory round trips with the whole RK4 step between
-            // them.  Here the transition and the tile indices are computed for BOTH actions while the first gather is in flight, and
-            // both candidates' gathers go out before the action is known: one round trip instead of two, the extra RK4 step runs in
-            // its shadow.  The taken candidate is exactly what the sequential code computes: the same bits.
-            if (do_c) {
-                float w_s[M::kT][A], w_n[A][M::kT][A];
-                M::gather_shared(c.W, g, fs, w_s);
-                float ns_b[A][D], r_b[A]; bool term_b[A]; typename M::Feat fn_b[A];
-#pragma unroll
-                for (int b = 0; b < A; ++b) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) ns_b[b][d] = s[d];
-                    term_b[b] = M::Dom::step(ns_b[b], b, r_b[b]);
-                    M::features(ns_b[b], g, fn_b[b]);
-                    M::gather_shared(c.W, g, fn_b[b], w_n[b]);
-                }
-                M::sum_gathered(w_s, q_s);
-                const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
-                a = policy_sample<A>(c.pol, q_s, x);                    // ---- phase C of batch-step t-1
-                const bool one = a != 0;                                // ---- phase A of batch-step t: the taken candidate
-#pragma unroll
-                for (int d = 0; d < D; ++d) ns[d] = one ? ns_b[1][d] : ns_b[0][d];
-                r = one ? r_b[1] : r_b[0]; term = one ? term_b[1] : term_b[0];
-#pragma unroll
-                for (int tt = 0; tt < M::kT; ++tt) fn.idx[tt] = one ? fn_b[1].idx[tt] : fn_b[0].idx[tt];
-                float w_sel[M::kT][A];
-#pragma unroll
-                for (int tt = 0; tt < M::kT; ++tt)
-#pragma unroll
-                    for (int b = 0; b < A; ++b) w_sel[tt][b] = one ? w_n[1][tt][b] : w_n[0][tt][b];
-                M::sum_gathered(w_sel, q_n);
-                spec_done = true;
-            }
-        }
-        if (!spec_done) {
         if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s);
         else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fs, q_s);
         else M::q_all(c, 0, g, fs, q_s);
@@ -756,7 +662,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         if constexpr (M::kDense) M::q_all_lds(sh_w, fn, q_n);
         else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fn, q_n);
         else M::q_all(c, 0, g, fn, q_n);
-        }
         ep += 1;
         const bool trunc = !term && cap > 0 && ep >= cap;
         U4 xin = U4{0, 0, 0, 0};
@@ -779,7 +684,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
     }
     if constexpr (!M::kDense) {
         if constexpr (M::kSparse) {
-            extern __shared__ long long tile_slice[];                   // cells*A 64-bit fixed-point accumulators when the host could afford it
             if (keys) {
                 // the scatter has a kernel of its own (k_tile_scatter): this one hands over, per learner, its term lr*e (rounded to
                 // fixed point there) and the T slice-relative entries it goes to (16 bits each: a slice has at most 8 192 entries)
@@ -790,14 +694,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
                     for (int tt = 0; tt < T; ++tt) keys[(int64_t)tt * N + i] = (uint16_t)((fs.idx[tt] - tt * cells) * A + a);
                     terms[i] = scale;
                 }
-            } else if (lds_slice_floats > 0) {
-                for (int j = threadIdx.x; j < 2 * lds_slice_floats; j += blockDim.x) tile_slice[j] = 0;      // two slices (ping-pong)
-                __syncthreads();
-                // lsb = 2^(floor(log2 |lr|) - 28), an exact power of two (the exponent field of lr, shifted)
-                const uint32_t eb = (__float_as_uint(c.alg.lr) >> 23) & 0xffu;
-                const int ex = (int)(eb < 30u ? 30u : eb) - 28;
-                const float inv_lsb = __uint_as_float((uint32_t)(254 - ex) << 23);
-                M::block_accumulate(fx, tile_slice, g, fs, a, scale, i < N, inv_lsb);
             } else {
                 M::accumulate(fx, g, fs, a, scale, i < N, FxScale(c.alg.lr).inv_lsb);
             }
@@ -806,106 +702,6 @@ __global__ __launch_bounds__(BLOCK) void k_shared_ca(Common c, BasisGeom g, uint
         }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
-}
-
-// ---- Shared tile coding, the step kernel SPLIT in two (round 4; used inside the captured step graph).  k_shared_ca is issue-bound
-// (~810 VALU instructions per learner-step at four waves per SIMD), the scatter and apply launches that follow it are latency-bound
-// (one LDS sweep, a few device atomics, a 2 MB table pass) -- and all three are strictly dependent through the weights.  But most of the
-// step kernel's instructions do not need the weights: the transition (RK4) and the tile indices of the successor depend on the action
-// only, and an action is one of A values.  So:
-//   k_tile_pre (t+1)   for every learner: the restart of a finished episode, the tile indices of s, and -- for EVERY action -- the
-//                      transition, its reward / terminal flag and the successor's tile indices.  Needs the state POST(t) left, no weights:
-//                      it runs on a second stream UNDER scatter(t) + apply(t).
-//   k_tile_post (t+1)  gathers Q(s,.), samples the action (phase C of step t), picks that action's candidate, gathers Q(s',.), takes the TD
-//                      error, hands keys and term to the scatter.  ~250 instructions: the critical path per batch-step becomes
-//                      post + scatter + apply.
-// Candidate b is exactly what k_shared_ca computes when the action is b: same functions, same order -- bit-identical (C3 bitwise tests).
-// STATUS: measured and OFF by default (RSRL_TILE_SPLIT=1 enables it) -- the fork / join per batch-step costs more in the graph runtime
-// than the overlap gains (34.4 us on the GPU's clock, 195 us wall, vs 22.0 us for the linear graph); see rsrl_hip.hip create_impl.
-// 16-bit keys: a tiling has at most 65 536 / A cells on this path (what the scatter kernel's keys need anyway).
-struct TilePre {
-    uint16_t* keys_s;   // [T][N]       slice-relative cell of s per tiling
-    uint16_t* keys_n;   // [A][T][N]    ... of the successor under action b
-    float* ns;          // [A][D][N]    successor under action b (before any restart)
-    float* r;           // [A][N]
-    uint8_t* term;      // [A][N]
-};
-template <class M>
-__global__ __launch_bounds__(kBlock) void k_tile_pre(Common c, BasisGeom g, const uint8_t* __restrict__ flags, TilePre p) {
-    constexpr int D = M::D, A = M::A, T = M::kT;
-    const int64_t N = c.n_envs;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    float s[D];
-    if (flags[i] != 0) M::Dom::reset(s);                          // the episode ended at the previous batch-step: it restarts (as k_shared_ca's phase C does)
-    else load_state<M>(c.state, N, i, s);
-    const int cells = g.F / T;
-    typename M::Feat fs;
-    M::features(s, g, fs);
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) p.keys_s[(int64_t)tt * N + i] = (uint16_t)(fs.idx[tt] - tt * cells);
-#pragma unroll
-    for (int b = 0; b < A; ++b) {
-        float ns[D], r;
-#pragma unroll
-        for (int d = 0; d < D; ++d) ns[d] = s[d];
-        const bool term = M::Dom::step(ns, b, r);
-        typename M::Feat fn;
-        M::features(ns, g, fn);
-#pragma unroll
-        for (int d = 0; d < D; ++d) p.ns[((int64_t)b * D + d) * N + i] = ns[d];
-        p.r[(int64_t)b * N + i] = r;
-        p.term[(int64_t)b * N + i] = term ? 1 : 0;
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt) p.keys_n[((int64_t)b * T + tt) * N + i] = (uint16_t)(fn.idx[tt] - tt * cells);
-    }
-}
-template <class M>
-__global__ __launch_bounds__(kBlock) void k_tile_post(Common c, BasisGeom g, uint64_t t, uint8_t* __restrict__ flags, TilePre p, uint16_t* __restrict__ keys,
-                                                      float* __restrict__ terms, const uint64_t* __restrict__ t_dev) {
-    if (t_dev) t += *t_dev;
-    if (c.dyn) { c.pol = c.dyn->pol; c.apol = c.dyn->apol; }
-    constexpr int D = M::D, A = M::A, T = M::kT;
-    const int64_t N = c.n_envs;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t gid = (uint32_t)(c.env_offset + i);
-    const uint32_t cap = c.max_episode_steps;
-    const int cells = g.F / T;
-    uint32_t ep = flags[i] != 0 ? 0u : c.ep_step[i];
-    int rel_s[T];
-    typename M::Feat fs;
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) { rel_s[tt] = (int)p.keys_s[(int64_t)tt * N + i]; fs.idx[tt] = tt * cells + rel_s[tt]; }
-    float q_s[A];
-    M::q_all_shared(c.W, g, fs, q_s);
-    const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
-    const int a = policy_sample<A>(c.pol, q_s, x);                // ---- phase C of batch-step t-1
-    // ---- phase A of batch-step t: the candidate of the action taken
-    float ns[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) ns[d] = p.ns[((int64_t)a * D + d) * N + i];
-    const float r = p.r[(int64_t)a * N + i];
-    const bool term = p.term[(int64_t)a * N + i] != 0;
-    typename M::Feat fn;
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) fn.idx[tt] = tt * cells + (int)p.keys_n[((int64_t)a * T + tt) * N + i];
-    float q_n[A];
-    M::q_all_shared(c.W, g, fn, q_n);
-    ep += 1;
-    const bool trunc = !term && cap > 0 && ep >= cap;
-    U4 xin = U4{0, 0, 0, 0};
-    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
-    float e;
-    (void)td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
-#pragma unroll
-    for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
-    c.action[i] = a;
-    c.ep_step[i] = ep;
-    flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
-#pragma unroll
-    for (int tt = 0; tt < T; ++tt) keys[(int64_t)tt * N + i] = (uint16_t)(rel_s[tt] * A + a);
-    terms[i] = c.alg.lr * e;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -77,16 +77,8 @@ __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float*
 // block: a sweep per tiling per 1 024 learners, ~300 touched entries each) a block here covers 8x the learners per sweep and
 // per flush: an eighth of the sweeps, a quarter of the device atomics.  The sums are integers: the same table whatever the
 // grouping -- bit-identical to the fused scatter and to the oracle.
-// W_apply != nullptr (single rank, every block of the grid resident): the APPLY is folded into this kernel -- k_apply_rep was a
-// third dependent launch per batch-step (4.7 us for 2 MB of traffic: a kernel boundary plus a handful of dependent loads).  The
-// blocks of ONE tiling meet at that tiling's arrival counter once their flushes have been performed (device atomics execute at
-// the memory side: s_waitcnt vmcnt(0) + barrier, then one arrival per block; the counter only ever grows, a block's round is
-// its own ticket / blocks-per-tiling), then each of them converts and applies its share of the tiling's entries:
-// W += fl(sum of the copies * lsb), copies cleared -- the same integers and the same single rounding as k_apply_rep.
 __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const float* __restrict__ terms, int64_t N, int S,
-                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb,
-                                                       float* __restrict__ W_apply, unsigned long long* __restrict__ arrive, float lsb,
-                                                       uint32_t* __restrict__ err, uint64_t timeout) {
+                                                       int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb) {
     extern __shared__ long long scatter_slice[];
     const int t = blockIdx.y;
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
@@ -117,38 +109,6 @@ __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restric
     for (int j = threadIdx.x; j < S; j += blockDim.x) {
         const long long v = scatter_slice[j];
         if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[j]), (unsigned long long)v);
-    }
-    if (!W_apply) return;
-    // ---- the tiling's blocks meet, then apply
-    __shared__ int go;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's flush atomics have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-        gu64_t* cnt = (gu64_t*)(arrive + (size_t)t * 16);          // one counter per tiling, 128 bytes apart
-        const unsigned long long mine = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (mine / gridDim.x + 1ull) * gridDim.x;
-        const uint64_t t_start = wall_clock64();
-        int ok = 1;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t_start > timeout) { atomicOr(err, 1u); ok = 0; break; }
-        }
-        go = ok;
-    }
-    __syncthreads();
-    if (!go) return;                                               // a block went missing: nothing is applied, the next sync reports it
-    const int per_e = (S + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int j0 = (int)blockIdx.x * per_e, j1 = j0 + per_e < S ? j0 + per_e : S;
-    for (int j = j0 + (int)threadIdx.x; j < j1; j += (int)blockDim.x) {
-        typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-        long long a = 0;
-        for (int r = 0; r < n_rep; ++r) {
-            long long* p = dW64 + (int64_t)r * rep_stride + (int64_t)t * S + j;
-            const long long v = (long long)__hip_atomic_load((gu64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // L2-bypassing: the atomics' result
-            if (v != 0) { a += v; __hip_atomic_store((gu64_t*)p, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        }
-        W_apply[(int64_t)t * S + j] += (float)a * lsb;
     }
 }
 
@@ -337,13 +297,6 @@ struct rsrl_hip_ctx {
     long long* sh_tab = nullptr;     // shared-W dense basis: 3 sets x kTabRep copies of the fixed-point delta table (models.hpp DeltaTab)
     long long* h_fx = nullptr;       // shared W: fixed-point delta table of rsrl_hip_handle (one entry per weight)
     bool tile_slice = false;         // shared tile coding: one tiling's slice (twice, as 64-bit words) fits LDS
-    unsigned long long* tile_arrive = nullptr;     // shared tile coding: one arrival counter per tiling (apply folded into the scatter kernel)
-    // shared tile coding, the step kernel split in two inside the step graph (models.hpp k_tile_pre / k_tile_post)
-    TilePre pre{};                   // what k_tile_pre hands to k_tile_post
-    hipStream_t stream2 = nullptr;   // k_tile_pre runs here, under the scatter + apply of the previous batch-step
-    std::vector<hipEvent_t> split_events;
-    bool split_now = false, split_fork = false;    // set by ensure_step_graph around the capture
-    int split_j = 0;
     uint16_t* sc_keys = nullptr;     // shared tile coding, separate scatter kernel: slice-relative entries [T][N]
     float* sc_terms = nullptr;       //   and terms lr*e [N] handed from the step kernel to k_tile_scatter
     uint64_t sh_tab_t = 0;           // batch-step counter the table rotation is in phase with (the end of the last shared train call)
@@ -742,10 +695,6 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->sh_tab) (void)hipFree(c->sh_tab);
     if (c->h_fx) (void)hipFree(c->h_fx);
     if (c->sc_keys) (void)hipFree(c->sc_keys);
-    for (void* q : {(void*)c->pre.keys_s, (void*)c->pre.keys_n, (void*)c->pre.ns, (void*)c->pre.r, (void*)c->pre.term}) if (q) (void)hipFree(q);
-    for (hipEvent_t e : c->split_events) (void)hipEventDestroy(e);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
-    if (c->tile_arrive) (void)hipFree(c->tile_arrive);
     if (c->sc_terms) (void)hipFree(c->sc_terms);
     if (c->W2) (void)hipFree(c->W2);
     if (c->qs_buf) (void)hipFree(c->qs_buf);
@@ -960,31 +909,16 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     // every learner adds its term to ONE copy with device atomics (same integers, same sum).
     if (shared && cfg->basis == RSRL_TILE_CODING) {
         c->tile_slice = (int64_t)(c->F / cfg->n_tilings) * c->A * 16 <= 128 * 1024;
-        const char* e = getenv("RSRL_TILE_REPLICAS");       // tuning knob.  Scatter fused into the step kernel (RSRL_TILE_FUSED_SCATTER=1), us per batch-step at
-        const bool fused_scatter = getenv("RSRL_TILE_FUSED_SCATTER") != nullptr;       // 262 144 envs: 2: 35.0, 4: 29.7, 8: 28.7, 16: 29.5; separate scatter kernel (the default,
-        int r = e ? atoi(e) : (fused_scatter ? 8 : 4);      // a quarter of the flushes): 1: 25.7, 2: 24.7, 4: 24.1, 8: 24.8, 16: 26.4
+        // copies of the delta table the scatter blocks flush into (RSRL_TILE_REPLICAS tunes it; us per batch-step at 262 144 learners: 1: 25.7,
+        // 2: 24.7, 4: 24.1, 8: 24.8, 16: 26.4).  The scatter fused into the step kernel measured 28.7-35.0: scripts/ab/round6_pruned_knobs.patch
+        const char* e = getenv("RSRL_TILE_REPLICAS");
+        const int r = e ? atoi(e) : 4;
         c->n_rep = !c->tile_slice ? 1 : (r < 1 ? 1 : (r > 16 ? 16 : r));                    // k_apply_rep sums up to 16 copies
         HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
-        if (c->tile_slice && !fused_scatter) {                           // the scatter as a kernel of its own (A/B knob: the fused one)
+        if (c->tile_slice) {                                             // the scatter is a kernel of its own (k_tile_scatter)
             HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
             HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(float) * (size_t)N));
-            // The split step (k_tile_pre / k_tile_post, models.hpp) inside the step graph: MEASURED AND OFF (round 4, 262 144 CartPole learners).
-            // Bit-identical (C3 bitwise tests with RSRL_TILE_SPLIT=1), but a hipGraph with a fork / join per batch-step runs its branches on
-            // separate queues: 34.4 us per batch-step on the GPU's own clock and 195 us wall (the host side of a 32-step, two-stream graph
-            // launch), against 22.0 for the linear three-launch graph.  hipExtAnyOrderLaunch (overlap inside ONE queue) is not supported on
-            // gfx9.  RSRL_TILE_SPLIT=1 keeps it reachable for A/B runs on a later runtime.
-            if (c->own_stream && getenv("RSRL_TILE_SPLIT")) {
-                const size_t Tn = (size_t)cfg->n_tilings, An = (size_t)c->A, Dn = (size_t)c->D;
-                HIP_TRY(hipMalloc((void**)&c->pre.keys_s, sizeof(uint16_t) * Tn * (size_t)N));
-                HIP_TRY(hipMalloc((void**)&c->pre.keys_n, sizeof(uint16_t) * An * Tn * (size_t)N));
-                HIP_TRY(hipMalloc((void**)&c->pre.ns, sizeof(float) * An * Dn * (size_t)N));
-                HIP_TRY(hipMalloc((void**)&c->pre.r, sizeof(float) * An * (size_t)N));
-                HIP_TRY(hipMalloc((void**)&c->pre.term, An * (size_t)N));
-                HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-            }
-            HIP_TRY(hipMalloc((void**)&c->tile_arrive, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings));
-            HIP_TRY(hipMemsetAsync(c->tile_arrive, 0, sizeof(unsigned long long) * 16 * (size_t)cfg->n_tilings, c->stream));
         }
     }
     if (shared) {
@@ -1963,64 +1897,34 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         if (xpart == 0) TRY(exchange_table(c, t));
         return RSRL_HIP_OK;
     }
-    bool fused_apply = false;
     if (xpart != 2 && !for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
-            // tile coding: one tiling's slice of the delta table privatised in LDS when it fits (<= 64 KiB)
-            int slice = 0; size_t lds = 0;
-            if (c->tile_slice) { const int64_t f = (int64_t)(c->F / c->cfg.n_tilings) * c->A; slice = (int)f; lds = (size_t)f * 16; }   // two slices of 64-bit fixed-point accumulators
             float* dwp = reinterpret_cast<float*>(c->dW_rep);
             const int nrep = c->n_rep;
             if constexpr (M::kSparse) {
                 if (c->sc_keys) {
-                    // step kernel (terms + entries per learner) -> scatter kernel: block (chunk, tiling), 8 192 learners per chunk
-                    if (c->split_now) {
-                        // inside the step graph: k_tile_pre of this batch-step has run (under the previous step's scatter + apply)
-                        hipLaunchKernelGGL((k_tile_post<M>), grid, block, 0, c->stream, k, g, t, c->flags, c->pre, c->sc_keys, c->sc_terms, t_dev);
-                        if (c->split_fork) {                             // ... and the next one's starts now, on the second stream
-                            hipEvent_t e_post = c->split_events[(size_t)(2 * c->split_j)], e_pre = c->split_events[(size_t)(2 * c->split_j + 1)];
-                            (void)hipEventRecord(e_post, c->stream);
-                            (void)hipStreamWaitEvent(c->stream2, e_post, 0);
-                            hipLaunchKernelGGL((k_tile_pre<M>), grid, block, 0, c->stream2, k, g, c->flags, c->pre);
-                            (void)hipEventRecord(e_pre, c->stream2);
-                        }
-                    } else
-                    hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, 0, nrep,
+                    // step kernel (terms + entries per learner) -> scatter kernel: block (chunk, tiling), 8 192 learners per chunk, one tiling's slice
+                    // of the delta table (64-bit fixed-point accumulators) in LDS
+                    const int slice = (int)((int64_t)(c->F / c->cfg.n_tilings) * c->A);
+                    hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, nrep,
                                        (int64_t)c->dw_elems, t_dev, c->sc_keys, c->sc_terms);
                     static const int chunks_env = getenv("RSRL_SCATTER_CHUNKS") ? atoi(getenv("RSRL_SCATTER_CHUNKS")) : 32;
                     int64_t per = (k.n_envs + chunks_env - 1) / chunks_env;
                     per = ((per + 1023) / 1024) * 1024;
                     const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
-                    // the apply rides in the scatter kernel when its blocks can meet: single rank, the whole grid resident
-                    // -- measured SLOWER than the third launch (24.4 against 23.7 us per batch-step at 262 144 learners: the wait for the flush
-                    // atomics, the returning arrival and the poll are three fabric round trips; round 2's ticket version: 34.6): A/B knob only
-#ifdef RSRL_AB_KNOBS
-                    fused_apply = !c->multi && getenv("RSRL_TILE_FUSED_APPLY") && chunks * (unsigned)c->cfg.n_tilings <= (unsigned)c->n_cu;
-#endif
+                    // (the apply folded into the scatter kernel -- its blocks meeting at a per-tiling arrival counter -- measured SLOWER than the third
+                    // launch: 24.4 against 23.7 us per batch-step at 262 144 learners; scripts/ab/round6_pruned_knobs.patch)
                     hipLaunchKernelGGL(k_tile_scatter, dim3(chunks, (unsigned)c->cfg.n_tilings), dim3(1024), (size_t)slice * 8, c->stream, c->sc_keys, c->sc_terms,
-                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb,
-                                       fused_apply ? c->W : (float*)nullptr, c->tile_arrive, tile_lsb((float)c->cfg.lr), c->d_peer_err, c->peer_timeout);
-                    return;
-                }
-                // 1024-learner blocks: the per-tiling sweep of the LDS slice is paid per block, not per learner
-                if (slice > 0) {
-                    hipLaunchKernelGGL((k_shared_ca<M, 1024>), dim3((unsigned)((k.n_envs + 1023) / 1024)), dim3(1024), lds, c->stream, k, g, t, do_c, dwp,
-                                       c->flags, d_stats, slice, nrep, (int64_t)c->dw_elems, t_dev);
+                                       (int64_t)k.n_envs, slice, (int)per, c->dW_rep, nrep, (int64_t)c->dw_elems, FxScale((float)c->cfg.lr).inv_lsb);
                     return;
                 }
             }
-            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, lds, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, slice, nrep,
-                               (int64_t)c->dw_elems, t_dev);
+            hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, k, g, t, do_c, dwp, c->flags, d_stats, nrep, (int64_t)c->dw_elems, t_dev);
         })) return NO_MODEL(c);
     KCHECK();
     const int n = (int)c->dw_elems;
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
-#ifdef RSRL_AB_KNOBS
-    static const bool skip_apply = getenv("RSRL_TILE_SKIP_APPLY") != nullptr;      // A/B builds only (-DRSRL_AB_KNOBS): the table is never applied
-#else
-    constexpr bool skip_apply = false;                                 // (the product library has no knob that drops the update)
-#endif
-    if (xpart != 2 && !fused_apply && !skip_apply) {
+    if (xpart != 2) {
         hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
                            tile_lsb((float)c->cfg.lr));
         KCHECK();
@@ -2032,7 +1936,6 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
             KCHECK();
         }
     }
-    if (c->split_now && c->split_fork) HIP_TRY(hipStreamWaitEvent(c->stream, c->split_events[(size_t)(2 * c->split_j + 1)], 0));   // join: the next k_tile_post needs it
     return RSRL_HIP_OK;
 }
 static int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last) {
@@ -2085,25 +1988,9 @@ static int ensure_step_graph(rsrl_hip_ctx* c, const Common& k, const BasisGeom& 
     HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     int rc = RSRL_HIP_OK;
     const int spg = steps_per_graph(c);
-    const bool split = kind == 2 && c->pre.keys_s != nullptr;          // shared tile coding: the step kernel split in two (models.hpp k_tile_pre / _post)
-    if (split) {
-        while (c->split_events.size() < (size_t)(2 * spg)) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(RSRL_HIP_EHIP, "hipEventCreate failed"); break; }
-            c->split_events.push_back(e);
-        }
-        // the first batch-step's k_tile_pre opens the graph on the main stream; every later one forks under the step before it
-        if (rc == RSRL_HIP_OK && !for_model(c, [&](auto tag) {
-                using M = typename decltype(tag)::type;
-                if constexpr (M::kSparse) hipLaunchKernelGGL((k_tile_pre<M>), dim3(grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, g, c->flags, c->pre);
-            })) rc = NO_MODEL(c);
-        c->split_now = true;
-    }
     for (int j = 0; j < spg && rc == RSRL_HIP_OK; ++j) {
-        c->split_fork = split && j + 1 < spg; c->split_j = j;
         rc = kind == 1 ? enqueue_k1_step(c, k, nullptr, (uint64_t)j, c->d_t) : enqueue_shared_step(c, k, g, nullptr, 1, (uint64_t)j, c->d_t);
     }
-    c->split_now = false; c->split_fork = false;
     if (rc == RSRL_HIP_OK) hipLaunchKernelGGL(k_advance_t, dim3(1), dim3(1), 0, c->stream, c->d_t, (uint64_t)spg);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
