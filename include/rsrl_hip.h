@@ -67,9 +67,10 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  *   the 4-D domains with f32 weights (W and the trace streamed from memory every step), or tile coding with one dense trace
  *   table of W's shape per learner -- the reference's traces are generic over the gradient buffer, traces.rs:6-12;
  *   round 5: weight_mode = RSRL_W_SHARED on tile coding -- ONE shared table, every learner its own SPARSE trace as params/sparse.rs:13-97
- *   offers: a list of at most 512 (entry, value) pairs, the entry with the smallest |value| making room once it is full; the table moves by the
+ *   offers: at most 512 (entry, value) pairs, kept as one sub-list of 512 / n_tilings per tiling (n_tilings 4, 8 or 16; a tiling's slice of the
+ *   table, cells * actions, at most 65 536 entries), the entry with the smallest |value| of a full sub-list making room; the table moves by the
  *   synchronous mini-batch rule W += sum_i alpha * residual_i * z_i in exact 64-bit fixed point.  Stepped by rsrl_hip_train only;
- *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists travel with a checkpoint, file version 5)
+ *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists travel with a checkpoint, file version 6)
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights: register-family Fourier bases, the generic Fourier orders, tile coding, and (round 5)
@@ -345,9 +346,12 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* ctx, int64_t env_index, const float* v
  *              if aux_kind is 3 (file version 3): u32 head[N], u32 len[N], f32 entries[D + 5][n_steps][N] -- every learner's
  *              Backup ring {s, a, q, residual, pi, mu} (q_sigma.rs:30-63), so that a QSigma run with n_steps > 1 resumes
  *              bit-identically too.  Files of version 2 (no aux_kind 3) are still read.
- *              if aux_kind is 4 (file version 5; SARSALambda / QLambda over ONE shared tile-coded table): u32 len[N], then for every learner
- *              in turn u32 key[len] (= feature index * A + action) and f32 value[len] -- its sparse trace (params/sparse.rs:13-97), in slot
- *              order, so that the run resumes bit-identically (the slot order decides which entry a full list overwrites).
+ *              if aux_kind is 4 (file version 6; SARSALambda / QLambda over ONE shared tile-coded table): u64 n_envs, u64 env_offset (whose
+ *              learners the lists belong to: a file of another shard is refused as a different configuration), u32 len[N], then for every
+ *              learner in turn u32 key[len] (= feature index * A + action) and f32 value[len] -- its sparse trace (params/sparse.rs:13-97),
+ *              the tilings' sub-lists one after the other, each in slot order, so that the run resumes bit-identically (the slot order decides
+ *              which entry a full sub-list overwrites).  Version 5 (round 5: no n_envs / env_offset, one list per learner) is still read; its
+ *              entries go to the sub-lists of their keys' tilings, and a file with more than 512 / n_tilings entries of one tiling is refused.
  *              A ctx with config.epsilon_decay writes file version 4: everything above, then f32 eps[N], every learner's current
  *              epsilon (the schedule's state), so that a resumed run continues the schedule.
  * load refuses a file whose header does not match the ctx's configuration or whose size is not exactly what the header

@@ -1397,10 +1397,12 @@ sampled_target:
  *   batch-step = the synchronous mini-batch rule of the shared-weight modes: every learner's residual (sarsa_lambda.rs:53-98,
  *   q_lambda.rs:56-99) and trace update against W_t; W_{t+1} = W_t + sum_i (alpha * residual_i) * z_i; a terminal transition empties z_i; then
  *   every learner samples from W_{t+1} and finished episodes restart.
- *   the list: ORC_SPARSE_CAP = 512 (key = tile index * A + action, value) entries per learner.  Per step: (1) every entry
- *   v <- rule(fma(rate, v, hit ? 1 : 0)) with hit = its key is one of the T new keys; (2) new keys not in the list, in tiling order: appended, or --
- *   list full -- written over the entry with the smallest |v| (ties: lowest slot), value rule(fma(rate, 0, 1)); (3) terms (alpha*residual) * v
- *   into the sum (float: 64-bit fixed point, lsb = 2^(floor(log2 alpha) - 28), clamped to +-2^42 -- exact and order-independent).
+ *   the list: ORC_SPARSE_CAP = 512 (key = tile index * A + action, value) entries per learner, held as T sub-lists of 512 / T entries, one per
+ *   tiling (a key belongs to one tiling; round 6: the device updates a learner's trace tiling by tiling inside its scatter kernel).  Per step and
+ *   tiling: (1) every entry v <- rule(fma(rate, v, hit ? 1 : 0)) with hit = its key is the tiling's new key; (2) the new key, if not in the
+ *   sub-list: appended, or -- sub-list full -- written over its entry with the smallest |v| (ties: lowest slot), value rule(fma(rate, 0, 1));
+ *   (3) terms (alpha*residual) * v into the sum (float: 64-bit fixed point, lsb = 2^(floor(log2 alpha) - 28), clamped to +-2^42 -- exact and
+ *   order-independent).
  * Returns -1 for any other configuration. */
 #define ORC_SPARSE_CAP 512
 int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
@@ -1420,7 +1422,7 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
     if (!run->sp_keys) {
         run->sp_keys = (uint32_t*)calloc((size_t)N * ORC_SPARSE_CAP, sizeof(uint32_t));
         run->sp_vals = (R*)calloc((size_t)N * ORC_SPARSE_CAP, sizeof(R));
-        run->sp_len = (int*)calloc((size_t)N, sizeof(int));
+        run->sp_len = (int*)calloc((size_t)N * (size_t)T, sizeof(int));
     }
     fresh = FN(fma_)(rate, (R)0.0, (R)1.0);
     if (ag->trace == ORC_TRACE_SATURATE) { fresh = (fresh < (R)1.0) ? fresh : (R)1.0; fresh = (fresh > (R)-1.0) ? fresh : (R)-1.0; }
@@ -1435,9 +1437,10 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
         memset(dW, 0, sizeof(R) * (size_t)F * A); memset(qacc, 0, sizeof(int64_t) * (size_t)F * A);
         for (i = 0; i < N; i++) {
             R* s = run->state + (size_t)i * D; R* ns = ns_all + (size_t)i * D;
-            uint32_t* K = run->sp_keys + (size_t)i * ORC_SPARSE_CAP; R* V = run->sp_vals + (size_t)i * ORC_SPARSE_CAP; int len = run->sp_len[i];
+            uint32_t* Kl = run->sp_keys + (size_t)i * ORC_SPARSE_CAP; R* Vl = run->sp_vals + (size_t)i * ORC_SPARSE_CAP; int* lens = run->sp_len + (size_t)i * T;
+            const int cap = ORC_SPARSE_CAP / T;
             R r, delta, e_, scale, q_s[ORC_MAX_ACTIONS], q_n[ORC_MAX_ACTIONS]; int a = run->action[i], term, trunc, is[ORC_MAX_TILINGS], in[ORC_MAX_TILINGS];
-            uint32_t nk[ORC_MAX_TILINGS], xin[4] = { 0, 0, 0, 0 }; int found[ORC_MAX_TILINGS]; float sf[8];
+            uint32_t xin[4] = { 0, 0, 0, 0 }; float sf[8];
             memcpy(ns, s, sizeof(R) * D);
             term = FN(orc_domain_step)(ag->domain, ns, a, &r);
             run->ep_step[i] += 1;
@@ -1449,38 +1452,40 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
             orc_tile_indices(b, sf, in);
             for (c = 0; c < A; c++) { q_s[c] = (R)0.0; q_n[c] = (R)0.0; }
             for (tt = 0; tt < T; tt++) for (c = 0; c < A; c++) { q_s[c] = q_s[c] + run->W[(size_t)is[tt] * A + c]; q_n[c] = q_n[c] + run->W[(size_t)in[tt] * A + c]; }
-            if (!sarsa && a != FN(orc_argmax_first)(q_s, A)) len = 0;                    /* Watkins's cut (q_lambda.rs:62-66) */
-            for (tt = 0; tt < T; tt++) { nk[tt] = (uint32_t)is[tt] * (uint32_t)A + (uint32_t)a; found[tt] = 0; }
-            for (e = 0; e < len; e++) {
-                int hit = 0; R v;
-                for (tt = 0; tt < T; tt++) if (K[e] == nk[tt]) { hit = 1; found[tt] = 1; }
-                v = FN(fma_)(rate, V[e], hit ? (R)1.0 : (R)0.0);
-                if (ag->trace == ORC_TRACE_SATURATE) { v = (v < (R)1.0) ? v : (R)1.0; v = (v > (R)-1.0) ? v : (R)-1.0; }
-                V[e] = v;
-            }
-            for (tt = 0; tt < T; tt++) {
-                int slot;
-                if (found[tt]) continue;
-                if (len < ORC_SPARSE_CAP) slot = len++;
-                else {
-                    R best = V[0] < 0 ? -V[0] : V[0]; slot = 0;
-                    for (e = 1; e < ORC_SPARSE_CAP; e++) { const R m = V[e] < 0 ? -V[e] : V[e]; if (m < best) { best = m; slot = e; } }
+            { const int cut = !sarsa && a != FN(orc_argmax_first)(q_s, A);            /* Watkins's cut (q_lambda.rs:62-66) */
+              if (sarsa) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xin);
+              delta = FN(td_from_q)(&tgt, q_s, a, q_n, r, term, xin, &e_);
+              scale = alpha * delta;
+              for (tt = 0; tt < T; tt++) {                                              /* the trace, tiling by tiling */
+                uint32_t* K = Kl + (size_t)tt * cap; R* V = Vl + (size_t)tt * cap; int len = cut ? 0 : lens[tt], found_ = 0;
+                const uint32_t nk_ = (uint32_t)is[tt] * (uint32_t)A + (uint32_t)a;
+                for (e = 0; e < len; e++) {
+                    const int hit = K[e] == nk_; R v;
+                    if (hit) found_ = 1;
+                    v = FN(fma_)(rate, V[e], hit ? (R)1.0 : (R)0.0);
+                    if (ag->trace == ORC_TRACE_SATURATE) { v = (v < (R)1.0) ? v : (R)1.0; v = (v > (R)-1.0) ? v : (R)-1.0; }
+                    V[e] = v;
                 }
-                K[slot] = nk[tt]; V[slot] = fresh;
+                if (!found_) {
+                    int slot;
+                    if (len < cap) slot = len++;
+                    else {
+                        R best = V[0] < 0 ? -V[0] : V[0]; slot = 0;
+                        for (e = 1; e < cap; e++) { const R m = V[e] < 0 ? -V[e] : V[e]; if (m < best) { best = m; slot = e; } }
+                    }
+                    K[slot] = nk_; V[slot] = fresh;
+                }
+                for (e = 0; e < len; e++) {
+                    const R term_ = scale * V[e];
+                    if (fixed) {
+                        float sc = (float)term_ * inv_lsb_f;
+                        sc = sc < -4.398046511104e12f ? -4.398046511104e12f : (sc > 4.398046511104e12f ? 4.398046511104e12f : sc);
+                        qacc[K[e]] += (int64_t)rintf(sc);
+                    } else dW[K[e]] += term_;
+                }
+                lens[tt] = term ? 0 : len;                                              /* trace.reset() */
+              }
             }
-            if (sarsa) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), run->t, ORC_BLK_INNER, xin);
-            delta = FN(td_from_q)(&tgt, q_s, a, q_n, r, term, xin, &e_);
-            scale = alpha * delta;
-            for (e = 0; e < len; e++) {
-                const R term_ = scale * V[e];
-                if (fixed) {
-                    float sc = (float)term_ * inv_lsb_f;
-                    sc = sc < -4.398046511104e12f ? -4.398046511104e12f : (sc > 4.398046511104e12f ? 4.398046511104e12f : sc);
-                    qacc[K[e]] += (int64_t)rintf(sc);
-                } else dW[K[e]] += term_;
-            }
-            if (term) len = 0;                                                           /* trace.reset() */
-            run->sp_len[i] = len;
             acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
         }
         { int j; for (j = 0; j < F * A; j++) run->W[j] += fixed ? (R)((float)qacc[j] * lsb_f) : dW[j]; }
@@ -1509,7 +1514,10 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
 void FN(orc_run_sparse_trace)(void* h, int64_t i, R* out) {
     FN(orc_run)* run = (FN(orc_run)*)h; int e;
     if (!run->sp_keys) return;
-    for (e = 0; e < run->sp_len[i]; e++) out[run->sp_keys[(size_t)i * ORC_SPARSE_CAP + e]] = run->sp_vals[(size_t)i * ORC_SPARSE_CAP + e];
+    { const int T = run->ag.basis.n_tilings, cap = ORC_SPARSE_CAP / T; int tt;
+      for (tt = 0; tt < T; tt++)
+        for (e = 0; e < run->sp_len[(size_t)i * T + tt]; e++)
+            out[run->sp_keys[(size_t)i * ORC_SPARSE_CAP + (size_t)tt * cap + e]] = run->sp_vals[(size_t)i * ORC_SPARSE_CAP + (size_t)tt * cap + e]; }
 }
 
 /* the wave family's initial policy.sample (k_wave_reset): Q(s0,.) in the wave order */

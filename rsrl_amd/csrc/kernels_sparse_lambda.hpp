@@ -12,13 +12,27 @@
 //     then every learner samples its next action from W_{t+1}; finished episodes restart (a step cap does not reset the trace)
 // The sum over learners runs in 64-bit fixed point (lsb = 2^(floor(log2 alpha) - 28), FxScale): exact, order-independent, reproducible.
 //
-// The list.  kSparseCap = 512 entries per learner (the reference's buffer grows without bound; 512 entries are 64 steps of 8 tilings that never
-// revisit a tile -- by then an accumulating trace has decayed to rate^64).  One WAVE per learner: slot s lives in lane s & 63, register s >> 6.
-// Per step, in this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
-//   1. every entry: v <- rule(fma(rate, v, hit ? 1 : 0)), hit = its key is one of the step's T new keys (the dense rule on the non-zero entries);
-//   2. the new keys that were not in the list, in tiling order: appended at slot len (value rule(fma(rate, 0, 1)) = 1) -- or, when the list is
-//      full, written over the entry with the smallest |v| (ties: the lowest slot), which is how the cap takes effect;
-//   3. the learner's terms (alpha * residual) * v go to the fixed-point table at their keys; a terminal transition then empties the list.
+// The list.  kSparseCap = 512 entries per learner (the reference's buffer grows without bound), held as T SUB-LISTS, one per tiling, of
+// kSparseCap / T entries each (64 entries per tiling at T = 8: 64 steps that never revisit a tile of that tiling -- by then an accumulating trace
+// has decayed to rate^64).  A key belongs to exactly one tiling (key / (cells * A)), a step brings at most one new key per tiling, and every
+// operation on the trace -- decay, hit, append, evict, the learner's terms, reset -- acts on the tilings independently.  So the unit of work is
+// (learner, tiling), and the trace update runs INSIDE the scatter kernel that already owns a tiling's slice of the delta table in LDS:
+//
+//   k_shared_ca   (models.hpp, one thread per learner; the one-step shared-table agents' step kernel)   phase C of the previous batch-step
+//                 (policy.sample from the updated table, restarts) + phase A of this one: transition, Q(s,.), Q(s',.), the TD target's residual;
+//                 hands over alpha * residual, the T new slice-relative keys, and flags (bit 0 terminal, bit 1 truncated, bit 2 Watkins's cut)
+//   k_sparse_trace_scatter   block (chunk of learners, tiling t), one WAVE per (learner, tiling) at a time: slot s of the sub-list lives in
+//                 lane s & 63, register s >> 6.  In this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
+//                   0. Q(lambda) and a was not argmax_first of Q(s,.): the sub-list is emptied first (q_lambda.rs:62-66);
+//                   1. every entry: v <- rule(fma(rate, v, hit ? 1 : 0)), hit = its key is the step's new key of this tiling;
+//                   2. the new key, if it was not in the sub-list: appended (value rule(fma(rate, 0, 1))) -- or, when the sub-list is full, written
+//                      over its entry with the smallest |v| (ties: the lowest slot), which is how the cap takes effect;
+//                   3. the learner's terms (alpha * residual) * v into the tiling's LDS slice (64-bit fixed point: exact, any order);
+//                      a terminal transition then empties the sub-list (sarsa_lambda.rs:91-93).
+//                 One sweep of the slice at the end: one device atomic per touched entry into one of n_rep copies of the table.
+//   k_apply_rep   W += fl(sum of the copies * lsb), copies cleared (multi-rank: the float delta goes through the exchange first).
+// Round 5's form -- one wave per LEARNER with the transition replicated over its 64 lanes, <= 512 device atomics per learner-step, four
+// launches -- ran at 246 us per batch-step at 16 384 CartPole learners; this one: profiles/r06_new_kernels.md.
 // Entries are never removed otherwise (a value that decays to a denormal stays, as a dense trace keeps it).
 #pragma once
 
@@ -27,15 +41,13 @@
 
 namespace rsrl {
 
-constexpr int kSparseCap = 512, kSparseRegs = kSparseCap / 64;
+constexpr int kSparseCap = 512;
 
 struct SparseTrace {
-    uint32_t* keys;    // [N][kSparseCap]
+    uint32_t* keys;    // [N][kSparseCap]: sub-list t in slots [t * cap_t, (t + 1) * cap_t); key = tile index * A + action
     float* vals;       // [N][kSparseCap]
-    uint32_t* len;     // [N]
+    uint32_t* len;     // [N][T]
 };
-// what phase A hands to phase C: the successor state (before any restart), reward / flags
-struct SparseMail { float* ns; uint8_t* flags; };      // ns [D][N]; flags: bit 0 terminal, bit 1 truncated
 
 // wave-wide (min |v|, slot) as one 64-bit key: |v| bits above the slot, so the smallest value wins and ties go to the lowest slot
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
@@ -47,146 +59,105 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-// phase A: one wave per learner
-template <int DOMAIN, int T>
-__global__ __launch_bounds__(kBlock) void k_sparse_lambda_step(Common c, BasisGeom g, LambdaParams lp, SparseTrace st, SparseMail mail,
-                                                               long long* __restrict__ fx, uint64_t t, DevStats* __restrict__ stats) {
-    using M = TileModel<DOMAIN, T>;
-    using Dom = Domain<DOMAIN>;
-    constexpr int D = M::D, A = M::A;
-    const int lane = threadIdx.x & 63;
-    const int64_t N = c.n_envs;
-    const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    double sum_abs = 0.0, sum_r = 0.0;
-    if (i < N) {
-        const bool sarsa = c.alg.kind == ALG_SARSA_LAMBDA;
-        AlgoParams alg = c.alg; alg.kind = sarsa ? ALG_SARSA : ALG_QLEARNING;      // the TD target formula
-        const uint32_t gid = (uint32_t)(c.env_offset + i);
-        float s[D], ns[D];
+// S = entries of one tiling's slice (cells * A); lds != 0: the slice is privatised in dynamic LDS (S * 8 bytes), else the terms go straight to
+// copy 0 of the table with device atomics (a slice too large for LDS: the same integers, the same sum).
+template <int T>
+__global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* __restrict__ new_keys, const float* __restrict__ terms,
+                                                               const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int S,
+                                                               int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
+                                                               float inv_lsb, int lds) {
+    constexpr int CAP = kSparseCap / T, REGS = (CAP + 63) / 64, U = 4;
+    extern __shared__ long long sparse_slice[];
+    const int t = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * per_block;
+    const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
+    const uint16_t* __restrict__ kt = new_keys + (int64_t)t * N;
+    const uint32_t base = (uint32_t)t * (uint32_t)S;                         // full key = base + slice-relative key
+    long long* __restrict__ dst = dW64 + (int64_t)(lds ? blockIdx.x % (unsigned)n_rep : 0u) * rep_stride + (int64_t)t * S;
+    if (lds) {
+        for (int j = threadIdx.x; j < S; j += blockDim.x) sparse_slice[j] = 0;
+        __syncthreads();
+    }
+    const float fresh = trace_merge(lp.trace, lp.rate, 0.0f, 1.0f);
+    for (int64_t ib = i0 + wave; ib < i1; ib += (int64_t)U * n_waves) {
+        // U learners' sub-lists in flight together (every load is independent of the lengths: masked afterwards)
+        uint32_t key[U][REGS]; float val[U][REGS]; int len[U]; uint32_t nk[U]; float sc[U]; uint8_t fl[U];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s[d] = c.state[(int64_t)d * N + i]; ns[d] = s[d]; }
-        const int a = __builtin_amdgcn_readfirstlane(c.action[i]);
-        float r;
-        const bool term = Dom::step(ns, a, r);
-        const uint32_t ep = c.ep_step[i] + 1;
-        const bool trunc = !term && c.max_episode_steps > 0 && ep >= c.max_episode_steps;
-        typename M::Feat fs, fn;
-        M::features(s, g, fs);
-        M::features(ns, g, fn);
-        float q_s[A], q_n[A];
-        M::q_all(c, 0, g, fs, q_s);
-        M::q_all(c, 0, g, fn, q_n);
-        // ---- the trace
-        uint32_t* __restrict__ K = st.keys + i * (int64_t)kSparseCap;
-        float* __restrict__ V = st.vals + i * (int64_t)kSparseCap;
-        int len = (int)st.len[i];
-        if (!sarsa && a != argmax_first<A>(q_s)) len = 0;                          // Watkins's cut
-        uint32_t key[kSparseRegs]; float val[kSparseRegs];
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = ib + (int64_t)u * n_waves;
+            const bool ok = i < i1;
+            const int64_t ii = ok ? i : i0;
+            len[u] = ok ? (int)st.len[ii * T + t] : 0;
+            nk[u] = base + (uint32_t)kt[ii]; sc[u] = terms[ii]; fl[u] = flags[ii];
 #pragma unroll
-        for (int e = 0; e < kSparseRegs; ++e) {
-            const int slot = e * 64 + lane;
-            key[e] = slot < len ? K[slot] : 0xffffffffu;
-            val[e] = slot < len ? V[slot] : 0.0f;
-        }
-        uint32_t nk[T]; bool found[T];
-#pragma unroll
-        for (int tt = 0; tt < T; ++tt) { nk[tt] = (uint32_t)fs.idx[tt] * A + (uint32_t)a; found[tt] = false; }
-#pragma unroll
-        for (int e = 0; e < kSparseRegs; ++e) {
-            bool hit = false;
-#pragma unroll
-            for (int tt = 0; tt < T; ++tt) {
-                const bool m = key[e] == nk[tt];
-                hit = hit || m;
-                found[tt] = found[tt] || (__ballot(m) != 0ull);
+            for (int e = 0; e < REGS; ++e) {
+                const int slot = e * 64 + lane;
+                const bool in = slot < CAP;
+                key[u][e] = in ? st.keys[ii * kSparseCap + t * CAP + slot] : 0xffffffffu;
+                val[u][e] = in ? st.vals[ii * kSparseCap + t * CAP + slot] : 0.0f;
             }
-            val[e] = trace_merge(lp.trace, lp.rate, val[e], hit ? 1.0f : 0.0f);
         }
-        const float fresh = trace_merge(lp.trace, lp.rate, 0.0f, 1.0f);
 #pragma unroll
-        for (int tt = 0; tt < T; ++tt) {
-            if (found[tt]) continue;                                               // (wave-uniform)
-            int slot;
-            if (len < kSparseCap) { slot = len; len += 1; }
-            else {
-                unsigned long long best = ~0ull;
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = ib + (int64_t)u * n_waves;
+            if (i >= i1) break;                                                    // (wave-uniform)
+            int ln = __builtin_amdgcn_readfirstlane(len[u]);
+            if (fl[u] & 4) ln = 0;                                                  // Watkins's cut
+            bool found = false;
 #pragma unroll
-                for (int e = 0; e < kSparseRegs; ++e) {
-                    const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[e]) & 0x7fffffffu) << 32) | (uint32_t)(e * 64 + lane);
-                    best = cand < best ? cand : best;
+            for (int e = 0; e < REGS; ++e) {
+                const bool live = e * 64 + lane < ln;
+                const bool hit = live && key[u][e] == nk[u];
+                found = found || (__ballot(hit) != 0ull);
+                val[u][e] = trace_merge(lp.trace, lp.rate, live ? val[u][e] : 0.0f, hit ? 1.0f : 0.0f);
+            }
+            if (!found) {
+                int slot;
+                if (ln < CAP) { slot = ln; ln += 1; }
+                else {
+                    unsigned long long best = ~0ull;
+#pragma unroll
+                    for (int e = 0; e < REGS; ++e) {
+                        if (e * 64 + lane >= CAP) continue;
+                        const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * 64 + lane);
+                        best = cand < best ? cand : best;
+                    }
+                    slot = (int)(uint32_t)wave_min_u64(best);
                 }
-                slot = (int)(uint32_t)wave_min_u64(best);
+#pragma unroll
+                for (int e = 0; e < REGS; ++e)
+                    if (slot == e * 64 + lane) { key[u][e] = nk[u]; val[u][e] = fresh; }
             }
 #pragma unroll
-            for (int e = 0; e < kSparseRegs; ++e)
-                if (slot == e * 64 + lane) { key[e] = nk[tt]; val[e] = fresh; }
-        }
-        // ---- residual against W_t, the learner's terms into the fixed-point table
-        U4 xin = U4{0, 0, 0, 0};
-        if (sarsa) xin = draw(c.seed, gid, t, BLK_INNER);                          // the agent's own draw (sarsa_lambda.rs:78)
-        float e_;
-        const float delta = td_error<A>(alg, c.apol, select_a<A>(q_s, a), q_n, r, term, xin, e_);
-        const float scale = lp.alpha * delta;
-        const float inv_lsb = FxScale(lp.alpha).inv_lsb;
+            for (int e = 0; e < REGS; ++e) {
+                if (e * 64 + lane >= ln) continue;
+                const unsigned long long q = fx_quantise(sc[u] * val[u][e], inv_lsb);
+                if (q == 0) continue;
+                if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e] - base]), q);
+                else fx_add(&dst[key[u][e] - base], q);
+            }
+            if (fl[u] & 1) ln = 0;                                                  // trace.reset()
 #pragma unroll
-        for (int e = 0; e < kSparseRegs; ++e)
-            if (e * 64 + lane < len) fx_add(&fx[key[e]], fx_quantise(scale * val[e], inv_lsb));
-        if (term) len = 0;                                                         // trace.reset()
-#pragma unroll
-        for (int e = 0; e < kSparseRegs; ++e) {
-            const int slot = e * 64 + lane;
-            if (slot < len) { K[slot] = key[e]; V[slot] = val[e]; }
-        }
-        if (lane == 0) {
-            st.len[i] = (uint32_t)len;
-#pragma unroll
-            for (int d = 0; d < D; ++d) mail.ns[(int64_t)d * N + i] = ns[d];
-            mail.flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
-            c.ep_step[i] = ep;
-            sum_abs = (double)fabsf(delta); sum_r = (double)r;
+            for (int e = 0; e < REGS; ++e) {
+                const int slot = e * 64 + lane;
+                if (slot < ln) { st.keys[i * kSparseCap + t * CAP + slot] = key[u][e]; st.vals[i * kSparseCap + t * CAP + slot] = val[u][e]; }
+            }
+            if (lane == 0) st.len[i * T + t] = (uint32_t)ln;
         }
     }
-    if (stats) block_stats_accumulate(stats, 0, 0, 0, sum_abs, sum_r);
-}
-
-// phase C: one thread per learner -- the behaviour policy's sample from W_{t+1}, restarts
-template <int DOMAIN, int T>
-__global__ __launch_bounds__(kBlock) void k_sparse_lambda_sample(Common c, BasisGeom g, SparseMail mail, uint64_t t, DevStats* __restrict__ stats) {
-    using M = TileModel<DOMAIN, T>;
-    using Dom = Domain<DOMAIN>;
-    constexpr int D = M::D, A = M::A;
-    const int64_t N = c.n_envs;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long n_ep = 0, n_trunc = 0, sum_len = 0;
-    if (i < N) {
-        const uint32_t gid = (uint32_t)(c.env_offset + i);
-        float ns[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) ns[d] = mail.ns[(int64_t)d * N + i];
-        const uint8_t fl = mail.flags[i];
-        uint32_t ep = c.ep_step[i];
-        if (fl) {                                                                  // the episode ended: restart (step cap: the trace lives on)
-            n_ep = 1; n_trunc = (fl & 2) ? 1 : 0; sum_len = ep; ep = 0;
-            Dom::reset(ns);
-        }
-        typename M::Feat fn;
-        M::features(ns, g, fn);
-        float q[A];
-        M::q_all(c, 0, g, fn, q);
-        const U4 x = draw(c.seed, gid, t, BLK_STEP);                               // (BLK_RESET is the same draw: the step's one behaviour sample)
-        const int na = policy_sample<A>(c.pol, q, x);
-#pragma unroll
-        for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
-        c.action[i] = na;
-        c.ep_step[i] = ep;
+    if (!lds) return;
+    __syncthreads();
+    for (int j = threadIdx.x; j < S; j += blockDim.x) {
+        const long long v = sparse_slice[j];
+        if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[j]), (unsigned long long)v);
     }
-    if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, 0.0, 0.0);
 }
 
 // Parameterised-style view of one learner's trace: the dense (F, A) matrix it stands for (zeros + the list's entries)
-__global__ void k_sparse_trace_get(SparseTrace st, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < (int)st.len[i]) out[st.keys[i * (int64_t)kSparseCap + s]] = st.vals[i * (int64_t)kSparseCap + s];
+__global__ void k_sparse_trace_get(SparseTrace st, int T, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x, cap = kSparseCap / T;
+    if (s < kSparseCap && s % cap < (int)st.len[i * T + s / cap]) out[st.keys[i * (int64_t)kSparseCap + s]] = st.vals[i * (int64_t)kSparseCap + s];
 }
 
 }  // namespace rsrl

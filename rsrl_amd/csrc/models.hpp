@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kBlock) void k_train_mem(Common c, BasisGeom g, uin
 // batch-step (policy.sample with the just-updated weights; finished episodes restart from Domain::default()), phase A
 // runs the transition and takes the TD error of this step against W_t and adds the learner's term lr*e*phi(s) to the
 // mini-batch delta.  phi(s) and Q(s,.) are computed once and serve both phases.  do_c = 0 on the first step of a
-// train call (the previous call already ran its phase C).  The env state becomes s'; flags[i] bit0 = terminal,
+// train call (the previous call already ran its phase C; bit 1 of do_c: record Q(lambda)'s cut).  The env state becomes s'; flags[i] bit0 = terminal,
 // bit1 = truncated, consumed by the next phase C.
 //   tile coding : the learner's term and its T slice-relative entries are handed to k_tile_scatter (per-tiling slice of the delta table
 //                 privatised in LDS, one device atomic per touched entry into one of n_rep copies of the table; k_apply_rep sums them);
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uin
         float s[D], ns[D], q_s[A];
         uint32_t ep = c.ep_step[i];
         bool done = false;
-        if (do_c) done = flags[i] != 0;
+        if (do_c & 1) done = (flags[i] & 3) != 0;
         if (done) { M::Dom::reset(s); ep = 0; }
         else load_state<M>(c.state, N, i, s);
         M::features(s, g, fs);
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uin
         if constexpr (M::kDense) M::q_all_lds(sh_w, fs, q_s);
         else if constexpr (M::kSparse) M::q_all_shared(c.W, g, fs, q_s);
         else M::q_all(c, 0, g, fs, q_s);
-        if (do_c) {                                                     // ---- phase C of batch-step t-1
+        if (do_c & 1) {                                                 // ---- phase C of batch-step t-1
             const U4 x = draw(c.seed, gid, t - 1, BLK_STEP);
             a = policy_sample<A>(c.pol, q_s, x);
         } else {
@@ -673,7 +673,8 @@ __global__ __launch_bounds__(kBlock) void k_shared_ca(Common c, BasisGeom g, uin
         for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = ns[d];
         c.action[i] = a;
         c.ep_step[i] = ep;
-        flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+        // (bit 2, asked for by do_c bit 1: Q(lambda)'s cut -- the action taken was not argmax_first of Q(s,.), q_lambda.rs:62-66 -- for the trace kernel)
+        flags[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0) | (((do_c & 2) && a != argmax_first<A>(q_s)) ? 4 : 0));
         sum_abs = (double)fabsf(delta); sum_r = (double)r;
         if (term || trunc) { n_ep = 1; n_trunc = trunc ? 1 : 0; sum_len = ep; }
     } else {
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(kBlock) void k_shared_c(Common c, BasisGeom g, uint
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const uint32_t gid = (uint32_t)(c.env_offset + i);
-    const bool done = flags[i] != 0;
+    const bool done = (flags[i] & 3) != 0;
     float s[D];
     if (done) {
         M::Dom::reset(s);

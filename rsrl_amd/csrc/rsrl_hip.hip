@@ -307,7 +307,8 @@ struct rsrl_hip_ctx {
     float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
     float* eps = nullptr;            // [N] per-learner EpsilonGreedy.epsilon (config.epsilon_decay != 1), else null
     // lambda agents over ONE shared tile table: every learner's sparse trace + the step's mailbox (kernels_sparse_lambda.hpp)
-    uint32_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr; float* sp_ns = nullptr;
+    uint32_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr;    // sparse traces: [N][kSparseCap] x 2, lengths [N][n_tilings]
+    bool sp_lds = false;             //   one tiling's slice of the delta table fits LDS (k_sparse_trace_scatter)
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop
     // ---- the trait-granular fast path (kernels_trait.hpp): register-family Fourier basis, per-learner f32 weights, learner-major layout
@@ -451,6 +452,10 @@ static void launch_wave_aux(const rsrl_hip_ctx* c, dim3 grid, Args... args) {
     else hipLaunchKernelGGL((k_wave_aux<2>), grid, dim3(kBlock), 0, c->stream, args...);
 }
 
+// the step kernel of the shared-weight loops (what rsrl_hip_timing_read names): the dense bases', shared tile coding's, the sparse-trace lambda agents'
+static inline const char* shared_kernel_name(const rsrl_hip_ctx* c) {
+    return c->cfg.basis == RSRL_FOURIER ? "k_shared_step" : (c->sp_keys ? "k_sparse_trace_scatter" : "k_shared_ca");
+}
 static inline unsigned grid_for(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 // resolution of the fixed-point delta tables of shared tile coding: 2^(floor(log2 |lr|) - 28), the same bits the kernel derives
 static inline float tile_lsb(float lr) {
@@ -712,7 +717,6 @@ int rsrl_hip_destroy(rsrl_hip_ctx* c) {
     if (c->sp_keys) (void)hipFree(c->sp_keys);
     if (c->sp_vals) (void)hipFree(c->sp_vals);
     if (c->sp_len) (void)hipFree(c->sp_len);
-    if (c->sp_ns) (void)hipFree(c->sp_ns);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->comm) (void)ncclCommDestroy(c->comm);
@@ -879,12 +883,22 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         KCHECK();
     }
     if (is_sparse_lambda(*cfg)) {
+        const int64_t slice = (int64_t)(c->F / cfg->n_tilings) * c->A;
+        if (slice > 65536) return fail(RSRL_HIP_EINVAL, "SARSALambda / QLambda over a shared tile table: one tiling's slice (cells * actions = %lld entries) must not "
+                                                        "exceed 65 536 (16-bit slice-relative keys between the step and the trace kernel)", (long long)slice);
         HIP_TRY(hipMalloc((void**)&c->sp_keys, sizeof(uint32_t) * (size_t)kSparseCap * (size_t)N));
         HIP_TRY(hipMalloc((void**)&c->sp_vals, sizeof(float) * (size_t)kSparseCap * (size_t)N));
-        HIP_TRY(hipMalloc((void**)&c->sp_len, sizeof(uint32_t) * (size_t)N));
-        HIP_TRY(hipMalloc((void**)&c->sp_ns, sizeof(float) * c->D * (size_t)N));
-        HIP_TRY(hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)N, c->stream));        // Trace::zeros: empty lists
-        if (wave_grid_for(N) > c->n_stat_slots) c->n_stat_slots = wave_grid_for(N);
+        HIP_TRY(hipMalloc((void**)&c->sp_len, sizeof(uint32_t) * (size_t)cfg->n_tilings * (size_t)N));
+        HIP_TRY(hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)cfg->n_tilings * (size_t)N, c->stream));        // Trace::zeros: empty lists
+        // (the lists are written only below their lengths; what lies beyond is never read as an entry, but a checkpoint copies whole rows)
+        HIP_TRY(hipMemsetAsync(c->sp_keys, 0, sizeof(uint32_t) * (size_t)kSparseCap * (size_t)N, c->stream));
+        HIP_TRY(hipMemsetAsync(c->sp_vals, 0, sizeof(float) * (size_t)kSparseCap * (size_t)N, c->stream));
+        c->sp_lds = slice * 8 <= 128 * 1024;
+        if (c->sp_lds && slice * 8 > 64 * 1024) {                       // more dynamic LDS than a kernel gets by default
+            const void* fn = cfg->n_tilings == 4 ? reinterpret_cast<const void*>(&k_sparse_trace_scatter<4>)
+                           : cfg->n_tilings == 8 ? reinterpret_cast<const void*>(&k_sparse_trace_scatter<8>) : reinterpret_cast<const void*>(&k_sparse_trace_scatter<16>);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slice * 8)) != hipSuccess) { (void)hipGetLastError(); c->sp_lds = false; }
+        }
     } else if (has_aux(cfg->algo)) {
         HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
         HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
@@ -913,10 +927,11 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         // 2: 24.7, 4: 24.1, 8: 24.8, 16: 26.4).  The scatter fused into the step kernel measured 28.7-35.0: scripts/ab/round6_pruned_knobs.patch
         const char* e = getenv("RSRL_TILE_REPLICAS");
         const int r = e ? atoi(e) : 4;
-        c->n_rep = !c->tile_slice ? 1 : (r < 1 ? 1 : (r > 16 ? 16 : r));                    // k_apply_rep sums up to 16 copies
+        const bool privatised = c->sp_keys ? c->sp_lds : c->tile_slice;
+        c->n_rep = !privatised ? 1 : (r < 1 ? 1 : (r > 16 ? 16 : r));                       // k_apply_rep sums up to 16 copies
         HIP_TRY(hipMalloc((void**)&c->dW_rep, sizeof(long long) * c->dw_elems * c->n_rep));
         HIP_TRY(hipMemsetAsync(c->dW_rep, 0, sizeof(long long) * c->dw_elems * c->n_rep, c->stream));
-        if (c->tile_slice) {                                             // the scatter is a kernel of its own (k_tile_scatter)
+        if (c->tile_slice || c->sp_keys) {                               // the scatter is a kernel of its own (k_tile_scatter; k_sparse_trace_scatter)
             HIP_TRY(hipMalloc((void**)&c->sc_keys, sizeof(uint16_t) * (size_t)cfg->n_tilings * (size_t)N));
             HIP_TRY(hipMalloc((void**)&c->sc_terms, sizeof(float) * (size_t)N));
         }
@@ -1484,7 +1499,7 @@ static int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
         HIP_TRY(hipMemsetAsync(oz.dev, 0, sizeof(float) * (size_t)n, c->stream));
-        hipLaunchKernelGGL(k_sparse_trace_get, dim3(kSparseCap / 256), dim3(256), 0, c->stream, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, env_index, oz.dev);
+        hipLaunchKernelGGL(k_sparse_trace_get, dim3(kSparseCap / 256), dim3(256), 0, c->stream, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, c->cfg.n_tilings, env_index, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
         if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1542,7 +1557,8 @@ int rsrl_hip_set_td_weights(rsrl_hip_ctx* c, int64_t env_index, const float* v) 
 namespace {
 constexpr uint32_t kCkptVersion = 3;          // files carrying aux_kind 3 (QSigma's n-step backups); every other file is still written as version 2
 constexpr uint32_t kCkptVersionEps = 4;       // ... or as version 4 when the ctx runs the per-learner epsilon schedule: f32 eps[N] follows the payload
-constexpr uint32_t kCkptVersionSparse = 5;    // files carrying aux_kind 4 (the sparse per-learner traces over a shared table)
+constexpr uint32_t kCkptVersionSparse = 6;    // files carrying aux_kind 4 (the sparse per-learner traces over a shared table): u64 n_envs, u64 env_offset, u32 len[N], lists
+constexpr uint32_t kCkptVersionSparse5 = 5;   // ... as round 5 wrote them (no n_envs / env_offset in front of the lengths): still read
 constexpr int64_t kSparseChunk = 4096;        // learners per staging chunk of the sparse lists
 constexpr size_t kCkptHeaderBytes = 72;
 struct Ckpt {
@@ -1613,14 +1629,26 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
         if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the QSigma backups: %s", hipGetErrorString(e));
         else if (fwrite(hl.data(), 4, 2 * N, f) != 2 * N || fwrite(buf.data(), 4, nf, f) != nf) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
     }
-    if (rc == RSRL_HIP_OK && h.aux_kind == 4) {                        // sparse traces: u32 len[N], then per learner its len keys and len values
-        const int64_t N = c->cfg.n_envs;
-        std::vector<uint32_t> len((size_t)N), keys((size_t)(kSparseChunk * kSparseCap));
+    if (rc == RSRL_HIP_OK && h.aux_kind == 4) {
+        // sparse traces: u64 n_envs, u64 env_offset (whose learners these are), u32 len[N], then per learner its len keys and its len values -- the
+        // sub-lists concatenated in tiling order (a key says which tiling it belongs to: the file does not depend on the cap per tiling)
+        const int64_t N = c->cfg.n_envs; const int T = c->cfg.n_tilings, cap = kSparseCap / T;
+        std::vector<uint32_t> lens((size_t)N * T), tot((size_t)N), keys((size_t)(kSparseChunk * kSparseCap));
         std::vector<float> vals((size_t)(kSparseChunk * kSparseCap));
-        hipError_t e = hipMemcpyAsync(len.data(), c->sp_len, 4 * (size_t)N, hipMemcpyDeviceToHost, c->stream);
+        hipError_t e = hipMemcpyAsync(lens.data(), c->sp_len, 4 * (size_t)N * T, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(RSRL_HIP_EHIP, "reading the sparse traces: %s", hipGetErrorString(e));
-        else if (fwrite(len.data(), 4, (size_t)N, f) != (size_t)N) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+        for (int64_t i = 0; rc == RSRL_HIP_OK && i < N; ++i) {
+            uint32_t sum = 0;
+            for (int t = 0; t < T; ++t) {
+                if (lens[(size_t)i * T + t] > (uint32_t)cap) rc = fail(RSRL_HIP_ESTATE, "learner %lld's sparse trace has %u entries in tiling %d", (long long)i, lens[(size_t)i * T + t], t);
+                sum += lens[(size_t)i * T + t];
+            }
+            tot[(size_t)i] = sum;
+        }
+        uint8_t who[16]; uint8_t* wp = who; put64(wp, (uint64_t)N); put64(wp, (uint64_t)c->cfg.env_offset);
+        if (rc == RSRL_HIP_OK && (fwrite(who, 1, 16, f) != 16 || fwrite(tot.data(), 4, (size_t)N, f) != (size_t)N)) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+        std::vector<uint32_t> kk((size_t)kSparseCap); std::vector<float> vv((size_t)kSparseCap);
         for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
             const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
             e = hipMemcpyAsync(keys.data(), c->sp_keys + i0 * kSparseCap, 4 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
@@ -1628,10 +1656,12 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc = fail(RSRL_HIP_EHIP, "reading the sparse traces: %s", hipGetErrorString(e)); break; }
             for (int64_t i = 0; rc == RSRL_HIP_OK && i < n; ++i) {
-                const size_t l = len[(size_t)(i0 + i)];
-                if (l > (size_t)kSparseCap) rc = fail(RSRL_HIP_ESTATE, "learner %lld's sparse trace has %zu entries", (long long)(i0 + i), l);
-                else if (fwrite(keys.data() + i * kSparseCap, 4, l, f) != l || fwrite(vals.data() + i * kSparseCap, 4, l, f) != l)
-                    rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
+                size_t l = 0;
+                for (int t = 0; t < T; ++t)
+                    for (uint32_t j = 0; j < lens[(size_t)(i0 + i) * T + t]; ++j, ++l) {
+                        kk[l] = keys[(size_t)(i * kSparseCap + t * cap) + j]; vv[l] = vals[(size_t)(i * kSparseCap + t * cap) + j];
+                    }
+                if (fwrite(kk.data(), 4, l, f) != l || fwrite(vv.data(), 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
             }
         }
     }
@@ -1653,9 +1683,9 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     Ckpt h{}; uint32_t version = 0; uint8_t hdr[kCkptHeaderBytes];
     int rc = RSRL_HIP_OK;
     if (fread(hdr, 1, sizeof(hdr), f) != sizeof(hdr) || !ckpt_decode(hdr, &h, &version)) rc = fail(RSRL_HIP_EINVAL, "%s is not a rsrl_hip weight file", path);
-    else if (version != kCkptVersion && version != 2u && version != kCkptVersionEps && version != kCkptVersionSparse)
-        rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2, %u, %u and %u", path, version, kCkptVersion, kCkptVersionEps,
-                  kCkptVersionSparse);
+    else if (version != kCkptVersion && version != 2u && version != kCkptVersionEps && version != kCkptVersionSparse && version != kCkptVersionSparse5)
+        rc = fail(RSRL_HIP_EINVAL, "%s has checkpoint version %u, this library reads versions 2, %u, %u, %u and %u", path, version, kCkptVersion, kCkptVersionEps,
+                  kCkptVersionSparse5, kCkptVersionSparse);
     // a QSigma file written before the backups travelled (version 2, aux_kind 0) is still read: the weights are loaded and the run
     // resumes from EMPTY n-step backups, as after a terminal transition (q_sigma.rs:154)
     // (the same for a sparse-trace file of ABI 7's first build, version 2 / aux_kind 0: the run resumes from EMPTY lists, Trace::zeros)
@@ -1668,7 +1698,8 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration%s", path,
                   h.has_eps != want.has_eps ? " (the per-learner epsilon schedule, config.epsilon_decay, is part of it)" : "");
     const size_t per = (size_t)c->F * c->Aw;
-    std::vector<uint32_t> sp_len_in;
+    std::vector<uint32_t> sp_len_in, sp_len_t;      // sparse traces: a learner's entries in the file; its sub-lists' lengths on the device
+    long sp_prefix = 0;
     if (rc == RSRL_HIP_OK) {                                             // a truncated file is refused before anything is touched
         long long expect = (long long)kCkptHeaderBytes + (long long)((h.aux_kind == 1 || h.aux_kind == 2) ? 2 : 1) * h.n_learners * (long long)per * 4 +
                            (h.aux_kind == 3 ? (long long)c->cfg.n_envs * 8 + (long long)qs_floats(c) * 4 : 0) +
@@ -1676,9 +1707,18 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         if (h.aux_kind == 4) {                                           // the lists are compact: their lengths say how long the file is
             const size_t N = (size_t)c->cfg.n_envs;
             sp_len_in.resize(N);
-            if (fseek(f, (long)(kCkptHeaderBytes + h.n_learners * (long long)per * 4), SEEK_SET) != 0 || fread(sp_len_in.data(), 4, N, f) != N)
-                rc = fail(RSRL_HIP_EINVAL, "%s is truncated (the sparse traces' lengths)", path);
-            expect += 4 * (long long)N;
+            sp_prefix = version == kCkptVersionSparse ? 16 : 0;
+            uint8_t who[16];
+            if (fseek(f, (long)(kCkptHeaderBytes + h.n_learners * (long long)per * 4), SEEK_SET) != 0 || (sp_prefix && fread(who, 1, 16, f) != 16))
+                rc = fail(RSRL_HIP_EINVAL, "%s is truncated (the sparse traces' owner)", path);
+            if (rc == RSRL_HIP_OK && sp_prefix) {                            // whose lists these are: the writer's shard, not only its size
+                const uint8_t* wp = who; const uint64_t n_in = get64(wp), off_in = get64(wp);
+                if (n_in != (uint64_t)N || off_in != (uint64_t)c->cfg.env_offset)
+                    rc = fail(RSRL_HIP_EINVAL, "%s was written by a different configuration (sparse traces of %llu learners at env_offset %llu; this ctx: %zu at %lld)", path,
+                              (unsigned long long)n_in, (unsigned long long)off_in, N, (long long)c->cfg.env_offset);
+            }
+            if (rc == RSRL_HIP_OK && fread(sp_len_in.data(), 4, N, f) != N) rc = fail(RSRL_HIP_EINVAL, "%s is truncated (the sparse traces' lengths)", path);
+            expect += sp_prefix + 4 * (long long)N;
             for (size_t i = 0; rc == RSRL_HIP_OK && i < N; ++i) {
                 if (sp_len_in[i] > (uint32_t)kSparseCap) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt sparse trace of learner %zu (%u entries)", path, i, sp_len_in[i]);
                 expect += 8 * (long long)sp_len_in[i];
@@ -1714,17 +1754,26 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         hipError_t e2 = hipMalloc((void**)&spk_new, 4 * (size_t)kSparseCap * (size_t)N);
         if (e2 == hipSuccess) e2 = hipMalloc((void**)&spv_new, 4 * (size_t)kSparseCap * (size_t)N);
         if (e2 != hipSuccess) rc = fail(e2 == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "staging buffers for the sparse traces: %s", hipGetErrorString(e2));
-        std::vector<uint32_t> keys((size_t)(kSparseChunk * kSparseCap));
-        std::vector<float> vals((size_t)(kSparseChunk * kSparseCap));
-        if (rc == RSRL_HIP_OK && fseek(f, 4 * (long)N, SEEK_CUR) != 0) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);      // (the lengths: read above)
-        const uint32_t n_keys = (uint32_t)c->F * (uint32_t)c->Aw;
+        std::vector<uint32_t> keys((size_t)(kSparseChunk * kSparseCap)), kk((size_t)kSparseCap);
+        std::vector<float> vals((size_t)(kSparseChunk * kSparseCap)), vv((size_t)kSparseCap);
+        if (rc == RSRL_HIP_OK && fseek(f, sp_prefix + 4 * (long)N, SEEK_CUR) != 0) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);      // (owner and lengths: read above)
+        const int T = c->cfg.n_tilings, cap = kSparseCap / T;
+        const uint32_t n_keys = (uint32_t)c->F * (uint32_t)c->Aw, slice = n_keys / (uint32_t)T;
+        sp_len_t.assign((size_t)N * T, 0u);
         for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
             const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
+            std::fill(keys.begin(), keys.end(), 0u); std::fill(vals.begin(), vals.end(), 0.0f);
             for (int64_t i = 0; rc == RSRL_HIP_OK && i < n; ++i) {
                 const size_t l = sp_len_in[(size_t)(i0 + i)];
-                if (fread(keys.data() + i * kSparseCap, 4, l, f) != l || fread(vals.data() + i * kSparseCap, 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
-                for (size_t k = 0; rc == RSRL_HIP_OK && k < l; ++k)
-                    if (keys[(size_t)(i * kSparseCap) + k] >= n_keys) rc = fail(RSRL_HIP_EINVAL, "%s: corrupt sparse trace of learner %lld (key out of range)", path, (long long)(i0 + i));
+                if (fread(kk.data(), 4, l, f) != l || fread(vv.data(), 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
+                for (size_t k = 0; rc == RSRL_HIP_OK && k < l; ++k) {         // every entry into the sub-list of its key's tiling
+                    if (kk[k] >= n_keys) { rc = fail(RSRL_HIP_EINVAL, "%s: corrupt sparse trace of learner %lld (key out of range)", path, (long long)(i0 + i)); break; }
+                    const uint32_t t = kk[k] / slice; uint32_t& lt = sp_len_t[(size_t)(i0 + i) * T + t];
+                    if (lt >= (uint32_t)cap) { rc = fail(RSRL_HIP_EINVAL, "%s: learner %lld's sparse trace holds more than %d entries of tiling %u (this library keeps "
+                                                                            "%d entries per learner as %d per tiling)", path, (long long)(i0 + i), cap, t, kSparseCap, cap); break; }
+                    keys[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = kk[k]; vals[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = vv[k];
+                    lt += 1;
+                }
             }
             if (rc != RSRL_HIP_OK) break;
             e2 = hipMemcpyAsync(spk_new + i0 * kSparseCap, keys.data(), 4 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
@@ -1751,7 +1800,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     fclose(f);
     (void)hipStreamSynchronize(c->stream);
     if (rc == RSRL_HIP_OK && old_qsigma && c->sp_len) {                // old file: no lists in it -> empty ones
-        hipError_t e2 = hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
+        hipError_t e2 = hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_tilings * (size_t)c->cfg.n_envs, c->stream);
         if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "clearing the sparse traces: %s", hipGetErrorString(e2));
     } else if (rc == RSRL_HIP_OK && old_qsigma) {                      // old file: no backups in it -> empty ones
         hipError_t e2 = hipMemsetAsync(c->qs_len, 0, sizeof(uint32_t) * (size_t)c->cfg.n_envs, c->stream);
@@ -1772,7 +1821,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the QSigma backups: %s", hipGetErrorString(e2));
     }
     if (rc == RSRL_HIP_OK && h.aux_kind == 4) {                        // the last step that can fail: the lengths
-        hipError_t e2 = hipMemcpyAsync(c->sp_len, sp_len_in.data(), 4 * sp_len_in.size(), hipMemcpyHostToDevice, c->stream);
+        hipError_t e2 = hipMemcpyAsync(c->sp_len, sp_len_t.data(), 4 * sp_len_t.size(), hipMemcpyHostToDevice, c->stream);
         if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
         if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the sparse traces: %s", hipGetErrorString(e2));
     }
@@ -1897,11 +1946,30 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
         if (xpart == 0) TRY(exchange_table(c, t));
         return RSRL_HIP_OK;
     }
+    // SARSALambda / QLambda over the shared table (sparse per-learner traces, kernels_sparse_lambda.hpp) ride the same three launches: the step
+    // kernel takes the TD target's residual (SARSA's / QLearning's formula, step size alpha), the scatter kernel is the one that also updates the traces
+    const bool sparse_lambda = c->sp_keys != nullptr;
+    const float step_size = (float)(sparse_lambda ? c->cfg.alpha : c->cfg.lr);
     if (xpart != 2 && !for_model(c, [&](auto tag) {
             using M = typename decltype(tag)::type;
             float* dwp = reinterpret_cast<float*>(c->dW_rep);
             const int nrep = c->n_rep;
             if constexpr (M::kSparse) {
+                if (sparse_lambda) {
+                    Common ks = k;
+                    ks.alg.kind = c->cfg.algo == RSRL_SARSA_LAMBDA ? ALG_SARSA : ALG_QLEARNING; ks.alg.lr = step_size;
+                    const int slice = (int)((int64_t)(c->F / c->cfg.n_tilings) * c->A);
+                    hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, ks, g, t, do_c | (c->cfg.algo == RSRL_Q_LAMBDA ? 2 : 0), dwp, c->flags, d_stats, nrep,
+                                       (int64_t)c->dw_elems, t_dev, c->sc_keys, c->sc_terms);
+                    static const int per_env = getenv("RSRL_SPARSE_CHUNK") ? atoi(getenv("RSRL_SPARSE_CHUNK")) : 512;
+                    const int per = per_env < 16 ? 16 : per_env;
+                    const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
+                    const SparseTrace st{c->sp_keys, c->sp_vals, c->sp_len};
+                    hipLaunchKernelGGL((k_sparse_trace_scatter<M::kT>), dim3(chunks, (unsigned)M::kT), dim3(1024), c->sp_lds ? (size_t)slice * 8 : 0, c->stream,
+                                       c->sc_keys, c->sc_terms, c->flags, st, make_lambda(c), (int64_t)k.n_envs, slice, per, c->dW_rep, nrep, (int64_t)c->dw_elems,
+                                       FxScale(step_size).inv_lsb, c->sp_lds ? 1 : 0);
+                    return;
+                }
                 if (c->sc_keys) {
                     // step kernel (terms + entries per learner) -> scatter kernel: block (chunk, tiling), 8 192 learners per chunk, one tiling's slice
                     // of the delta table (64-bit fixed-point accumulators) in LDS
@@ -1926,7 +1994,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
     const bool multi = c->multi;           // an exchange is attached: finalize -> exchange -> apply, also for a communicator of size 1
     if (xpart != 2) {
         hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
-                           tile_lsb((float)c->cfg.lr));
+                           tile_lsb(step_size));
         KCHECK();
     }
     if (multi) {
@@ -2192,50 +2260,6 @@ static int persist_launch(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, 
 // runs the halves of all its ranks in lock-step with the all-reduces grouped between them):
 //   A: every learner's step (transition, TD error, sparse trace, fixed-point scatter of alpha * residual * z) + the table -> float delta
 //   B: W += delta (summed over the ranks by then), the behaviour policy's sample with the updated table
-static int sparse_lambda_half_a(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
-    const SparseTrace st{c->sp_keys, c->sp_vals, c->sp_len};
-    const SparseMail mail{c->sp_ns, c->flags};
-    const LambdaParams lp = make_lambda(c);
-    const int n = (int)c->dw_elems;
-    const int64_t N = k.n_envs;
-    if (!for_model(c, [&](auto tag) {
-            using M = typename decltype(tag)::type;
-            if constexpr (M::kSparse)
-                hipLaunchKernelGGL((k_sparse_lambda_step<M::kDomain, M::kT>), dim3(wave_grid_for(N)), dim3(kBlock), 0, c->stream, k, g, lp, st, mail, c->h_fx, c->t, d_stats);
-        })) return NO_MODEL(c);
-    KCHECK();
-    hipLaunchKernelGGL(k_fx_finalize, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->h_fx, c->dW, n, tile_lsb((float)c->cfg.alpha));
-    KCHECK();
-    return RSRL_HIP_OK;
-}
-static int sparse_lambda_half_b(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats) {
-    const SparseMail mail{c->sp_ns, c->flags};
-    const int n = (int)c->dw_elems;
-    const int64_t N = k.n_envs;
-    hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
-    KCHECK();
-    for_model(c, [&](auto tag) {
-        using M = typename decltype(tag)::type;
-        if constexpr (M::kSparse)
-            hipLaunchKernelGGL((k_sparse_lambda_sample<M::kDomain, M::kT>), dim3(grid_for(N)), dim3(kBlock), 0, c->stream, k, g, mail, c->t, d_stats);
-    });
-    KCHECK();
-    c->kernel_name = "k_sparse_lambda_step";
-    return RSRL_HIP_OK;
-}
-static int train_sparse_lambda(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, int64_t n_steps, DevStats* d_stats) {
-    for (int64_t j = 0; j < n_steps; ++j) {
-        TRY(timing_begin(c));
-        TRY(sparse_lambda_half_a(c, k, g, d_stats));
-        TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
-        if (c->multi && c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
-        TRY(sparse_lambda_half_b(c, k, g, d_stats));
-        TRY(timing_end(c, 1));
-        c->t += 1;
-    }
-    return RSRL_HIP_OK;
-}
-
 static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->tq_valid = false;                 // the weights move behind the trait path's hand-over cache
@@ -2243,21 +2267,6 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
     if (d_stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(DevStats) * c->n_stat_slots, c->stream));
     Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_sparse_lambda(c->cfg)) {
-        TRY(train_sparse_lambda(c, k, g, n_steps, d_stats));
-        if (stats_out) {
-            HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(DevStats) * c->n_stat_slots, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            memset(stats_out, 0, sizeof(*stats_out));
-            stats_out->env_steps = (uint64_t)n_steps * (uint64_t)c->cfg.n_envs;
-            for (size_t b = 0; b < c->n_stat_slots; ++b) {
-                stats_out->episodes += c->h_stats[b].episodes; stats_out->episodes_truncated += c->h_stats[b].episodes_truncated;
-                stats_out->sum_episode_steps += c->h_stats[b].sum_episode_steps;
-                stats_out->sum_abs_td_error += c->h_stats[b].sum_abs_td_error; stats_out->sum_reward += c->h_stats[b].sum_reward;
-            }
-        }
-        return RSRL_HIP_OK;
-    }
     const bool shared = c->cfg.weight_mode == RSRL_W_SHARED;
     const bool fourier = c->cfg.basis == RSRL_FOURIER;
     const int64_t spl = shared ? 1 : fuse_depth(c);
@@ -2307,7 +2316,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             TRY(timing_begin(c));
             HIP_TRY(hipGraphLaunch(c->step_graph_exec, c->stream));
             TRY(timing_end(c, (uint32_t)spg));
-            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? (c->k1_quad ? "k_step_reg_q4" : "k_step_reg_lm") : "k_step_reg") : (fourier ? "k_shared_step" : "k_shared_ca");
+            c->kernel_name = stream_k1 ? (c->w_ls != 1 ? (c->k1_quad ? "k_step_reg_q4" : "k_step_reg_lm") : "k_step_reg") : shared_kernel_name(c);
             c->t += (uint64_t)spg;
             if (peer_steps) c->peer_seq += (uint64_t)spg;
             done += spg;
@@ -2318,7 +2327,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
         TRY(timing_begin(c));
         if (shared) {
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
-            c->kernel_name = fourier ? "k_shared_step" : "k_shared_ca";
+            c->kernel_name = shared_kernel_name(c);
         } else if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
             launch_wave_aux(c, dim3(wave_grid_for(k.n_envs)), k, make_wave_aux(c), (float*)c->W, c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr,
                             (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
@@ -2951,31 +2960,6 @@ int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps) {
         return RSRL_HIP_OK;
     }
     // RCCL: lock-step, the all-reduces of a batch-step grouped
-    if (is_sparse_lambda(ctxs[0]->cfg)) {
-        // the lambda agents over a shared tile table step their own kernels (sparse traces): their halves in lock-step, the float delta all-reduced between
-        for (int64_t j = 0; j < n_steps; ++j) {
-            for (int i = 0; i < n; ++i) {
-                rsrl_hip_ctx* c = ctxs[i];
-                HIP_TRY(hipSetDevice(c->cfg.device));
-                c->tq_valid = false; c->q_valid = false;
-                TRY(sparse_lambda_half_a(c, make_common(c), make_geom(c), nullptr));
-            }
-            NCCL_TRY(ncclGroupStart());
-            for (int i = 0; i < n; ++i) {
-                rsrl_hip_ctx* c = ctxs[i];
-                HIP_TRY(hipSetDevice(c->cfg.device));
-                NCCL_TRY(ncclAllReduce(c->dW, c->dW, c->dw_elems, ncclFloat, ncclSum, c->comm, c->stream));
-            }
-            NCCL_TRY(ncclGroupEnd());
-            for (int i = 0; i < n; ++i) {
-                rsrl_hip_ctx* c = ctxs[i];
-                HIP_TRY(hipSetDevice(c->cfg.device));
-                TRY(sparse_lambda_half_b(c, make_common(c), make_geom(c), nullptr));
-                c->t += 1;
-            }
-        }
-        return RSRL_HIP_OK;
-    }
     std::vector<Common> ks((size_t)n);
     for (int i = 0; i < n; ++i) {
         rsrl_hip_ctx* c = ctxs[i];
@@ -3002,7 +2986,7 @@ int rsrl_hip_group_train(rsrl_hip_ctx* const* ctxs, int n, int64_t n_steps) {
             HIP_TRY(hipSetDevice(c->cfg.device));
             TRY(enqueue_shared_step(c, ks[(size_t)i], make_geom(c), nullptr, j == 0 ? 0 : 1, c->t, nullptr, 2));
             c->t += 1;
-            c->kernel_name = c->cfg.basis == RSRL_FOURIER ? "k_shared_step" : "k_shared_ca";
+            c->kernel_name = shared_kernel_name(c);
         }
     }
     for (int i = 0; i < n; ++i) {

@@ -1,6 +1,7 @@
 """Eligibility traces over ONE SHARED tile-coded table (VERDICT r4 missing #1): SARSALambda / QLambda with weight_mode = SHARED, basis = TILE_CODING.
 The reference's Trace<B, R> is generic over its buffer and ships a sparse one (traces.rs:5-12, params/sparse.rs:13-97): every learner keeps a sparse
-trace (<= 512 entries), the table is updated by the synchronous mini-batch rule through exact fixed-point sums (rsrl_amd/csrc/kernels_sparse_lambda.hpp).
+trace (<= 512 entries, as one sub-list of 512 / T per tiling), the table is updated by the synchronous mini-batch rule through exact fixed-point sums
+(rsrl_amd/csrc/kernels_sparse_lambda.hpp: the step kernel of the one-step shared-table agents + the trace update inside the LDS scatter kernel).
 Bitwise against the oracle's restatement (f32d), tolerance against the same rule in f64."""
 import numpy as np
 import pytest
@@ -49,6 +50,12 @@ def test_sparse_traces_bitwise_and_f64(ra, orc, name, N, K, kw):
         assert st["episodes"] + st2["episodes"] == ost["episodes"] and st["env_steps"] + st2["env_steps"] == N * K
         assert abs(st["sum_abs_td_error"] + st2["sum_abs_td_error"] - ost["sum_abs_td_error"]) <= 1e-4 * (1 + ost["sum_abs_td_error"])
         assert c.fx_saturations() == sat0
+        with ra.Context(basis=ra.TILE_CODING, weight_mode=ra.W_SHARED, seed=7, alpha=alpha, n_envs=N, **kw) as g:      # no statistics: the captured step graphs
+            g.reset()
+            g.train(K - 7, want_stats=False)
+            g.train(7, want_stats=False)
+            assert np.array_equal(g.get_weights(), W) and np.array_equal(g.states, c.states) and np.array_equal(g.actions, c.actions)
+            assert np.array_equal(g.get_traces(N - 1), c.get_traces(N - 1))
         # the reference's precision: the same rule in f64 (trajectories part ways where an argmax is decided by an fp32 rounding)
         if K <= 200:
             same = np.all(np.abs(c.states.T - r64.state) <= 1e-4 * (1 + np.abs(r64.state)), axis=1) & (c.actions == r64.action)
@@ -66,8 +73,8 @@ def test_sparse_traces_bitwise_and_f64(ra, orc, name, N, K, kw):
 
 
 def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
-    # file version 5 / aux kind 4: every learner's list in slot order -- with lists that are FULL (the slot order decides which entry the next new
-    # key overwrites), so the resumed run is the straight one bit for bit
+    # file version 6 / aux kind 4: whose lists (n_envs, env_offset), then every learner's sub-lists in tiling and slot order -- with lists that are FULL (the
+    # slot order decides which entry the next new key overwrites), so the resumed run is the straight one bit for bit
     kw = dict(domain=0, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.3, gamma=0.99, lam=0.97, trace=2, max_episode_steps=0,
               weight_mode=ra.W_SHARED, seed=7, alpha=0.1 / 8 / 64, n_envs=64)
     path = str(tmp_path / "sparse.rsrlw")
@@ -95,7 +102,7 @@ def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
         open(cut, "wb").write(raw[:-1])
         with pytest.raises(ra.RsrlHipError):
             b.load_weights(cut)
-        off = 72 + b.F * b.A * 4                                                         # header, the one shared table, then u32 len[N]
+        off = 72 + b.F * b.A * 4 + 16                                                    # header, the one shared table, u64 n_envs, u64 env_offset, then u32 len[N]
         bad = bytearray(raw); bad[off:off + 4] = (513).to_bytes(4, "little")
         open(cut, "wb").write(bytes(bad))
         with pytest.raises(ra.RsrlHipError):
@@ -109,6 +116,9 @@ def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
     with ra.Context(**dict(kw, lam=0.5, n_envs=32)) as other:                            # another learner count: refused
         with pytest.raises(ra.RsrlHipError):
             other.load_weights(path)
+    with ra.Context(**dict(kw, env_offset=64)) as shard:                                 # the same count, ANOTHER shard of the learners: refused, and says so
+        with pytest.raises(ra.RsrlHipError, match="env_offset"):
+            shard.load_weights(path)
 
 
 def test_sparse_lambda_is_refused_where_it_does_not_exist(ra):
