@@ -69,7 +69,8 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  *   round 5: weight_mode = RSRL_W_SHARED on tile coding -- ONE shared table, every learner its own SPARSE trace as params/sparse.rs:13-97
  *   offers: at most 512 (entry, value) pairs, kept as one sub-list of 512 / n_tilings per tiling (n_tilings 4, 8 or 16; a tiling's slice of the
  *   table, cells * actions, at most 65 536 entries), the entry with the smallest |value| of a full sub-list making room; the table moves by the
- *   synchronous mini-batch rule W += sum_i alpha * residual_i * z_i in exact 64-bit fixed point.  Stepped by rsrl_hip_train only;
+ *   synchronous mini-batch rule W += sum_i alpha * residual_i * z_i in exact 64-bit fixed point.  Stepped by rsrl_hip_train, or by
+ *   rsrl_hip_handle with transition i taken as LEARNER i's (its trace is the one that moves; M <= n_envs: ABI unchanged, round 6);
  *   rsrl_hip_get_traces shows a learner's list as the dense (F, A) matrix it stands for; the lists travel with a checkpoint, file version 6)
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through

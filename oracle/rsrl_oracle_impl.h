@@ -1180,7 +1180,9 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
  *   - Q(s',a) with the updated column is re-evaluated (no rank-1 shortcut in this family); Q(s,.) is carried;
  *   - bf16 weight storage (w_bf16 != 0): every UPDATED weight is rounded to bf16 by stochastic rounding with the 16-bit
  *     window (e >> 2) of word (e & 3) of the lane's Philox block (block id 16 + lane), e = j*8 + v.
- *   - the eligibility-trace agents (round 3; rsrl_amd/csrc/kernels_wave_lambda.hpp, f32 weights only): orc_handle_lambda's
+ *     Round 6: also for SARSALambda / QLambda, GreedyGQ, TD and TDLambda (W bf16, the trace / fa_td's weights f32): every entry of W that is
+ *     stored in a step is rounded ONCE, after all of the step's updates of it, with block id 16 + 64 * column + lane.
+ *   - the eligibility-trace agents (round 3; rsrl_amd/csrc/kernels_wave_lambda.hpp): orc_handle_lambda's
  *     operations with the wave-order dot products -- Q(s,.) carried, Q(s',.) with the pre-update weights, z = rule(rate*z + g)
  *     and w += alpha*residual*z on every entry, then Q(s',.) of ALL columns with the updated weights.
  * One-step control agents and SARSALambda / QLambda, per-env weights; returns -1 otherwise. */
@@ -1234,6 +1236,16 @@ static R FN(wave_dot)(const R* phi, const R* W, int A, int a) {
     }
     return FN(wave_total)(part);
 }
+/* stochastic rounding to bf16 of element el = j*8 + v of a lane (kernels_wave.hpp sr_bits / round_bf16_sr): the 16-bit window (el >> 2) of word
+ * (el & 3) of the lane's Philox block is added below the kept mantissa, then truncation */
+static inline R FN(sr_bf16)(R x, const uint32_t* rnd, int el) {
+    float xw = (float)x; uint32_t bits;
+    memcpy(&bits, &xw, 4);
+    bits += (rnd[el & 3] >> (el >> 2)) & 0xffffu;
+    bits &= 0xffff0000u;
+    memcpy(&xw, &bits, 4);
+    return (R)xw;
+}
 int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) {
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
     int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), d, j, l, v, AW = ag->n_actions;     /* AW: columns of the weight matrix */
@@ -1244,8 +1256,8 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
         return -1;                   /* the schedule on the wave family: one-step agents and the lambda agents (k_train_wave / _pk <ESCHED>, k_wave_lambda) */
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
-          (ORC_IS_LAMBDA(ag->algo) && !w_bf16 && run->Z) || (ag->algo == ORC_GREEDY_GQ && !w_bf16 && run->Z) ||
-          (ag->algo == ORC_TD && !w_bf16) || (ag->algo == ORC_TD_LAMBDA && !w_bf16 && run->Z) || (ag->algo == ORC_Q_SIGMA && !w_bf16 && run->qs))) return -1;
+          (ORC_IS_LAMBDA(ag->algo) && run->Z) || (ag->algo == ORC_GREEDY_GQ && run->Z) ||
+          ag->algo == ORC_TD || (ag->algo == ORC_TD_LAMBDA && run->Z) || (ag->algo == ORC_Q_SIGMA && !w_bf16 && run->qs))) return -1;
     if (ORC_IS_PRED(ag->algo)) AW = 1;
     phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
     for (i = 0; i < N; i++) {
@@ -1285,14 +1297,24 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                 na_star = FN(orc_find_max)(q_n, A, &m);
                 delta = term ? (r - qsa) : (r + (R)ag->gamma * m - qsa);
                 sc1 = (R)ag->lr * delta; sc2 = (R)ag->lr * (-(R)ag->gamma * td_est); sc3 = (R)ag->lr_td * (delta - td_est);
-                for (l = 0; l < 64; l++)
+                for (l = 0; l < 64; l++) {
+                    uint32_t rnd1[4] = { 0, 0, 0, 0 }, rnd2[4] = { 0, 0, 0, 0 };
+                    if (w_bf16) {
+                        orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + 64u * (uint32_t)a + (uint32_t)l, rnd1);
+                        orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + 64u * (uint32_t)na_star + (uint32_t)l, rnd2);
+                    }
                     for (j = 0; j < 8; j++)
                         for (v = 0; v < 8; v++) {
                             const size_t row = FN(wave_row)(l, j, v); const int e_ = (l * 8 + j) * 8 + v;
                             W[row * A + a] = FN(fma_)(sc1, phi_s[e_], W[row * A + a]);
                             if (!term) W[row * A + na_star] = FN(fma_)(sc2, phi_n[e_], W[row * A + na_star]);
                             V[row * A + a] = FN(fma_)(sc3, phi_s[e_], V[row * A + a]);
+                            if (w_bf16) {                                       /* one rounding per stored entry, after both updates when the columns coincide */
+                                W[row * A + a] = FN(sr_bf16)(W[row * A + a], rnd1, j * 8 + v);
+                                if (!term && na_star != a) W[row * A + na_star] = FN(sr_bf16)(W[row * A + na_star], rnd2, j * 8 + v);
+                            }
                         }
+                }
                 for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);
                 goto sampled_target;
             }
@@ -1300,7 +1322,9 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                 /* TD / TDLambda on the wave family: td.rs:31-59, td_lambda.rs:41-78; one weight column, V(s) in the wave order */
                 R* Z = run->Z ? run->Z + (size_t)i * F : NULL; R rate = (R)orc_trace_rate(ag);
                 delta = term ? (r - q_s[0]) : (r + (R)ag->gamma * q_n[0] - q_s[0]);
-                for (l = 0; l < 64; l++)
+                for (l = 0; l < 64; l++) {
+                    uint32_t rnd[4] = { 0, 0, 0, 0 };
+                    if (w_bf16) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + (uint32_t)l, rnd);
                     for (j = 0; j < 8; j++)
                         for (v = 0; v < 8; v++) {
                             const size_t row = FN(wave_row)(l, j, v); const int e_ = (l * 8 + j) * 8 + v;
@@ -1312,7 +1336,9 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                             } else {
                                 W[row] = FN(fma_)((R)ag->lr * delta, phi_s[e_], W[row]);
                             }
+                            if (w_bf16) W[row] = FN(sr_bf16)(W[row], rnd, j * 8 + v);
                         }
+                }
                 q_n[0] = FN(wave_dot)(phi_n, W, 1, 0);
                 goto sampled_target;
             }
@@ -1329,8 +1355,10 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                     delta = r + (R)ag->gamma * q_n[na_in] - qsa;
                 } else { FN(orc_find_max)(q_n, A, &m); delta = r + (R)ag->gamma * m - qsa; }
                 scale = (R)ag->alpha * delta;
-                for (l = 0; l < 64; l++)
-                    for (j = 0; j < 8; j++)
+                for (l = 0; l < 64; l++) {
+                  uint32_t rnd[ORC_MAX_ACTIONS][4];
+                  for (c = 0; c < A; c++) { rnd[c][0] = rnd[c][1] = rnd[c][2] = rnd[c][3] = 0; if (w_bf16) orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + 64u * (uint32_t)c + (uint32_t)l, rnd[c]); }
+                  for (j = 0; j < 8; j++)
                         for (v = 0; v < 8; v++)
                             for (c = 0; c < A; c++) {
                                 const size_t at = FN(wave_row)(l, j, v) * A + c;
@@ -1338,8 +1366,10 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                                 R z = FN(fma_)(rate, Z[at], g);
                                 if (ag->trace == ORC_TRACE_SATURATE) { z = (z < (R)1.0) ? z : (R)1.0; z = (z > (R)-1.0) ? z : (R)-1.0; }
                                 W[at] = FN(fma_)(scale, z, W[at]);
+                                if (w_bf16) W[at] = FN(sr_bf16)(W[at], rnd[c], j * 8 + v);
                                 Z[at] = term ? (R)0.0 : z;
                             }
+                }
                 for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);          /* every column moved */
                 goto sampled_target;
             }

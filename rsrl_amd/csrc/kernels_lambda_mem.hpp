@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_train_lambda_mem4(Common c, LambdaParam
         {
             FeatWalk<D> w; w.start(p, order, F);
             float ps_re = 0.0f, ps_im = 0.0f, pn_re = 0.0f, pn_im = 0.0f;
-#pragma unroll 4
+#pragma unroll 16
             for (; w.f < F; w.advance()) {
                 if (w.pre_stale && w.f != F - 1) { walk_prefix<D>(tab, cur, lane, w, ps_re, ps_im); walk_prefix<D>(tab, nxt, lane, w, pn_re, pn_im); w.pre_stale = false; }
                 const float phs = walk_phi<D>(tab, cur, lane, w, ps_re, ps_im), phn = walk_phi<D>(tab, nxt, lane, w, pn_re, pn_im);
@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void k_train_lambda_mem4(Common c, LambdaParam
         {
             FeatWalk<D> w; w.start(p, order, F);
             float ps_re = 0.0f, ps_im = 0.0f, pn_re = 0.0f, pn_im = 0.0f;
-            constexpr int G = 4;                                        // features per group: every load of a group is issued before its first store
+            constexpr int G = 8;                                        // features per group: every load of a group is issued before its first store
+                                                                        // (pass 1 unrolled x 16, G = 8: 72.6 -> 69.7 us at 16 384 learners; x 16 / G = 16: 69.3)
             while (w.f < F) {
                 float zv[G][A], wv[G][A], phs[G], phn[G]; int fi[G];
 #pragma unroll

@@ -63,8 +63,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // copy 0 of the table with device atomics (a slice too large for LDS: the same integers, the same sum).
 template <int T>
 __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* __restrict__ new_keys, const float* __restrict__ terms,
-                                                               const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int S,
-                                                               int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
+                                                               const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int64_t key_stride,
+                                                               int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
                                                                float inv_lsb, int lds) {
     constexpr int CAP = kSparseCap / T, REGS = (CAP + 63) / 64, U = 4;
     extern __shared__ long long sparse_slice[];
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
-    const uint16_t* __restrict__ kt = new_keys + (int64_t)t * N;
+    const uint16_t* __restrict__ kt = new_keys + (int64_t)t * key_stride;      // (N: the learners stepped, 0 .. N-1; key_stride: the ctx's learner count)
     const uint32_t base = (uint32_t)t * (uint32_t)S;                         // full key = base + slice-relative key
     long long* __restrict__ dst = dW64 + (int64_t)(lds ? blockIdx.x % (unsigned)n_rep : 0u) * rep_stride + (int64_t)t * S;
     if (lds) {
@@ -152,6 +152,42 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
         const long long v = sparse_slice[j];
         if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&dst[j]), (unsigned long long)v);
     }
+}
+
+// Handler::handle of the sparse-trace agents (sarsa_lambda.rs:63-98, q_lambda.rs:56-99) on caller-supplied transitions: transition i is LEARNER i's (its
+// trace is the one that moves; Mn <= the ctx's learners).  This kernel is k_shared_ca's phase A on the caller's (s, a, r, s', terminal): the residual
+// against the shared table and the hand-over to k_sparse_trace_scatter; c.alg carries the TD target's formula and step size (as in the driver loop).
+template <class M>
+__global__ __launch_bounds__(kBlock) void k_sparse_handle(Common c, BasisGeom g, const float* __restrict__ from, const int32_t* __restrict__ act,
+                                                          const float* __restrict__ rew, const float* __restrict__ to, const uint8_t* __restrict__ termf,
+                                                          int64_t Mn, uint64_t t, int want_cut, uint8_t* __restrict__ flags, uint16_t* __restrict__ keys,
+                                                          float* __restrict__ terms, float* __restrict__ td_out) {
+    constexpr int D = M::D, A = M::A, T = M::kT;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Mn) return;
+    const uint32_t gid = (uint32_t)(c.env_offset + i);
+    float s[D], ns[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
+    const int a = clamp_action<A>(act[i]);
+    const float r = rew[i];
+    const bool term = termf[i] != 0;
+    typename M::Feat fs, fn;
+    M::features(s, g, fs);
+    M::features(ns, g, fn);
+    float q_s[A], q_n[A];
+    M::q_all_shared(c.W, g, fs, q_s);
+    M::q_all_shared(c.W, g, fn, q_n);
+    U4 xin = U4{0, 0, 0, 0};
+    if (c.alg.kind == ALG_SARSA) xin = draw(c.seed, gid, t, BLK_INNER);
+    float e;
+    const float delta = td_dispatch<A>(c.alg, c.apol, q_s, a, q_n, r, term, xin, e);
+    const int cells = g.F / T;
+#pragma unroll
+    for (int tt = 0; tt < T; ++tt) keys[(int64_t)tt * c.n_envs + i] = (uint16_t)((fs.idx[tt] - tt * cells) * A + a);
+    terms[i] = c.alg.lr * e;
+    flags[i] = (uint8_t)((term ? 1 : 0) | ((want_cut && a != argmax_first<A>(q_s)) ? 4 : 0));
+    if (td_out) td_out[i] = delta;
 }
 
 // Parameterised-style view of one learner's trace: the dense (F, A) matrix it stands for (zeros + the list's entries)

@@ -1,5 +1,6 @@
 // kernels_wave_aux.hpp -- the agents with a SECOND per-learner matrix, and the prediction agents, on the WAVE family (Fourier order 7 on a 4-D
-// state space, F = 4096, one wavefront per learner, f32 weights; round 5 -- the reference's agents are generic over the approximator):
+// state space, F = 4096, one wavefront per learner; round 5 -- the reference's agents are generic over the approximator; weights f32, or (round 6)
+// bf16 with stochastic rounding -- the SECOND matrix (fa_td's weights / the trace) stays f32):
 //   GreedyGQ::handle   rsrl/src/control/td/greedy_gq.rs:73-141      fa_q = W, fa_td = V (the ctx's auxiliary matrix), both f32[N][A][F]
 //   TD::handle         rsrl/src/prediction/td/td.rs:31-59           one weight column w, f32[N][1][F]
 //   TDLambda::handle   rsrl/src/prediction/td/td_lambda.rs:41-78    + the trace z (auxiliary matrix, f32[N][1][F]); rules traces.rs:188-240
@@ -14,6 +15,9 @@
 //   TDLambda   z = rule(rate*z + phi(s)) (rate 0 after a terminal transition: the trace was reset), w += td * z, V(s') with the updated w.
 // Element by element the operations are those of the register-family kernels (kernels_gq.hpp, kernels_td.hpp); every dot product runs over (j, v)
 // in WaveFourier::dot()'s order: bit-identical to the oracle's wave-order loop (orc_run_train_wave).
+// bf16 (WT = bf16_t): W is read as bf16, arithmetic f32; every entry of W that is STORED is rounded once, after all of the step's updates of it, by
+// stochastic rounding with the lane's Philox block 16 + 64 * b + lane of the step (column b; window of element e = j * 8 + v as in k_train_wave),
+// and the dot products of the sweep run over the rounded values -- what a fresh evaluation would read.
 #pragma once
 
 #include "kernels_wave.hpp"
@@ -34,13 +38,13 @@ struct WaveAuxParams {
 };
 
 // <phi, column> with the column streamed from memory, dot()'s order (4 interleaved chains over (j, v), then the wave total)
-template <int DOMAIN>
-__device__ __forceinline__ float wave_col_dot(const float* __restrict__ col, int lane, const float (&phi)[8][8]) {
+template <int DOMAIN, class WT = float>
+__device__ __forceinline__ float wave_col_dot(const WT* __restrict__ col, int lane, const float (&phi)[8][8]) {
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float w8[8];
-        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, w8);
+        WaveIO<WT>::load8(col, (int64_t)j * 512 + lane * 8, w8);
 #pragma unroll
         for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi[j][v], w8[v], acc[v & 3]);
     }
@@ -49,14 +53,15 @@ __device__ __forceinline__ float wave_col_dot(const float* __restrict__ col, int
 
 // from == nullptr: the driver loop, n_steps batch-steps of the wave's learner.  Otherwise Handler::handle on ONE caller-supplied transition per
 // learner (Mn of them; the prediction agents ignore `act`).
-template <int DOMAIN>
-__global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap, float* __restrict__ Wbase, uint64_t t0, int n_steps,
+template <int DOMAIN, class WT = float>
+__global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap, WT* __restrict__ Wbase, uint64_t t0, int n_steps,
                                                      DevStats* __restrict__ stats, const float* __restrict__ from, const int32_t* __restrict__ act,
                                                      const float* __restrict__ rew, const float* __restrict__ to, const uint8_t* __restrict__ termf,
                                                      int64_t Mn, float* __restrict__ td_out) {
     using WF = WaveFourier<DOMAIN>;
     using Dom = Domain<DOMAIN>;
-    using IO = WaveIO<float>;
+    using IO = WaveIO<WT>;
+    using IOX = WaveIO<float>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
     const int lane = threadIdx.x & 63;
     const int64_t N = c.n_envs;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
         const float gamma = c.alg.gamma, lr = c.alg.lr;
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
-        float* __restrict__ Wi = Wbase + i * (int64_t)Aw * F;
+        WT* __restrict__ Wi = Wbase + i * (int64_t)Aw * F;
         float* __restrict__ Xi = ap.aux ? ap.aux + i * (int64_t)Aw * F : nullptr;
         float s[D];
         int a = 0; uint32_t ep = 0;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
         for (int b = 0; b < A; ++b) q_s[b] = 0.0f;
         WF::project(s, lane, phi_s);
 #pragma unroll
-        for (int b = 0; b < A; ++b) if (b < Aw) q_s[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_s);       // GQ: Q(s,.); prediction: q_s[0] = V(s)
+        for (int b = 0; b < A; ++b) if (b < Aw) q_s[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_s);       // GQ: Q(s,.); prediction: q_s[0] = V(s)
         float facc_abs = 0.0f, facc_r = 0.0f;
         bool cut = false;                                                              // TDLambda: the previous transition was terminal
         for (int k = 0; k < (driver ? n_steps : 1); ++k) {
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
             for (int b = 0; b < A; ++b) q_n[b] = 0.0f;
             WF::project(ns, lane, phi_n);
 #pragma unroll
-            for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_n);   // PRE-update weights
+            for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_n);   // PRE-update weights
             float delta;
             if (gq) {
                 const float qsa = select_a<A>(q_s, a);
@@ -127,6 +132,8 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
                 for (int b = 0; b < A; ++b) {
                     const bool hit1 = a == b, hit2 = !term && na_star == b;            // wave-uniform
                     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    U4 rnd = U4{0, 0, 0, 0};
+                    if constexpr (IO::kBf16) { if (hit1 || hit2) rnd = draw(c.seed, gid, t, BLK_SR_BASE + 64u * (uint32_t)b + (uint32_t)lane); }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int64_t off = (int64_t)b * F + j * 512 + lane * 8;
@@ -136,16 +143,22 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
 #pragma unroll
                             for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc1, phi_s[j][v], w8[v]);
                             float v8[8];
-                            IO::load8(Xi, off, v8);
+                            IOX::load8(Xi, off, v8);
 #pragma unroll
                             for (int v = 0; v < 8; ++v) v8[v] = fmaf(sc3, phi_s[j][v], v8[v]);
-                            IO::store8(Xi, off, v8);
+                            IOX::store8(Xi, off, v8);
                         }
                         if (hit2) {
 #pragma unroll
                             for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc2, phi_n[j][v], w8[v]);
                         }
-                        if (hit1 || hit2) IO::store8(Wi, off, w8);
+                        if (hit1 || hit2) {
+                            if constexpr (IO::kBf16) {
+#pragma unroll
+                                for (int v = 0; v < 8; ++v) w8[v] = round_bf16_sr(w8[v], sr_bits(rnd, j * 8 + v));
+                            }
+                            IO::store8(Wi, off, w8);
+                        }
 #pragma unroll
                         for (int v = 0; v < 8; ++v) acc[v & 3] = fmaf(phi_n[j][v], w8[v], acc[v & 3]);
                     }
@@ -157,13 +170,15 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
                 const float rate_eff = cut ? 0.0f : ap.rate;
                 const float sc = lr * delta;
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                U4 rnd = U4{0, 0, 0, 0};
+                if constexpr (IO::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + (uint32_t)lane);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int64_t off = (int64_t)j * 512 + lane * 8;
                     float w8[8], z8[8];
                     IO::load8(Wi, off, w8);
                     if (lam) {
-                        IO::load8(Xi, off, z8);
+                        IOX::load8(Xi, off, z8);
 #pragma unroll
                         for (int v = 0; v < 8; ++v) {
                             float zz = fmaf(rate_eff, z8[v], 1.0f * phi_s[j][v]);      // WBuf::decay_add with the indicator 1
@@ -171,10 +186,14 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
                             w8[v] = fmaf(delta, zz, w8[v]);                            // ScaledGradientUpdate{alpha: td_error}: no learning rate
                             z8[v] = term ? 0.0f : zz;                                  // trace.reset() after a terminal transition
                         }
-                        IO::store8(Xi, off, z8);
+                        IOX::store8(Xi, off, z8);
                     } else {
 #pragma unroll
                         for (int v = 0; v < 8; ++v) w8[v] = fmaf(sc, phi_s[j][v], w8[v]);
+                    }
+                    if constexpr (IO::kBf16) {
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) w8[v] = round_bf16_sr(w8[v], sr_bits(rnd, j * 8 + v));
                     }
                     IO::store8(Wi, off, w8);
 #pragma unroll
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
                 Dom::reset(ns);
                 WF::project(ns, lane, phi_n);
 #pragma unroll
-                for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN>(Wi + (int64_t)b * F, lane, phi_n);
+                for (int b = 0; b < A; ++b) if (b < Aw) q_n[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
                 na = policy_sample<A>(pol, q_n, xr);
             }
@@ -322,8 +341,8 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
 }
 
 // V(s) of a prediction agent for M caller-supplied states (Function<(S,)> of the ScalarLFA), one wave per state
-template <int DOMAIN>
-__global__ __launch_bounds__(kBlock) void k_wave_v_evaluate(const float* __restrict__ Wbase, const float* __restrict__ states, int64_t Mn, float* __restrict__ out) {
+template <int DOMAIN, class WT = float>
+__global__ __launch_bounds__(kBlock) void k_wave_v_evaluate(const WT* __restrict__ Wbase, const float* __restrict__ states, int64_t Mn, float* __restrict__ out) {
     using WF = WaveFourier<DOMAIN>;
     constexpr int D = WF::D, F = WF::F;
     const int lane = threadIdx.x & 63;
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_v_evaluate(const float* __restr
     for (int d = 0; d < D; ++d) s[d] = states[(int64_t)d * Mn + i];
     float phi[8][8];
     WF::project(s, lane, phi);
-    const float v = wave_col_dot<DOMAIN>(Wbase + i * (int64_t)F, lane, phi);
+    const float v = wave_col_dot<DOMAIN, WT>(Wbase + i * (int64_t)F, lane, phi);
     if (lane == 0) out[i] = v;
 }
 

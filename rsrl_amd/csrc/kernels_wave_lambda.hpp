@@ -1,6 +1,6 @@
 // kernels_wave_lambda.hpp -- eligibility-trace control (SARSALambda / QLambda, rsrl/src/control/td/sarsa_lambda.rs:53-98,
 // q_lambda.rs:56-99; trace rules rsrl/src/traces.rs:188-240) on the WAVE family: Fourier order 7 on a 4-D state space,
-// F = 4096 features, one wavefront per learner (kernels_wave.hpp), f32 weights.
+// F = 4096 features, one wavefront per learner (kernels_wave.hpp); weights f32, or (round 6) bf16 with stochastic rounding and the trace in f32.
 //
 // Every entry of W moves at every step (W += alpha * residual * Z), and W + Z are 96 KiB per learner: neither the registers of
 // a wave (k_train_wave keeps W alone there, 192 of them) nor its share of the LDS hold both, so this family member is a memory
@@ -13,6 +13,10 @@
 // next step's Q(s, .) -- falls out of the sweep: every column's lane partial runs over (j, v) in dot()'s order, four chains,
 // then the wave total.  Element by element the operations are project() / dot() / trace_merge() / fmaf of the granular kernels:
 // bit-identical to the oracle's wave-order loop (orc_run_train_wave with a lambda agent).
+// bf16 weights (WT = bf16_t; the storage format of BASELINE configs[4], here for the trace agents): W is read as bf16, the arithmetic and the
+// trace stay f32, and EVERY entry of W -- all of them move -- is rounded back by stochastic rounding with the lane's Philox block 16 + 64 * b + lane
+// of the step (column b; the 16-bit window of element e = j * 8 + v as in k_train_wave), so that Q(s', .) of the sweep is the dot product over
+// the stored values.  W traffic halves: 4 A F + 2 x 2 A F bytes per learner-step instead of 4 x 4 A F.
 #pragma once
 
 #include "kernels_wave.hpp"
@@ -22,14 +26,15 @@ namespace rsrl {
 
 // from == nullptr: the driver loop, n_steps batch-steps of the wave's learner.  Otherwise Handler::handle on ONE caller-supplied
 // transition per learner (Mn of them).
-template <int DOMAIN>
-__global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams lp, float* __restrict__ Wbase, uint64_t t0, int n_steps,
+template <int DOMAIN, class WT = float>
+__global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams lp, WT* __restrict__ Wbase, uint64_t t0, int n_steps,
                                                         DevStats* __restrict__ stats, const float* __restrict__ from, const int32_t* __restrict__ act,
                                                         const float* __restrict__ rew, const float* __restrict__ to, const uint8_t* __restrict__ termf,
                                                         int64_t Mn, float* __restrict__ td_out) {
     using WF = WaveFourier<DOMAIN>;
     using Dom = Domain<DOMAIN>;
-    using IO = WaveIO<float>;
+    using IO = WaveIO<WT>;
+    using IOZ = WaveIO<float>;
     constexpr int D = WF::D, A = WF::A, F = WF::F;
     const int lane = threadIdx.x & 63;
     const int64_t N = c.n_envs;
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
         AlgoParams alg = c.alg; alg.kind = sarsa ? ALG_SARSA : ALG_QLEARNING;      // the TD target formula
         const uint32_t gid = (uint32_t)(c.env_offset + i);
         const uint32_t cap = c.max_episode_steps;
-        float* __restrict__ Wi = Wbase + i * (int64_t)(A * F);
+        WT* __restrict__ Wi = Wbase + i * (int64_t)(A * F);
         float* __restrict__ Zi = lp.Z + i * (int64_t)(A * F);
         float s[D];
         int a; uint32_t ep = 0;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
         }
         float phi_s[8][8], q_s[A];
         WF::project(s, lane, phi_s);
-        WF::template q_from_mem<float>(Wi, lane, phi_s, q_s);
+        WF::template q_from_mem<WT>(Wi, lane, phi_s, q_s);
         float facc_abs = 0.0f, facc_r = 0.0f;
         // the per-learner epsilon schedule (Common::eps, examples/sarsa_lambda.rs:68): the learner is the wave's, its epsilon wave-uniform
         PolicyParams pol = c.pol;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
             }
             float phi_n[8][8], q_n[A];
             WF::project(ns, lane, phi_n);
-            WF::template q_from_mem<float>(Wi, lane, phi_n, q_n);              // PRE-update weights
+            WF::template q_from_mem<WT>(Wi, lane, phi_n, q_n);              // PRE-update weights
             // ---- trace decay rate: Q(lambda) cuts the trace unless the action taken was argmax_first of Q(s,.)   q_lambda.rs:62-66
             float rate_eff = lp.rate;
             if (!sarsa) rate_eff = (a != argmax_first<A>(q_s)) ? 0.0f : lp.rate;
@@ -94,21 +99,24 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
             for (int b = 0; b < A; ++b) {
                 const bool hit = a == b;                                       // wave-uniform
                 float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                U4 rnd = U4{0, 0, 0, 0};
+                if constexpr (IO::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + 64u * (uint32_t)b + (uint32_t)lane);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int64_t off = (int64_t)b * F + j * 512 + lane * 8;
                     float z8[8], w8[8];
-                    IO::load8(Zi, off, z8);
+                    IOZ::load8(Zi, off, z8);
                     IO::load8(Wi, off, w8);
 #pragma unroll
                     for (int v = 0; v < 8; ++v) {
                         const float zz = trace_merge(lp.trace, rate_eff, z8[v], hit ? phi_s[j][v] : 0.0f);
-                        const float ww = fmaf(scale, zz, w8[v]);
+                        float ww = fmaf(scale, zz, w8[v]);
+                        if constexpr (IO::kBf16) ww = round_bf16_sr(ww, sr_bits(rnd, j * 8 + v));
                         acc[v & 3] = fmaf(phi_n[j][v], ww, acc[v & 3]);
                         z8[v] = term ? 0.0f : zz;                              // trace.reset() after a terminal transition
                         w8[v] = ww;
                     }
-                    IO::store8(Zi, off, z8);
+                    IOZ::store8(Zi, off, z8);
                     IO::store8(Wi, off, w8);
                 }
                 q_n[b] = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void k_wave_lambda(Common c, LambdaParams l
                 n_ep += 1; n_trunc += 1; sum_len += ep; ep = 0;
                 Dom::reset(ns);
                 WF::project(ns, lane, phi_n);
-                WF::template q_from_mem<float>(Wi, lane, phi_n, q_n);
+                WF::template q_from_mem<WT>(Wi, lane, phi_n, q_n);
                 const U4 xr = draw(c.seed, gid, t, BLK_RESET);
                 na = policy_sample<A>(pol, q_n, xr);
             }

@@ -320,7 +320,7 @@ struct rsrl_hip_ctx {
     struct TraitPend { int stage = 0; const int32_t* act = nullptr; float* from = nullptr; float* to = nullptr; float* rew = nullptr;
                        uint8_t* term = nullptr; float* td = nullptr; uint64_t t_handle = 0; } tp;
     uint8_t* flags = nullptr;        // shared-W: terminal/truncated flags between phase A and phase C
-    size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0;
+    size_t w_elems = 0; size_t dw_elems = 0; size_t w_bytes = 0; size_t z_bytes = 0;      // (the auxiliary matrix Z -- traces / fa_td weights -- is f32 whatever W's storage)
     int64_t w_stride = 0;            // stride between (action, feature) rows of W
     int64_t w_ls = 1;                // stride between learners (A*F in the learner-major single-step layout, else 1)
     DevStats* d_stats = nullptr; DevStats* h_stats = nullptr;   // one slot per thread block
@@ -446,10 +446,20 @@ static WaveAuxParams make_wave_aux(const rsrl_hip_ctx* c) {
     ap.rate = tp.rate; ap.trace = tp.trace;
     return ap;
 }
+template <int DM, class WT> struct WaveTag { static constexpr int domain = DM; using wt = WT; };
+template <class Fn>
+static bool for_wave(const rsrl_hip_ctx* c, Fn&& fn) {
+    const bool bf = c->cfg.weight_dtype == RSRL_W_BF16;
+    if (c->cfg.domain == RSRL_CART_POLE) { if (bf) fn(WaveTag<1, bf16_t>{}); else fn(WaveTag<1, float>{}); return true; }
+    if (c->cfg.domain == RSRL_ACROBOT) { if (bf) fn(WaveTag<2, bf16_t>{}); else fn(WaveTag<2, float>{}); return true; }
+    return false;
+}
 template <class... Args>
-static void launch_wave_aux(const rsrl_hip_ctx* c, dim3 grid, Args... args) {
-    if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_aux<1>), grid, dim3(kBlock), 0, c->stream, args...);
-    else hipLaunchKernelGGL((k_wave_aux<2>), grid, dim3(kBlock), 0, c->stream, args...);
+static void launch_wave_aux(const rsrl_hip_ctx* c, dim3 grid, const Common& k, const WaveAuxParams& ap, Args... args) {      // (W: the ctx's, in its storage type)
+    for_wave(c, [&](auto tag) {
+        using T = decltype(tag); using WT = typename T::wt;
+        hipLaunchKernelGGL((k_wave_aux<T::domain, WT>), grid, dim3(kBlock), 0, c->stream, k, ap, (WT*)c->W, args...);
+    });
 }
 
 // the step kernel of the shared-weight loops (what rsrl_hip_timing_read names): the dense bases', shared tile coding's, the sparse-trace lambda agents'
@@ -493,16 +503,8 @@ static BasisGeom make_geom(const rsrl_hip_ctx* c) {
     return BasisGeom{c->F, c->cfg.basis == RSRL_FOURIER ? c->cfg.order : c->cfg.tiles_per_dim};
 }
 // wave family (one wavefront per learner): Fourier order 7 on the 4-D domains, f32 or bf16 weights
-template <int DM, class WT> struct WaveTag { static constexpr int domain = DM; using wt = WT; };
 static bool is_wave(const rsrl_hip_config& cfg) {
     return cfg.basis == RSRL_FOURIER && cfg.order == kWaveOrder && (cfg.domain == RSRL_CART_POLE || cfg.domain == RSRL_ACROBOT);
-}
-template <class Fn>
-static bool for_wave(const rsrl_hip_ctx* c, Fn&& fn) {
-    const bool bf = c->cfg.weight_dtype == RSRL_W_BF16;
-    if (c->cfg.domain == RSRL_CART_POLE) { if (bf) fn(WaveTag<1, bf16_t>{}); else fn(WaveTag<1, float>{}); return true; }
-    if (c->cfg.domain == RSRL_ACROBOT) { if (bf) fn(WaveTag<2, bf16_t>{}); else fn(WaveTag<2, float>{}); return true; }
-    return false;
 }
 static inline unsigned wave_grid_for(int64_t items) { return (unsigned)((items + (kBlock / 64) - 1) / (kBlock / 64)); }
 #define NO_MODEL(c) fail(RSRL_HIP_EINVAL, "no kernel for basis %d domain %d order %d tilings %d", (c)->cfg.basis, (c)->cfg.domain, (c)->cfg.order, (c)->cfg.n_tilings)
@@ -787,8 +789,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         return fail(RSRL_HIP_EINVAL, "basis %d (order %d / %d tilings) on domain %d has no kernel yet", cfg->basis, cfg->order, cfg->n_tilings, cfg->domain);
     if (is_pred(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;
-        if (!tile_ok && (cfg->basis != RSRL_FOURIER || cfg->weight_mode != RSRL_W_PER_ENV || (is_wave(*cfg) && cfg->weight_dtype != RSRL_W_F32)))
-            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a Fourier basis (f32 on the order-7 wave family) "
+        if (!tile_ok && (cfg->basis != RSRL_FOURIER || cfg->weight_mode != RSRL_W_PER_ENV))
+            return fail(RSRL_HIP_EINVAL, "the prediction agents (TD, TDLambda) need per-learner weights on a Fourier basis "
                                          "or on tile coding");
         if (cfg->policy != RSRL_RANDOM) return fail(RSRL_HIP_EINVAL, "prediction agents have no Q function: the behaviour policy must be RSRL_RANDOM");
         if (cfg->algo == RSRL_TD_LAMBDA) {
@@ -797,17 +799,16 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         }
     }
     if (cfg->algo == RSRL_GREEDY_GQ) {
-        if (cfg->weight_mode != RSRL_W_PER_ENV || (is_wave(*cfg) && cfg->weight_dtype != RSRL_W_F32))
-            return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights (f32 on the order-7 wave family)");
+        if (cfg->weight_mode != RSRL_W_PER_ENV) return fail(RSRL_HIP_EINVAL, "GreedyGQ needs per-learner weights");
         if (!(cfg->lr_td >= 0.0)) return fail(RSRL_HIP_EINVAL, "lr_td must be >= 0");
     }
     if (is_lambda(cfg->algo)) {
         const bool tile_ok = cfg->basis == RSRL_TILE_CODING && cfg->weight_mode == RSRL_W_PER_ENV;     // dense per-learner trace tables
-        const bool wave_ok = cfg->basis == RSRL_FOURIER && is_wave(*cfg) && cfg->weight_mode == RSRL_W_PER_ENV && cfg->weight_dtype == RSRL_W_F32;
+        const bool wave_ok = cfg->basis == RSRL_FOURIER && is_wave(*cfg) && cfg->weight_mode == RSRL_W_PER_ENV;      // (f32, or bf16 + stochastic rounding: round 6)
         // ... or sparse per-learner traces over ONE shared table (traces.rs:5-12 over params/sparse.rs; round 5)
         const bool sparse_ok = is_sparse_lambda(*cfg) && (cfg->n_tilings == 4 || cfg->n_tilings == 8 || cfg->n_tilings == 16);
         if (!tile_ok && !wave_ok && !sparse_ok && (cfg->basis != RSRL_FOURIER || is_wave(*cfg) || cfg->weight_mode != RSRL_W_PER_ENV))
-            return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a Fourier basis (f32 on the order-7 wave family) "
+            return fail(RSRL_HIP_EINVAL, "the eligibility-trace agents need per-learner weights on a Fourier basis "
                                          "or on tile coding (per-learner tables, or one shared table with sparse per-learner traces)");
         if (cfg->trace < 0 || cfg->trace > RSRL_TRACE_DUTCH) return fail(RSRL_HIP_EINVAL, "unknown trace rule %d", cfg->trace);
         if (!(cfg->lambda >= 0.0 && cfg->lambda <= 1.0)) return fail(RSRL_HIP_EINVAL, "lambda must be in [0, 1]");
@@ -900,8 +901,9 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(slice * 8)) != hipSuccess) { (void)hipGetLastError(); c->sp_lds = false; }
         }
     } else if (has_aux(cfg->algo)) {
-        HIP_TRY(hipMalloc((void**)&c->Z, c->w_bytes));
-        HIP_TRY(hipMemsetAsync(c->Z, 0, c->w_bytes, c->stream));                  // Trace::zeros
+        c->z_bytes = c->w_elems * 4;
+        HIP_TRY(hipMalloc((void**)&c->Z, c->z_bytes));
+        HIP_TRY(hipMemsetAsync(c->Z, 0, c->z_bytes, c->stream));                  // Trace::zeros
     }
     if (shared) {
         HIP_TRY(hipMalloc((void**)&c->flags, (size_t)N));
@@ -1209,8 +1211,10 @@ static int qop(rsrl_hip_ctx* c, int op, const float* states, int64_t M_, float* 
     if (op == QOP_SAMPLE) c->api_calls++;
     const BasisGeom g = make_geom(c);
     if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && is_wave(c->cfg)) {
-        if (c->cfg.domain == RSRL_CART_POLE) hipLaunchKernelGGL((k_wave_v_evaluate<1>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, (const float*)c->W, d_states, M_, of.dev);
-        else hipLaunchKernelGGL((k_wave_v_evaluate<2>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, (const float*)c->W, d_states, M_, of.dev);
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_v_evaluate<T::domain, WT>), dim3(wave_grid_for(M_)), dim3(kBlock), 0, c->stream, (const WT*)c->W, d_states, M_, of.dev);
+        });
     } else if (is_pred(c->cfg.algo) && op == QOP_EVALUATE && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, false, 0, c->stream, k, g, make_td(c), 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, M_,
                             of.dev, d_states)) return NO_MODEL(c);
@@ -1375,13 +1379,46 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
     TRY(stage_out(c, 5, td_error_out, (size_t)M, &otd));
     const Common k = make_common(c);
     const BasisGeom g = make_geom(c);
-    if (is_sparse_lambda(c->cfg))
-        return fail(RSRL_HIP_ESTATE, "SARSALambda / QLambda over a shared tile table keep one sparse trace per LEARNER of the ctx: they are stepped by rsrl_hip_train "
-                                     "(caller-supplied transitions have no learner to attach a trace to)");
+    if (is_sparse_lambda(c->cfg)) {
+        // transition i is LEARNER i's (round 6): its residual against the shared table, its trace, the mini-batch's delta -- the driver loop's three launches on
+        // the caller's transitions (kernels_sparse_lambda.hpp)
+        const float step_size = (float)c->cfg.alpha;
+        Common ks = k;
+        ks.alg.kind = c->cfg.algo == RSRL_SARSA_LAMBDA ? ALG_SARSA : ALG_QLEARNING; ks.alg.lr = step_size;
+        const int slice = (int)((int64_t)(c->F / c->cfg.n_tilings) * c->A);
+        if (!for_model(c, [&](auto tag) {
+                using Mo = typename decltype(tag)::type;
+                if constexpr (Mo::kSparse) {
+                    hipLaunchKernelGGL((k_sparse_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, ks, g, d_from, d_act, d_rew, d_to, d_term, M, c->t,
+                                       c->cfg.algo == RSRL_Q_LAMBDA ? 1 : 0, c->flags, c->sc_keys, c->sc_terms, otd.dev);
+                    const int per = 512;
+                    hipLaunchKernelGGL((k_sparse_trace_scatter<Mo::kT>), dim3((unsigned)((M + per - 1) / per), (unsigned)Mo::kT), dim3(1024), c->sp_lds ? (size_t)slice * 8 : 0,
+                                       c->stream, c->sc_keys, c->sc_terms, c->flags, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, make_lambda(c), M,
+                                       (int64_t)c->cfg.n_envs, slice, per, c->dW_rep, c->n_rep, (int64_t)c->dw_elems, FxScale(step_size).inv_lsb, c->sp_lds ? 1 : 0);
+                }
+            })) return NO_MODEL(c);
+        KCHECK();
+        const int n = (int)c->dw_elems;
+        hipLaunchKernelGGL(k_apply_rep, dim3(((n + 1) / 2 + 255) / 256), dim3(256), 0, c->stream, c->multi ? (float*)nullptr : c->W, c->dW, c->dW_rep, c->n_rep, n,
+                           tile_lsb(step_size));
+        KCHECK();
+        if (c->multi) {
+            TRY(exchange_dw(c, c->t, nullptr, k.xdelta));
+            if (c->cfg.exchange == RSRL_EXCHANGE_PEER) c->peer_seq += 1;
+            hipLaunchKernelGGL(k_apply_dw, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->W, c->dW, n);
+            KCHECK();
+        }
+        c->q_valid = false; c->tq_valid = false;
+        c->t += 1;
+        bool sync = !all_device;
+        TRY(flush_out(c, &otd, &sync));
+        if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+        return RSRL_HIP_OK;
+    }
     if (trait_fast(c)) {
         TRY(launch_trait_handle(c, k, d_from, d_act, d_rew, d_to, d_term, M, c->t, otd.dev));
     } else if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
-        launch_wave_aux(c, dim3(wave_grid_for(M)), k, make_wave_aux(c), (float*)c->W, c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+        launch_wave_aux(c, dim3(wave_grid_for(M)), k, make_wave_aux(c), c->t, 1, (DevStats*)nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
     } else if (is_pred(c->cfg.algo) && c->cfg.basis == RSRL_TILE_CODING) {
         if (!launch_td_tile(c->cfg.domain, c->cfg.n_tilings, c->cfg.algo == RSRL_TD_LAMBDA, M, c->stream, k, g, make_td(c), c->t, 1, nullptr, d_from, d_rew,
                             d_to, d_term, M, otd.dev, nullptr)) return NO_MODEL(c);
@@ -1410,8 +1447,11 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
         if (!launch_lambda_tile(c->cfg.domain, c->cfg.n_tilings, M, c->stream, k, g, make_lambda(c), c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
                                 M, otd.dev)) return NO_MODEL(c);
     } else if (is_lambda(c->cfg.algo) && is_wave(c->cfg)) {
-        if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
-        else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+        for_wave(c, [&](auto tag) {
+            using T = decltype(tag); using WT = typename T::wt;
+            hipLaunchKernelGGL((k_wave_lambda<T::domain, WT>), dim3(wave_grid_for(M)), dim3(kBlock), 0, c->stream, k, make_lambda(c), (WT*)c->W, c->t, 1, (DevStats*)nullptr,
+                               d_from, d_act, d_rew, d_to, d_term, M, otd.dev);
+        });
     } else if (is_lambda(c->cfg.algo) && is_generic_fourier(c->cfg)) {
         if (!launch_lambda_model(c->cfg, dim3(grid_for(M)), dim3(kBlock), c->stream, k, make_lambda(c), g, c->t, 1, nullptr, d_from, d_act, d_rew, d_to, d_term,
                                  M, otd.dev)) return NO_MODEL(c);
@@ -1732,9 +1772,9 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
     // every learner has been read -- a failing load leaves the ctx exactly as it was
     float* W_old = c->W; float* Z_old = c->Z; float* W_new = nullptr; float* Z_new = nullptr;
     hipError_t e = hipMalloc((void**)&W_new, c->w_bytes);
-    if (e == hipSuccess && Z_old) e = hipMalloc((void**)&Z_new, c->w_bytes);
+    if (e == hipSuccess && Z_old) e = hipMalloc((void**)&Z_new, c->z_bytes);
     if (e == hipSuccess) e = hipMemcpyAsync(W_new, W_old, c->w_bytes, hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess && Z_old) e = hipMemcpyAsync(Z_new, Z_old, c->w_bytes, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && Z_old) e = hipMemcpyAsync(Z_new, Z_old, c->z_bytes, hipMemcpyDeviceToDevice, c->stream);
     if (e != hipSuccess) {
         if (W_new) (void)hipFree(W_new);
         if (Z_new) (void)hipFree(Z_new);
@@ -1966,7 +2006,7 @@ static int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom
                     const unsigned chunks = (unsigned)((k.n_envs + per - 1) / per);
                     const SparseTrace st{c->sp_keys, c->sp_vals, c->sp_len};
                     hipLaunchKernelGGL((k_sparse_trace_scatter<M::kT>), dim3(chunks, (unsigned)M::kT), dim3(1024), c->sp_lds ? (size_t)slice * 8 : 0, c->stream,
-                                       c->sc_keys, c->sc_terms, c->flags, st, make_lambda(c), (int64_t)k.n_envs, slice, per, c->dW_rep, nrep, (int64_t)c->dw_elems,
+                                       c->sc_keys, c->sc_terms, c->flags, st, make_lambda(c), (int64_t)k.n_envs, (int64_t)k.n_envs, slice, per, c->dW_rep, nrep, (int64_t)c->dw_elems,
                                        FxScale(step_size).inv_lsb, c->sp_lds ? 1 : 0);
                     return;
                 }
@@ -2329,7 +2369,7 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             TRY(enqueue_shared_step(c, k, g, d_stats, done == 0 ? 0 : 1, c->t, nullptr));
             c->kernel_name = shared_kernel_name(c);
         } else if (is_wave(c->cfg) && is_wave_aux_algo(c->cfg.algo)) {
-            launch_wave_aux(c, dim3(wave_grid_for(k.n_envs)), k, make_wave_aux(c), (float*)c->W, c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr,
+            launch_wave_aux(c, dim3(wave_grid_for(k.n_envs)), k, make_wave_aux(c), c->t, chunk, d_stats, (const float*)nullptr, (const int32_t*)nullptr,
                             (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
             c->kernel_name = "k_wave_aux";
             KCHECK();
@@ -2375,8 +2415,11 @@ static int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out
             c->kernel_name = "k_lambda_tile";
             KCHECK();
         } else if (is_lambda(c->cfg.algo) && is_wave(c->cfg)) {
-            if (c->cfg.domain == 1) hipLaunchKernelGGL((k_wave_lambda<1>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
-            else hipLaunchKernelGGL((k_wave_lambda<2>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), c->W, c->t, chunk, d_stats, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            for_wave(c, [&](auto tag) {
+                using T = decltype(tag); using WT = typename T::wt;
+                hipLaunchKernelGGL((k_wave_lambda<T::domain, WT>), dim3(wave_grid_for(k.n_envs)), dim3(kBlock), 0, c->stream, k, make_lambda(c), (WT*)c->W, c->t, chunk, d_stats,
+                                   (const float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const uint8_t*)nullptr, (int64_t)0, (float*)nullptr);
+            });
             c->kernel_name = "k_wave_lambda";
             KCHECK();
         } else if (is_lambda(c->cfg.algo) && is_generic_fourier(c->cfg)) {
@@ -2646,7 +2689,7 @@ int rsrl_hip_checksum(rsrl_hip_ctx* c, uint64_t out[2]) {
     const size_t N = (size_t)c->cfg.n_envs;
     if (c->w_ls != 1) hipLaunchKernelGGL(k_checksum_lm, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->W, (int64_t)N, c->A * c->F, d);
     else run(c->W, c->w_bytes, 0, 0);
-    run(c->Z, c->Z ? c->w_bytes : 0, (size_t)1 << 40, 0);
+    run(c->Z, c->Z ? c->z_bytes : 0, (size_t)1 << 40, 0);
     run(c->state, sizeof(float) * c->D * N, 0, 1);
     run(c->action, sizeof(int32_t) * N, (size_t)1 << 36, 1);
     run(c->ep_step, sizeof(uint32_t) * N, (size_t)1 << 37, 1);

@@ -93,10 +93,16 @@ CONFIGS = {
     "c5s": dict(what="configs[4] in small at a stable step size: lr 2.5e-4 (lr |phi|^2 ~ 0.5)", M=8, K=200, K_free=2000,
                 cap=100, bf16=True, kw=dict(domain=2, order=7, algo=2, policy=2, tau=1.0, gamma=0.99, lr=0.00025, alpha=1.0)),
     # the agents widened onto the order-7 wave family in round 5 (kernels_wave_aux.hpp), teacher-forced against f64 like the configurations above
+    # (no bf16 leg for GreedyGQ here: its second update goes to the column argmax of Q(s',.) picks UNDER THE RUN'S OWN W, and near the zero initialisation the
+    # action gaps are below bf16's rounding noise -- the bf16 and f32 runs update different columns (measured: |W_bf16 - W_f32| = 0.43 max|W| after 200 steps, 8x the
+    # random-walk bound the TD / SARSALambda legs keep: 0.80 / 0.61 of it).  GreedyGQ's bf16 arithmetic is pinned per transition instead:
+    # tests/test_gpu_wave_aux.py::test_single_transitions_vs_f64[bf16] -- every stored entry within one bf16 ulp of f64, unbiased.)
     "w7_gq": dict(what="GreedyGQ on Acrobot Fourier(7), eps-greedy: W and fa_td's V", M=6, K=200, K_free=1000, cap=100,
                   kw=dict(domain=2, order=7, algo=6, policy=1, epsilon=0.1, gamma=0.99, lr=0.0002, lr_td=0.001)),
-    "w7_td": dict(what="TD (state values) on CartPole Fourier(7), Random behaviour", M=6, K=200, K_free=1000, cap=100,
+    "w7_td": dict(what="TD (state values) on CartPole Fourier(7), Random behaviour (f32 and bf16 weights)", M=6, K=200, K_free=1000, cap=100, bf16=True,
                   kw=dict(domain=1, order=7, algo=7, policy=3, gamma=0.99, lr=0.0002)),
+    "w7_sl": dict(what="SARSALambda (accumulating trace, lambda 0.8) on CartPole Fourier(7), eps-greedy (f32 and bf16 weights, the trace f32)", M=6, K=200, K_free=1000, cap=100,
+                  bf16=True, kw=dict(domain=1, order=7, algo=3, policy=1, epsilon=0.1, gamma=0.99, alpha=0.0001, lam=0.8, trace=0)),
 }
 
 

@@ -20,9 +20,13 @@ CASES = [
     ("k_wave_aux TDLambda", dict(domain=1, order=7, algo=ra.TD_LAMBDA, policy=ra.RANDOM, gamma=0.9, lam=0.5, n_envs=8192), 4 * F7 * 4),
     ("k_wave_qsigma", dict(domain=2, order=7, algo=ra.Q_SIGMA, policy=1, epsilon=0.1, gamma=0.99, lr=1e-4, alpha=0.5, sigma=0.5, n_steps=4, n_envs=8192), (3 * F7 + F7) * 4),
     ("k_wave_lambda SARSALambda", dict(domain=2, order=7, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99, alpha=1e-4, lam=0.8, n_envs=8192), 4 * 3 * F7 * 4),
-    ("k_sparse_lambda_step", dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99,
+    ("k_sparse_trace_scatter", dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99,
                                   alpha=0.1 / 8 / 16384, lam=0.9, weight_mode=ra.W_SHARED, n_envs=16384), 2 * 512 * 8 + 16 * 2 * 4 + 512 * 8),
     ("k_train_lambda_mem", dict(domain=1, order=3, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99, alpha=1e-3, lam=0.8, n_envs=16384), 4 * 256 * 2 * 4),
+    # (16 384 learners x 4 threads are ONE wave per SIMD; the BASELINE configurations' 65 536 learners fill the device)
+    ("k_train_lambda_mem 65536", dict(domain=1, order=3, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99, alpha=1e-3, lam=0.8, n_envs=65536), 4 * 256 * 2 * 4),
+    ("k_sparse_trace_scatter 65536", dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99,
+                                          alpha=0.1 / 8 / 65536, lam=0.9, weight_mode=ra.W_SHARED, n_envs=65536), 2 * 512 * 8 + 16 * 2 * 4 + 512 * 8),
     ("k_lambda_tile", dict(domain=1, basis=ra.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=ra.SARSA_LAMBDA, policy=1, epsilon=0.1, gamma=0.99, alpha=0.01, lam=0.8,
                            n_envs=1024), 4 * 32768 * 2 * 4),
 ]

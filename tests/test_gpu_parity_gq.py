@@ -87,8 +87,8 @@ def test_gq_configurations(ra):
         ra.Context(n_envs=8, algo=6, basis=ra.TILE_CODING, weight_mode=ra.W_SHARED)
     with ra.Context(n_envs=8, algo=6, domain=2, order=7):                   # the order-7 wave family: since round 5 (tests/test_gpu_wave_aux.py) ...
         pass
-    with pytest.raises(ra.RsrlHipError):                                    # ... with f32 weights
-        ra.Context(n_envs=8, algo=6, domain=2, order=7, weight_dtype=ra.W_BF16)
+    with ra.Context(n_envs=8, algo=6, domain=2, order=7, weight_dtype=ra.W_BF16):      # ... and with bf16 weights since round 6 (fa_td's stay f32)
+        pass
     with ra.Context(n_envs=8, algo=0) as c:
         with pytest.raises(ra.RsrlHipError):
             c.get_td_weights(0)

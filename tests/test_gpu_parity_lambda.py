@@ -97,8 +97,8 @@ def test_lambda_error_paths(ra):
         pass                                                                                        # (tests/test_gpu_sparse_lambda.py)
     with ra.Context(algo=3, domain=2, order=7, n_envs=4):                   # the order-7 wave family: built in round 3 (tests/test_gpu_wave_lambda.py)
         pass
-    with pytest.raises(ra.RsrlHipError):                                    # ... with f32 tables only
-        ra.Context(algo=3, domain=2, order=7, n_envs=4, weight_dtype=ra.W_BF16)
+    with ra.Context(algo=3, domain=2, order=7, n_envs=4, weight_dtype=ra.W_BF16):      # ... with bf16 tables + stochastic rounding since round 6
+        pass
     with pytest.raises(ra.RsrlHipError):
         ra.Context(algo=3, lam=1.5, n_envs=4)
     with ra.Context(n_envs=4) as c:

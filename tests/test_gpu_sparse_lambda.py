@@ -64,12 +64,38 @@ def test_sparse_traces_bitwise_and_f64(ra, orc, name, N, K, kw):
         else:                                                       # a long run on one shared table: every learner feels the first flipped argmax; as a population
             assert abs(ost["sum_abs_td_error"] - st64["sum_abs_td_error"]) <= 0.05 * st64["sum_abs_td_error"]
             assert np.max(np.abs(W - r64.weights)) <= 0.25 * np.abs(r64.weights).max()
-        with pytest.raises(ra.RsrlHipError):                        # a caller-supplied transition has no learner to attach a trace to
-            c.handle(c.states, c.actions, np.zeros(N, np.float32), c.states, np.zeros(N, np.uint8))
         with pytest.raises(ra.RsrlHipError):
             c.set_traces(np.zeros((c.F, c.A), np.float32), 0)
     if "evicting" in name:                                          # the cap did take effect: some learner's list is full
         assert max(int((run.sparse_trace(i) != 0).sum()) for i in range(N)) == 512
+
+
+@pytest.mark.parametrize("algo,domain,T", [(3, 1, 8), (4, 1, 8), (4, 2, 4), (3, 0, 16)])
+def test_handle_is_the_driver_loops_step_on_the_callers_transitions(ra, algo, domain, T):
+    # Handler::handle (sarsa_lambda.rs:63-98, q_lambda.rs:56-99) with transition i taken as learner i's: on the transitions the driver loop would have taken,
+    # from the same table and the same traces, it leaves the same table and the same traces, bit for bit (and the driver loop is bitwise against the oracle)
+    N = 200
+    kw = dict(domain=domain, basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=6, algo=algo, policy=1, epsilon=0.3, gamma=0.97, lam=0.85, trace=algo - 3,
+              max_episode_steps=1000, weight_mode=ra.W_SHARED, seed=5, alpha=0.1 / T / N, n_envs=N)
+    with ra.Context(**kw) as a, ra.Context(**kw) as b:
+        a.reset(); b.reset()
+        a.train(25); b.train(25)
+        for _ in range(6):
+            acts = b.actions.copy()
+            frm, nxt, rew, term = b.domain_step(acts)              # b's environments advance; its agent is taught by hand
+            td = b.handle(frm, acts, rew, nxt, term)
+            sa = a.train(1)
+            assert abs(np.abs(td).sum() - sa["sum_abs_td_error"]) <= 1e-5 * (1 + sa["sum_abs_td_error"])
+            assert np.array_equal(a.get_weights(), b.get_weights())
+            for i in (0, 77, N - 1):
+                assert np.array_equal(a.get_traces(i), b.get_traces(i)), i
+            b.states, b.actions = a.states, a.actions              # (the loop's own draws for the next action: keep the two runs on one trajectory)
+            b.episode_steps = a.episode_steps
+        # a batch of fewer transitions than learners: learners 0 .. M-1 learn, the others' traces stay
+        z_last = b.get_traces(N - 1)
+        s = b.states
+        b.handle(s[:, :50].copy(), b.actions[:50].copy(), np.ones(50, np.float32), s[:, :50].copy(), np.zeros(50, np.uint8))
+        assert np.array_equal(b.get_traces(N - 1), z_last) and not np.array_equal(b.get_weights(), a.get_weights())
 
 
 def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):

@@ -44,8 +44,14 @@ def _okw(kw):
     return o
 
 
-@pytest.mark.parametrize("name,domain,kw,K", CASES, ids=[c[0] for c in CASES])
+BF16_CASES = [(n + "_bf16", d, dict(k, weight_dtype=1), K) for n, d, k, K in CASES if k["algo"] in (6, 7, 8) and n not in ("gq_acrobot_greedy", "td_acrobot", "tdl_cartpole_accumulate")]
+
+
+@pytest.mark.parametrize("name,domain,kw,K", CASES + BF16_CASES, ids=[c[0] for c in CASES + BF16_CASES])
 def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K):
+    # *_bf16 (round 6): W stored as bf16 with stochastic rounding of every stored entry (Philox block 16 + 64 * column + lane), fa_td's weights / the trace f32
+    bf16 = kw.get("weight_dtype", 0) == 1
+    kw = {k: v for k, v in kw.items() if k != "weight_dtype"}
     N = 7                                                      # two thread blocks, the second one partially filled
     ag = orc.make_agent(domain=domain, order=7, seed=9, max_episode_steps=13, **_okw(kw))
     run = orc.Run(ag, N, "f32d")
@@ -53,10 +59,10 @@ def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K)
         run.reset_wave()
     else:
         run.reset()
-    run.train_wave(K)
+    run.train_wave(K, bf16=bf16)
     pred = kw["algo"] in (7, 8)
     for spl in (0, 1, 5):                                      # any split into launches: one, K, ceil(K / 5)
-        with ra.Context(domain=domain, order=7, n_envs=N, seed=9, max_episode_steps=13, steps_per_launch=spl, **kw) as c:
+        with ra.Context(domain=domain, order=7, n_envs=N, seed=9, max_episode_steps=13, steps_per_launch=spl, weight_dtype=ra.W_BF16 if bf16 else ra.W_F32, **kw) as c:
             assert c.F == 4096 and c.n_out == (1 if pred else c.A)
             c.reset()
             st = c.train(K)
@@ -71,6 +77,8 @@ def test_free_running_bitwise_vs_wave_order_oracle(ra, orc, name, domain, kw, K)
                     assert np.array_equal(c.get_traces(i), run.traces[i]), (name, spl, i)
             assert st["env_steps"] == N * K
             assert np.isfinite(run.weights).all() and np.abs(run.weights).max() > 0
+            if bf16:
+                assert np.all((run.weights.view(np.uint32) & 0xffff) == 0)
 
 
 def test_qsigma_single_transitions_vs_f64(ra, orc):
@@ -99,9 +107,11 @@ def test_qsigma_single_transitions_vs_f64(ra, orc):
             assert not np.array_equal(c.get_weights(i), Ws[i])      # the anchor did move
 
 
-@pytest.mark.parametrize("algo,domain", [(6, 1), (6, 2), (7, 2), (8, 1)])
-def test_single_transitions_vs_f64(ra, orc, algo, domain):
-    # Handler::handle on caller-supplied transitions, against the reference-precision oracle (identical fp32-representable inputs)
+@pytest.mark.parametrize("algo,domain,bf16", [(6, 1, False), (6, 2, False), (7, 2, False), (8, 1, False), (6, 2, True), (7, 1, True), (8, 2, True)])
+def test_single_transitions_vs_f64(ra, orc, algo, domain, bf16):
+    # Handler::handle on caller-supplied transitions, against the reference-precision oracle (identical fp32-representable inputs).
+    # bf16 (round 6): from bf16-representable weights, every stored entry of W lands within ONE bf16 ulp of the f64 result (stochastic rounding moves a value to
+    # one of its two neighbours) and the roundings are unbiased over the entries; fa_td's weights / the trace stay f32
     M = 6
     rng = np.random.default_rng(algo * 10 + domain)
     pol = 3 if algo in (7, 8) else 1
@@ -111,8 +121,10 @@ def test_single_transitions_vs_f64(ra, orc, algo, domain):
     n_out = 1 if algo in (7, 8) else A
     s = rand_states(orc, domain, M, 21)
     a = rng.integers(0, A, M).astype(np.int32)
-    with ra.Context(domain=domain, order=7, algo=algo, policy=pol, seed=4, n_envs=M, **kw) as c:
+    with ra.Context(domain=domain, order=7, algo=algo, policy=pol, seed=4, n_envs=M, weight_dtype=ra.W_BF16 if bf16 else ra.W_F32, **kw) as c:
         Ws = [(rng.normal(size=(4096, n_out)) * 0.02).astype(np.float32) for _ in range(M)]
+        if bf16:
+            Ws = [(w.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32) for w in Ws]
         Xs = [(rng.normal(size=(4096, n_out)) * 0.02).astype(np.float32) for _ in range(M)]
         for i in range(M):
             c.set_weights(Ws[i], i)
@@ -141,7 +153,17 @@ def test_single_transitions_vs_f64(ra, orc, algo, domain):
                     assert np.max(np.abs(c.get_traces(i).reshape(-1) - z1)) <= 3e-6
             assert abs(td[i] - d) <= 1e-4 * (1 + abs(d)), (i, td[i], d)
             tol = 3e-6 * (1 + abs(d)) if algo != 8 else 1e-5 * (1 + abs(d)) * (1 + np.abs(Xs[i]).max() * 50)
-            assert np.max(np.abs(c.get_weights(i) - W)) <= tol, (i, np.max(np.abs(c.get_weights(i) - W)), tol)
+            if not bf16:
+                assert np.max(np.abs(c.get_weights(i) - W)) <= tol, (i, np.max(np.abs(c.get_weights(i) - W)), tol)
+            else:
+                Wd = c.get_weights(i)
+                assert np.all((Wd.view(np.uint32) & 0xffff) == 0)
+                ulp = 2.0 ** (np.floor(np.log2(np.abs(W) + 1e-300)) - 7)
+                err = (Wd.astype(np.float64) - W) / ulp
+                moved = np.abs(W - Ws[i].astype(np.float64)) > 0                       # the entries the step stored
+                assert moved.any() and np.max(np.abs(err[moved])) <= 1.0 + 1e-3 + tol / ulp[moved].min(), (i, np.max(np.abs(err[moved])))
+                assert np.array_equal(Wd[~moved], Ws[i][~moved])
+                assert abs(err[moved].mean()) <= 0.06, (i, err[moved].mean())               # unbiased: the mean of ~4 096+ roundings uniform in (-1, 1) ulp
 
 
 def test_wave_aux_entry_points_and_checkpoint(ra, tmp_path):
@@ -172,7 +194,14 @@ def test_wave_aux_entry_points_and_checkpoint(ra, tmp_path):
         with pytest.raises(ra.RsrlHipError):
             c.rollout_greedy(10)
         assert c.project(c.states).shape == (4096, 3)
-    # still refused where no kernel exists: bf16 weights for these agents
-    for algo, pol in ((6, 1), (7, 3), (8, 3)):
-        with pytest.raises(ra.RsrlHipError):
-            ra.Context(domain=2, order=7, algo=algo, policy=pol, n_envs=2, weight_dtype=ra.W_BF16)
+    # still refused where no kernel exists: bf16 weights for QSigma
+    with pytest.raises(ra.RsrlHipError):
+        ra.Context(domain=2, order=7, algo=9, policy=1, n_envs=2, weight_dtype=ra.W_BF16)
+    # bf16 (round 6): the granular entry points of GreedyGQ / TD read the bf16 tables
+    with ra.Context(domain=2, order=7, algo=6, policy=1, n_envs=3, lr=1e-4, lr_td=1e-4, weight_dtype=ra.W_BF16) as c:
+        c.reset(); c.train(6)
+        assert c.q_evaluate(c.states).shape == (3, 3) and np.abs(c.get_weights(1)).max() > 0
+        assert np.all((c.get_weights(1).view(np.uint32) & 0xffff) == 0)
+    with ra.Context(domain=1, order=7, algo=7, policy=3, n_envs=3, lr=1e-4, weight_dtype=ra.W_BF16) as c:
+        c.reset(); c.train(6)
+        assert np.all(np.isfinite(c.q_evaluate(c.states)))

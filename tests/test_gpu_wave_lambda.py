@@ -14,16 +14,18 @@ def ra():
     return rsrl_amd
 
 
-@pytest.mark.parametrize("algo,trace,domain", [(3, 0, 2), (3, 1, 1), (4, 2, 2), (4, 0, 1)])
-def test_train_wave_lambda_bitwise(ra, orc, algo, trace, domain):
+@pytest.mark.parametrize("algo,trace,domain,bf16", [(3, 0, 2, False), (3, 1, 1, False), (4, 2, 2, False), (4, 0, 1, False),
+                                                     (3, 0, 2, True), (4, 1, 1, True), (3, 2, 1, True)])
+def test_train_wave_lambda_bitwise(ra, orc, algo, trace, domain, bf16):
+    # bf16 (round 6): W stored as bf16, every entry rounded stochastically at every step (Philox block 16 + 64 * column + lane), the trace f32
     N, K = 10, 40
     kw = dict(gamma=0.99, alpha=0.0005, lam=0.8, epsilon=0.2)
     ag = orc.make_agent(domain=domain, order=7, algo=algo, policy=orc.EGREEDY, seed=11, trace=trace, max_episode_steps=13, env_offset=5, **kw)
     run = orc.Run(ag, N, "f32d")
     run.reset_wave()
-    ost = run.train_wave(K)
+    ost = run.train_wave(K, bf16=bf16)
     with ra.Context(domain=domain, order=7, n_envs=N, algo=algo, policy=ra.EPSILON_GREEDY, seed=11, trace=trace, max_episode_steps=13,
-                    env_offset=5, **kw) as c:
+                    env_offset=5, weight_dtype=ra.W_BF16 if bf16 else ra.W_F32, **kw) as c:
         c.reset()
         st = [c.train(k) for k in (17, 1, 22)]
         assert np.array_equal(c.states.T, run.state) and np.array_equal(c.actions, run.action)
@@ -31,17 +33,20 @@ def test_train_wave_lambda_bitwise(ra, orc, algo, trace, domain):
             assert np.array_equal(c.get_weights(i), run.weights[i]), i
             assert np.array_equal(c.get_traces(i), run.traces[i]), i
         assert np.abs(run.weights).max() > 0 and np.abs(run.traces).max() > 0
+        if bf16:
+            assert np.all((run.weights.view(np.uint32) & 0xffff) == 0) and np.any((run.traces.view(np.uint32) & 0xffff) != 0)
         assert sum(s["episodes"] for s in st) == ost["episodes"] > 0
         assert sum(s["episodes_truncated"] for s in st) == ost["episodes_truncated"]
         assert sum(s["env_steps"] for s in st) == N * K
         assert abs(sum(s["sum_abs_td_error"] for s in st) - ost["sum_abs_td_error"]) <= 1e-6 * ost["sum_abs_td_error"]
 
 
-def test_handle_wave_lambda_equals_the_driver_loop_step(ra):
+@pytest.mark.parametrize("bf16", [False, True])
+def test_handle_wave_lambda_equals_the_driver_loop_step(ra, bf16):
     # Handler::handle on the transitions the driver loop would have taken, from the same (W, Z): same TD bookkeeping, same bits
     N = 6
     kw = dict(domain=2, order=7, n_envs=N, algo=ra.SARSA_LAMBDA, policy=ra.EPSILON_GREEDY, epsilon=0.3, seed=2, gamma=0.98, alpha=0.001, lam=0.9,
-              trace=ra.TRACE_SATURATE, max_episode_steps=1000)
+              trace=ra.TRACE_SATURATE, max_episode_steps=1000, weight_dtype=ra.W_BF16 if bf16 else ra.W_F32)
     with ra.Context(**kw) as a, ra.Context(**kw) as b:
         a.reset(); b.reset()
         a.train(9); b.train(9)
@@ -73,7 +78,16 @@ def test_wave_lambda_checkpoint_and_errors(ra, tmp_path):
         assert np.array_equal(c.states, states)
         for i in range(5):
             assert np.array_equal(c.get_weights(i), w_ref[i]) and np.array_equal(c.get_traces(i), z_ref[i])
-    with pytest.raises(ra.RsrlHipError):
-        ra.Context(**{**kw, "weight_dtype": ra.W_BF16})            # every weight moves every step: f32 tables only
+    with ra.Context(**{**kw, "weight_dtype": ra.W_BF16}) as c, ra.Context(**{**kw, "weight_dtype": ra.W_BF16}) as d:      # bf16 weights travel as their f32 values
+        c.reset(); c.train(25)
+        p16 = str(tmp_path / "wl16.bin")
+        c.save_weights(p16)
+        d.reset(); d.load_weights(p16)
+        d.states, d.actions = c.states, c.actions
+        d.episode_steps = c.episode_steps
+        c.train(10); d.train(10)
+        assert np.array_equal(c.states, d.states)
+        for i in range(5):
+            assert np.array_equal(c.get_weights(i), d.get_weights(i)) and np.array_equal(c.get_traces(i), d.get_traces(i))
     with pytest.raises(ra.RsrlHipError):
         ra.Context(**{**kw, "weight_mode": ra.W_SHARED})
