@@ -23,10 +23,12 @@ PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get(
                     for name in ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip")}
 
 
-# rsrl_hip.hip (generic / shared-W kernels): the runtime dispatch over agents and policies leaves a few 3-float arrays
+ABI_UNITS = ("abi_ctx.hip", "abi_trait.hip", "abi_weights.hip", "abi_train.hip", "abi_group.hip", "kernels_util.hip")      # the C ABI's translation units (ctx.hpp; one file until round 6)
+# the ABI units (generic / shared-W kernels): the runtime dispatch over agents and policies leaves a few 3-float arrays
 # (Q(s,.), Q(s',.)) as allocas; promoted to LDS next to the 37 KiB reduction tile of k_shared_ca they made the kernel 2-4x
-# slower (measured 7.7 us with the arrays in scratch, 21-34 us promoted) -- keep them out of LDS in this translation unit.
-PER_SOURCE_FLAGS["rsrl_hip.hip"] = ["-mllvm", "-disable-promote-alloca-to-lds"]
+# slower (measured 7.7 us with the arrays in scratch, 21-34 us promoted) -- keep them out of LDS in these translation units.
+for _u in ABI_UNITS:
+    PER_SOURCE_FLAGS[_u] = ["-mllvm", "-disable-promote-alloca-to-lds"]
 
 
 def hipcc():
@@ -86,9 +88,9 @@ def is_stale():
 
 
 # The assembly post-pass is applied ONLY where its gain was measured (k_train_reg +1.0-1.3 %, k_train_wave +6 %, k_shared_persist
-# ~+10 %; the last two live in rsrl_hip.hip) and ONLY under the compiler whose hazard recogniser it was validated against: any other
+# ~+10 %; the last two are launched from abi_train.hip -- the ABI's units keep the pass they were validated with as one file) and ONLY under the compiler whose hazard recogniser it was validated against: any other
 # `hipcc --version` compiles every source in one plain hipcc call (fail closed -- a new recogniser may place wait states for other reasons).
-NOP_FILTER_SOURCES = ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip", "rsrl_hip.hip")
+NOP_FILTER_SOURCES = ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip") + ABI_UNITS
 NOP_FILTER_VALIDATED_HIPCC = "roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5"     # substring of `hipcc --version` (AMD clang 22.0.0git)
 NOP_COUNTS_PATH = LIB_PATH.replace(".so", ".nop_filter.json")
 _warned_version = False

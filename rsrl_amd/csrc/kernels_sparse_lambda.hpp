@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void k_sparse_handle(Common c, BasisGeom g,
 }
 
 // Parameterised-style view of one learner's trace: the dense (F, A) matrix it stands for (zeros + the list's entries)
-__global__ void k_sparse_trace_get(SparseTrace st, int T, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
+static __global__ void k_sparse_trace_get(SparseTrace st, int T, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x, cap = kSparseCap / T;
     if (s < kSparseCap && s % cap < (int)st.len[i * T + s / cap]) out[st.keys[i * (int64_t)kSparseCap + s]] = st.vals[i * (int64_t)kSparseCap + s];
 }

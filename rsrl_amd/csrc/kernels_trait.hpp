@@ -14,7 +14,7 @@
 //                                 for -- left in the ctx's cache, keyed by the state it belongs to (s', or the new episode's s0 after a terminal transition).
 //   k_trait_sample                policy.sample: a learner whose state is bit for bit the cache's key takes Q(s,.) from the cache (20 B instead of 432 B),
 //                                 any other learner evaluates Q from its weights and refreshes its cache entry.
-//   k_trait_lm<.., TRAIT_STEP>    the four calls of one batch-step in ONE launch (rsrl_hip.hip defers the calls of a ctx-owned stream and launches this
+//   k_trait_lm<.., TRAIT_STEP>    the four calls of one batch-step in ONE launch (abi_trait.hip defers the calls of a ctx-owned stream and launches this
 //                                 kernel when they arrive in the loop's order with device pointers; every output array of the separate calls is written).
 //
 // The hand-over is INVISIBLE in the results: it holds the bits a fresh evaluation yields (the untouched columns' dot products are unchanged by the update,

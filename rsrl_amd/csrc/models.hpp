@@ -47,8 +47,8 @@ struct FxScale {
         lsb = __builtin_bit_cast(float, ex << 23); inv_lsb = __builtin_bit_cast(float, (254u - ex) << 23);
     }
 };
-// terms clamped so far on this device (translation-unit-local symbol: only rsrl_hip.hip's kernels quantise; read by
-// rsrl_hip_fx_saturations).  A clamped term means the shared-W update departed from W += lr*e*phi: never silently.
+// terms clamped so far on this device (a translation-unit-local symbol: every unit whose kernels quantise has a reader, ctx.hpp RSRL_DEFINE_FX_READER;
+// rsrl_hip_fx_saturations adds them up).  A clamped term means the shared-W update departed from W += lr*e*phi: never silently.
 static __device__ unsigned int g_fx_saturations;
 __device__ __forceinline__ unsigned long long fx_quantise(float v, float inv_lsb) {
     const float raw = v * inv_lsb;
@@ -236,7 +236,7 @@ struct TileModel {
 #pragma unroll
         for (int t = 0; t < T; ++t) fx_add(&fx[ft.idx[t] * A + a], term);
     }
-    // (The driver loop privatises each tiling's slice of the delta table in LDS: k_tile_scatter, rsrl_hip.hip.)  The accumulators are
+    // (The driver loop privatises each tiling's slice of the delta table in LDS: k_tile_scatter, kernels_util.hip.)  The accumulators are
     // 64-bit FIXED-POINT integers, not floats: ds_add_f32 retires ONE LANE PER ~3 CYCLES whatever the addresses are (193 cycles per
     // wave-instruction even for 64 conflict-free addresses, profiles/r02_ubench_lds_atomic.txt), ds_add_u64 costs 6 cycles for distinct
     // addresses and 2 per duplicate of the most crowded one.  A term lr*e is scaled by the power of two 1/lsb (exact) and rounded to an

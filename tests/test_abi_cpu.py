@@ -189,7 +189,7 @@ def test_asm_filter_scope_and_counts():
     # are pinned, so a toolchain or source change that moves them is noticed (and re-validated on the GPU) rather than shipped silently
     import json
     from rsrl_amd import _build
-    assert set(_build.NOP_FILTER_SOURCES) == {"train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip", "rsrl_hip.hip"}
+    assert set(_build.NOP_FILTER_SOURCES) == {"train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip"} | set(_build.ABI_UNITS)
     assert _build.nop_filter_applies("/x/train_reg_d0b.hip") == _build.nop_filter_enabled()
     assert not _build.nop_filter_applies("/x/train_td.hip") and not _build.nop_filter_applies("/x/train_gq.hip")
     if _build.hipcc_version() and _build.NOP_FILTER_VALIDATED_HIPCC in _build.hipcc_version() and os.environ.get("RSRL_NOP_FILTER", "1") != "0":
@@ -211,7 +211,7 @@ def test_asm_filter_fails_closed_on_an_unknown_compiler(monkeypatch):
 
 # wait states removed per translation unit in the shipped build (rsrl_amd/lib/librsrl_hip.nop_filter.json, written by _build); re-validate on the GPU
 # (tests -m gpu, scripts/ab_bits.py) before changing these
-EXPECTED_NOP_COUNTS = {"rsrl_hip.hip": 1279, "train_reg_d0a.hip": 528, "train_reg_d0b.hip": 315, "train_reg_d1.hip": 20, "train_reg_d2.hip": 21}
+EXPECTED_NOP_COUNTS = {"abi_ctx.hip": 0, "abi_group.hip": 0, "abi_train.hip": 1144, "abi_trait.hip": 59, "abi_weights.hip": 0, "kernels_util.hip": 76, "train_reg_d0a.hip": 528, "train_reg_d0b.hip": 315, "train_reg_d1.hip": 20, "train_reg_d2.hip": 21}
 
 
 def test_campaign_scripts_compile():
