@@ -554,11 +554,20 @@ def _leg_summary(rec, copy_gbps=None):
         out["us_per_launch"] = out.pop("us")
     if "kernel_us_per_batch_step" in rec:
         out["kernel_us"] = _num(rec["kernel_us_per_batch_step"])
+    if "floor_us" in rec:
+        out["floor_us"] = _num(rec["floor_us"]); out["floor_frac"] = _num(rec.get("floor_frac"))
     if rl.get("profile_digest_matches") is False:
         out["profile_digest_matches"] = False
     return {k: v for k, v in out.items() if v is not None}
 
 
+# C3's floor in THIS formulation (one more formulation or a written floor; DESIGN 4.4 has the formulations that were built and lost):
+# a batch-step is three DEPENDENT launches -- W_{t+1} needs every learner's term, every learner's action needs W_{t+1}.
+C3_FLOOR = {"floor_us": 13.6,
+            "floor": "k_shared_ca at the issue rate of its 4 waves per SIMD: 893 VALU per learner-step (PMC) x 4 waves x 2.55 cycles (the fast class at >= 2 waves per "
+                     "SIMD, profiles/r05_ubench_valu_pair.txt) / 2.4 GHz = 3.8 us, + its two dependent gather round trips through L2 (2 x ~0.9 us) = 5.6 us; "
+                     "k_tile_scatter and k_apply_rep are each one dependent launch of the captured graph, ~4.0 us whatever they do (k_apply_rep moves 2 MB in 4.4 us; "
+                     "an 11.4 us grid barrier is the alternative, profiles/r05_ubench_grid_barrier.txt): 5.6 + 2 x 4.0"}
 COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline")
 LEG_KEYS = ("trait_loop", "trait_loop_unfused", "trait_loop_1m", "value_no_coalesce", "roofline_streaming", "roofline_streaming_hbm", "c3_shared_tiles",
@@ -791,6 +800,10 @@ def main():
             "SURVEY 8(d): 208 B/env-step, of which 48 B are the HBM stream (state, action, counter) and 160 B are gathers / atomic "
             "read-modify-writes of the shared table served by L2; the batch-step is three DEPENDENT launches (step, scatter, apply): latency-bound, "
             "none of the three fractions binds", also=("k_tile_scatter", "k_apply_rep")), 120)
+        if isinstance(c3, dict) and "error" not in c3:
+            c3.update(C3_FLOOR)
+            if c3.get("us_per_batch_step"):
+                c3["floor_frac"] = C3_FLOOR["floor_us"] / c3["us_per_batch_step"]
         c5 = guarded(lambda: config_leg(
             rsrl_amd, "BASELINE.json configs[4], one GPU's share: 32768 Acrobot envs, ExpectedSARSA + Fourier(7) + Softmax, bf16 weights, per-env W",
             dict(domain=rsrl_amd.ACROBOT, order=7, algo=rsrl_amd.EXPECTED_SARSA, policy=rsrl_amd.SOFTMAX, tau=1.0, gamma=0.99, lr=0.001, alpha=1.0,

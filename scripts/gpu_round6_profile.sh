@@ -13,10 +13,11 @@ cd $R
 bash scripts/gpu_profile.sh > gpurun_out/gpu_profile.log 2>&1
 O=$R/gpurun_out/prof/trait
 cd /tmp
-for variant in fused unfused; do
+for variant in fused unfused generic; do
   mkdir -p $O/$variant
   if [ $variant = unfused ]; then export RSRL_NO_TRAIT_DEFER=1; else unset RSRL_NO_TRAIT_DEFER; fi
-  CMD="python $R/scripts/trait_loop.py 65536 300"
+  SPL=1; [ $variant = generic ] && SPL=0      # steps_per_launch = 1: the learner-major layout the fast trait kernels (k_trait_lm) read
+  CMD="python $R/scripts/trait_loop.py 65536 300 $SPL"
   $CMD 2> $O/$variant/plain.err | grep "^{" > $O/$variant/plain.json
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$variant/kt -o k -- $CMD > $O/$variant/kt.json 2> $O/$variant/kt.log
   timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$variant/p1 -o p -- $CMD > $O/$variant/p1.json 2> $O/$variant/p1.log

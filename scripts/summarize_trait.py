@@ -16,15 +16,18 @@ md = [f"# The trait-granular loop under rocprofv3 ({tag}, 1 x MI355X, 65 536 Mou
       "`scripts/trait_loop.py`: `rsrl_hip_domain_step -> rsrl_hip_handle -> rsrl_hip_domain_reset -> rsrl_hip_policy_sample(NULL)` per batch-step, one C-ABI call per",
       "trait method (`examples/q_learning.rs:40-52`).  Algorithmic bytes per env-step if every call streams what it needs once: "
       f"{trait_loop.ALG_BYTES_LOOP} B (`trait_loop.ALG_BYTES`).", ""]
-for variant, what in (("fused", "default: the four calls of a batch-step are deferred and run as ONE launch (`k_trait_lm<step>`)"),
-                      ("unfused", "`RSRL_NO_TRAIT_DEFER=1`: one kernel per call, Q(s',.) handed from `handle` to `sample` through the ctx's cache")):
+for variant, what in (("fused", "learner-major W (`steps_per_launch = 1`), default: the four calls of a batch-step are deferred and run as ONE launch (`k_trait_lm<step>`)"),
+                      ("unfused", "learner-major W, `RSRL_NO_TRAIT_DEFER=1`: one kernel per call, Q(s',.) handed from `handle` to `sample` through the ctx's cache"),
+                      ("generic", "feature-major W (`steps_per_launch = 0`: the layout of the fused driver loop): the generic one-thread-per-transition kernels "
+                                  "`k_handle` / `k_qop` (`models.hpp`), no hand-over -- `sample` evaluates Q(s',.) again")):
     d = os.path.join(G, variant)
     plain = sp.first_json(os.path.join(d, "plain.json")) or {}
     md += [f"## {variant} -- {what}", "",
            f"plain run: {plain.get('us_per_batch_step', float('nan')):.2f} us per batch-step wall, {plain.get('value', 0):.3e} env-steps/s, "
            f"{plain.get('frac_of_8TBps', 0):.3f} of 8 TB/s on the algorithmic bytes", "", sp.stats_table(os.path.join(d, "kt"), top=6), ""]
     rows = ["| kernel | avg us (trace) | HBM bytes fetched / launch | written / launch | per env-step | algorithmic per env-step | traffic / algorithmic |", "|---|---|---|---|---|---|---|"]
-    for sub, alg in (("k_trait_lm", None), ("k_domain_step", trait_loop.ALG_BYTES["domain_step"]), ("k_domain_reset", trait_loop.ALG_BYTES["domain_reset"])):
+    for sub, alg in (("k_trait_lm", None), ("k_handle", trait_loop.ALG_BYTES["handle"]), ("k_qop", trait_loop.ALG_BYTES["policy_sample_reeval"]),
+                     ("k_domain_step", trait_loop.ALG_BYTES["domain_step"]), ("k_domain_reset", trait_loop.ALG_BYTES["domain_reset"])):
         us = sp.kernel_avg_us(os.path.join(d, "kt"), sub)
         f = sp.counter_means(os.path.join(d, "p1"), sub)[0].get("FETCH_SIZE")
         w = sp.counter_means(os.path.join(d, "p2"), sub)[0].get("WRITE_SIZE")
