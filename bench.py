@@ -525,6 +525,31 @@ def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extr
         return {"workload": name, "error": repr(e)}
 
 
+def hbm_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what):
+    """A leg whose kernels are memory sweeps: env-steps/s, HIP-event kernel time per batch-step, and SURVEY 8(d)-style algorithmic bytes per env-step x the kernel
+    rate against 8 TB/s (no instruction-mix constants needed: nothing here depends on a committed profile)."""
+    try:
+        ctx = rsrl_amd.Context(**kw)
+        ctx.reset()
+        ctx.train(warmup, want_stats=False)
+        ctx.sync()
+        ctx.timing_enable(True)
+        t0 = time.perf_counter()
+        ctx.train(steps, want_stats=False)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ms, n, kn = ctx.timing_read()
+        ctx.close()
+        per_step = ms * 1e-3 / max(1, steps)
+        ach = bytes_per_env_step * kw["n_envs"] / per_step if per_step > 0 else 0.0
+        return {"workload": name, "value": kw["n_envs"] * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
+                "kernel_us_per_batch_step": per_step * 1e6,
+                "roofline": {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                             "algorithmic_bytes_per_env_step": bytes_per_env_step, "what": what}}
+    except Exception as e:
+        return {"workload": name, "error": repr(e)}
+
+
 def _num(x, digits=5):
     """a number at `digits` significant digits (the compact line is for a parser and a reader, not for reproducing bits)"""
     if isinstance(x, bool) or x is None:
@@ -571,7 +596,7 @@ C3_FLOOR = {"floor_us": 13.6,
 COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline")
 LEG_KEYS = ("trait_loop", "trait_loop_unfused", "trait_loop_1m", "value_no_coalesce", "roofline_streaming", "roofline_streaming_hbm", "c3_shared_tiles",
-            "c5_wave_bf16", "shared_w", "shared_w_rccl")
+            "c5_wave_bf16", "lambda_shared_tiles", "lambda_generic_order", "shared_w", "shared_w_rccl")
 COMPACT_LIMIT = 6000      # bytes; the driver's parser lost the 24 KB line of round 5 (BENCH_r05.json: parsed = null) -- tests/test_bench_line_cpu.py
 
 
@@ -812,6 +837,22 @@ def main():
             "bf16 per VGPR, 96 of them) for the whole launch, so the figure is an equivalent, not moved bytes: two waves per SIMD, 4.4 cycles per "
             "VALU instruction against the measured 2.5 (fast class) / 4.9 (slow class: packed, shifts, bfe, perm, readlane ...) of "
             "profiles/r05_ubench_valu_pair.txt: VALU-issue bound (DESIGN 4.6)"), 180)
+    # the eligibility-trace kernels rebuilt in round 6, at the BASELINE configurations' learner count
+    lam_shared = lam_generic = None
+    if not args.no_config_legs and world <= ndev:
+        lam_shared = guarded(lambda: hbm_leg(
+            rsrl_amd, "SARSALambda over ONE shared tile table (8 x 8^4), sparse per-learner traces, 65536 CartPole envs",
+            dict(domain=rsrl_amd.CART_POLE, basis=rsrl_amd.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536,
+                 policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99, alpha=0.0125 / 65536, lam=0.9, weight_mode=rsrl_amd.W_SHARED, max_episode_steps=200,
+                 env_offset=rank * 65536, device=device), 256, 64, 2 * 512 * 8 + 16 * 2 * 4 + 512 * 8,
+            "per learner-step: the trace list read and written (512 x 8 B each way) + 2 x 8 gathers + one 8-byte term per entry; k_shared_ca -> "
+            "k_sparse_trace_scatter -> k_apply_rep (kernels_sparse_lambda.hpp); round 5's form: 0.10"), 120)
+        lam_generic = guarded(lambda: hbm_leg(
+            rsrl_amd, "SARSALambda on a generic Fourier order (CartPole, order 3: F = 256), per-learner W and trace in memory, 65536 envs",
+            dict(domain=rsrl_amd.CART_POLE, order=3, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99,
+                 alpha=1e-3, lam=0.8, max_episode_steps=200, env_offset=rank * 65536, device=device), 128, 32, 4 * 256 * 2 * 4,
+            "per learner-step: W and Z read and written once (4 x A F x 4 B); k_train_lambda_mem4, four threads per learner (kernels_lambda_mem.hpp); "
+            "round 5's one-thread form: 0.03"), 120)
     # shared-W legs: `shared_w` = what a user gets (exchange AUTO: the one-hop peer exchange whenever every rank's device reaches every
     # other's, and then the persistent kernel); `shared_w_rccl` = the any-topology fallback asked for explicitly
     shared = shared_rccl = None
@@ -908,6 +949,10 @@ def main():
             out["c3_shared_tiles"] = c3
         if c5 is not None:
             out["c5_wave_bf16"] = c5
+        if lam_shared is not None:
+            out["lambda_shared_tiles"] = lam_shared
+        if lam_generic is not None:
+            out["lambda_generic_order"] = lam_generic
         if shared is not None:
             out["shared_w"] = shared
         if shared_rccl is not None:

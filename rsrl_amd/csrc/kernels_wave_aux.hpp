@@ -297,13 +297,27 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
             const float res = qsigma_handle<M>(c, qp, g, i, N, s, clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i])), rew[i], ns, termf[i] != 0, xin);
             if (td_out && M::lane() == 0) td_out[i] = res;
         } else {
+            // The driver loop (round 6): qsigma_handle<M>'s operations, with what the loop knows used instead of re-read -- Q(s,a) is the carried Q(s',.) of the
+            // previous step (same state, same weights, the same dot product), Q(s',.) after the anchor's update differs from the pre-update evaluation in the
+            // anchor's column only, and that column's dot product falls out of the update sweep (over the stored values, in dot()'s order): per learner-step W is
+            // read 5 F and written F instead of 9 F and F.  Every value is the one the generic form computes (the oracle's wave-order loop, bitwise).
             const uint32_t cap = c.max_episode_steps;
+            const int lane = M::lane();
+            float* __restrict__ Wi = c.W + i * (int64_t)(A * M::F);
             float s[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
             int a = __builtin_amdgcn_readfirstlane(c.action[i]);
             uint32_t ep = c.ep_step[i];
             float facc_abs = 0.0f, facc_r = 0.0f;
+            typename M::Feat fs;
+            float q_s[A];
+            M::features(s, g, fs);
+            M::q_all(c, i, g, fs, q_s);
+            const int n = qp.n_steps;
+            uint32_t head = qp.head[i], len = qp.len[i];
+            const int64_t fs_stride = (int64_t)n * N;
+            auto at = [&](int field, uint32_t slot) -> float& { return qp.buf[(int64_t)field * fs_stride + (int64_t)slot * N + i]; };
             for (int k = 0; k < n_steps; ++k) {
                 const uint64_t t = t0 + (uint64_t)k;
                 float ns[D];
@@ -314,20 +328,98 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
                 ep += 1;
                 const bool trunc = !term && cap > 0 && ep >= cap;
                 const U4 xin = draw(c.seed, gid, t, BLK_INNER);
-                const float res = qsigma_handle<M>(c, qp, g, i, N, s, a, r, ns, term, xin);
-                if (term || trunc) {
+                // ---- QSigma::handle (q_sigma.rs:138-201)
+                const float qa = select_a<A>(q_s, a);
+                typename M::Feat fn;
+                float q_n[A];
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = 0.0f;
+                float residual, pi, mu;
+                M::features(ns, g, fn);                                            // (a terminal s' too: the anchor's sweep multiplies by it, the result is dropped)
+                if (term) {
+                    residual = r - qa; pi = 0.0f; mu = 1.0f;
+                } else {
+                    M::q_all(c, i, g, fn, q_n);
+                    const int na = policy_sample<A>(c.apol, q_n, xin);
+                    const float nqsna = select_a<A>(q_n, na);
+                    float exp_nqs;
+                    const uint32_t mask = argmaxima_mask_max<A>(q_n, exp_nqs);
+                    pi = ((mask >> na) & 1u) ? 1.0f / (float)__popc(mask) : 0.0f;
+                    mu = policy_eval_sa<A>(c.apol, q_n, na);
+                    residual = r + c.alg.gamma * (qp.sigma * nqsna + (1.0f - qp.sigma) * exp_nqs) - qa;
+                }
+                {
+                    const uint32_t slot = (head + len) % (uint32_t)n;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) at(d, slot) = s[d];
+                        at(D, slot) = __int_as_float(a);
+                        at(D + 1, slot) = qa; at(D + 2, slot) = residual; at(D + 3, slot) = pi; at(D + 4, slot) = mu;
+                    }
+                    len += 1;
+                }
+                const bool restart = term || trunc;
+                if ((int)len >= n) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");            // lane 0's ring stores above are read back by every lane below
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    float gret = at(D + 1, head), z = 1.0f, isr = 1.0f;
+                    for (int kk = 0; kk < n; ++kk) {
+                        const uint32_t s1 = (head + (uint32_t)kk) % (uint32_t)n;
+                        gret += z * at(D + 2, s1);
+                        if (kk + 1 < n) {
+                            const uint32_t s2 = (head + (uint32_t)kk + 1u) % (uint32_t)n;
+                            z *= c.alg.gamma * ((1.0f - qp.sigma) * at(D + 3, s2) + qp.sigma);
+                        }
+                        isr *= 1.0f - qp.sigma + qp.sigma * at(D + 3, s1) / at(D + 4, s1);
+                    }
+                    float as_[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) as_[d] = at(d, head);
+                    const int aa = __builtin_amdgcn_readfirstlane(clamp_action<A>(__float_as_int(at(D, head))));
+                    head = (head + 1u) % (uint32_t)n; len -= 1;
+                    typename M::Feat fa;
+                    M::features(as_, g, fa);
+                    float* __restrict__ col = Wi + (int64_t)aa * M::F;
+                    const float qsa = wave_col_dot<DOMAIN>(col, lane, fa.phi);
+                    const float scale = c.alg.lr * (qp.alpha * isr * (gret - qsa));
+                    // the anchor's column: w += scale * phi(anchor), and <phi(s'), the new column> in the same sweep (used when s' is the state the policy samples at)
+                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float w8[8];
+                        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, w8);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) {
+                            w8[v] = fmaf(scale, fa.phi[j][v], w8[v]);
+                            acc[v & 3] = fmaf(fn.phi[j][v], w8[v], acc[v & 3]);
+                        }
+                        WaveIO<float>::store8(col, (int64_t)j * 512 + lane * 8, w8);
+                    }
+                    if (!restart) {
+                        const float qpost = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+#pragma unroll
+                        for (int b = 0; b < A; ++b) q_n[b] = (b == aa) ? qpost : q_n[b];
+                    }
+                }
+                if (term) len = 0;
+                const float res = residual;
+                if (restart) {
                     n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; ep = 0;
                     Dom::reset(ns);
+                    M::features(ns, g, fn);
+                    M::q_all(c, i, g, fn, q_n);                                    // the UPDATED weights at s0
                 }
-                typename M::Feat fn; float q_n[A];
-                M::features(ns, g, fn);
-                M::q_all(c, i, g, fn, q_n);                                        // the UPDATED weights at s' (or at s0 after the episode ended)
                 const U4 x = draw(c.seed, gid, t, BLK_STEP);
                 a = __builtin_amdgcn_readfirstlane(policy_sample<A>(c.pol, q_n, x));
                 facc_abs += fabsf(res); facc_r += r;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s[d] = ns[d];
+                fs = fn;
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
             }
+            if (lane == 0) { qp.head[i] = head; qp.len[i] = len; }
             if (M::lane() == 0) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
