@@ -671,6 +671,11 @@ def emit(full, detail_path=None):
             if len(text) <= COMPACT_LIMIT:
                 break
     sys.stdout.flush()
+    try:                                     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a file: without this
+        import ctypes                        # flush the banner lands AFTER the line (at exit) and the line is no longer the last one of stdout
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(text, flush=True)
 
 

@@ -23,7 +23,7 @@ PER_SOURCE_FLAGS = {name: ["-mllvm", "-amdgpu-sched-strategy=" + os.environ.get(
                     for name in ("train_reg_d0a.hip", "train_reg_d0b.hip", "train_reg_d1.hip", "train_reg_d2.hip")}
 
 
-ABI_UNITS = ("abi_ctx.hip", "abi_trait.hip", "abi_weights.hip", "abi_train.hip", "abi_group.hip", "kernels_util.hip")      # the C ABI's translation units (ctx.hpp; one file until round 6)
+ABI_UNITS = ("abi_ctx.hip", "abi_trait.hip", "abi_weights.hip", "abi_train.hip", "abi_group.hip", "kernels_util.hip", "launch_shared.hip")      # the C ABI's translation units (ctx.hpp; one file until round 6)
 # the ABI units (generic / shared-W kernels): the runtime dispatch over agents and policies leaves a few 3-float arrays
 # (Q(s,.), Q(s',.)) as allocas; promoted to LDS next to the 37 KiB reduction tile of k_shared_ca they made the kernel 2-4x
 # slower (measured 7.7 us with the arrays in scratch, 21-34 us promoted) -- keep them out of LDS in these translation units.

@@ -449,9 +449,9 @@ int rsrl_hip_fx_saturations(rsrl_hip_ctx* c, uint64_t* count_out) {
     if (!count_out) return fail(RSRL_HIP_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    unsigned int n[3] = {0, 0, 0};
-    if (fx_saturations_train(&n[0]) || fx_saturations_trait(&n[1]) || fx_saturations_util(&n[2])) { (void)hipGetLastError(); return fail(RSRL_HIP_EHIP, "reading the saturation counters"); }
-    *count_out = (uint64_t)n[0] + n[1] + n[2];
+    unsigned int n[4] = {0, 0, 0, 0};
+    if (fx_saturations_train(&n[0]) || fx_saturations_trait(&n[1]) || fx_saturations_util(&n[2]) || fx_saturations_launch(&n[3])) { (void)hipGetLastError(); return fail(RSRL_HIP_EHIP, "reading the saturation counters"); }
+    *count_out = (uint64_t)n[0] + n[1] + n[2] + n[3];
     return RSRL_HIP_OK;
 }
 RSRL_API_END

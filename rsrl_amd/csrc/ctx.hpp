@@ -5,7 +5,7 @@
 //   abi_weights.hip  Parameterised (weights, traces, fa_td), checkpoints, checksums
 //   abi_train.hip    the fused driver loop: launch shapes, step graphs, the persistent shared-W kernel, rollouts
 //   abi_group.hip    multi-rank: RCCL communicators, the peer exchange set-up, single-process groups
-//   kernels_util.hip the small kernels and the kernel-template launches more than one of those units needs (one copy of the machine code)
+//   kernels_util.hip, launch_shared.hip   the small kernels / the kernel-template launches more than one of those units needs (one copy of the machine code)
 #pragma once
 //
 // One ctx = one HIP device + one stream + one (domain, basis, algo, policy, N, W-mode)
@@ -51,7 +51,7 @@ static inline bool is_pred(int algo) { return algo == RSRL_TD || algo == RSRL_TD
 static inline bool has_aux(int algo) { return is_lambda(algo) || algo == RSRL_GREEDY_GQ || algo == RSRL_TD_LAMBDA; }   // second matrix of W's shape
 
 // ---- the small kernels more than one unit launches, and the launches of kernel templates two units would otherwise both instantiate: defined ONCE, in
-// kernels_util.hip (a kernel's host stub is an ordinary function: another unit launches it through this declaration)
+// kernels_util.hip / launch_shared.hip (a kernel's host stub is an ordinary function: another unit launches it through this declaration)
 __global__ __launch_bounds__(256) void k_apply_rep(float* __restrict__ W, float* __restrict__ dW, long long* __restrict__ rep, int n_rep, int n, float lsb);
 __global__ __launch_bounds__(1024) void k_tile_scatter(const uint16_t* __restrict__ keys, const float* __restrict__ terms, int64_t N, int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride, float inv_lsb);
 __global__ __launch_bounds__(256) void k_fx_finalize(long long* __restrict__ fx, float* __restrict__ dW, int n, float lsb);
@@ -465,7 +465,8 @@ int launch_domain_reset(rsrl_hip_ctx* c, const Common& k, const uint8_t* d_mask)
     int name(unsigned int* n) { return hipMemcpyFromSymbol(n, HIP_SYMBOL(g_fx_saturations), sizeof(*n), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1; }
 int fx_saturations_train(unsigned int* n);      // abi_train.hip: k_shared_step / k_shared_ca / k_shared_persist
 int fx_saturations_trait(unsigned int* n);      // abi_trait.hip: k_handle on shared weights
-int fx_saturations_util(unsigned int* n);       // kernels_util.hip: k_tile_scatter, k_sparse_trace_scatter
+int fx_saturations_util(unsigned int* n);       // kernels_util.hip: k_tile_scatter
+int fx_saturations_launch(unsigned int* n);     // launch_shared.hip: k_sparse_trace_scatter
 int train_now(rsrl_hip_ctx* c, int64_t n_steps, rsrl_hip_stats* stats_out);                                                              // abi_train.hip
 int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, DevStats* d_stats, int do_c, uint64_t t, const uint64_t* t_dev, int xpart = 0);
 int enqueue_shared_c(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, uint64_t t_last);
