@@ -649,6 +649,16 @@ def compact_line(full, detail_path="bench_detail.json"):
     return line
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio, which is block-buffered when stdout is a file or a pipe: unflushed, the banner lands at process exit,
+    AFTER the result line, and the line is no longer the last one of stdout"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def emit(full, detail_path=None):
     """detail -> bench_detail.json (--detail PATH, else next to bench.py and under gpurun_out/ when that exists) and stderr; the compact line -> stdout, LAST"""
     detail = json.dumps(full)
@@ -671,11 +681,7 @@ def emit(full, detail_path=None):
             if len(text) <= COMPACT_LIMIT:
                 break
     sys.stdout.flush()
-    try:                                     # RCCL prints its version banner through C stdio, which is block-buffered when stdout is a file: without this
-        import ctypes                        # flush the banner lands AFTER the line (at exit) and the line is no longer the last one of stdout
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
+    _flush_c_stdio()
     print(text, flush=True)
 
 
@@ -872,6 +878,10 @@ def main():
             shared_rccl = guarded(lambda: shared_w_leg(cp, rsrl_amd, make_sharded_context, rsrl_amd.EXCHANGE_RCCL), 240)
     hung = any(isinstance(x, dict) and x.get("error") == "timeout" for x in (streaming, streaming_hbm, shared, shared_rccl, c3, c5, trait, trait_unfused, trait_1m))
 
+    # every rank's C stdio (RCCL's banner) goes out BEFORE rank 0 composes the result: the result line is the last line of the job's stdout
+    _flush_c_stdio()
+    if world > 1 and not hung:
+        guarded(cp.barrier, 120)
     if rank == 0:
         total_steps = args.steps * repeats
         total_env_steps = total_steps * args.envs * world

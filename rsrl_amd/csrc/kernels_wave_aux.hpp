@@ -299,8 +299,8 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
         } else {
             // The driver loop (round 6): qsigma_handle<M>'s operations, with what the loop knows used instead of re-read -- Q(s,a) is the carried Q(s',.) of the
             // previous step (same state, same weights, the same dot product), Q(s',.) after the anchor's update differs from the pre-update evaluation in the
-            // anchor's column only, and that column's dot product falls out of the update sweep (over the stored values, in dot()'s order): per learner-step W is
-            // read 5 F and written F instead of 9 F and F.  Every value is the one the generic form computes (the oracle's wave-order loop, bitwise).
+            // anchor's column only, and that column -- read once, held in registers -- gives both the anchor's Q and, after the update, its dot product with phi(s') (over
+            // the stored values, in dot()'s order): per learner-step W is read 4 F and written F instead of 9 F and F.  Every value is the one the generic form computes (the oracle's wave-order loop, bitwise).
             const uint32_t cap = c.max_episode_steps;
             const int lane = M::lane();
             float* __restrict__ Wi = c.W + i * (int64_t)(A * M::F);
@@ -381,20 +381,27 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
                     typename M::Feat fa;
                     M::features(as_, g, fa);
                     float* __restrict__ col = Wi + (int64_t)aa * M::F;
-                    const float qsa = wave_col_dot<DOMAIN>(col, lane, fa.phi);
+                    // the anchor's column is read ONCE and held (64 registers per lane): <phi(anchor), column> in dot()'s order, then w += scale * phi(anchor) and
+                    // <phi(s'), the new column> from the registers (used when s' is the state the policy samples at)
+                    float wc[8][8];
+                    float qacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, wc[j]);
+#pragma unroll
+                        for (int v = 0; v < 8; ++v) qacc[v & 3] = fmaf(fa.phi[j][v], wc[j][v], qacc[v & 3]);
+                    }
+                    const float qsa = wave_sum_uniform((qacc[0] + qacc[1]) + (qacc[2] + qacc[3]));
                     const float scale = c.alg.lr * (qp.alpha * isr * (gret - qsa));
-                    // the anchor's column: w += scale * phi(anchor), and <phi(s'), the new column> in the same sweep (used when s' is the state the policy samples at)
                     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        float w8[8];
-                        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, w8);
 #pragma unroll
                         for (int v = 0; v < 8; ++v) {
-                            w8[v] = fmaf(scale, fa.phi[j][v], w8[v]);
-                            acc[v & 3] = fmaf(fn.phi[j][v], w8[v], acc[v & 3]);
+                            wc[j][v] = fmaf(scale, fa.phi[j][v], wc[j][v]);
+                            acc[v & 3] = fmaf(fn.phi[j][v], wc[j][v], acc[v & 3]);
                         }
-                        WaveIO<float>::store8(col, (int64_t)j * 512 + lane * 8, w8);
+                        WaveIO<float>::store8(col, (int64_t)j * 512 + lane * 8, wc[j]);
                     }
                     if (!restart) {
                         const float qpost = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
