@@ -75,13 +75,14 @@ typedef enum { RSRL_FOURIER = 0, RSRL_TILE_CODING = 1 } rsrl_basis;
  * PAL (persistent advantage learning), pal.rs:18-60 -- a drop-in sibling of QLearning (uses `alpha`)
  * and GreedyGQ, greedy_gq.rs:49-142 -- fa_q (SGD(lr)) plus a second approximator fa_td (SGD(lr_td), weights through
  *   rsrl_hip_get/set_td_weights); per-learner weights: register-family Fourier bases, the generic Fourier orders, tile coding, and (round 5)
- *   the order-7 wave family with f32 weights (one wavefront per learner, W and V streamed: kernels_wave_aux.hpp) */
+ *   the order-7 wave family (one wavefront per learner, W and V streamed: kernels_wave_aux.hpp; round 6: W as bf16 with stochastic rounding too -- for every agent of
+ *   that family: the trace / fa_td's weights / QSigma's backups stay f32) */
 typedef enum { RSRL_QLEARNING = 0, RSRL_SARSA = 1, RSRL_EXPECTED_SARSA = 2, RSRL_SARSA_LAMBDA = 3, RSRL_Q_LAMBDA = 4,
                RSRL_PAL = 5, RSRL_GREEDY_GQ = 6,
                /* prediction (state-value function on a ScalarLFA, ONE weight column; behaviour policy RSRL_RANDOM):
                 *   TD prediction/td/td.rs:25-59 (SGD(lr)), TDLambda prediction/td/td_lambda.rs:25-78 (step = the TD error);
                 *   per-learner weights: register-family Fourier bases (fused, register-resident), the other Fourier orders (one thread
-                *   per learner, w and z in memory), tile coding (one block per learner) or (round 5) the order-7 wave family with f32 weights
+                *   per learner, w and z in memory), tile coding (one block per learner) or (round 5) the order-7 wave family (f32 weights; bf16 since round 6)
                 *   (one wavefront per learner, w and z streamed: kernels_wave_aux.hpp) */
                RSRL_TD = 7, RSRL_TD_LAMBDA = 8,
                /* QSigma, the n-step Q(sigma) agent (control/td/q_sigma.rs:80-202; config.sigma, config.n_steps, alpha, gamma, and the

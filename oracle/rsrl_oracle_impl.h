@@ -1180,7 +1180,7 @@ int FN(orc_run_train_dev)(void* h, int64_t n_steps, orc_stats* st) {
  *   - Q(s',a) with the updated column is re-evaluated (no rank-1 shortcut in this family); Q(s,.) is carried;
  *   - bf16 weight storage (w_bf16 != 0): every UPDATED weight is rounded to bf16 by stochastic rounding with the 16-bit
  *     window (e >> 2) of word (e & 3) of the lane's Philox block (block id 16 + lane), e = j*8 + v.
- *     Round 6: also for SARSALambda / QLambda, GreedyGQ, TD and TDLambda (W bf16, the trace / fa_td's weights f32): every entry of W that is
+ *     Round 6: also for SARSALambda / QLambda, GreedyGQ, TD, TDLambda and QSigma (W bf16, the trace / fa_td's weights / the backups f32): every entry of W that is
  *     stored in a step is rounded ONCE, after all of the step's updates of it, with block id 16 + 64 * column + lane.
  *   - the eligibility-trace agents (round 3; rsrl_amd/csrc/kernels_wave_lambda.hpp): orc_handle_lambda's
  *     operations with the wave-order dot products -- Q(s,.) carried, Q(s',.) with the pre-update weights, z = rule(rate*z + g)
@@ -1250,14 +1250,14 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
     FN(orc_run)* run = (FN(orc_run)*)h; const orc_agent* ag = &run->ag; const orc_basis* b = &ag->basis;
     int D = b->dim, A = ag->n_actions, F = orc_basis_nfeat(b), d, j, l, v, AW = ag->n_actions;     /* AW: columns of the weight matrix */
     int64_t N = run->n_envs, i, k;
-    R *phi_s, *phi_n, *tmp;
+    R *phi_s, *phi_n, *tmp, *w_before = NULL;
     orc_stats acc; memset(&acc, 0, sizeof(acc));
     if (FN(eps_sched)(ag) && !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL || ORC_IS_LAMBDA(ag->algo)))
         return -1;                   /* the schedule on the wave family: one-step agents and the lambda agents (k_train_wave / _pk <ESCHED>, k_wave_lambda) */
     if (b->kind != ORC_FOURIER || b->order != 7 || D != 4 || F != 4096 || ag->shared_w || sizeof(R) != 4 ||
         !(ag->algo == ORC_QLEARNING || ag->algo == ORC_SARSA || ag->algo == ORC_EXPECTED_SARSA || ag->algo == ORC_PAL ||
           (ORC_IS_LAMBDA(ag->algo) && run->Z) || (ag->algo == ORC_GREEDY_GQ && run->Z) ||
-          ag->algo == ORC_TD || (ag->algo == ORC_TD_LAMBDA && run->Z) || (ag->algo == ORC_Q_SIGMA && !w_bf16 && run->qs))) return -1;
+          ag->algo == ORC_TD || (ag->algo == ORC_TD_LAMBDA && run->Z) || (ag->algo == ORC_Q_SIGMA && run->qs))) return -1;
     if (ORC_IS_PRED(ag->algo)) AW = 1;
     phi_s = (R*)malloc(sizeof(R) * 4096); phi_n = (R*)malloc(sizeof(R) * 4096);
     for (i = 0; i < N; i++) {
@@ -1283,9 +1283,24 @@ int FN(orc_run_train_wave)(void* h, int64_t n_steps, orc_stats* st, int w_bf16) 
                 /* QSigma on the wave family (kernels_wave_aux.hpp k_wave_qsigma): q_sigma.rs:138-201 through the wave-order switch; the n-step
                  * backup, the anchor's update and the residual are orc_handle_qsigma's */
                 orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, ORC_BLK_INNER, xin);
+                if (w_bf16) { if (!w_before) w_before = (R*)malloc(sizeof(R) * (size_t)F * A); memcpy(w_before, W, sizeof(R) * (size_t)F * A); }
                 FN(g_wave_order) = 1;
                 delta = FN(orc_handle_qsigma)(ag, W, &run->qs[i], s, a, r, ns_pre, term, xin);
                 FN(g_wave_order) = 0;
+                if (w_bf16) {
+                    /* bf16 storage (round 6): the anchor's column -- the only one a step moves -- is rounded stochastically entry by entry before it is stored
+                     * (block id 16 + 64 * column + lane).  An entry the update left where it was is bf16-representable already and the rounding keeps it: rounding
+                     * the entries that moved is rounding the column. */
+                    int col = -1; size_t at;
+                    for (at = 0; at < (size_t)F * A && col < 0; at++) if (W[at] != w_before[at]) col = (int)(at % (size_t)A);
+                    if (col >= 0)
+                        for (l = 0; l < 64; l++) {
+                            uint32_t rnd[4];
+                            orc_draw(ag->seed, (uint64_t)(ag->env_offset + i), t, 16u + 64u * (uint32_t)col + (uint32_t)l, rnd);
+                            for (j = 0; j < 8; j++)
+                                for (v = 0; v < 8; v++) { R* wp = &W[FN(wave_row)(l, j, v) * A + col]; *wp = FN(sr_bf16)(*wp, rnd, j * 8 + v); }
+                        }
+                }
                 for (j = 0; j < A; j++) q_n[j] = FN(wave_dot)(phi_n, W, A, j);          /* (phi_n is phi of the restart state after a terminal step) */
                 goto sampled_target;
             }
@@ -1416,7 +1431,7 @@ sampled_target:
         run->action[i] = a; run->ep_step[i] = ep;
     }
     run->t += (uint64_t)n_steps;
-    free(phi_s); free(phi_n);
+    free(phi_s); free(phi_n); free(w_before);
     if (st) *st = acc;
     return 0;
 }

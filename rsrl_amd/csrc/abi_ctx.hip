@@ -108,8 +108,7 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     if (cfg->algo < 0 || cfg->algo > RSRL_Q_SIGMA) return fail(RSRL_HIP_EINVAL, "unknown algo %d", cfg->algo);
     if (cfg->algo == RSRL_Q_SIGMA) {
         // any basis but the order-7 wave family: register-family Fourier, the generic Fourier orders, tile coding (per-learner tables)
-        if (cfg->weight_mode != RSRL_W_PER_ENV || cfg->weight_dtype != RSRL_W_F32)
-            return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner f32 weights");
+        if (cfg->weight_mode != RSRL_W_PER_ENV) return fail(RSRL_HIP_EINVAL, "QSigma needs per-learner weights");
         if (!(cfg->sigma >= 0.0 && cfg->sigma <= 1.0)) return fail(RSRL_HIP_EINVAL, "sigma must be in [0, 1]");
         if (cfg->n_steps < 1 || cfg->n_steps > 32) return fail(RSRL_HIP_EINVAL, "n_steps must be in [1, 32]");
     }

@@ -240,48 +240,26 @@ __global__ __launch_bounds__(kBlock) void k_wave_aux(Common c, WaveAuxParams ap,
 }
 
 // ---------------------------------------------------------------------------------------
-// QSigma on the wave family: the Model interface qsigma_handle<M> is written against (kernels_qsigma.hpp), one WAVE per learner
+// QSigma on the wave family (q_sigma.rs:80-202; kernels_qsigma.hpp has the register / memory families' form and the one repaired line of the reference)
 // ---------------------------------------------------------------------------------------
-// The n-step backup, its propagation and every decision are wave-uniform scalar work (all lanes alike, the ring in memory as on the other
-// families); what the 64 lanes share is the approximator: features = the lane's 64 of the 4096, Q = lane partials + the wave total in dot()'s
-// order, the anchor's column update = one coalesced sweep of that column.
-template <int DOMAIN>
-struct WaveModel {
-    using WF = WaveFourier<DOMAIN>;
-    using Dom = Domain<DOMAIN>;
-    static constexpr int D = WF::D, A = WF::A, F = WF::F;
-    struct Feat { float phi[8][8]; };
-    __device__ static __forceinline__ int lane() { return (int)(threadIdx.x & 63); }
-    __device__ static __forceinline__ void features(const float (&s)[D], const BasisGeom&, Feat& f) { WF::project(s, lane(), f.phi); }
-    __device__ static __forceinline__ float q_index(const Common& c, int64_t i, const BasisGeom&, const Feat& f, int a) {
-        return wave_col_dot<DOMAIN>(c.W + (i * A + __builtin_amdgcn_readfirstlane(a)) * (int64_t)F, lane(), f.phi);
-    }
-    __device__ static __forceinline__ void q_all(const Common& c, int64_t i, const BasisGeom&, const Feat& f, float (&q)[A]) {
-#pragma unroll
-        for (int b = 0; b < A; ++b) q[b] = wave_col_dot<DOMAIN>(c.W + (i * A + b) * (int64_t)F, lane(), f.phi);
-    }
-    __device__ static __forceinline__ void update(const Common& c, int64_t i, const BasisGeom&, const Feat& f, int a, float scale) {
-        float* __restrict__ col = c.W + (i * A + __builtin_amdgcn_readfirstlane(a)) * (int64_t)F;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float w8[8];
-            WaveIO<float>::load8(col, (int64_t)j * 512 + lane() * 8, w8);
-#pragma unroll
-            for (int v = 0; v < 8; ++v) w8[v] = fmaf(scale, f.phi[j][v], w8[v]);
-            WaveIO<float>::store8(col, (int64_t)j * 512 + lane() * 8, w8);
-        }
-    }
-};
-
-// from == nullptr: the driver loop (k_train_qsigma's, one wave per learner); otherwise Handler::handle on Mn caller-supplied transitions
-template <int DOMAIN>
-__global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, uint64_t t0, int n_steps, DevStats* __restrict__ stats,
+// The n-step backup, its propagation and every decision are wave-uniform scalar work (all lanes alike, the ring in memory as on the other families: lane 0 writes
+// it); what the 64 lanes share is the approximator: features = the lane's 64 of the 4096, Q = lane partials + the wave total in dot()'s order, the anchor's column
+// update = one coalesced sweep of that column.  Operation by operation qsigma_handle<M> (kernels_qsigma.hpp), with what the loop knows used instead of re-read
+// (round 6): Q(s,a) is the carried Q(s',.) of the previous step (same state, same weights, the same dot product); Q(s',.) after the anchor's update differs from the
+// pre-update evaluation in the anchor's column only; and that column -- read ONCE, held in 64 registers per lane -- gives the anchor's Q and, after the update, its
+// dot product with phi(s') over the stored values: per learner-step W is read 4 F and written F instead of 9 F and F (146 -> 123.5 us per batch-step at 8 192
+// learners).  bf16 (WT = bf16_t, round 6): the column's entries are rounded stochastically before they are stored (Philox block 16 + 64 * column + lane of the step,
+// window of element e = j * 8 + v), the dot product with phi(s') runs over the rounded values.
+// from == nullptr: the driver loop, n_steps batch-steps of the wave's learner; otherwise Handler::handle on ONE caller-supplied transition per learner (Mn of them).
+template <int DOMAIN, class WT = float>
+__global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, WT* __restrict__ Wbase, uint64_t t0, int n_steps, DevStats* __restrict__ stats,
                                                         const float* __restrict__ from, const int32_t* __restrict__ act, const float* __restrict__ rew,
                                                         const float* __restrict__ to, const uint8_t* __restrict__ termf, int64_t Mn, float* __restrict__ td_out) {
-    using M = WaveModel<DOMAIN>;
+    using WF = WaveFourier<DOMAIN>;
     using Dom = Domain<DOMAIN>;
-    constexpr int D = M::D, A = M::A;
-    const BasisGeom g{M::F, kWaveOrder};
+    using IO = WaveIO<WT>;
+    constexpr int D = WF::D, A = WF::A, F = WF::F;
+    const int lane = threadIdx.x & 63;
     const int64_t N = c.n_envs;
     const bool driver = from == nullptr;
     const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);      // learner of this wave (uniform)
@@ -289,152 +267,161 @@ __global__ __launch_bounds__(kBlock) void k_wave_qsigma(Common c, QsParams qp, u
     double sum_abs = 0.0, sum_r = 0.0;
     if (i < (driver ? N : Mn)) {
         const uint32_t gid = (uint32_t)(c.env_offset + i);
-        if (!driver) {
-            float s[D], ns[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) { s[d] = from[(int64_t)d * Mn + i]; ns[d] = to[(int64_t)d * Mn + i]; }
-            const U4 xin = draw(c.seed, gid, t0, BLK_INNER);
-            const float res = qsigma_handle<M>(c, qp, g, i, N, s, clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i])), rew[i], ns, termf[i] != 0, xin);
-            if (td_out && M::lane() == 0) td_out[i] = res;
-        } else {
-            // The driver loop (round 6): qsigma_handle<M>'s operations, with what the loop knows used instead of re-read -- Q(s,a) is the carried Q(s',.) of the
-            // previous step (same state, same weights, the same dot product), Q(s',.) after the anchor's update differs from the pre-update evaluation in the
-            // anchor's column only, and that column -- read once, held in registers -- gives both the anchor's Q and, after the update, its dot product with phi(s') (over
-            // the stored values, in dot()'s order): per learner-step W is read 4 F and written F instead of 9 F and F.  Every value is the one the generic form computes (the oracle's wave-order loop, bitwise).
-            const uint32_t cap = c.max_episode_steps;
-            const int lane = M::lane();
-            float* __restrict__ Wi = c.W + i * (int64_t)(A * M::F);
-            float s[D];
+        const uint32_t cap = c.max_episode_steps;
+        WT* __restrict__ Wi = Wbase + i * (int64_t)(A * F);
+        float s[D];
+        int a; uint32_t ep = 0;
+        if (driver) {
 #pragma unroll
             for (int d = 0; d < D; ++d) s[d] = c.state[(int64_t)d * N + i];
-            int a = __builtin_amdgcn_readfirstlane(c.action[i]);
-            uint32_t ep = c.ep_step[i];
-            float facc_abs = 0.0f, facc_r = 0.0f;
-            typename M::Feat fs;
-            float q_s[A];
-            M::features(s, g, fs);
-            M::q_all(c, i, g, fs, q_s);
-            const int n = qp.n_steps;
-            uint32_t head = qp.head[i], len = qp.len[i];
-            const int64_t fs_stride = (int64_t)n * N;
-            auto at = [&](int field, uint32_t slot) -> float& { return qp.buf[(int64_t)field * fs_stride + (int64_t)slot * N + i]; };
-            for (int k = 0; k < n_steps; ++k) {
-                const uint64_t t = t0 + (uint64_t)k;
-                float ns[D];
+            a = __builtin_amdgcn_readfirstlane(c.action[i]); ep = c.ep_step[i];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = from[(int64_t)d * Mn + i];
+            a = clamp_action<A>(__builtin_amdgcn_readfirstlane(act[i]));
+        }
+        float facc_abs = 0.0f, facc_r = 0.0f;
+        float phi_s[8][8], q_s[A];
+        WF::project(s, lane, phi_s);
+#pragma unroll
+        for (int b = 0; b < A; ++b) q_s[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_s);
+        const int n = qp.n_steps;
+        uint32_t head = qp.head[i], len = qp.len[i];
+        const int64_t fs_stride = (int64_t)n * N;
+        auto at = [&](int field, uint32_t slot) -> float& { return qp.buf[(int64_t)field * fs_stride + (int64_t)slot * N + i]; };
+        for (int k = 0; k < (driver ? n_steps : 1); ++k) {
+            const uint64_t t = t0 + (uint64_t)k;
+            float ns[D], r;
+            bool term, trunc = false;
+            if (driver) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) ns[d] = s[d];
-                float r;
-                const bool term = Dom::step(ns, a, r);
+                term = Dom::step(ns, a, r);
                 ep += 1;
-                const bool trunc = !term && cap > 0 && ep >= cap;
-                const U4 xin = draw(c.seed, gid, t, BLK_INNER);
-                // ---- QSigma::handle (q_sigma.rs:138-201)
-                const float qa = select_a<A>(q_s, a);
-                typename M::Feat fn;
-                float q_n[A];
+                trunc = !term && cap > 0 && ep >= cap;
+            } else {
 #pragma unroll
-                for (int b = 0; b < A; ++b) q_n[b] = 0.0f;
-                float residual, pi, mu;
-                M::features(ns, g, fn);                                            // (a terminal s' too: the anchor's sweep multiplies by it, the result is dropped)
-                if (term) {
-                    residual = r - qa; pi = 0.0f; mu = 1.0f;
-                } else {
-                    M::q_all(c, i, g, fn, q_n);
-                    const int na = policy_sample<A>(c.apol, q_n, xin);
-                    const float nqsna = select_a<A>(q_n, na);
-                    float exp_nqs;
-                    const uint32_t mask = argmaxima_mask_max<A>(q_n, exp_nqs);
-                    pi = ((mask >> na) & 1u) ? 1.0f / (float)__popc(mask) : 0.0f;
-                    mu = policy_eval_sa<A>(c.apol, q_n, na);
-                    residual = r + c.alg.gamma * (qp.sigma * nqsna + (1.0f - qp.sigma) * exp_nqs) - qa;
-                }
-                {
-                    const uint32_t slot = (head + len) % (uint32_t)n;
-                    if (lane == 0) {
-#pragma unroll
-                        for (int d = 0; d < D; ++d) at(d, slot) = s[d];
-                        at(D, slot) = __int_as_float(a);
-                        at(D + 1, slot) = qa; at(D + 2, slot) = residual; at(D + 3, slot) = pi; at(D + 4, slot) = mu;
-                    }
-                    len += 1;
-                }
-                const bool restart = term || trunc;
-                if ((int)len >= n) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");            // lane 0's ring stores above are read back by every lane below
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    float gret = at(D + 1, head), z = 1.0f, isr = 1.0f;
-                    for (int kk = 0; kk < n; ++kk) {
-                        const uint32_t s1 = (head + (uint32_t)kk) % (uint32_t)n;
-                        gret += z * at(D + 2, s1);
-                        if (kk + 1 < n) {
-                            const uint32_t s2 = (head + (uint32_t)kk + 1u) % (uint32_t)n;
-                            z *= c.alg.gamma * ((1.0f - qp.sigma) * at(D + 3, s2) + qp.sigma);
-                        }
-                        isr *= 1.0f - qp.sigma + qp.sigma * at(D + 3, s1) / at(D + 4, s1);
-                    }
-                    float as_[D];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) as_[d] = at(d, head);
-                    const int aa = __builtin_amdgcn_readfirstlane(clamp_action<A>(__float_as_int(at(D, head))));
-                    head = (head + 1u) % (uint32_t)n; len -= 1;
-                    typename M::Feat fa;
-                    M::features(as_, g, fa);
-                    float* __restrict__ col = Wi + (int64_t)aa * M::F;
-                    // the anchor's column is read ONCE and held (64 registers per lane): <phi(anchor), column> in dot()'s order, then w += scale * phi(anchor) and
-                    // <phi(s'), the new column> from the registers (used when s' is the state the policy samples at)
-                    float wc[8][8];
-                    float qacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        WaveIO<float>::load8(col, (int64_t)j * 512 + lane * 8, wc[j]);
-#pragma unroll
-                        for (int v = 0; v < 8; ++v) qacc[v & 3] = fmaf(fa.phi[j][v], wc[j][v], qacc[v & 3]);
-                    }
-                    const float qsa = wave_sum_uniform((qacc[0] + qacc[1]) + (qacc[2] + qacc[3]));
-                    const float scale = c.alg.lr * (qp.alpha * isr * (gret - qsa));
-                    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                        for (int v = 0; v < 8; ++v) {
-                            wc[j][v] = fmaf(scale, fa.phi[j][v], wc[j][v]);
-                            acc[v & 3] = fmaf(fn.phi[j][v], wc[j][v], acc[v & 3]);
-                        }
-                        WaveIO<float>::store8(col, (int64_t)j * 512 + lane * 8, wc[j]);
-                    }
-                    if (!restart) {
-                        const float qpost = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
-#pragma unroll
-                        for (int b = 0; b < A; ++b) q_n[b] = (b == aa) ? qpost : q_n[b];
-                    }
-                }
-                if (term) len = 0;
-                const float res = residual;
-                if (restart) {
-                    n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; ep = 0;
-                    Dom::reset(ns);
-                    M::features(ns, g, fn);
-                    M::q_all(c, i, g, fn, q_n);                                    // the UPDATED weights at s0
-                }
-                const U4 x = draw(c.seed, gid, t, BLK_STEP);
-                a = __builtin_amdgcn_readfirstlane(policy_sample<A>(c.pol, q_n, x));
-                facc_abs += fabsf(res); facc_r += r;
-#pragma unroll
-                for (int d = 0; d < D; ++d) s[d] = ns[d];
-                fs = fn;
-#pragma unroll
-                for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+                for (int d = 0; d < D; ++d) ns[d] = to[(int64_t)d * Mn + i];
+                r = rew[i]; term = termf[i] != 0;
             }
-            if (lane == 0) { qp.head[i] = head; qp.len[i] = len; }
-            if (M::lane() == 0) {
+            const U4 xin = draw(c.seed, gid, t, BLK_INNER);
+            // ---- QSigma::handle (q_sigma.rs:138-201)
+            const float qa = select_a<A>(q_s, a);                                      // :140
+            float phi_n[8][8], q_n[A];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_n[b] = 0.0f;
+            WF::project(ns, lane, phi_n);                                             // (a terminal s' too: the anchor's sweep multiplies by it, the result is dropped)
+            float residual, pi, mu;
+            if (term) {
+                residual = r - qa; pi = 0.0f; mu = 1.0f;                              // :142-153
+            } else {
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_n);
+                const int na = policy_sample<A>(c.apol, q_n, xin);                   // :157 the agent's own draw
+                const float nqsna = select_a<A>(q_n, na);
+                float exp_nqs;
+                const uint32_t mask = argmaxima_mask_max<A>(q_n, exp_nqs);            // :161
+                pi = ((mask >> na) & 1u) ? 1.0f / (float)__popc(mask) : 0.0f;         // :163-167
+                mu = policy_eval_sa<A>(c.apol, q_n, na);                              // :168
+                residual = r + c.alg.gamma * (qp.sigma * nqsna + (1.0f - qp.sigma) * exp_nqs) - qa;    // :170-171
+            }
+            // ---- update_backup (:107-128): push, then one update of the anchor once n_steps entries are held
+            {
+                const uint32_t slot = (head + len) % (uint32_t)n;
+                if (lane == 0) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) at(d, slot) = s[d];
+                    at(D, slot) = __int_as_float(a);
+                    at(D + 1, slot) = qa; at(D + 2, slot) = residual; at(D + 3, slot) = pi; at(D + 4, slot) = mu;
+                }
+                len += 1;
+            }
+            const bool restart = driver && (term || trunc);
+            if ((int)len >= n) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                // lane 0's ring stores above are read back by every lane below
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // Backup::propagate (:46-63) with the dead out-of-bounds z update of the last iteration dropped (kernels_qsigma.hpp header)
+                float gret = at(D + 1, head), z = 1.0f, isr = 1.0f;
+                for (int kk = 0; kk < n; ++kk) {
+                    const uint32_t s1 = (head + (uint32_t)kk) % (uint32_t)n;
+                    gret += z * at(D + 2, s1);
+                    if (kk + 1 < n) {
+                        const uint32_t s2 = (head + (uint32_t)kk + 1u) % (uint32_t)n;
+                        z *= c.alg.gamma * ((1.0f - qp.sigma) * at(D + 3, s2) + qp.sigma);
+                    }
+                    isr *= 1.0f - qp.sigma + qp.sigma * at(D + 3, s1) / at(D + 4, s1);
+                }
+                float as_[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) as_[d] = at(d, head);
+                const int aa = __builtin_amdgcn_readfirstlane(clamp_action<A>(__float_as_int(at(D, head))));
+                head = (head + 1u) % (uint32_t)n; len -= 1;                           // pop (:116)
+                float phi_a[8][8];
+                WF::project(as_, lane, phi_a);
+                WT* __restrict__ col = Wi + (int64_t)aa * F;
+                float wc[8][8];
+                float qacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    IO::load8(col, (int64_t)j * 512 + lane * 8, wc[j]);
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) qacc[v & 3] = fmaf(phi_a[j][v], wc[j][v], qacc[v & 3]);
+                }
+                const float qsa = wave_sum_uniform((qacc[0] + qacc[1]) + (qacc[2] + qacc[3]));      // :117 with the CURRENT weights
+                const float scale = c.alg.lr * (qp.alpha * isr * (gret - qsa));                      // :122; Handler<StateActionUpdate>: W[:,a] += lr*error*phi
+                U4 rnd = U4{0, 0, 0, 0};
+                if constexpr (IO::kBf16) rnd = draw(c.seed, gid, t, BLK_SR_BASE + 64u * (uint32_t)aa + (uint32_t)lane);
+                float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) {
+                        float x = fmaf(scale, phi_a[j][v], wc[j][v]);
+                        if constexpr (IO::kBf16) x = round_bf16_sr(x, sr_bits(rnd, j * 8 + v));
+                        wc[j][v] = x;
+                        acc[v & 3] = fmaf(phi_n[j][v], x, acc[v & 3]);
+                    }
+                    IO::store8(col, (int64_t)j * 512 + lane * 8, wc[j]);
+                }
+                if (!restart && !term) {
+                    const float qpost = wave_sum_uniform((acc[0] + acc[1]) + (acc[2] + acc[3]));
+#pragma unroll
+                    for (int b = 0; b < A; ++b) q_n[b] = (b == aa) ? qpost : q_n[b];
+                }
+            }
+            if (term) len = 0;                                                        // backup.clear() (:154)
+            if (!driver) { if (lane == 0 && td_out) td_out[i] = residual; break; }
+            if (restart) {
+                n_ep += 1; n_trunc += trunc ? 1 : 0; sum_len += ep; ep = 0;
+                Dom::reset(ns);
+                WF::project(ns, lane, phi_n);
+#pragma unroll
+                for (int b = 0; b < A; ++b) q_n[b] = wave_col_dot<DOMAIN, WT>(Wi + (int64_t)b * F, lane, phi_n);      // the UPDATED weights at s0
+            }
+            const U4 x = draw(c.seed, gid, t, BLK_STEP);
+            a = __builtin_amdgcn_readfirstlane(policy_sample<A>(c.pol, q_n, x));
+            facc_abs += fabsf(residual); facc_r += r;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s[d] = ns[d];
+#pragma unroll
+            for (int b = 0; b < A; ++b) q_s[b] = q_n[b];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int v = 0; v < 8; ++v) phi_s[j][v] = phi_n[j][v];
+        }
+        if (lane == 0) {
+            qp.head[i] = head; qp.len[i] = len;
+            if (driver) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) c.state[(int64_t)d * N + i] = s[d];
                 c.action[i] = a;
                 c.ep_step[i] = ep;
                 sum_abs = (double)facc_abs; sum_r = (double)facc_r;
-            } else { n_ep = 0; n_trunc = 0; sum_len = 0; }
+            }
         }
+        if (lane != 0 || !driver) { n_ep = 0; n_trunc = 0; sum_len = 0; }
     }
     if (stats) block_stats_accumulate(stats, n_ep, n_trunc, sum_len, sum_abs, sum_r);
 }

@@ -13,8 +13,7 @@ void launch_wave_agent(const rsrl_hip_ctx* c, const Common& k, int64_t items, ui
         if (is_wave_aux_algo(c->cfg.algo)) {
             hipLaunchKernelGGL((k_wave_aux<T::domain, WT>), grid, block, 0, c->stream, k, make_wave_aux(c), (WT*)c->W, t, n_steps, d_stats, from, act, rew, to, term, M, td_out);
         } else if (c->cfg.algo == RSRL_Q_SIGMA) {
-            if constexpr (!WaveIO<WT>::kBf16)            // (QSigma on the wave family: f32 weights only -- rsrl_hip_create refuses the rest)
-                hipLaunchKernelGGL((k_wave_qsigma<T::domain>), grid, block, 0, c->stream, k, make_qs(c), t, n_steps, d_stats, from, act, rew, to, term, M, td_out);
+            hipLaunchKernelGGL((k_wave_qsigma<T::domain, WT>), grid, block, 0, c->stream, k, make_qs(c), (WT*)c->W, t, n_steps, d_stats, from, act, rew, to, term, M, td_out);
         } else {
             hipLaunchKernelGGL((k_wave_lambda<T::domain, WT>), grid, block, 0, c->stream, k, make_lambda(c), (WT*)c->W, t, n_steps, d_stats, from, act, rew, to, term, M, td_out);
         }

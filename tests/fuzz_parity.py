@@ -82,7 +82,7 @@ def sample(rng):
         dev.update(epsilon_decay=0.97, epsilon_min=0.01)
     elif family == "wave":
         method = "train_wave"
-        if (algo in ONE_STEP[:3] or algo in LAMBDA or algo in (ra.GREEDY_GQ, ra.TD, ra.TD_LAMBDA)) and rng.random() < 0.5:      # bf16 + stochastic rounding (the trace / aux agents: round 6)
+        if (algo in ONE_STEP[:3] or algo in LAMBDA or algo in (ra.GREEDY_GQ, ra.TD, ra.TD_LAMBDA, ra.Q_SIGMA)) and rng.random() < 0.5:      # bf16 + stochastic rounding (the trace / aux agents: round 6)
             dev["weight_dtype"] = ra.W_BF16
             mkw["bf16"] = True
     elif family == "shared_dense":

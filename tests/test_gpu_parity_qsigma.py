@@ -80,6 +80,6 @@ def test_qsigma_free_running_bitwise(ra, orc, domain, order, n_steps, sigma, pol
 def test_qsigma_rejects_what_it_cannot_run(ra):
     # (tile coding and the generic Fourier orders: built in round 4, tests/test_gpu_round4.py)
     for bad in (dict(weight_mode=ra.W_SHARED), dict(basis=ra.TILE_CODING, weight_mode=ra.W_SHARED), dict(sigma=1.5), dict(n_steps=0), dict(n_steps=33),
-                dict(domain=2, order=7, weight_dtype=ra.W_BF16)):          # (the order-7 wave family: built in round 5 with f32 weights, tests/test_gpu_wave_aux.py)
+                dict(domain=0, order=3, weight_dtype=ra.W_BF16)):          # (bf16 weights: the order-7 wave family only, round 6 -- tests/test_gpu_wave_aux.py)
         with pytest.raises(ra.RsrlHipError):
             ra.Context(n_envs=8, algo=ra.Q_SIGMA, **bad)

@@ -480,8 +480,8 @@ def test_gq_and_qsigma_off_the_register_family_bitwise(ra, orc, name, kw, tmp_pa
             d2.reset(); d2.train(40)
             assert np.array_equal(d2.states, ref[0]) and all(np.array_equal(d2.get_weights(i), w) for i, w in zip((0, N - 1), ref[1]))
     for bad in (dict(algo=6, lr_td=0.01, basis=1, weight_mode=1), dict(algo=9, basis=1, weight_mode=1),
-                dict(algo=9, domain=1, order=7, weight_dtype=1)):
-        with pytest.raises(ra.RsrlHipError):                     # (the order-7 wave family runs both since round 5 -- QSigma with f32 weights only: tests/test_gpu_wave_aux.py)
+                dict(algo=9, domain=0, order=3, weight_dtype=1)):
+        with pytest.raises(ra.RsrlHipError):                     # (the order-7 wave family runs both since round 5, with bf16 weights since round 6: tests/test_gpu_wave_aux.py)
             ra.Context(n_envs=8, policy=1, **bad)
 
 

@@ -44,7 +44,7 @@ def _okw(kw):
     return o
 
 
-BF16_CASES = [(n + "_bf16", d, dict(k, weight_dtype=1), K) for n, d, k, K in CASES if k["algo"] in (6, 7, 8) and n not in ("gq_acrobot_greedy", "td_acrobot", "tdl_cartpole_accumulate")]
+BF16_CASES = [(n + "_bf16", d, dict(k, weight_dtype=1), K) for n, d, k, K in CASES if n not in ("gq_acrobot_greedy", "td_acrobot", "tdl_cartpole_accumulate", "qsigma_cartpole_n4")]
 
 
 @pytest.mark.parametrize("name,domain,kw,K", CASES + BF16_CASES, ids=[c[0] for c in CASES + BF16_CASES])
@@ -194,9 +194,12 @@ def test_wave_aux_entry_points_and_checkpoint(ra, tmp_path):
         with pytest.raises(ra.RsrlHipError):
             c.rollout_greedy(10)
         assert c.project(c.states).shape == (4096, 3)
-    # still refused where no kernel exists: bf16 weights for QSigma
+    # QSigma with bf16 weights: the wave family only (round 6)
     with pytest.raises(ra.RsrlHipError):
-        ra.Context(domain=2, order=7, algo=9, policy=1, n_envs=2, weight_dtype=ra.W_BF16)
+        ra.Context(domain=0, order=3, algo=9, policy=1, n_envs=2, weight_dtype=ra.W_BF16)
+    with ra.Context(domain=2, order=7, algo=9, policy=1, n_envs=2, weight_dtype=ra.W_BF16, n_steps=2, lr=1e-4) as c:
+        c.reset(); c.train(8)
+        assert np.all((c.get_weights(0).view(np.uint32) & 0xffff) == 0) and np.abs(c.get_weights(0)).max() > 0
     # bf16 (round 6): the granular entry points of GreedyGQ / TD read the bf16 tables
     with ra.Context(domain=2, order=7, algo=6, policy=1, n_envs=3, lr=1e-4, lr_td=1e-4, weight_dtype=ra.W_BF16) as c:
         c.reset(); c.train(6)
