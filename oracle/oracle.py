@@ -138,6 +138,8 @@ def _declare(L):
         g("orc_run_train_sparse_lambda").argtypes = [C.c_void_p, C.c_int64, C.POINTER(Stats)]
         g("orc_run_sparse_trace").argtypes = [C.c_void_p, C.c_int64, Rp]
         g("orc_run_teacher").argtypes = [C.c_void_p, C.POINTER(Stats), Rp, C.POINTER(C.c_int32), Rp, Rp, C.POINTER(C.c_uint8), Rp]
+        g("orc_run_teacher_sparse_lambda").argtypes = [C.c_void_p, C.POINTER(Stats), Rp, C.POINTER(C.c_int32), Rp, Rp, C.POINTER(C.c_uint8), Rp]
+        g("orc_run_teacher_sparse_lambda").restype = C.c_int
         g("orc_run_eps").restype = Rp
         g("orc_run_eps").argtypes = [C.c_void_p]
         g("orc_handle_lambda").restype = R
@@ -494,6 +496,19 @@ class Run:
         self._f("orc_run_teacher")(self._h, C.byref(st), _ptr(out["frm"], self._ct), out["action"].ctypes.data_as(C.POINTER(C.c_int32)),
                                    _ptr(out["reward"], self._ct), _ptr(out["to"], self._ct),
                                    out["terminal"].ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(out["td"], self._ct))
+        out["stats"] = st.as_dict()
+        return out
+
+    def teacher_step_sparse_lambda(self):
+        """teacher_step() for SARSALambda / QLambda over ONE shared tile table with sparse per-learner traces (orc_run_train_sparse_lambda's rule)"""
+        st = Stats()
+        out = dict(frm=np.empty((self.n, self.D), dtype=self._dt), action=np.empty(self.n, dtype=np.int32),
+                   reward=np.empty(self.n, dtype=self._dt), to=np.empty((self.n, self.D), dtype=self._dt),
+                   terminal=np.empty(self.n, dtype=np.uint8), td=np.empty(self.n, dtype=self._dt))
+        if self._f("orc_run_teacher_sparse_lambda")(self._h, C.byref(st), _ptr(out["frm"], self._ct), out["action"].ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    _ptr(out["reward"], self._ct), _ptr(out["to"], self._ct),
+                                                    out["terminal"].ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(out["td"], self._ct)) != 0:
+            raise ValueError("teacher_step_sparse_lambda: SARSALambda / QLambda on tile coding with shared weights only")
         out["stats"] = st.as_dict()
         return out
 

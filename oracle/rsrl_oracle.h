@@ -138,6 +138,7 @@ void orc_agent_init(orc_agent* ag, int domain, int basis_kind, int order, int n_
     int   orc_run_train_sparse_lambda_##S(void* h, int64_t n_steps, orc_stats* st);                   \
     void  orc_run_sparse_trace_##S(void* h, int64_t i, R* out);                                         \
     void  orc_run_teacher_##S(void* h, orc_stats* st, R* from, int32_t* act, R* rew, R* to, uint8_t* term, R* td); \
+    int   orc_run_teacher_sparse_lambda_##S(void* h, orc_stats* st, R* from, int32_t* act, R* rew, R* to, uint8_t* term, R* td); \
     void  orc_run_train_hook_##S(void* h, int64_t n_steps, orc_stats* st,                               \
                                  void (*dw_hook)(R* dW, int n, void* user), void* user);                \
     int   orc_run_rollout_greedy_##S(void* h, int64_t step_limit, uint32_t* n_states, R* total_reward); \

@@ -1491,6 +1491,11 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
             run->ep_step[i] += 1;
             trunc = !term && ag->max_episode_steps > 0 && run->ep_step[i] >= ag->max_episode_steps;
             flag_all[i] = (uint8_t)((term ? 1 : 0) | (trunc ? 2 : 0));
+            if (run->round32) for (d = 0; d < D; d++) ns[d] = (R)(float)ns[d];          /* teacher forcing: the transition as a fp32 caller receives it */
+            if (run->tape_from) {
+                memcpy(run->tape_from + (size_t)i * D, s, sizeof(R) * D); memcpy(run->tape_to + (size_t)i * D, ns, sizeof(R) * D);
+                run->tape_act[i] = a; run->tape_rew[i] = r; run->tape_term[i] = (uint8_t)term;
+            }
             for (d = 0; d < D; d++) sf[d] = (float)s[d];
             orc_tile_indices(b, sf, is);
             for (d = 0; d < D; d++) sf[d] = (float)ns[d];
@@ -1531,6 +1536,7 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
                 lens[tt] = term ? 0 : len;                                              /* trace.reset() */
               }
             }
+            if (run->tape_td) run->tape_td[i] = delta;
             acc.sum_abs_td_error += fabs((double)delta); acc.sum_reward += (double)r; acc.env_steps += 1;
         }
         { int j; for (j = 0; j < F * A; j++) run->W[j] += fixed ? (R)((float)qacc[j] * lsb_f) : dW[j]; }
@@ -1554,6 +1560,17 @@ int FN(orc_run_train_sparse_lambda)(void* h, int64_t n_steps, orc_stats* st) {
     free(ns_all); free(flag_all); free(dW); free(qacc);
     if (st) *st = acc;
     return 0;
+}
+/* one batch-step of the sparse-trace loop as a TEACHER (orc_run_teacher's contract: successor states rounded to fp32, the transitions the agents saw on the tape):
+ * replayed through rsrl_hip_handle -- transition i is learner i's -- device and oracle learn from identical inputs.  Returns orc_run_train_sparse_lambda's status. */
+int FN(orc_run_teacher_sparse_lambda)(void* h, orc_stats* st, R* from, int32_t* act, R* rew, R* to, uint8_t* term, R* td) {
+    FN(orc_run)* run = (FN(orc_run)*)h; int rc;
+    run->round32 = 1;
+    run->tape_from = from; run->tape_act = act; run->tape_rew = rew; run->tape_to = to; run->tape_term = term; run->tape_td = td;
+    rc = FN(orc_run_train_sparse_lambda)(h, 1, st);
+    run->tape_from = NULL; run->tape_act = NULL; run->tape_rew = NULL; run->tape_to = NULL; run->tape_term = NULL; run->tape_td = NULL;
+    run->round32 = 0;
+    return rc;
 }
 /* learner i's sparse trace as the dense (F, A) matrix it stands for; `out` holds F*A zeros on entry */
 void FN(orc_run_sparse_trace)(void* h, int64_t i, R* out) {

@@ -98,6 +98,37 @@ def test_handle_is_the_driver_loops_step_on_the_callers_transitions(ra, algo, do
         assert np.array_equal(b.get_traces(N - 1), z_last) and not np.array_equal(b.get_weights(), a.get_weights())
 
 
+@pytest.mark.parametrize("algo,domain,trace", [(3, 1, 0), (3, 0, 2), (4, 1, 1)])
+def test_teacher_forced_vs_f64(ra, orc, algo, domain, trace):
+    # the reference's precision: the f64 oracle runs the sparse-trace loop as a teacher (successor states rounded to fp32, orc_run_teacher_sparse_lambda) and every
+    # batch-step's transitions go through rsrl_hip_handle (transition i = learner i): device and oracle learn from IDENTICAL inputs.  SURVEY 8(d): teacher-forced
+    # max|dW| <= 1e-3 max(1, max|W|); asserted far tighter, relative to max|W| itself.  (An agent's own draw / Watkins's cut is a discrete decision a rounding can tip:
+    # the seeds below have none in these horizons.)
+    N, K = 192, 250
+    kw = dict(domain=domain, n_tilings=8, tiles_per_dim=8, algo=algo, policy=1, epsilon=0.15, gamma=0.98, lam=0.85, trace=trace, max_episode_steps=80)
+    alpha = 0.1 / 8 / N
+    ag = orc.make_agent(**dict(kw, basis=orc.TILE, shared_w=True, seed=3, alpha=alpha))
+    run = orc.Run(ag, N, "f64")
+    run.reset()
+    with ra.Context(basis=ra.TILE_CODING, weight_mode=ra.W_SHARED, seed=3, alpha=alpha, n_envs=N, **kw) as c:
+        c.reset()
+        td_err = 0.0
+        for _ in range(K):
+            t = run.teacher_step_sparse_lambda()
+            frm, to = np.ascontiguousarray(t["frm"].T, dtype=np.float32), np.ascontiguousarray(t["to"].T, dtype=np.float32)
+            td = c.handle(frm, t["action"], t["reward"].astype(np.float32), to, t["terminal"])
+            td_err = max(td_err, float(np.max(np.abs(td - t["td"]) / (1 + np.abs(t["td"])))))
+        W64 = np.array(run.weights).reshape(c.F, c.A)
+        W = c.get_weights().astype(np.float64)
+        wmax = np.abs(W64).max()
+        assert wmax > 1e-4
+        z_err = max(float(np.abs(c.get_traces(i).astype(np.float64) - run.sparse_trace(i)).max()) for i in (0, N // 3, N - 1))
+        print(f"sparse lambda teacher-forced: td {td_err:.2e}  w {np.abs(W - W64).max() / wmax:.2e} of max|W| {wmax:.2e}  z {z_err:.2e}")
+        assert td_err <= 2e-5, td_err                                                   # measured 2.5e-8 / 6.4e-6 (MountainCar: |W| 3.5) / 2.8e-8
+        assert np.abs(W - W64).max() <= 4e-6 * wmax, (np.abs(W - W64).max(), wmax)      # measured 3.8e-7 / 1.0e-6 / 1.7e-7 of max|W|
+        assert z_err <= 1e-6, z_err                                                     # measured 2.6e-7 / 2.4e-7 / 2.2e-8
+
+
 def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
     # file version 6 / aux kind 4: whose lists (n_envs, env_offset), then every learner's sub-lists in tiling and slot order -- with lists that are FULL (the
     # slot order decides which entry the next new key overwrites), so the resumed run is the straight one bit for bit
