@@ -27,8 +27,6 @@ BOUNDS_BF16 = {"td": 0.25, "w": 0.05, "q": 0.25}                # bf16 storage +
 
 def run_case(rng, idx):
     family, dev, okw, method, mkw = fp.sample(rng)
-    if family == "sparse_lambda":                               # stepped by rsrl_hip_train only: no handle to teacher-force
-        return None
     shared = dev.get("weight_mode", ra.W_PER_ENV) == ra.W_SHARED
     n = min(dev["n_envs"], 48) if not shared else min(dev["n_envs"], 512)
     dev = dict(dev, n_envs=n)
@@ -49,7 +47,7 @@ def run_case(rng, idx):
         hist = []
         try:
             for _ in range(K):
-                t = run.teacher_step()
+                t = run.teacher_step_sparse_lambda() if family == "sparse_lambda" else run.teacher_step()      # (transition i = learner i: round 6)
                 frm, to = np.ascontiguousarray(t["frm"].T, dtype=np.float32), np.ascontiguousarray(t["to"].T, dtype=np.float32)
                 td = c.handle(frm, t["action"], t["reward"].astype(np.float32), to, t["terminal"])
                 with np.errstate(invalid="ignore"):
