@@ -21,6 +21,8 @@ CASES = [
     ("cartpole_q_saturate", 300, 200, dict(domain=1, n_tilings=8, tiles_per_dim=8, algo=4, policy=1, epsilon=0.2, gamma=0.99, lam=0.8, trace=1, max_episode_steps=60)),
     ("mountaincar_sarsa_dutch_evicting", 64, 900, dict(domain=0, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.3, gamma=0.99, lam=0.97, trace=2, max_episode_steps=0)),
     ("acrobot_q_accumulate_softmax", 96, 120, dict(domain=2, n_tilings=4, tiles_per_dim=6, algo=4, policy=2, tau=0.5, gamma=0.95, lam=0.7, trace=0, max_episode_steps=50)),
+    # a tiling's slice of 20 000 entries (160 KB as 64-bit accumulators: beyond the LDS): the scatter kernel adds its terms with device atomics instead
+    ("cartpole_q_slice_beyond_lds", 128, 80, dict(domain=1, n_tilings=4, tiles_per_dim=10, algo=4, policy=1, epsilon=0.2, gamma=0.99, lam=0.8, trace=0, max_episode_steps=40)),
     ("cartpole_sarsa_4096", 4096, 60, dict(domain=1, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.1, gamma=0.99, lam=0.9, trace=0, max_episode_steps=40)),
 ]
 
@@ -181,6 +183,8 @@ def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
 def test_sparse_lambda_is_refused_where_it_does_not_exist(ra):
     with pytest.raises(ra.RsrlHipError):                            # a shared DENSE basis has no sparse gradient
         ra.Context(domain=0, order=3, algo=3, policy=1, weight_mode=ra.W_SHARED, n_envs=8)
+    with pytest.raises(ra.RsrlHipError, match="65 536"):            # a tiling's slice beyond the 16-bit slice-relative keys between the step and the trace kernel
+        ra.Context(domain=1, basis=ra.TILE_CODING, n_tilings=4, tiles_per_dim=14, algo=3, policy=1, weight_mode=ra.W_SHARED, n_envs=8, alpha=0.001, lam=0.5)
     with ra.Context(domain=1, basis=ra.TILE_CODING, algo=3, policy=1, weight_mode=ra.W_SHARED, n_envs=8, alpha=0.001, lam=0.5) as c:
         c.reset()
         c.train(3)
