@@ -21,6 +21,12 @@ def canned():
     full["trait_loop"] = trait
     full["trait_loop_unfused"] = dict(trait, us_per_batch_step=18.4, frac=0.30, kernel="k_trait_lm<handle>")
     full["trait_loop_1m"] = dict(trait, learners=1048576, us_per_batch_step=165.9, frac=0.536)
+    lam = {"workload": "w" * 300, "value": 4.8e8, "unit": "env-steps/s", "us_per_batch_step": 135.7, "kernel_us_per_batch_step": 133.6,
+           "roofline": {"bound": "hbm", "kernel": "k_sparse_trace_scatter", "achieved": 6092.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.7615, "what": "v" * 600}}
+    full["lambda_shared_tiles"] = lam                                     # round 6's legs: the rebuilt eligibility-trace kernels, C3's written floor
+    full["lambda_generic_order"] = dict(lam, value=4.3e8, us_per_batch_step=152.3, roofline=dict(lam["roofline"], kernel="k_train_lambda_mem", frac=0.441))
+    if isinstance(full.get("c3_shared_tiles"), dict):
+        full["c3_shared_tiles"].update({"floor_us": 13.6, "floor": "f" * 700, "floor_frac": 0.62})
     full["hbm_copy_measured"] = {"GBps": 5100.0, "bytes": 2 ** 30, "reps": 10, "what": "y" * 500}
     full["greedy_rollout"] = {"limit": 1000, "compared": 256, "terminated_frac": 1.0, "identical_n_states_frac": 0.996, "min_argmax_margin": 3.1e-9,
                               "max_min_margin_of_differing": 3.1e-9, "note": "z" * 700}
@@ -50,8 +56,10 @@ def test_compact_line_is_small_parsable_and_complete():
     cb = back["cpu_baseline"]
     assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["cores"] >= 1
     legs = back["legs"]
-    for k in ("trait_loop", "trait_loop_unfused", "trait_loop_1m", "streaming", "streaming_1m", "c3_shared_tiles", "c5_wave_bf16", "shared_w", "shared_w_rccl"):
+    for k in ("trait_loop", "trait_loop_unfused", "trait_loop_1m", "streaming", "streaming_1m", "c3_shared_tiles", "c5_wave_bf16", "lambda_shared_tiles",
+              "lambda_generic_order", "shared_w", "shared_w_rccl"):
         assert {"value", "frac"} <= set(legs[k]) and ("us" in legs[k]), (k, legs[k])
+    assert legs["c3_shared_tiles"]["floor_us"] == 13.6 and legs["lambda_shared_tiles"]["kernel"] == "k_sparse_trace_scatter"
     assert legs["trait_loop"]["frac_of_measured_copy"] > legs["trait_loop"]["frac"]        # 5.1 TB/s measured < 8 TB/s published
     gr = back["greedy_rollout"]
     assert gr["terminated_frac"] > 0 and "min_argmax_margin" in gr and gr["compared"] == 256
