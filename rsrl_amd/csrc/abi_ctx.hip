@@ -201,7 +201,8 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
     c->Aw = is_pred(cfg->algo) ? 1 : c->A;
     c->w_elems = (size_t)c->Aw * c->F * (size_t)(shared ? 1 : N);
     // a ctx that steps one batch-step per launch streams W every step: learner-major rows (W[N][A][F]) let k_step_reg_lm
-    // write back only the touched column (RSRL_K1_FEATURE_MAJOR=1 keeps the feature-major layout, for A/B runs)
+    // write back only the touched column (RSRL_K1_FEATURE_MAJOR=1 keeps the feature-major layout, for A/B runs).  NOT the default layout: the fused loop runs on it
+    // bit for bit, but its strided load / store of W costs 71 against 26 us per 20-step launch and 1.3 % of the coalesced rate (round 6, measured)
     if (!shared && cfg->steps_per_launch == 1 && cfg->basis == RSRL_FOURIER && !is_wave(*cfg) && !is_generic_fourier(*cfg) &&
         !has_aux(cfg->algo) && !is_pred(cfg->algo) && cfg->algo != RSRL_Q_SIGMA && (c->A * c->F) % 4 == 0 && c->F % 4 == 0 &&
         (uint64_t)c->w_elems * 4ull < (1ull << 32) && !getenv("RSRL_K1_FEATURE_MAJOR")) {
