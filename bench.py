@@ -525,7 +525,7 @@ def config_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, extr
         return {"workload": name, "error": repr(e)}
 
 
-def hbm_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what):
+def hbm_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, bytes_fn=None):
     """A leg whose kernels are memory sweeps: env-steps/s, HIP-event kernel time per batch-step, and SURVEY 8(d)-style algorithmic bytes per env-step x the kernel
     rate against 8 TB/s (no instruction-mix constants needed: nothing here depends on a committed profile)."""
     try:
@@ -539,15 +539,27 @@ def hbm_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what):
         ctx.sync()
         dt = time.perf_counter() - t0
         ms, n, kn = ctx.timing_read()
+        extra = {}
+        if bytes_fn is not None:                  # bytes that depend on what the run left behind (the sparse traces' live entries)
+            bytes_per_env_step, extra = bytes_fn(ctx)
         ctx.close()
         per_step = ms * 1e-3 / max(1, steps)
         ach = bytes_per_env_step * kw["n_envs"] / per_step if per_step > 0 else 0.0
         return {"workload": name, "value": kw["n_envs"] * steps / dt, "unit": "env-steps/s", "us_per_batch_step": dt / steps * 1e6,
                 "kernel_us_per_batch_step": per_step * 1e6,
                 "roofline": {"bound": "hbm", "kernel": kn, "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
-                             "algorithmic_bytes_per_env_step": bytes_per_env_step, "what": what}}
+                             "algorithmic_bytes_per_env_step": bytes_per_env_step, "what": what, **extra}}
     except Exception as e:
         return {"workload": name, "error": repr(e)}
+
+
+def sparse_trace_bytes(ctx):
+    """bytes per learner-step of the sparse-trace lambda agents on what the lists really hold: every LIVE entry read, written back and added as one 8-byte term
+    (3 x 8 B), + the 2 x T gathers.  (12 416 B -- FULL 512-entry lists, the figure round 5's 0.10 was quoted on -- overstates it: lists are ~1/6 full.)"""
+    import numpy as np
+    n = ctx.N
+    live = float(np.mean([int((ctx.get_traces(i) != 0).sum()) for i in range(0, n, max(1, n // 48))]))
+    return 3 * live * 8 + 16 * 2 * 4, {"mean_live_entries": live, "frac_on_full_lists_formula_bytes": 12416}
 
 
 def _num(x, digits=5):
@@ -856,8 +868,9 @@ def main():
             dict(domain=rsrl_amd.CART_POLE, basis=rsrl_amd.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536,
                  policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99, alpha=0.0125 / 65536, lam=0.9, weight_mode=rsrl_amd.W_SHARED, max_episode_steps=200,
                  env_offset=rank * 65536, device=device), 256, 64, 2 * 512 * 8 + 16 * 2 * 4 + 512 * 8,
-            "per learner-step: the trace list read and written (512 x 8 B each way) + 2 x 8 gathers + one 8-byte term per entry; k_shared_ca -> "
-            "k_sparse_trace_scatter -> k_apply_rep (kernels_sparse_lambda.hpp); round 5's form: 0.10"), 120)
+            "per learner-step: every LIVE trace entry read, written back and added as one 8-byte term + 2 x 8 gathers (mean_live_entries of 512 per learner, measured "
+            "after the run); k_shared_ca -> k_sparse_trace_scatter -> k_apply_rep (kernels_sparse_lambda.hpp): latency- and line-bound (a sub-list of ~11 live entries "
+            "is one partly used 128-byte line each way), not bandwidth-bound.  Round 5's form took 246 us per batch-step at 16 384 learners, this one 37", sparse_trace_bytes), 180)
         lam_generic = guarded(lambda: hbm_leg(
             rsrl_amd, "SARSALambda on a generic Fourier order (CartPole, order 3: F = 256), per-learner W and trace in memory, 65536 envs",
             dict(domain=rsrl_amd.CART_POLE, order=3, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99,

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                                                                const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int64_t key_stride,
                                                                int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
                                                                float inv_lsb, int lds) {
-    constexpr int CAP = kSparseCap / T, REGS = (CAP + 63) / 64, U = 4;
+    constexpr int CAP = kSparseCap / T, REGS = (CAP + 63) / 64, U = 4;      // sub-lists in flight per wave (8: 2-3x SLOWER, 74.8 / 310 us at 16 384 / 65 536 learners -- measured, round 6)
     extern __shared__ long long sparse_slice[];
     const int t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -80,29 +80,44 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
         __syncthreads();
     }
     const float fresh = trace_merge(lp.trace, lp.rate, 0.0f, 1.0f);
+    // the sub-lists' lengths run ONE batch ahead of their entries: from the second batch on a batch's loads touch only the live slots (a list is rarely full: the rest
+    // of its 256-byte row is dead weight, and the kernel runs at the box's copy bandwidth) without a dependent round trip in front of them.  65 536 CartPole learners:
+    // 122 -> 102 us per batch-step; at 16 384 (latency-bound: one block per CU) nothing to gain
+    int len_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + wave + (int64_t)u * n_waves;
+        len_next[u] = i < i1 ? (int)st.len[i * T + t] : 0;
+    }
     for (int64_t ib = i0 + wave; ib < i1; ib += (int64_t)U * n_waves) {
-        // U learners' sub-lists in flight together (every load is independent of the lengths: masked afterwards)
+        const bool first = ib == i0 + wave;
+        // U learners' sub-lists in flight together
         uint32_t key[U][REGS]; float val[U][REGS]; int len[U]; uint32_t nk[U]; float sc[U]; uint8_t fl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = ib + (int64_t)u * n_waves;
             const bool ok = i < i1;
             const int64_t ii = ok ? i : i0;
-            len[u] = ok ? (int)st.len[ii * T + t] : 0;
+            len[u] = __builtin_amdgcn_readfirstlane(len_next[u]);
             nk[u] = base + (uint32_t)kt[ii]; sc[u] = terms[ii]; fl[u] = flags[ii];
 #pragma unroll
             for (int e = 0; e < REGS; ++e) {
                 const int slot = e * 64 + lane;
-                const bool in = slot < CAP;
+                const bool in = slot < (first ? CAP : len[u]);                       // (len <= CAP; the first batch does not wait for its lengths)
                 key[u][e] = in ? st.keys[ii * kSparseCap + t * CAP + slot] : 0xffffffffu;
                 val[u][e] = in ? st.vals[ii * kSparseCap + t * CAP + slot] : 0.0f;
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            const int64_t i = ib + (int64_t)(U + u) * n_waves;
+            len_next[u] = i < i1 ? (int)st.len[i * T + t] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             const int64_t i = ib + (int64_t)u * n_waves;
             if (i >= i1) break;                                                    // (wave-uniform)
-            int ln = __builtin_amdgcn_readfirstlane(len[u]);
+            int ln = len[u];
             if (fl[u] & 4) ln = 0;                                                  // Watkins's cut
             bool found = false;
 #pragma unroll
