@@ -101,9 +101,8 @@ int enqueue_shared_step(rsrl_hip_ctx* c, const Common& k, const BasisGeom& g, De
                     ks.alg.kind = c->cfg.algo == RSRL_SARSA_LAMBDA ? ALG_SARSA : ALG_QLEARNING; ks.alg.lr = step_size;
                     hipLaunchKernelGGL((k_shared_ca<M>), grid, block, 0, c->stream, ks, g, t, do_c | (c->cfg.algo == RSRL_Q_LAMBDA ? 2 : 0), dwp, c->flags, d_stats, nrep,
                                        (int64_t)c->dw_elems, t_dev, c->sc_keys, c->sc_terms);
-                    static const int per_env = getenv("RSRL_SPARSE_CHUNK") ? atoi(getenv("RSRL_SPARSE_CHUNK")) : 512;
-                    const int per = per_env < 16 ? 16 : per_env;
-                    launch_sparse_trace_scatter(c, (int64_t)k.n_envs, per);
+                    static const int per_env = getenv("RSRL_SPARSE_CHUNK") ? atoi(getenv("RSRL_SPARSE_CHUNK")) : 0;      // (A/B; 0: launch_shared.hip's rule)
+                    launch_sparse_trace_scatter(c, (int64_t)k.n_envs, per_env > 0 && per_env < 16 ? 16 : per_env);
                     return;
                 }
                 if (c->sc_keys) {

@@ -315,7 +315,7 @@ int rsrl_hip_handle(rsrl_hip_ctx* c, const float* from_states, const int32_t* ac
                 if constexpr (Mo::kSparse) {
                     hipLaunchKernelGGL((k_sparse_handle<Mo>), dim3(grid_for(M)), dim3(kBlock), 0, c->stream, ks, g, d_from, d_act, d_rew, d_to, d_term, M, c->t,
                                        c->cfg.algo == RSRL_Q_LAMBDA ? 1 : 0, c->flags, c->sc_keys, c->sc_terms, otd.dev);
-                    launch_sparse_trace_scatter(c, M, 512);
+                    launch_sparse_trace_scatter(c, M, 0);
                 }
             })) return NO_MODEL(c);
         KCHECK();

@@ -21,8 +21,8 @@
 //   k_shared_ca   (models.hpp, one thread per learner; the one-step shared-table agents' step kernel)   phase C of the previous batch-step
 //                 (policy.sample from the updated table, restarts) + phase A of this one: transition, Q(s,.), Q(s',.), the TD target's residual;
 //                 hands over alpha * residual, the T new slice-relative keys, and flags (bit 0 terminal, bit 1 truncated, bit 2 Watkins's cut)
-//   k_sparse_trace_scatter   block (chunk of learners, tiling t), one WAVE per (learner, tiling) at a time: slot s of the sub-list lives in
-//                 lane s & 63, register s >> 6.  In this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
+//   k_sparse_trace_scatter   block (chunk of learners, tiling t), one 16-LANE GROUP per (learner, tiling) at a time (four learners per wave): slot s of the
+//                 sub-list lives in lane s & 15 of the group, register s >> 4.  In this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
 //                   0. Q(lambda) and a was not argmax_first of Q(s,.): the sub-list is emptied first (q_lambda.rs:62-66);
 //                   1. every entry: v <- rule(fma(rate, v, hit ? 1 : 0)), hit = its key is the step's new key of this tiling;
 //                   2. the new key, if it was not in the sub-list: appended (value rule(fma(rate, 0, 1))) -- or, when the sub-list is full, written
@@ -49,116 +49,158 @@ struct SparseTrace {
     uint32_t* len;     // [N][T]
 };
 
-// wave-wide (min |v|, slot) as one 64-bit key: |v| bits above the slot, so the smallest value wins and ties go to the lowest slot
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+// (min |v|, slot) over a 16-lane group as one 64-bit key: |v| bits above the slot, so the smallest value wins and ties go to the lowest slot
+__device__ __forceinline__ unsigned long long group16_min_u64(unsigned long long v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 8; o > 0; o >>= 1) {
         const unsigned long long w = __shfl_xor(v, o, 64);
         v = w < v ? w : v;
     }
     return v;
 }
+// the largest of a per-group value (equal over a group's 16 lanes) over the wave's four groups: wave-uniform
+__device__ __forceinline__ int wave_max_of_groups(int v) {
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+#ifndef RSRL_SP_U
+#define RSRL_SP_U 4
+#endif
 
 // S = entries of one tiling's slice (cells * A); lds != 0: the slice is privatised in dynamic LDS (S * 8 bytes), else the terms go straight to
 // copy 0 of the table with device atomics (a slice too large for LDS: the same integers, the same sum).
+//
+// Mapping (round 6, second form): a sub-list belongs to a GROUP of 16 lanes -- slot s in lane s & 15 of the group, register s >> 4 -- so a wave carries four
+// learners' sub-lists of one tiling at a time and skips, wave-uniformly, the registers beyond the longest of the four.  A CartPole learner's sub-list holds ~11 live
+// entries of 64: with one WAVE per sub-list (the first form) 53 of 64 lanes idled through every instruction and the kernel was issue-bound at a sixth of the lanes.
+// Nothing about the values moves: every entry's arithmetic is its own, the eviction key orders (|v|, slot) as before, the sum is exact in any order.
 template <int T>
 __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* __restrict__ new_keys, const float* __restrict__ terms,
                                                                const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int64_t key_stride,
                                                                int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
                                                                float inv_lsb, int lds) {
-    constexpr int CAP = kSparseCap / T, REGS = (CAP + 63) / 64, U = 4;      // sub-lists in flight per wave (8: 2-3x SLOWER, 74.8 / 310 us at 16 384 / 65 536 learners -- measured, round 6)
+    constexpr int CAP = kSparseCap / T, G = 16, REGS = CAP / G, LPW = 64 / G, U = REGS > 4 ? (RSRL_SP_U > 2 ? 2 : RSRL_SP_U) : RSRL_SP_U;   // U x LPW sub-lists in flight per wave
+    static_assert(CAP % G == 0, "a sub-list is a whole number of 16-slot registers");
     extern __shared__ long long sparse_slice[];
     const int t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int grp = lane >> 4, gl = lane & 15;
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = new_keys + (int64_t)t * key_stride;      // (N: the learners stepped, 0 .. N-1; key_stride: the ctx's learner count)
     const uint32_t base = (uint32_t)t * (uint32_t)S;                         // full key = base + slice-relative key
     long long* __restrict__ dst = dW64 + (int64_t)(lds ? blockIdx.x % (unsigned)n_rep : 0u) * rep_stride + (int64_t)t * S;
+    // everything below indexes the block's learners by a 32-bit number relative to i0 on wave-uniform base pointers (scalar base + 32-bit byte offset
+    // addressing: a 64-bit address per array and sub-list in flight cost 124 VGPRs -- the whole register file of a CU for one 1 024-thread block, which a
+    // co-tenant's waiting kernel could then keep from ever starting: tests/fuzz_ranks.py, G ranks on one device)
+    const uint32_t nb = (uint32_t)(i1 - i0);                                 // learners of this block (<= per_block <= 2^20: byte offsets below stay under 2^32)
+    const char* __restrict__ kbase = reinterpret_cast<const char*>(st.keys + i0 * kSparseCap + t * CAP);
+    char* __restrict__ kbase_w = reinterpret_cast<char*>(st.keys + i0 * kSparseCap + t * CAP);
+    char* __restrict__ vbase = reinterpret_cast<char*>(st.vals + i0 * kSparseCap + t * CAP);
+    char* __restrict__ lbase = reinterpret_cast<char*>(st.len + i0 * T + t);
+    const char* __restrict__ ktb = reinterpret_cast<const char*>(kt + i0);
+    const char* __restrict__ tmb = reinterpret_cast<const char*>(terms + i0);
+    const char* __restrict__ flb = reinterpret_cast<const char*>(flags + i0);
+    const uint32_t ustride = (uint32_t)n_waves * LPW;                         // learners one u of the block covers
+    // the sub-lists' lengths run ONE batch ahead of their entries (the first batch's are fetched under the clearing of the slice): a batch's loads touch only the
+    // live slots -- a list is rarely full, the rest of its row is dead weight -- without a dependent round trip in front of them
+    int len_next[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t r = (uint32_t)wave * LPW + grp + (uint32_t)u * ustride;
+        len_next[u] = r < nb ? (int)*reinterpret_cast<const uint32_t*>(lbase + r * (uint32_t)(T * 4)) : 0;
+    }
     if (lds) {
         for (int j = threadIdx.x; j < S; j += blockDim.x) sparse_slice[j] = 0;
         __syncthreads();
     }
     const float fresh = trace_merge(lp.trace, lp.rate, 0.0f, 1.0f);
-    // the sub-lists' lengths run ONE batch ahead of their entries: from the second batch on a batch's loads touch only the live slots (a list is rarely full: the rest
-    // of its 256-byte row is dead weight, and the kernel runs at the box's copy bandwidth) without a dependent round trip in front of them.  65 536 CartPole learners:
-    // 122 -> 102 us per batch-step; at 16 384 (latency-bound: one block per CU) nothing to gain
-    int len_next[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t i = i0 + wave + (int64_t)u * n_waves;
-        len_next[u] = i < i1 ? (int)st.len[i * T + t] : 0;
-    }
-    for (int64_t ib = i0 + wave; ib < i1; ib += (int64_t)U * n_waves) {
-        const bool first = ib == i0 + wave;
-        // U learners' sub-lists in flight together
+    for (uint32_t rb = (uint32_t)wave * LPW; rb < nb; rb += (uint32_t)U * ustride) {       // (wave-uniform: rb is the wave's first learner of the batch)
         uint32_t key[U][REGS]; float val[U][REGS]; int len[U]; uint32_t nk[U]; float sc[U]; uint8_t fl[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = ib + (int64_t)u * n_waves;
-            const bool ok = i < i1;
-            const int64_t ii = ok ? i : i0;
-            len[u] = __builtin_amdgcn_readfirstlane(len_next[u]);
-            nk[u] = base + (uint32_t)kt[ii]; sc[u] = terms[ii]; fl[u] = flags[ii];
+            const uint32_t r = rb + grp + (uint32_t)u * ustride;
+            const uint32_t rr = r < nb ? r : 0u;
+            len[u] = len_next[u];                                                    // (0 beyond the block's last learner)
+            nk[u] = base + (uint32_t)*reinterpret_cast<const uint16_t*>(ktb + rr * 2u);
+            sc[u] = *reinterpret_cast<const float*>(tmb + rr * 4u);
+            fl[u] = *reinterpret_cast<const uint8_t*>(flb + rr);
+            const int mx = wave_max_of_groups(len[u]);
+            const uint32_t ro = rr * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;  // byte offset of the group's lane in the learner's row
 #pragma unroll
             for (int e = 0; e < REGS; ++e) {
-                const int slot = e * 64 + lane;
-                const bool in = slot < (first ? CAP : len[u]);                       // (len <= CAP; the first batch does not wait for its lengths)
-                key[u][e] = in ? st.keys[ii * kSparseCap + t * CAP + slot] : 0xffffffffu;
-                val[u][e] = in ? st.vals[ii * kSparseCap + t * CAP + slot] : 0.0f;
+                key[u][e] = 0xffffffffu; val[u][e] = 0.0f;
+                if (e * G >= mx) continue;                                           // (wave-uniform)
+                if (e * G + gl < len[u]) {
+                    key[u][e] = *reinterpret_cast<const uint32_t*>(kbase + ro + (uint32_t)(e * G * 4));
+                    val[u][e] = *reinterpret_cast<const float*>(vbase + ro + (uint32_t)(e * G * 4));
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = ib + (int64_t)(U + u) * n_waves;
-            len_next[u] = i < i1 ? (int)st.len[i * T + t] : 0;
+            const uint32_t r = rb + grp + (uint32_t)(U + u) * ustride;
+            len_next[u] = r < nb ? (int)*reinterpret_cast<const uint32_t*>(lbase + r * (uint32_t)(T * 4)) : 0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t i = ib + (int64_t)u * n_waves;
-            if (i >= i1) break;                                                    // (wave-uniform)
-            int ln = len[u];
+            if (rb + (uint32_t)u * ustride >= nb) break;                            // (wave-uniform: not even the wave's first group has a learner)
+            const uint32_t r = rb + grp + (uint32_t)u * ustride;
+            const bool ok = r < nb;
+            const uint32_t ro = r * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;   // (used where ok)
+            int ln = len[u];                                                        // (0 where !ok)
             if (fl[u] & 4) ln = 0;                                                  // Watkins's cut
-            bool found = false;
+            int mx = wave_max_of_groups(ln);
+            unsigned long long hits = 0ull;
 #pragma unroll
             for (int e = 0; e < REGS; ++e) {
-                const bool live = e * 64 + lane < ln;
+                if (e * G >= mx) continue;                                           // (wave-uniform)
+                const bool live = e * G + gl < ln;
                 const bool hit = live && key[u][e] == nk[u];
-                found = found || (__ballot(hit) != 0ull);
+                hits |= __ballot(hit);
                 val[u][e] = trace_merge(lp.trace, lp.rate, live ? val[u][e] : 0.0f, hit ? 1.0f : 0.0f);
             }
-            if (!found) {
-                int slot;
-                if (ln < CAP) { slot = ln; ln += 1; }
-                else {
-                    unsigned long long best = ~0ull;
+            const bool need = ok && ((uint32_t)(hits >> (grp * G)) & 0xffffu) == 0u;  // the group's learner brings a key its sub-list does not hold
+            const bool full = ln >= CAP;
+            int slot = ln;
+            if (__ballot(need && full) != 0ull) {                                   // some group evicts: then its every register is live (mx == CAP)
+                unsigned long long best = ~0ull;
 #pragma unroll
-                    for (int e = 0; e < REGS; ++e) {
-                        if (e * 64 + lane >= CAP) continue;
-                        const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * 64 + lane);
-                        best = cand < best ? cand : best;
-                    }
-                    slot = (int)(uint32_t)wave_min_u64(best);
+                for (int e = 0; e < REGS; ++e) {
+                    const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * G + gl);
+                    best = cand < best ? cand : best;
                 }
-#pragma unroll
-                for (int e = 0; e < REGS; ++e)
-                    if (slot == e * 64 + lane) { key[u][e] = nk[u]; val[u][e] = fresh; }
+                const int ev = (int)(uint32_t)group16_min_u64(best);
+                if (full) slot = ev;
             }
+            if (need && !full) ln += 1;
+#pragma unroll
+            for (int e = 0; e < REGS; ++e)
+                if (need && slot == e * G + gl) { key[u][e] = nk[u]; val[u][e] = fresh; }
+            mx = wave_max_of_groups(ln);
 #pragma unroll
             for (int e = 0; e < REGS; ++e) {
-                if (e * 64 + lane >= ln) continue;
+                if (e * G >= mx) continue;                                           // (wave-uniform)
+                if (e * G + gl >= ln) continue;
                 const unsigned long long q = fx_quantise(sc[u] * val[u][e], inv_lsb);
                 if (q == 0) continue;
                 if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e] - base]), q);
                 else fx_add(&dst[key[u][e] - base], q);
             }
             if (fl[u] & 1) ln = 0;                                                  // trace.reset()
+            mx = wave_max_of_groups(ln);
 #pragma unroll
             for (int e = 0; e < REGS; ++e) {
-                const int slot = e * 64 + lane;
-                if (slot < ln) { st.keys[i * kSparseCap + t * CAP + slot] = key[u][e]; st.vals[i * kSparseCap + t * CAP + slot] = val[u][e]; }
+                if (e * G >= mx) continue;                                           // (wave-uniform)
+                const int sl = e * G + gl;
+                if (sl < ln) {
+                    *reinterpret_cast<float*>(vbase + ro + (uint32_t)(e * G * 4)) = val[u][e];
+                    if (need && sl == slot) *reinterpret_cast<uint32_t*>(kbase_w + ro + (uint32_t)(e * G * 4)) = key[u][e];      // (the one key of the sub-list this step can change)
+                }
             }
-            if (lane == 0) st.len[i * T + t] = (uint32_t)ln;
+            if (gl == 0 && ok) *reinterpret_cast<uint32_t*>(lbase + r * (uint32_t)(T * 4)) = (uint32_t)ln;
         }
     }
     if (!lds) return;

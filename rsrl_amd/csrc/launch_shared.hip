@@ -28,7 +28,16 @@ static void sparse_scatter_launch(const rsrl_hip_ctx* c, int64_t n_learners, int
                        c->sc_keys, c->sc_terms, c->flags, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, make_lambda(c), n_learners, (int64_t)c->cfg.n_envs, slice, per,
                        c->dW_rep, c->n_rep, (int64_t)c->dw_elems, FxScale(step_size).inv_lsb, c->sp_lds ? 1 : 0);
 }
+// per_block <= 0: ONE block per compute unit over the (chunk, tiling) grid -- every block clears and sweeps its 8 S-byte slice and issues one device atomic per touched
+// entry, so fewer, larger blocks win until compute units idle (65 536 CartPole learners, 8 tilings: 72.7 / 66.1 / 62.6 / 104.6 us at 512 / 1 024 / 2 048 / 4 096
+// learners per block; 262 144: 269 / 244 / 229 at 512 / 2 048 / 8 192; 8 192: 26.1 / 21.3 / 26.8 at 128 / 256 / 512 -- scripts/gpu_sparse_scatter_ab.sh)
 void launch_sparse_trace_scatter(const rsrl_hip_ctx* c, int64_t n_learners, int per_block) {
+    if (per_block <= 0) {
+        const int64_t cus = c->n_cu > 0 ? c->n_cu : 256;
+        int64_t per = (n_learners * c->cfg.n_tilings + cus - 1) / cus;
+        per = ((per + 63) / 64) * 64;                                        // (a block's sixteen waves carry 64 learners at a time)
+        per_block = (int)(per < 64 ? 64 : per > (1 << 20) ? (1 << 20) : per);
+    }
     if (c->cfg.n_tilings == 4) sparse_scatter_launch<4>(c, n_learners, per_block);
     else if (c->cfg.n_tilings == 8) sparse_scatter_launch<8>(c, n_learners, per_block);
     else sparse_scatter_launch<16>(c, n_learners, per_block);

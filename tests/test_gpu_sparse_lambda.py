@@ -23,6 +23,9 @@ CASES = [
     ("acrobot_q_accumulate_softmax", 96, 120, dict(domain=2, n_tilings=4, tiles_per_dim=6, algo=4, policy=2, tau=0.5, gamma=0.95, lam=0.7, trace=0, max_episode_steps=50)),
     # a tiling's slice of 20 000 entries (160 KB as 64-bit accumulators: beyond the LDS): the scatter kernel adds its terms with device atomics instead
     ("cartpole_q_slice_beyond_lds", 128, 80, dict(domain=1, n_tilings=4, tiles_per_dim=10, algo=4, policy=1, epsilon=0.2, gamma=0.99, lam=0.8, trace=0, max_episode_steps=40)),
+    # learner counts that leave a wave's last 16-lane groups without a learner (four learners per wave), 16 tilings (two registers per sub-list)
+    ("cartpole_sarsa_ragged_301", 301, 150, dict(domain=1, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.1, gamma=0.99, lam=0.9, trace=0, max_episode_steps=60)),
+    ("mountaincar_sarsa_16_tilings_77_evicting", 77, 500, dict(domain=0, n_tilings=16, tiles_per_dim=8, algo=3, policy=1, epsilon=0.3, gamma=0.99, lam=0.95, trace=1, max_episode_steps=0)),
     ("cartpole_sarsa_4096", 4096, 60, dict(domain=1, n_tilings=8, tiles_per_dim=8, algo=3, policy=1, epsilon=0.1, gamma=0.99, lam=0.9, trace=0, max_episode_steps=40)),
 ]
 
