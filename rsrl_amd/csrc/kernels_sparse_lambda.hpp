@@ -65,6 +65,15 @@ __device__ __forceinline__ int wave_max_of_groups(int v) {
     return ab > cd ? ab : cd;
 }
 
+// fn(integral_constant<NR>) with NR the smallest of {1, 2, 4, ..., REGS} whose NR x 16 slots hold `slots` entries (slots is wave-uniform)
+template <int REGS, class F>
+__device__ __forceinline__ void sparse_dispatch_regs(int slots, F&& fn) {
+    if constexpr (REGS >= 2) { if (slots <= 16) { fn(std::integral_constant<int, 1>{}); return; } }
+    if constexpr (REGS >= 4) { if (slots <= 32) { fn(std::integral_constant<int, 2>{}); return; } }
+    if constexpr (REGS >= 8) { if (slots <= 64) { fn(std::integral_constant<int, 4>{}); return; } }
+    fn(std::integral_constant<int, REGS>{});
+}
+
 #ifndef RSRL_SP_U
 #define RSRL_SP_U 4
 #endif
@@ -127,17 +136,20 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
             nk[u] = base + (uint32_t)*reinterpret_cast<const uint16_t*>(ktb + rr * 2u);
             sc[u] = *reinterpret_cast<const float*>(tmb + rr * 4u);
             fl[u] = *reinterpret_cast<const uint8_t*>(flb + rr);
-            const int mx = wave_max_of_groups(len[u]);
             const uint32_t ro = rr * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;  // byte offset of the group's lane in the learner's row
 #pragma unroll
-            for (int e = 0; e < REGS; ++e) {
-                key[u][e] = 0xffffffffu; val[u][e] = 0.0f;
-                if (e * G >= mx) continue;                                           // (wave-uniform)
-                if (e * G + gl < len[u]) {
-                    key[u][e] = *reinterpret_cast<const uint32_t*>(kbase + ro + (uint32_t)(e * G * 4));
-                    val[u][e] = *reinterpret_cast<const float*>(vbase + ro + (uint32_t)(e * G * 4));
-                }
-            }
+            for (int e = 0; e < REGS; ++e) { key[u][e] = 0xffffffffu; val[u][e] = 0.0f; }
+            // NR: the registers the longest of the wave's four sub-lists reaches, as a compile-time constant of a straight-line body (a wave-uniform branch per
+            // register and loop instead cost ~50 taken branches per batch with short lists)
+            sparse_dispatch_regs<REGS>(wave_max_of_groups(len[u]), [&](auto nr) {
+                constexpr int NR = decltype(nr)::value;
+#pragma unroll
+                for (int e = 0; e < NR; ++e)
+                    if (e * G + gl < len[u]) {
+                        key[u][e] = *reinterpret_cast<const uint32_t*>(kbase + ro + (uint32_t)(e * G * 4));
+                        val[u][e] = *reinterpret_cast<const float*>(vbase + ro + (uint32_t)(e * G * 4));
+                    }
+            });
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -150,57 +162,57 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
             const uint32_t r = rb + grp + (uint32_t)u * ustride;
             const bool ok = r < nb;
             const uint32_t ro = r * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;   // (used where ok)
-            int ln = len[u];                                                        // (0 where !ok)
-            if (fl[u] & 4) ln = 0;                                                  // Watkins's cut
-            int mx = wave_max_of_groups(ln);
-            unsigned long long hits = 0ull;
+            // (the loaded lengths + 1: an append can open the next register; a cut or a reset only shortens)
+            sparse_dispatch_regs<REGS>(wave_max_of_groups(len[u]) + 1, [&](auto nr) {
+                constexpr int NR = decltype(nr)::value;
+                int ln = len[u];                                                    // (0 where !ok)
+                if (fl[u] & 4) ln = 0;                                              // Watkins's cut
+                unsigned long long hits = 0ull;
 #pragma unroll
-            for (int e = 0; e < REGS; ++e) {
-                if (e * G >= mx) continue;                                           // (wave-uniform)
-                const bool live = e * G + gl < ln;
-                const bool hit = live && key[u][e] == nk[u];
-                hits |= __ballot(hit);
-                val[u][e] = trace_merge(lp.trace, lp.rate, live ? val[u][e] : 0.0f, hit ? 1.0f : 0.0f);
-            }
-            const bool need = ok && ((uint32_t)(hits >> (grp * G)) & 0xffffu) == 0u;  // the group's learner brings a key its sub-list does not hold
-            const bool full = ln >= CAP;
-            int slot = ln;
-            if (__ballot(need && full) != 0ull) {                                   // some group evicts: then its every register is live (mx == CAP)
-                unsigned long long best = ~0ull;
-#pragma unroll
-                for (int e = 0; e < REGS; ++e) {
-                    const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * G + gl);
-                    best = cand < best ? cand : best;
+                for (int e = 0; e < NR; ++e) {
+                    const bool live = e * G + gl < ln;
+                    const bool hit = live && key[u][e] == nk[u];
+                    hits |= __ballot(hit);
+                    val[u][e] = trace_merge(lp.trace, lp.rate, live ? val[u][e] : 0.0f, hit ? 1.0f : 0.0f);
                 }
-                const int ev = (int)(uint32_t)group16_min_u64(best);
-                if (full) slot = ev;
-            }
-            if (need && !full) ln += 1;
+                const bool need = ok && ((uint32_t)(hits >> (grp * G)) & 0xffffu) == 0u;  // the group's learner brings a key its sub-list does not hold
+                const bool full = ln >= CAP;
+                int slot = ln;
+                if constexpr (NR == REGS) {
+                    if (__ballot(need && full) != 0ull) {                           // some group evicts (its every register is live: NR == REGS)
+                        unsigned long long best = ~0ull;
 #pragma unroll
-            for (int e = 0; e < REGS; ++e)
-                if (need && slot == e * G + gl) { key[u][e] = nk[u]; val[u][e] = fresh; }
-            mx = wave_max_of_groups(ln);
-#pragma unroll
-            for (int e = 0; e < REGS; ++e) {
-                if (e * G >= mx) continue;                                           // (wave-uniform)
-                if (e * G + gl >= ln) continue;
-                const unsigned long long q = fx_quantise(sc[u] * val[u][e], inv_lsb);
-                if (q == 0) continue;
-                if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e] - base]), q);
-                else fx_add(&dst[key[u][e] - base], q);
-            }
-            if (fl[u] & 1) ln = 0;                                                  // trace.reset()
-            mx = wave_max_of_groups(ln);
-#pragma unroll
-            for (int e = 0; e < REGS; ++e) {
-                if (e * G >= mx) continue;                                           // (wave-uniform)
-                const int sl = e * G + gl;
-                if (sl < ln) {
-                    *reinterpret_cast<float*>(vbase + ro + (uint32_t)(e * G * 4)) = val[u][e];
-                    if (need && sl == slot) *reinterpret_cast<uint32_t*>(kbase_w + ro + (uint32_t)(e * G * 4)) = key[u][e];      // (the one key of the sub-list this step can change)
+                        for (int e = 0; e < REGS; ++e) {
+                            const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * G + gl);
+                            best = cand < best ? cand : best;
+                        }
+                        const int ev = (int)(uint32_t)group16_min_u64(best);
+                        if (full) slot = ev;
+                    }
                 }
-            }
-            if (gl == 0 && ok) *reinterpret_cast<uint32_t*>(lbase + r * (uint32_t)(T * 4)) = (uint32_t)ln;
+                if (need && !full) ln += 1;
+#pragma unroll
+                for (int e = 0; e < NR; ++e)
+                    if (need && slot == e * G + gl) { key[u][e] = nk[u]; val[u][e] = fresh; }
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    if (e * G + gl >= ln) continue;
+                    const unsigned long long q = fx_quantise(sc[u] * val[u][e], inv_lsb);
+                    if (q == 0) continue;
+                    if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e] - base]), q);
+                    else fx_add(&dst[key[u][e] - base], q);
+                }
+                if (fl[u] & 1) ln = 0;                                              // trace.reset()
+#pragma unroll
+                for (int e = 0; e < NR; ++e) {
+                    const int sl = e * G + gl;
+                    if (sl < ln) {
+                        *reinterpret_cast<float*>(vbase + ro + (uint32_t)(e * G * 4)) = val[u][e];
+                        if (need && sl == slot) *reinterpret_cast<uint32_t*>(kbase_w + ro + (uint32_t)(e * G * 4)) = key[u][e];      // (the one key of the sub-list this step can change)
+                    }
+                }
+                if (gl == 0 && ok) *reinterpret_cast<uint32_t*>(lbase + r * (uint32_t)(T * 4)) = (uint32_t)ln;
+            });
         }
     }
     if (!lds) return;
