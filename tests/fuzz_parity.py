@@ -109,6 +109,8 @@ def sample(rng):
 
 def run_case(rng, idx):
     family, dev, okw, method, mkw = sample(rng)
+    while os.environ.get("FUZZ_FAMILY") and family != os.environ["FUZZ_FAMILY"]:      # one family only (e.g. after a change to its kernels)
+        family, dev, okw, method, mkw = sample(rng)
     n = dev["n_envs"]
     total = int(rng.choice([40, 90, 150])) if family != "wave" else int(rng.choice([8, 20, 60]))
     if os.environ.get("FUZZ_LONG"):      # long horizons: across the default fuse depth (4 096), many graph replays, thousands of episodes
