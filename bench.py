@@ -554,14 +554,14 @@ def hbm_leg(rsrl_amd, name, kw, steps, warmup, bytes_per_env_step, what, bytes_f
 
 
 def sparse_trace_bytes(ctx):
-    """HBM bytes per learner-step of the sparse-trace lambda agents on what the lists really hold: every LIVE entry's key and value read, its value written back
-    (12 B: a key is written only where the step appended / evicted, one per tiling), + the 2 x T gathers, the T new keys, the T lengths both ways.  The per-entry
+    """HBM bytes per learner-step of the sparse-trace lambda agents on what the lists really hold: every LIVE entry's 16-bit key and value read, its value written
+    back (10 B: a key is written only where the step appended / evicted, one per tiling), + the 2 x T gathers, the T new keys, the T lengths both ways.  The per-entry
     8-byte term goes into LDS, not HBM.  (Earlier figures of this leg: 12 416 B = FULL 512-entry lists x 24 B, the one round 5's 0.10 was quoted on; then
-    24 B x live entries.  Both counted the LDS term and the key write-back this kernel no longer does.)"""
+    24 B x live entries.  Both counted the LDS term and a 32-bit key read AND written back.)"""
     import numpy as np
     n = ctx.N
     live = float(np.mean([int((ctx.get_traces(i) != 0).sum()) for i in range(0, n, max(1, n // 48))]))
-    return 12 * live + 16 * 2 * 4 + 8 * (4 + 2 + 8), {"mean_live_entries": live, "bytes_by_the_previous_accounting": 3 * live * 8 + 16 * 2 * 4}
+    return 10 * live + 16 * 2 * 4 + 8 * (4 + 2 + 8), {"mean_live_entries": live, "bytes_by_the_previous_accounting": 3 * live * 8 + 16 * 2 * 4}
 
 
 def _num(x, digits=5):
@@ -870,11 +870,11 @@ def main():
             dict(domain=rsrl_amd.CART_POLE, basis=rsrl_amd.TILE_CODING, n_tilings=8, tiles_per_dim=8, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536,
                  policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99, alpha=0.0125 / 65536, lam=0.9, weight_mode=rsrl_amd.W_SHARED, max_episode_steps=200,
                  env_offset=rank * 65536, device=device), 256, 64, 2 * 512 * 8 + 16 * 2 * 4 + 512 * 8,
-            "per learner-step: every LIVE trace entry's key + value read and its value written back (12 B) + 2 x 8 gathers + the new keys and lengths (mean_live_entries "
+            "per learner-step: every LIVE trace entry's 16-bit key + value read and its value written back (10 B) + 2 x 8 gathers + the new keys and lengths (mean_live_entries "
             "of 512 per learner, measured after the run); k_shared_ca -> k_sparse_trace_scatter -> k_apply_rep (kernels_sparse_lambda.hpp): a 16-lane group per "
             "(learner, tiling), four learners per wave, one block per CU; with short lists latency- and line-bound (a sub-list of ~11-20 live entries "
-            "is one partly used 128-byte line each way); with full lists (a learned policy: episodes end at the step cap, nothing resets) 0.75 of the measured copy "
-            "bandwidth.  Round 5's form took 246 us per batch-step at 16 384 learners, this one 27", sparse_trace_bytes), 180)
+            "is one partly used 128-byte line each way); with full lists (a learned policy: episodes end at the step cap, nothing resets) the scatter kernel runs at the "
+            "measured copy bandwidth (75 us per batch-step).  Round 5's form took 246 us per batch-step at 16 384 learners, this one 27", sparse_trace_bytes), 180)
         lam_generic = guarded(lambda: hbm_leg(
             rsrl_amd, "SARSALambda on a generic Fourier order (CartPole, order 3: F = 256), per-learner W and trace in memory, 65536 envs",
             dict(domain=rsrl_amd.CART_POLE, order=3, algo=rsrl_amd.SARSA_LAMBDA, n_envs=65536, policy=rsrl_amd.EPSILON_GREEDY, epsilon=0.1, gamma=0.99,

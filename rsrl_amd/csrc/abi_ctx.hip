@@ -246,12 +246,12 @@ static int create_impl(const rsrl_hip_config* cfg, rsrl_hip_ctx* c) {
         const int64_t slice = (int64_t)(c->F / cfg->n_tilings) * c->A;
         if (slice > 65536) return fail(RSRL_HIP_EINVAL, "SARSALambda / QLambda over a shared tile table: one tiling's slice (cells * actions = %lld entries) must not "
                                                         "exceed 65 536 (16-bit slice-relative keys between the step and the trace kernel)", (long long)slice);
-        HIP_TRY(hipMalloc((void**)&c->sp_keys, sizeof(uint32_t) * (size_t)kSparseCap * (size_t)N));
+        HIP_TRY(hipMalloc((void**)&c->sp_keys, sizeof(uint16_t) * (size_t)kSparseCap * (size_t)N));
         HIP_TRY(hipMalloc((void**)&c->sp_vals, sizeof(float) * (size_t)kSparseCap * (size_t)N));
         HIP_TRY(hipMalloc((void**)&c->sp_len, sizeof(uint32_t) * (size_t)cfg->n_tilings * (size_t)N));
         HIP_TRY(hipMemsetAsync(c->sp_len, 0, sizeof(uint32_t) * (size_t)cfg->n_tilings * (size_t)N, c->stream));        // Trace::zeros: empty lists
         // (the lists are written only below their lengths; what lies beyond is never read as an entry, but a checkpoint copies whole rows)
-        HIP_TRY(hipMemsetAsync(c->sp_keys, 0, sizeof(uint32_t) * (size_t)kSparseCap * (size_t)N, c->stream));
+        HIP_TRY(hipMemsetAsync(c->sp_keys, 0, sizeof(uint16_t) * (size_t)kSparseCap * (size_t)N, c->stream));
         HIP_TRY(hipMemsetAsync(c->sp_vals, 0, sizeof(float) * (size_t)kSparseCap * (size_t)N, c->stream));
         c->sp_lds = slice * 8 <= 128 * 1024;
         if (c->sp_lds && slice * 8 > 64 * 1024) c->sp_lds = sparse_trace_scatter_allow_lds(cfg->n_tilings, (int)(slice * 8));      // more dynamic LDS than a kernel gets by default

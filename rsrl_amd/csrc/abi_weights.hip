@@ -54,7 +54,7 @@ int traces_rw(rsrl_hip_ctx* c, int64_t env_index, float* out, const float* in) {
         OutBuf<float> oz;
         TRY(stage_out(c, 0, out, (size_t)n, &oz));
         HIP_TRY(hipMemsetAsync(oz.dev, 0, sizeof(float) * (size_t)n, c->stream));
-        hipLaunchKernelGGL(k_sparse_trace_get, dim3(kSparseCap / 256), dim3(256), 0, c->stream, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, c->cfg.n_tilings, env_index, oz.dev);
+        hipLaunchKernelGGL(k_sparse_trace_get, dim3(kSparseCap / 256), dim3(256), 0, c->stream, SparseTrace{c->sp_keys, c->sp_vals, c->sp_len}, c->cfg.n_tilings, n / c->cfg.n_tilings, env_index, oz.dev);
         KCHECK();
         bool sync = false; TRY(flush_out(c, &oz, &sync));
         if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -187,7 +187,9 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
         // sparse traces: u64 n_envs, u64 env_offset (whose learners these are), u32 len[N], then per learner its len keys and its len values -- the
         // sub-lists concatenated in tiling order (a key says which tiling it belongs to: the file does not depend on the cap per tiling)
         const int64_t N = c->cfg.n_envs; const int T = c->cfg.n_tilings, cap = kSparseCap / T;
-        std::vector<uint32_t> lens((size_t)N * T), tot((size_t)N), keys((size_t)(kSparseChunk * kSparseCap));
+        const uint32_t slice = (uint32_t)c->F * (uint32_t)c->Aw / (uint32_t)T;                 // entries of one tiling's slice: the device's keys are relative to it
+        std::vector<uint32_t> lens((size_t)N * T), tot((size_t)N);
+        std::vector<uint16_t> keys((size_t)(kSparseChunk * kSparseCap));
         std::vector<float> vals((size_t)(kSparseChunk * kSparseCap));
         hipError_t e = hipMemcpyAsync(lens.data(), c->sp_len, 4 * (size_t)N * T, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -205,7 +207,7 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
         std::vector<uint32_t> kk((size_t)kSparseCap); std::vector<float> vv((size_t)kSparseCap);
         for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
             const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
-            e = hipMemcpyAsync(keys.data(), c->sp_keys + i0 * kSparseCap, 4 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(keys.data(), c->sp_keys + i0 * kSparseCap, 2 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(vals.data(), c->sp_vals + i0 * kSparseCap, 4 * (size_t)(n * kSparseCap), hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc = fail(RSRL_HIP_EHIP, "reading the sparse traces: %s", hipGetErrorString(e)); break; }
@@ -213,7 +215,8 @@ int rsrl_hip_save_weights(rsrl_hip_ctx* c, const char* path) {
                 size_t l = 0;
                 for (int t = 0; t < T; ++t)
                     for (uint32_t j = 0; j < lens[(size_t)(i0 + i) * T + t]; ++j, ++l) {
-                        kk[l] = keys[(size_t)(i * kSparseCap + t * cap) + j]; vv[l] = vals[(size_t)(i * kSparseCap + t * cap) + j];
+                        kk[l] = (uint32_t)t * slice + (uint32_t)keys[(size_t)(i * kSparseCap + t * cap) + j];      // (the file holds FULL keys: tile index * A + action)
+                        vv[l] = vals[(size_t)(i * kSparseCap + t * cap) + j];
                     }
                 if (fwrite(kk.data(), 4, l, f) != l || fwrite(vv.data(), 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "short write to %s", path);
             }
@@ -302,13 +305,14 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
             if (fread(w.data(), sizeof(float), per, f) != per) { rc = fail(RSRL_HIP_EINVAL, "%s: read error", path); break; }
             rc = pass == 0 ? rsrl_hip_set_weights(c, i, w.data()) : traces_rw(c, i, nullptr, w.data());
         }
-    uint32_t* spk_new = nullptr; float* spv_new = nullptr;              // sparse traces: shadow lists, switched in at the end like W
+    uint16_t* spk_new = nullptr; float* spv_new = nullptr;              // sparse traces: shadow lists, switched in at the end like W
     if (rc == RSRL_HIP_OK && h.aux_kind == 4) {
         const int64_t N = c->cfg.n_envs;
-        hipError_t e2 = hipMalloc((void**)&spk_new, 4 * (size_t)kSparseCap * (size_t)N);
+        hipError_t e2 = hipMalloc((void**)&spk_new, 2 * (size_t)kSparseCap * (size_t)N);
         if (e2 == hipSuccess) e2 = hipMalloc((void**)&spv_new, 4 * (size_t)kSparseCap * (size_t)N);
         if (e2 != hipSuccess) rc = fail(e2 == hipErrorOutOfMemory ? RSRL_HIP_ENOMEM : RSRL_HIP_EHIP, "staging buffers for the sparse traces: %s", hipGetErrorString(e2));
-        std::vector<uint32_t> keys((size_t)(kSparseChunk * kSparseCap)), kk((size_t)kSparseCap);
+        std::vector<uint16_t> keys((size_t)(kSparseChunk * kSparseCap));
+        std::vector<uint32_t> kk((size_t)kSparseCap);
         std::vector<float> vals((size_t)(kSparseChunk * kSparseCap)), vv((size_t)kSparseCap);
         if (rc == RSRL_HIP_OK && fseek(f, sp_prefix + 4 * (long)N, SEEK_CUR) != 0) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);      // (owner and lengths: read above)
         const int T = c->cfg.n_tilings, cap = kSparseCap / T;
@@ -316,7 +320,7 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
         sp_len_t.assign((size_t)N * T, 0u);
         for (int64_t i0 = 0; rc == RSRL_HIP_OK && i0 < N; i0 += kSparseChunk) {
             const int64_t n = std::min<int64_t>(kSparseChunk, N - i0);
-            std::fill(keys.begin(), keys.end(), 0u); std::fill(vals.begin(), vals.end(), 0.0f);
+            std::fill(keys.begin(), keys.end(), (uint16_t)0); std::fill(vals.begin(), vals.end(), 0.0f);
             for (int64_t i = 0; rc == RSRL_HIP_OK && i < n; ++i) {
                 const size_t l = sp_len_in[(size_t)(i0 + i)];
                 if (fread(kk.data(), 4, l, f) != l || fread(vv.data(), 4, l, f) != l) rc = fail(RSRL_HIP_EINVAL, "%s: read error", path);
@@ -325,12 +329,13 @@ int rsrl_hip_load_weights(rsrl_hip_ctx* c, const char* path) {
                     const uint32_t t = kk[k] / slice; uint32_t& lt = sp_len_t[(size_t)(i0 + i) * T + t];
                     if (lt >= (uint32_t)cap) { rc = fail(RSRL_HIP_EINVAL, "%s: learner %lld's sparse trace holds more than %d entries of tiling %u (this library keeps "
                                                                             "%d entries per learner as %d per tiling)", path, (long long)(i0 + i), cap, t, kSparseCap, cap); break; }
-                    keys[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = kk[k]; vals[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = vv[k];
+                    keys[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = (uint16_t)(kk[k] - t * slice);      // (relative to the tiling's slice: < slice <= 65 536)
+                    vals[(size_t)(i * kSparseCap + (int64_t)t * cap) + lt] = vv[k];
                     lt += 1;
                 }
             }
             if (rc != RSRL_HIP_OK) break;
-            e2 = hipMemcpyAsync(spk_new + i0 * kSparseCap, keys.data(), 4 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
+            e2 = hipMemcpyAsync(spk_new + i0 * kSparseCap, keys.data(), 2 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(spv_new + i0 * kSparseCap, vals.data(), 4 * (size_t)(n * kSparseCap), hipMemcpyHostToDevice, c->stream);
             if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);                 // (the staging vectors are reused by the next chunk)
             if (e2 != hipSuccess) rc = fail(RSRL_HIP_EHIP, "installing the sparse traces: %s", hipGetErrorString(e2));

@@ -118,7 +118,7 @@ struct rsrl_hip_ctx {
     float* qs_buf = nullptr; uint32_t* qs_head = nullptr; uint32_t* qs_len = nullptr;     // QSigma: per-learner n-step backups
     float* eps = nullptr;            // [N] per-learner EpsilonGreedy.epsilon (config.epsilon_decay != 1), else null
     // lambda agents over ONE shared tile table: every learner's sparse trace + the step's mailbox (kernels_sparse_lambda.hpp)
-    uint32_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr;    // sparse traces: [N][kSparseCap] x 2, lengths [N][n_tilings]
+    uint16_t* sp_keys = nullptr; float* sp_vals = nullptr; uint32_t* sp_len = nullptr;    // sparse traces: [N][kSparseCap] slice-relative keys (16 bit) and values, lengths [N][n_tilings]
     bool sp_lds = false;             //   one tiling's slice of the delta table fits LDS (k_sparse_trace_scatter)
     float* Z = nullptr;              // auxiliary matrix f32[A][F][N]: eligibility traces (lambda agents) / fa_td weights (GreedyGQ)
     bool q_valid = false;            // false whenever weights / states were changed from outside the driver loop

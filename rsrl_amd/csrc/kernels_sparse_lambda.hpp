@@ -44,7 +44,8 @@ namespace rsrl {
 constexpr int kSparseCap = 512;
 
 struct SparseTrace {
-    uint32_t* keys;    // [N][kSparseCap]: sub-list t in slots [t * cap_t, (t + 1) * cap_t); key = tile index * A + action
+    uint16_t* keys;    // [N][kSparseCap]: sub-list t in slots [t * cap_t, (t + 1) * cap_t); a key is RELATIVE to its tiling's slice: (tile index - t * cells) * A + action
+                       // (a slice holds at most 65 536 entries -- the step kernel's hand-over is 16 bit too --: 10 B of HBM traffic per live entry and step instead of 12)
     float* vals;       // [N][kSparseCap]
     uint32_t* len;     // [N][T]
 };
@@ -99,7 +100,6 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = new_keys + (int64_t)t * key_stride;      // (N: the learners stepped, 0 .. N-1; key_stride: the ctx's learner count)
-    const uint32_t base = (uint32_t)t * (uint32_t)S;                         // full key = base + slice-relative key
     long long* __restrict__ dst = dW64 + (int64_t)(lds ? blockIdx.x % (unsigned)n_rep : 0u) * rep_stride + (int64_t)t * S;
     // everything below indexes the block's learners by a 32-bit number relative to i0 on wave-uniform base pointers (scalar base + 32-bit byte offset
     // addressing: a 64-bit address per array and sub-list in flight cost 124 VGPRs -- the whole register file of a CU for one 1 024-thread block, which a
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
             const uint32_t r = rb + grp + (uint32_t)u * ustride;
             const uint32_t rr = r < nb ? r : 0u;
             len[u] = len_next[u];                                                    // (0 beyond the block's last learner)
-            nk[u] = base + (uint32_t)*reinterpret_cast<const uint16_t*>(ktb + rr * 2u);
+            nk[u] = (uint32_t)*reinterpret_cast<const uint16_t*>(ktb + rr * 2u);             // (slice-relative, as the lists' keys)
             sc[u] = *reinterpret_cast<const float*>(tmb + rr * 4u);
             fl[u] = *reinterpret_cast<const uint8_t*>(flb + rr);
-            const uint32_t ro = rr * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;  // byte offset of the group's lane in the learner's row
+            const uint32_t ro = rr * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;  // byte offset of the group's lane in the learner's row of values (keys: half)
 #pragma unroll
             for (int e = 0; e < REGS; ++e) { key[u][e] = 0xffffffffu; val[u][e] = 0.0f; }
             // NR: the registers the longest of the wave's four sub-lists reaches, as a compile-time constant of a straight-line body (a wave-uniform branch per
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
 #pragma unroll
                 for (int e = 0; e < NR; ++e)
                     if (e * G + gl < len[u]) {
-                        key[u][e] = *reinterpret_cast<const uint32_t*>(kbase + ro + (uint32_t)(e * G * 4));
+                        key[u][e] = (uint32_t)*reinterpret_cast<const uint16_t*>(kbase + (ro >> 1) + (uint32_t)(e * G * 2));
                         val[u][e] = *reinterpret_cast<const float*>(vbase + ro + (uint32_t)(e * G * 4));
                     }
             });
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                     if (e * G + gl >= ln) continue;
                     const unsigned long long q = fx_quantise(sc[u] * val[u][e], inv_lsb);
                     if (q == 0) continue;
-                    if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e] - base]), q);
-                    else fx_add(&dst[key[u][e] - base], q);
+                    if (lds) atomicAdd(reinterpret_cast<unsigned long long*>(&sparse_slice[key[u][e]]), q);
+                    else fx_add(&dst[key[u][e]], q);
                 }
                 if (fl[u] & 1) ln = 0;                                              // trace.reset()
 #pragma unroll
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                     const int sl = e * G + gl;
                     if (sl < ln) {
                         *reinterpret_cast<float*>(vbase + ro + (uint32_t)(e * G * 4)) = val[u][e];
-                        if (need && sl == slot) *reinterpret_cast<uint32_t*>(kbase_w + ro + (uint32_t)(e * G * 4)) = key[u][e];      // (the one key of the sub-list this step can change)
+                        if (need && sl == slot) *reinterpret_cast<uint16_t*>(kbase_w + (ro >> 1) + (uint32_t)(e * G * 2)) = (uint16_t)key[u][e];      // (the one key of the sub-list this step can change)
                     }
                 }
                 if (gl == 0 && ok) *reinterpret_cast<uint32_t*>(lbase + r * (uint32_t)(T * 4)) = (uint32_t)ln;
@@ -260,9 +260,9 @@ __global__ __launch_bounds__(kBlock) void k_sparse_handle(Common c, BasisGeom g,
 }
 
 // Parameterised-style view of one learner's trace: the dense (F, A) matrix it stands for (zeros + the list's entries)
-static __global__ void k_sparse_trace_get(SparseTrace st, int T, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
+static __global__ void k_sparse_trace_get(SparseTrace st, int T, int slice, int64_t i, float* __restrict__ out /* zero-filled [F][A] */) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x, cap = kSparseCap / T;
-    if (s < kSparseCap && s % cap < (int)st.len[i * T + s / cap]) out[st.keys[i * (int64_t)kSparseCap + s]] = st.vals[i * (int64_t)kSparseCap + s];
+    if (s < kSparseCap && s % cap < (int)st.len[i * T + s / cap]) out[(s / cap) * slice + (int)st.keys[i * (int64_t)kSparseCap + s]] = st.vals[i * (int64_t)kSparseCap + s];
 }
 
 }  // namespace rsrl

@@ -46,10 +46,10 @@ def main():
             us = ms * 1e3 / K
             n_envs = kw["n_envs"]
             extra = {}
-            if kn == "k_sparse_trace_scatter":       # what the lists really hold: HBM bytes on the LIVE entries (key + value read, value written: 12 B; bench.py's accounting)
+            if kn == "k_sparse_trace_scatter":       # what the lists really hold: HBM bytes on the LIVE entries (16-bit key + value read, value written: 10 B; bench.py's accounting)
                 import numpy as np
                 live = float(np.mean([int((c.get_traces(i) != 0).sum()) for i in range(0, n_envs, max(1, n_envs // 64))]))
-                bytes_per = round(12 * live + 16 * 2 * 4 + 8 * (4 + 2 + 8))
+                bytes_per = round(10 * live + 16 * 2 * 4 + 8 * (4 + 2 + 8))
                 extra = {"mean_live_entries": round(live, 1), "full_list_formula_bytes": 12416}
             print(json.dumps({"what": name, **extra, "kernel": kn, "learners": n_envs, "us_per_batch_step": round(us, 3), "env_steps_per_s": round(n_envs / us * 1e6, 1),
                               "algorithmic_bytes_per_learner_step": bytes_per, "algorithmic_GBps": round(bytes_per * n_envs / us / 1e3, 1),

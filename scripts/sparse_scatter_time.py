@@ -29,7 +29,7 @@ def main():
         ms, _, kn = c.timing_read()
         us = ms * 1e3 / K
         live = float(np.mean([int((c.get_traces(i) != 0).sum()) for i in range(0, n, max(1, n // 64))]))
-        real = 3 * live * 8 + 16 * 2 * 4
+        real = 10 * live + 16 * 2 * 4 + 8 * (4 + 2 + 8)      # HBM bytes per learner-step (bench.py's accounting)
         print(json.dumps({"kernel": kn, "learners": n, "tilings": T, "warm": warm, "chunk": os.environ.get("RSRL_SPARSE_CHUNK", "auto"), "us_per_batch_step": round(us, 2),
                           "mean_live_entries": round(live, 1), "GBps_on_live_entries": round(real * n / us / 1e3, 1), "checksum": c.checksum()}), flush=True)
 
