@@ -75,10 +75,6 @@ __device__ __forceinline__ void sparse_dispatch_regs(int slots, F&& fn) {
     fn(std::integral_constant<int, REGS>{});
 }
 
-#ifndef RSRL_SP_U
-#define RSRL_SP_U 4
-#endif
-
 // S = entries of one tiling's slice (cells * A); lds != 0: the slice is privatised in dynamic LDS (S * 8 bytes), else the terms go straight to
 // copy 0 of the table with device atomics (a slice too large for LDS: the same integers, the same sum).
 //
@@ -91,7 +87,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                                                                const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int64_t key_stride,
                                                                int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
                                                                float inv_lsb, int lds) {
-    constexpr int CAP = kSparseCap / T, G = 16, REGS = CAP / G, LPW = 64 / G, U = REGS > 4 ? (RSRL_SP_U > 2 ? 2 : RSRL_SP_U) : RSRL_SP_U;   // U x LPW sub-lists in flight per wave
+    constexpr int CAP = kSparseCap / T, G = 16, REGS = CAP / G, LPW = 64 / G, U = REGS > 4 ? 2 : 4;   // U x LPW sub-lists in flight per wave
     static_assert(CAP % G == 0, "a sub-list is a whole number of 16-slot registers");
     extern __shared__ long long sparse_slice[];
     const int t = blockIdx.y;
