@@ -183,6 +183,39 @@ def test_sparse_traces_travel_with_the_checkpoint(ra, tmp_path):
             shard.load_weights(path)
 
 
+@pytest.mark.parametrize("T,domain", [(4, 1), (16, 0)])
+def test_checkpoint_file_holds_full_keys_whatever_the_lists_hold_in_memory(ra, tmp_path, T, domain):
+    # in memory a key is 16 bit and relative to its tiling's slice; the FILE holds tile index * A + action (include/rsrl_hip.h): learner 0's list read back from
+    # the file is the dense matrix get_traces shows, and a second ctx resumes from it bit for bit -- at 4 and at 16 tilings
+    kw = dict(domain=domain, basis=ra.TILE_CODING, n_tilings=T, tiles_per_dim=6, algo=3, policy=1, epsilon=0.2, gamma=0.99, lam=0.9, trace=0, max_episode_steps=0,
+              weight_mode=ra.W_SHARED, seed=11, alpha=0.1 / T / 40, n_envs=40)
+    path = str(tmp_path / "keys.rsrlw")
+    with ra.Context(**kw) as a, ra.Context(**kw) as b:
+        a.reset()
+        a.train(120)
+        a.save_weights(path)
+        raw = open(path, "rb").read()
+        off = 72 + a.F * a.A * 4 + 16
+        lens = np.frombuffer(raw, np.uint32, 40, off)
+        k0 = off + 4 * 40
+        keys = np.frombuffer(raw, np.uint32, int(lens[0]), k0)
+        vals = np.frombuffer(raw, np.float32, int(lens[0]), k0 + 4 * int(lens[0]))
+        assert lens[0] > T and len(set(keys.tolist())) == len(keys) and keys.max() < a.F * a.A
+        assert len(set((keys // (a.F * a.A // T)).tolist())) == T                        # entries of every tiling, as full keys
+        dense = np.zeros(a.F * a.A, np.float32)
+        dense[keys] = vals
+        assert np.array_equal(dense.reshape(a.F, a.A), a.get_traces(0))
+        s, act = a.states.copy(), a.actions.copy()
+        a.train(60)
+        b.reset()
+        b.load_weights(path)
+        b.states, b.actions = s, act
+        b.train(60)
+        assert np.array_equal(a.get_weights(), b.get_weights()) and np.array_equal(a.states, b.states)
+        for i in (0, 17, 39):
+            assert np.array_equal(a.get_traces(i), b.get_traces(i)), i
+
+
 def test_sparse_lambda_is_refused_where_it_does_not_exist(ra):
     with pytest.raises(ra.RsrlHipError):                            # a shared DENSE basis has no sparse gradient
         ra.Context(domain=0, order=3, algo=3, policy=1, weight_mode=ra.W_SHARED, n_envs=8)
