@@ -21,8 +21,8 @@
 //   k_shared_ca   (models.hpp, one thread per learner; the one-step shared-table agents' step kernel)   phase C of the previous batch-step
 //                 (policy.sample from the updated table, restarts) + phase A of this one: transition, Q(s,.), Q(s',.), the TD target's residual;
 //                 hands over alpha * residual, the T new slice-relative keys, and flags (bit 0 terminal, bit 1 truncated, bit 2 Watkins's cut)
-//   k_sparse_trace_scatter   block (chunk of learners, tiling t), one 16-LANE GROUP per (learner, tiling) at a time (four learners per wave): slot s of the
-//                 sub-list lives in lane s & 15 of the group, register s >> 4.  In this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
+//   k_sparse_trace_scatter   block (chunk of learners, tiling t), one GROUP of 8 or 16 lanes per (learner, tiling) at a time (eight or four learners per wave): slot s of the
+//                 sub-list lives in lane s % G of the group, register s / G.  In this order (restated one for one by the oracle, orc_run_train_sparse_lambda):
 //                   0. Q(lambda) and a was not argmax_first of Q(s,.): the sub-list is emptied first (q_lambda.rs:62-66);
 //                   1. every entry: v <- rule(fma(rate, v, hit ? 1 : 0)), hit = its key is the step's new key of this tiling;
 //                   2. the new key, if it was not in the sub-list: appended (value rule(fma(rate, 0, 1))) -- or, when the sub-list is full, written
@@ -50,49 +50,53 @@ struct SparseTrace {
     uint32_t* len;     // [N][T]
 };
 
-// (min |v|, slot) over a 16-lane group as one 64-bit key: |v| bits above the slot, so the smallest value wins and ties go to the lowest slot
-__device__ __forceinline__ unsigned long long group16_min_u64(unsigned long long v) {
+// (min |v|, slot) over a G-lane group as one 64-bit key: |v| bits above the slot, so the smallest value wins and ties go to the lowest slot
+template <int G>
+__device__ __forceinline__ unsigned long long group_min_u64(unsigned long long v) {
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
+    for (int o = G / 2; o > 0; o >>= 1) {
         const unsigned long long w = __shfl_xor(v, o, 64);
         v = w < v ? w : v;
     }
     return v;
 }
-// the largest of a per-group value (equal over a group's 16 lanes) over the wave's four groups: wave-uniform
+// the largest of a per-group value (equal over a group's G lanes) over the wave's 64 / G groups: wave-uniform
+template <int G>
 __device__ __forceinline__ int wave_max_of_groups(int v) {
-    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    const int ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
+    int m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+    for (int g = 1; g < 64 / G; ++g) { const int x = __builtin_amdgcn_readlane(v, g * G); m = x > m ? x : m; }
+    return m;
 }
-
-// fn(integral_constant<NR>) with NR the smallest of {1, 2, 4, ..., REGS} whose NR x 16 slots hold `slots` entries (slots is wave-uniform)
-template <int REGS, class F>
+// fn(integral_constant<NR>) with NR the smallest of {1, 2, 4, ..., REGS} whose NR x G slots hold `slots` entries (slots is wave-uniform)
+template <int REGS, int G, class F>
 __device__ __forceinline__ void sparse_dispatch_regs(int slots, F&& fn) {
-    if constexpr (REGS >= 2) { if (slots <= 16) { fn(std::integral_constant<int, 1>{}); return; } }
-    if constexpr (REGS >= 4) { if (slots <= 32) { fn(std::integral_constant<int, 2>{}); return; } }
-    if constexpr (REGS >= 8) { if (slots <= 64) { fn(std::integral_constant<int, 4>{}); return; } }
+    if constexpr (REGS >= 2) { if (slots <= G) { fn(std::integral_constant<int, 1>{}); return; } }
+    if constexpr (REGS >= 4) { if (slots <= 2 * G) { fn(std::integral_constant<int, 2>{}); return; } }
+    if constexpr (REGS >= 8) { if (slots <= 4 * G) { fn(std::integral_constant<int, 4>{}); return; } }
     fn(std::integral_constant<int, REGS>{});
 }
 
 // S = entries of one tiling's slice (cells * A); lds != 0: the slice is privatised in dynamic LDS (S * 8 bytes), else the terms go straight to
 // copy 0 of the table with device atomics (a slice too large for LDS: the same integers, the same sum).
 //
-// Mapping (round 6, second form): a sub-list belongs to a GROUP of 16 lanes -- slot s in lane s & 15 of the group, register s >> 4 -- so a wave carries four
-// learners' sub-lists of one tiling at a time and skips, wave-uniformly, the registers beyond the longest of the four.  A CartPole learner's sub-list holds ~11 live
+// Mapping (round 6, second form): a sub-list belongs to a GROUP of G lanes -- slot s in lane s % G of the group, register s / G -- so a wave carries 64 / G
+// learners' sub-lists of one tiling at a time and runs, wave-uniformly, only the registers the longest of them reaches.  A CartPole learner's sub-list holds ~11 live
 // entries of 64: with one WAVE per sub-list (the first form) 53 of 64 lanes idled through every instruction and the kernel was issue-bound at a sixth of the lanes.
-// Nothing about the values moves: every entry's arithmetic is its own, the eviction key orders (|v|, slot) as before, the sum is exact in any order.
+// G = 8 at 8 and 16 tilings (eight learners per wave; 65 536 learners: 50.9 -> 46.7 us per batch-step with short lists, 75.0 / 75.2 with full ones, against G = 16),
+// 16 at 4 tilings (128 slots per sub-list would be sixteen registers).  Nothing about the values moves: every entry's arithmetic is its own, the eviction key orders
+// (|v|, slot) as before, the sum is exact in any order.
 template <int T>
 __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* __restrict__ new_keys, const float* __restrict__ terms,
                                                                const uint8_t* __restrict__ flags, SparseTrace st, LambdaParams lp, int64_t N, int64_t key_stride,
                                                                int S, int per_block, long long* __restrict__ dW64, int n_rep, int64_t rep_stride,
                                                                float inv_lsb, int lds) {
-    constexpr int CAP = kSparseCap / T, G = 16, REGS = CAP / G, LPW = 64 / G, U = REGS > 4 ? 2 : 4;   // U x LPW sub-lists in flight per wave
-    static_assert(CAP % G == 0, "a sub-list is a whole number of 16-slot registers");
+    constexpr int CAP = kSparseCap / T, G = T >= 8 ? 8 : 16, REGS = CAP / G, LPW = 64 / G, U = REGS > 4 ? 2 : 4;   // U x LPW sub-lists in flight per wave
+    static_assert(CAP % G == 0 && 64 % G == 0, "a sub-list is a whole number of G-slot registers, a wave a whole number of groups");
     extern __shared__ long long sparse_slice[];
     const int t = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const int grp = lane >> 4, gl = lane & 15;
+    const int grp = lane / G, gl = lane % G;
     const int64_t i0 = (int64_t)blockIdx.x * per_block;
     const int64_t i1 = i0 + per_block < N ? i0 + per_block : N;
     const uint16_t* __restrict__ kt = new_keys + (int64_t)t * key_stride;      // (N: the learners stepped, 0 .. N-1; key_stride: the ctx's learner count)
@@ -135,9 +139,9 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
             const uint32_t ro = rr * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;  // byte offset of the group's lane in the learner's row of values (keys: half)
 #pragma unroll
             for (int e = 0; e < REGS; ++e) { key[u][e] = 0xffffffffu; val[u][e] = 0.0f; }
-            // NR: the registers the longest of the wave's four sub-lists reaches, as a compile-time constant of a straight-line body (a wave-uniform branch per
+            // NR: the registers the longest of the wave's sub-lists reaches, as a compile-time constant of a straight-line body (a wave-uniform branch per
             // register and loop instead cost ~50 taken branches per batch with short lists)
-            sparse_dispatch_regs<REGS>(wave_max_of_groups(len[u]), [&](auto nr) {
+            sparse_dispatch_regs<REGS, G>(wave_max_of_groups<G>(len[u]), [&](auto nr) {
                 constexpr int NR = decltype(nr)::value;
 #pragma unroll
                 for (int e = 0; e < NR; ++e)
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
             const bool ok = r < nb;
             const uint32_t ro = r * (uint32_t)(kSparseCap * 4) + (uint32_t)gl * 4u;   // (used where ok)
             // (the loaded lengths + 1: an append can open the next register; a cut or a reset only shortens)
-            sparse_dispatch_regs<REGS>(wave_max_of_groups(len[u]) + 1, [&](auto nr) {
+            sparse_dispatch_regs<REGS, G>(wave_max_of_groups<G>(len[u]) + 1, [&](auto nr) {
                 constexpr int NR = decltype(nr)::value;
                 int ln = len[u];                                                    // (0 where !ok)
                 if (fl[u] & 4) ln = 0;                                              // Watkins's cut
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                     hits |= __ballot(hit);
                     val[u][e] = trace_merge(lp.trace, lp.rate, live ? val[u][e] : 0.0f, hit ? 1.0f : 0.0f);
                 }
-                const bool need = ok && ((uint32_t)(hits >> (grp * G)) & 0xffffu) == 0u;  // the group's learner brings a key its sub-list does not hold
+                const bool need = ok && ((uint32_t)(hits >> (grp * G)) & ((1u << G) - 1u)) == 0u;  // the group's learner brings a key its sub-list does not hold
                 const bool full = ln >= CAP;
                 int slot = ln;
                 if constexpr (NR == REGS) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(1024) void k_sparse_trace_scatter(const uint16_t* _
                             const unsigned long long cand = ((unsigned long long)(__builtin_bit_cast(uint32_t, val[u][e]) & 0x7fffffffu) << 32) | (uint32_t)(e * G + gl);
                             best = cand < best ? cand : best;
                         }
-                        const int ev = (int)(uint32_t)group16_min_u64(best);
+                        const int ev = (int)(uint32_t)group_min_u64<G>(best);
                         if (full) slot = ev;
                     }
                 }

@@ -35,7 +35,7 @@ void launch_sparse_trace_scatter(const rsrl_hip_ctx* c, int64_t n_learners, int 
     if (per_block <= 0) {
         const int64_t cus = c->n_cu > 0 ? c->n_cu : 256;
         int64_t per = (n_learners * c->cfg.n_tilings + cus - 1) / cus;
-        per = ((per + 63) / 64) * 64;                                        // (a block's sixteen waves carry 64 learners at a time)
+        per = ((per + 63) / 64) * 64;                                        // (a block's sixteen waves carry 64 or 128 learners at a time)
         per_block = (int)(per < 64 ? 64 : per > (1 << 20) ? (1 << 20) : per);
     }
     if (c->cfg.n_tilings == 4) sparse_scatter_launch<4>(c, n_learners, per_block);
